@@ -1,0 +1,405 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the UNMODIFIED reference files.
+
+Container-only (needs /root/reference, which never travels to the GPU box).  The reference's python
+files are imported as they lie under /root/reference on top of the torch-CPU stand-ins in
+oracle/refshim/ (TensorFlow / TFP / gym are not installable here).  Everything random is an explicit,
+seeded input that is stored next to the outputs, so a fixture is pure data: inputs + what the reference
+computed from them.
+
+    python tests/golden/make_golden.py            # rewrites tests/golden/*.npz
+
+Fixtures (all float32 unless the name ends in _f64, which is the same graph run in float64 from the
+same float32-rounded inputs - the error yard-stick of SURVEY.md §8c):
+  env_step_mpc_rl.npz    the reference's own recorded trajectory mpc/mpc_rl.npy, re-packed as arrays
+  env_step_ref.npz       PathTrackingEnv.reset(init_obs)/step for N agents x T steps (a1-a5)
+  model_rollout_ref.npz  PathTrackingModel.rollout_out x 25 with a fixed action sequence + noise (a6)
+  pendulum_model_ref.npz InvertedPendulumModel.rollout_out x 25 (a7)
+  mpg_{v1,v2}_H{H}_B{B}.npz   MPGLearner.compute_gradient (a11-a17) at iterations 100 and 9000
+  nadp_H{H}_B{B}.npz     NADPLearner.compute_gradient on the pendulum model (a18)
+  td3_H{H}_B{B}.npz      TD3Learner.compute_gradient with recorded smoothing noise (a19)
+  segment_tree_ref.npz   SumSegmentTree / MinSegmentTree primitives (a22)
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get('MPG_REFERENCE', '/root/reference')
+sys.path.insert(0, os.path.join(ROOT, 'oracle', 'refshim'))
+sys.path.insert(0, REF)
+np.int = int                                            # path_tracking_env.py:371 (numpy < 1.24 era)
+
+import torch                                            # noqa: E402
+import tensorflow as tf                                 # noqa: E402  (the stand-in)
+
+OBS_SCALE_PT = [1., 1., 2., 1., 2.4, 1 / 1200]
+OBS_SCALE_PD = [0.001, 1 / 3, 0.1, 0.5]
+
+
+# ------------------------------------------------------------------------------------------------
+# seeded inputs
+# ------------------------------------------------------------------------------------------------
+def orthogonal(rng, rows, cols, gain):
+    a = rng.standard_normal((max(rows, cols), min(rows, cols)))
+    q, r = np.linalg.qr(a)
+    q = q * np.sign(np.diag(r))
+    if rows < cols:
+        q = q.T
+    return (gain * q[:rows, :cols]).astype(np.float32)
+
+
+def mlp_weights(rng, din, H, dout, bias_jitter=0.05):
+    """Keras-shaped list [W1,b1,W2,b2,W3,b3], kernels (in,out).  Biases get a small non-zero value so
+    that bias handling is exercised (the reference initialises them to 0)."""
+    return [orthogonal(rng, din, H, np.sqrt(2.)), (bias_jitter * rng.standard_normal(H)).astype(np.float32),
+            orthogonal(rng, H, H, np.sqrt(2.)), (bias_jitter * rng.standard_normal(H)).astype(np.float32),
+            orthogonal(rng, H, dout, 1.), (bias_jitter * rng.standard_normal(dout)).astype(np.float32)]
+
+
+def reset_law_obs(rng, n):
+    """obs drawn like PathTrackingEnv.reset() (path_tracking_env.py:426-437) but from a seeded Generator."""
+    x = rng.uniform(0, 600, n).astype(np.float32)
+    dy = rng.normal(0, 1, n).astype(np.float32)
+    dphi = rng.normal(0, np.pi / 9, n).astype(np.float32)
+    vx = rng.uniform(15, 25, n).astype(np.float32)
+    beta = rng.normal(0, 0.15, n).astype(np.float32)
+    vy = (vx * np.tan(beta)).astype(np.float32)
+    r = rng.normal(0, 0.3, n).astype(np.float32)
+    return np.stack([vx - np.float32(20.), vy, r, dy, dphi, x], 1).astype(np.float32)
+
+
+def mpg_args(version, B, H, env='PathTracking-v0'):
+    pt = env == 'PathTracking-v0'
+    d = dict(policy_type='PolicyWithQs', buffer_type='normal', env_id=env, num_agent=8, num_future_data=0,
+             alg_name='MPG', learner_version=version, sample_num_in_learner=25, M=1,
+             deriv_interval_policy=False, num_rollout_list_for_policy_update=[0, 25],
+             num_rollout_list_for_q_estimation=[], eta=0.1, rule_based_bias_total_ite=9000,
+             gamma=0.98, gradient_clip_norm=3, num_batch_reuse=1,
+             batch_size=512, explore_sigma=0.1, max_buffer_size=500000, replay_starts=3000,
+             replay_batch_size=B, replay_alpha=0.6, replay_beta=0.4,
+             obs_dim=6 if pt else 4, act_dim=2 if pt else 1,
+             value_model_cls='MLP', value_num_hidden_layers=2, value_num_hidden_units=H,
+             value_hidden_activation='elu', value_lr_schedule=[8e-5, 100000, 8e-6],
+             policy_model_cls='MLP', policy_num_hidden_layers=2, policy_num_hidden_units=H,
+             policy_hidden_activation='elu', policy_out_activation='tanh' if pt else 'linear',
+             policy_lr_schedule=[3e-5, 100000, 3e-6], alpha=None, alpha_lr_schedule=None,
+             policy_only=False, double_Q=(version in ('MPG-v2', 'TD3')), target=True, tau=0.005,
+             delay_update=2, deterministic_policy=True, action_range=None if pt else 3.,
+             obs_ptype='scale', obs_scale=OBS_SCALE_PT if pt else OBS_SCALE_PD, rew_ptype='scale',
+             rew_scale=0.01 if pt else 1., rew_shift=0.,
+             policy_smoothing_sigma=0.2, policy_smoothing_clip=0.5)
+    return argparse.Namespace(**d)
+
+
+class NoiseStream(object):
+    """Feeds recorded N(0,1) draws to the stand-in's tf.random / tfd.Normal, in call order."""
+
+    def __init__(self, arrays):
+        self.arrays = list(arrays)
+        self.k = 0
+
+    def __call__(self, shape):
+        a = self.arrays[self.k]
+        self.k += 1
+        assert int(np.prod(shape)) == a.size, (shape, a.shape)
+        return a.reshape(shape)
+
+
+TARGET_SCALE = np.float32(0.97)
+
+
+def add_targets(nets):
+    """Target nets = online nets * 0.97 (float32 product), so that target != online is exercised while the
+    fixture only has to carry the online tensors (consumers rebuild the targets with the same product)."""
+    for k in list(nets):
+        nets[k + '_target'] = [(w * TARGET_SCALE).astype(np.float32) for w in nets[k]]
+
+
+def sub64(x, H):
+    """float64-run tensors are the error yard-stick only: keep every 8th element at H=256, as float32."""
+    x = np.asarray(x)
+    return (x[::8] if (H >= 256 and x.ndim == 1 and x.size > 4096) else x).astype(np.float32)
+
+
+def set_policy_weights(pwq, nets):
+    """nets: dict name -> keras list.  Targets start as copies unless given explicitly."""
+    order = [m.name for m in pwq.models] + [m.name for m in pwq.target_models]
+    pwq.set_weights([nets[n] for n in order])
+
+
+def flat(ws):
+    return np.concatenate([np.asarray(w, dtype=np.float64).ravel() for w in ws]).astype(
+        np.asarray(ws[0]).dtype)
+
+
+# ------------------------------------------------------------------------------------------------
+# fixtures
+# ------------------------------------------------------------------------------------------------
+def fx_mpc_rl():
+    d = np.load(os.path.join(REF, 'mpc', 'mpc_rl.npy'), allow_pickle=True)
+    out = {}
+    for who in ('mpc', 'rl'):
+        out[who + '_obs'] = np.stack([t[who + '_obs'][0] for t in d]).astype(np.float32)
+        out[who + '_action'] = np.stack([np.asarray(t[who + '_action'], dtype=np.float32) for t in d])
+        out[who + '_rew'] = np.array([np.float32(t[who + '_rew']) for t in d], dtype=np.float32)
+    np.savez_compressed(os.path.join(HERE, 'env_step_mpc_rl.npz'), **out)
+
+
+def fx_env_step(N=64, T=6, seed=0):
+    from envs_and_models.path_tracking_env import PathTrackingEnv
+    rng = np.random.Generator(np.random.PCG64(seed))
+    env = PathTrackingEnv(num_agent=N, num_future_data=0)
+    obs0 = reset_law_obs(rng, N)
+    # a few hand-picked rows to hit the wraps/clips: x near the 1200 m period, large heading error, slow car
+    obs0[0, 5] = 1199.5
+    obs0[1, 5] = 0.3
+    obs0[2, 4] = 3.1
+    obs0[3, 0] = -18.5
+    obs0[4, 0] = 14.9
+    actions = rng.uniform(-1.3, 1.3, (T, N, 2)).astype(np.float32)       # beyond [-1,1]: env clips
+    env.reset(init_obs=obs0.copy())
+    obs_l, rew_l, done_l, full_l, others_l = [], [], [], [], []
+    for t in range(T):
+        o, r, dn, _ = env.step(actions[t])
+        obs_l.append(o.copy()), rew_l.append(r.copy()), done_l.append(dn.copy())
+        full_l.append(env.veh_full_state.copy())
+    np.savez_compressed(os.path.join(HERE, 'env_step_ref.npz'), obs0=obs0, actions=actions,
+             obs=np.stack(obs_l).astype(np.float32), reward=np.stack(rew_l).astype(np.float32),
+             done=np.stack(done_l).astype(np.uint8), full_state=np.stack(full_l).astype(np.float32))
+
+
+def fx_model_rollout(N=64, T=25, seed=1):
+    from envs_and_models.path_tracking_env import PathTrackingModel
+    rng = np.random.Generator(np.random.PCG64(seed))
+    obs0 = reset_law_obs(rng, N)
+    obs0[0, 4] = 3.12
+    obs0[1, 0] = 14.95                     # v_x close to the upper clip (35) after +20
+    obs0[2, 0] = -18.9                     # v_x close to the lower clip (1)
+    actions = rng.uniform(-1, 1, (T, N, 2)).astype(np.float32)
+    eps = rng.standard_normal((T, N)).astype(np.float32)
+    out = dict(obs0=obs0, actions=actions, eps=eps)
+    for tag, dt in (('', torch.float32), ('_f64', torch.float64)):
+        tf.set_ref_dtype(dt)
+        tf.set_noise_source(NoiseStream(list(eps)))
+        m = PathTrackingModel()
+        m.reset(tf.constant(obs0))
+        obs_l, rew_l = [], []
+        for t in range(T):
+            o, r = m.rollout_out(tf.constant(actions[t]))
+            obs_l.append(o.numpy()), rew_l.append(r.numpy())
+        out['obs' + tag] = np.stack(obs_l)
+        out['reward' + tag] = np.stack(rew_l)
+    tf.set_ref_dtype(torch.float32)
+    tf.set_noise_source(None)
+    np.savez_compressed(os.path.join(HERE, 'model_rollout_ref.npz'), **out)
+
+
+def fx_pendulum_model(N=64, T=25, seed=2):
+    from envs_and_models.inverted_pendulum_model import InvertedPendulumModel
+    rng = np.random.Generator(np.random.PCG64(seed))
+    obs0 = (rng.standard_normal((N, 4)) * np.array([0.5, 0.1, 0.5, 0.5])).astype(np.float32)
+    actions = rng.uniform(-3, 3, (T, N, 1)).astype(np.float32)
+    eps = rng.standard_normal((T, N)).astype(np.float32)
+    out = dict(obs0=obs0, actions=actions, eps=eps)
+    for tag, dt in (('', torch.float32), ('_f64', torch.float64)):
+        tf.set_ref_dtype(dt)
+        tf.set_noise_source(NoiseStream(list(eps)))
+        m = InvertedPendulumModel()
+        m.reset(tf.constant(obs0))
+        obs_l, rew_l = [], []
+        for t in range(T):
+            o, r = m.rollout_out(tf.constant(actions[t]))
+            obs_l.append(o.numpy()), rew_l.append(r.numpy())
+        out['obs' + tag] = np.stack(obs_l)
+        out['reward' + tag] = np.stack(rew_l)
+    tf.set_ref_dtype(torch.float32)
+    tf.set_noise_source(None)
+    np.savez_compressed(os.path.join(HERE, 'pendulum_model_ref.npz'), **out)
+
+
+def make_replay_batch_pt(rng, B):
+    """(obs, act, RAW reward, obs', done) produced by the reference env itself (worker.py:108-111)."""
+    from envs_and_models.path_tracking_env import PathTrackingEnv
+    env = PathTrackingEnv(num_agent=B, num_future_data=0)
+    obs = reset_law_obs(rng, B)
+    act = np.clip(rng.uniform(-1, 1, (B, 2)) + 0.1 * rng.standard_normal((B, 2)), -1.2, 1.2).astype(np.float32)
+    env.reset(init_obs=obs.copy())
+    obs2, rew, done, _ = env.step(act)
+    return [obs, act, rew.astype(np.float32), obs2.astype(np.float32), done.astype(np.float32)]
+
+
+def fx_mpg(version, H, B, seed):
+    from learners.mpg_learner import MPGLearner
+    from policy import PolicyWithQs
+    rng = np.random.Generator(np.random.PCG64(seed))
+    args = mpg_args(version, B, H)
+    nets = {'policy': mlp_weights(rng, 6, H, 4), 'Q1': mlp_weights(rng, 8, H, 1)}
+    if version == 'MPG-v2':
+        nets['Q2'] = mlp_weights(rng, 8, H, 1)
+    add_targets(nets)
+    batch = make_replay_batch_pt(rng, B)
+    eps = rng.standard_normal((25, B)).astype(np.float32)
+    out = dict(batch_obs=batch[0], batch_actions=batch[1], batch_rewards=batch[2], batch_obs_tp1=batch[3],
+               batch_dones=batch[4], eps=eps, iterations=np.array([100, 9000]))
+    for k, v in nets.items():
+        if not k.endswith('_target'):
+            out['w_' + k] = flat(v)
+    out['target_scale'] = TARGET_SCALE
+    for tag, dt in (('', torch.float32), ('_f64', torch.float64)):
+        tf.set_ref_dtype(dt)
+        learner = MPGLearner(PolicyWithQs, args)
+        set_policy_weights(learner.policy_with_value, nets)
+        for it in (100, 9000):
+            learner.counter = 0
+            tf.set_noise_source(NoiseStream(list(eps)))
+            grads = learner.compute_gradient(batch, None, None, it)
+            st = learner.get_stats()
+            p = 'it%d_' % it
+            out[p + 'grads' + tag] = flat(grads) if tag == '' else sub64(flat(grads), H)
+            out[p + 'targets' + tag] = np.asarray(learner.batch_data['batch_targets'])
+            for key in ('value_mean', 'policy_total_loss', 'policy_gradient_norm', 'q_loss1',
+                        'q_gradient_norm1', 'q_loss2', 'q_gradient_norm2'):
+                if key in st:
+                    out[p + key + tag] = np.asarray(st[key])
+            out[p + 'w_list' + tag] = np.asarray(st['w_list'])
+            out[p + 'all_losses' + tag] = np.asarray(st['all_losses'])
+        if version == 'MPG-v1' and tag == '':
+            ro = learner.sample(batch[0].astype(np.float32), batch[1].astype(np.float32))
+            out['nstep_all_rewards'] = ro['all_rewards']
+            out['nstep_last_obs'] = ro['all_obs_tp1'][-1]
+        if tag == '':
+            # un-clipped pieces, handy when a clipped comparison fails
+            tf.set_noise_source(NoiseStream(list(eps)))
+            pg, loss, vm, ws, _, al = learner.policy_forward_and_backward(
+                learner.batch_data['batch_obs'], tf.convert_to_tensor(100, dtype=tf.float32), None, None)
+            out['it100_policy_grad_unclipped'] = flat([g.numpy() for g in pg])
+            out['td_error'] = np.asarray(learner.compute_td_error())
+    tf.set_ref_dtype(torch.float32)
+    tf.set_noise_source(None)
+    np.savez_compressed(os.path.join(HERE, 'mpg_%s_H%d_B%d.npz' % (version[-2:], H, B)), **out)
+
+
+def fx_nadp(H, B, seed):
+    from learners.nadp import NADPLearner
+    from policy import PolicyWithQs
+    rng = np.random.Generator(np.random.PCG64(seed))
+    args = mpg_args('NADP', B, H, env='InvertedPendulumConti-v0')
+    args.num_rollout_list_for_policy_update = [25]
+    args.num_rollout_list_for_q_estimation = [25]
+    args.delay_update = 1
+    nets = {'policy': mlp_weights(rng, 4, H, 2), 'Q1': mlp_weights(rng, 5, H, 1)}
+    add_targets(nets)
+    obs = (rng.standard_normal((B, 4)) * np.array([0.5, 0.1, 0.5, 0.5])).astype(np.float32)
+    act = rng.uniform(-3, 3, (B, 1)).astype(np.float32)
+    batch = [obs, act, np.zeros(B, np.float32), obs.copy(), np.zeros(B, np.float32)]
+    eps_q = rng.standard_normal((25, B)).astype(np.float32)      # Q-target rollout draws first (nadp.py:175)
+    eps_pi = rng.standard_normal((25, B)).astype(np.float32)
+    out = dict(batch_obs=obs, batch_actions=act, eps_q=eps_q, eps_pi=eps_pi)
+    for k, v in nets.items():
+        if not k.endswith('_target'):
+            out['w_' + k] = flat(v)
+    out['target_scale'] = TARGET_SCALE
+    for tag, dt in (('', torch.float32), ('_f64', torch.float64)):
+        tf.set_ref_dtype(dt)
+        learner = NADPLearner(PolicyWithQs, args)
+        set_policy_weights(learner.policy_with_value, nets)
+        tf.set_noise_source(NoiseStream(list(eps_q) + list(eps_pi)))
+        grads = learner.compute_gradient(batch, None, None, 0)
+        st = learner.get_stats()
+        out['grads' + tag] = flat(grads) if tag == '' else sub64(flat(grads), H)
+        for key in ('q_loss', 'policy_loss', 'value_mean', 'q_gradient_norm', 'policy_gradient_norm'):
+            out[key + tag] = np.asarray(st[key])
+    tf.set_ref_dtype(torch.float32)
+    tf.set_noise_source(None)
+    np.savez_compressed(os.path.join(HERE, 'nadp_H%d_B%d.npz' % (H, B)), **out)
+
+
+def fx_td3(H, B, seed):
+    from learners.td3 import TD3Learner
+    from policy import PolicyWithQs
+    rng = np.random.Generator(np.random.PCG64(seed))
+    args = mpg_args('TD3', B, H)
+    nets = {'policy': mlp_weights(rng, 6, H, 4), 'Q1': mlp_weights(rng, 8, H, 1), 'Q2': mlp_weights(rng, 8, H, 1)}
+    add_targets(nets)
+    batch = make_replay_batch_pt(rng, B)
+    smooth = rng.standard_normal((B, 2)).astype(np.float32)
+    out = dict(batch_obs=batch[0], batch_actions=batch[1], batch_rewards=batch[2], batch_obs_tp1=batch[3],
+               batch_dones=batch[4], smooth_eps=smooth)
+    for k, v in nets.items():
+        if not k.endswith('_target'):
+            out['w_' + k] = flat(v)
+    out['target_scale'] = TARGET_SCALE
+    for tag, dt in (('', torch.float32), ('_f64', torch.float64)):
+        tf.set_ref_dtype(dt)
+        learner = TD3Learner(PolicyWithQs, args)
+        set_policy_weights(learner.policy_with_value, nets)
+        tf.set_noise_source(NoiseStream([smooth]))
+        grads = learner.compute_gradient(batch, None, None, 0)
+        st = learner.get_stats()
+        out['grads' + tag] = flat(grads) if tag == '' else sub64(flat(grads), H)
+        out['targets' + tag] = np.asarray(learner.batch_data['batch_targets'])
+        for key in ('q_loss1', 'q_loss2', 'policy_loss', 'value_mean', 'value_var', 'q_gradient_norm1',
+                    'q_gradient_norm2', 'policy_gradient_norm'):
+            out[key + tag] = np.asarray(st[key])
+        if tag == '':
+            out['td_error'] = np.asarray(learner.compute_td_error())
+    tf.set_ref_dtype(torch.float32)
+    tf.set_noise_source(None)
+    np.savez_compressed(os.path.join(HERE, 'td3_H%d_B%d.npz' % (H, B)), **out)
+
+
+def fx_segment_tree(seed=5):
+    from utils.segment_tree import MinSegmentTree, SumSegmentTree
+    rng = np.random.Generator(np.random.PCG64(seed))
+    cap, n = 1024, 700
+    prios = (np.abs(rng.standard_normal(n)) + 1e-6)
+    st, mt = SumSegmentTree(cap), MinSegmentTree(cap)
+    for i, p in enumerate(prios):
+        st[i] = float(p) ** 0.6
+        mt[i] = float(p) ** 0.6
+    total = st.sum(0, n)               # buffer.py:141 (inclusive end; leaf n is 0)
+    u = rng.uniform(0, 1, 512)
+    idx = np.array([st.find_prefixsum_idx(float(x) * total) for x in u], dtype=np.int64)
+    ranges = rng.integers(0, n, (64, 2))
+    ranges.sort(axis=1)
+    sums = np.array([st.sum(int(a), int(b)) for a, b in ranges])
+    mins = np.array([mt.min(int(a), int(b)) for a, b in ranges])
+    # update a few priorities (buffer.py:166-189) and re-query
+    upd_idx = rng.integers(0, n, 100)
+    upd_p = np.abs(rng.standard_normal(100)) + 1e-6
+    for i, p in zip(upd_idx, upd_p):
+        st[int(i)] = float(p) ** 0.6
+        mt[int(i)] = float(p) ** 0.6
+    total2 = st.sum(0, n)
+    idx2 = np.array([st.find_prefixsum_idx(float(x) * total2) for x in u], dtype=np.int64)
+    np.savez_compressed(os.path.join(HERE, 'segment_tree_ref.npz'), capacity=cap, n=n, prios=prios, alpha=0.6, u=u,
+             total=total, idx=idx, ranges=ranges, range_sums=sums, range_mins=mins, min_all=mt.min(),
+             upd_idx=upd_idx, upd_p=upd_p, total2=total2, idx2=idx2, min_all2=mt.min(),
+             edge_idx=np.array([st.find_prefixsum_idx(0.0), st.find_prefixsum_idx(total2)]))
+
+
+def main():
+    torch.manual_seed(0)
+    fx_mpc_rl()
+    fx_segment_tree()
+    fx_env_step()
+    fx_model_rollout()
+    fx_pendulum_model()
+    for version in ('MPG-v2', 'MPG-v1'):
+        fx_mpg(version, 32, 64, seed=10)
+        fx_mpg(version, 256, 64, seed=11)
+    fx_nadp(32, 64, seed=20)
+    fx_nadp(256, 64, seed=21)
+    fx_td3(32, 64, seed=30)
+    fx_td3(256, 64, seed=31)
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith('.npz'):
+            print('%-28s %8.1f KB' % (f, os.path.getsize(os.path.join(HERE, f)) / 1024))
+
+
+if __name__ == '__main__':
+    main()
