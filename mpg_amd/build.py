@@ -1,0 +1,72 @@
+"""Builds libmpg_hip.so (gfx950) in-tree with hipcc.  `python -m mpg_amd.build [--force]`.
+
+hipcc cross-compiles without a GPU, so this also runs in the CPU-only build container; the resulting .so
+travels with the repo snapshot to the GPU box (it is git-ignored, not gpurun-ignored)."""
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+OBJ = os.path.join(HERE, 'build')
+LIB = os.path.join(HERE, 'libmpg_hip.so')
+ARCH = 'gfx950'
+
+COMMON = ['-O3', '-fPIC', '-std=c++17', '--offload-arch=' + ARCH, '-Wall', '-Wno-unused-function', '-Wno-bitwise-instead-of-logical',
+          '-I' + os.path.join(HERE, '..', 'include')]
+# per-file extras: the real-env kernel mirrors the reference op-by-op, so no fused multiply-adds there
+EXTRA = {'env_path_tracking.hip': ['-ffp-contract=off']}
+
+
+def hipcc():
+    for c in (os.environ.get('HIPCC'), shutil.which('hipcc'), '/opt/rocm/bin/hipcc'):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError('hipcc not found: libmpg_hip.so cannot be built (this package has no CPU fallback)')
+
+
+def sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith(('.hip', '.cpp')))
+
+
+def _stamp(src, flags):
+    h = hashlib.sha1(' '.join(flags).encode())
+    for f in [src] + [os.path.join(CSRC, x) for x in sorted(os.listdir(CSRC)) if x.endswith('.h')] + \
+            [os.path.join(HERE, '..', 'include', 'mpg_hip.h')]:
+        with open(f, 'rb') as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def build(force=False, verbose=True):
+    os.makedirs(OBJ, exist_ok=True)
+    cc = hipcc()
+    objs, rebuilt = [], False
+    for s in sources():
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(OBJ, s + '.o')
+        flags = COMMON + EXTRA.get(s, []) + (['-x', 'hip'] if s.endswith('.hip') else [])
+        stamp_file = obj + '.stamp'
+        stamp = _stamp(src, flags)
+        if force or not os.path.exists(obj) or not os.path.exists(stamp_file) or open(stamp_file).read() != stamp:
+            cmd = [cc] + flags + ['-c', src, '-o', obj]
+            if verbose:
+                print('[mpg_amd.build]', ' '.join(cmd), flush=True)
+            subprocess.check_call(cmd)
+            with open(stamp_file, 'w') as fh:
+                fh.write(stamp)
+            rebuilt = True
+        objs.append(obj)
+    if rebuilt or not os.path.exists(LIB):
+        cmd = [cc, '-shared', '-fPIC', '--offload-arch=' + ARCH, '-o', LIB] + objs
+        if verbose:
+            print('[mpg_amd.build]', ' '.join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == '__main__':
+    build(force='--force' in sys.argv)
+    print(LIB)

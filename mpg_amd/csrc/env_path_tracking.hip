@@ -1,0 +1,231 @@
+// K1: PathTrackingEnv - vectorised real-environment stepping for gfx950.
+//
+// One lane per agent; the 20 sub-steps of VehicleDynamics.simulation run in registers, the agent's state
+// block is read once and written once (SoA [8][n], coalesced).  The arithmetic follows the reference
+// operation-by-operation (envs_and_models/path_tracking_env.py:78-138,144-179,181-199,204-220,410-487):
+// this translation unit is compiled with -ffp-contract=off so that every float32 product and sum rounds
+// exactly where numpy / TF round it; only the transcendental library calls (sin, cos, atan, tan, log,
+// sqrt) differ from the reference's by their last-ulp behaviour.
+//
+// State block (opaque to callers): v_x, v_y, r, y, phi, x, delta_y, delta_phi.
+#include "mpg_common.h"
+
+namespace {
+
+constexpr float PI_F = 3.14159265358979323846f;          // float32(np.pi)
+constexpr float TWO_PI_F = (float)(2.0 * 3.14159265358979323846);   // float32(2*np.pi)
+constexpr float PERIOD = 1200.f;                          // path_tracking_env.py:205
+
+// vehicle parameters, path_tracking_env.py:60-68 (cast to float32 like :86-93)
+constexpr float C_f = -128915.5f, C_r = -85943.6f, A_ = 1.06f, B_ = 1.85f, MASS = 1412.f, I_z = 1536.7f,
+                MIU = 1.0f, G_ = 9.81f;
+
+struct PathRef {
+    float y, phi;
+};
+
+// ReferencePath.compute_path_y / compute_path_phi, path_tracking_env.py:207-220.
+// numpy evaluates (x - shift) * 2 * np.pi / T in float32, one rounding per operator; y and the slope are
+// accumulated curve by curve into a float32 zero array.
+__device__ __forceinline__ PathRef path_ref(float x) {
+    const float Amp[3] = {7.5f, 2.5f, -5.f};
+    const float T[3] = {200.f, 300.f, 400.f};
+    float y = 0.f, d = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float arg = (((x - 0.f) * 2.f) * PI_F) / T[i];
+        float s, c;
+        sincosf(arg, &s, &c);
+        y = y + Amp[i] * s;
+        // magnitude * 2 * np.pi / T is a python-float (double) scalar, rounded once when it meets the array
+        const float k = (float)((double)Amp[i] * 2.0 * 3.14159265358979323846 / (double)T[i]);
+        d = d + k * c;
+    }
+    PathRef r;
+    r.y = y;
+    r.phi = atanf(d);
+    return r;
+}
+
+__device__ __forceinline__ float wrap_pi(float a) {        // :168-169 / :176-177
+    if (a > PI_F) a = a - TWO_PI_F;
+    if (a <= -PI_F) a = a + TWO_PI_F;
+    return a;
+}
+
+__global__ void __launch_bounds__(64) k_reset_from_obs(int n, float* __restrict__ st, const float* __restrict__ obs) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* o = obs + (size_t)i * 6;
+    float vx = o[0] + 20.f, vy = o[1], r = o[2], dy = o[3], dphi = o[4], x = o[5];   // _get_state :404-408
+    PathRef p = path_ref(x);                                                          // :415-417
+    st[0 * (size_t)n + i] = vx;
+    st[1 * (size_t)n + i] = vy;
+    st[2 * (size_t)n + i] = r;
+    st[3 * (size_t)n + i] = dy + p.y;      // :420
+    st[4 * (size_t)n + i] = dphi + p.phi;  // :419 (no wrap here, as in the reference)
+    st[5 * (size_t)n + i] = x;
+    st[6 * (size_t)n + i] = dy;
+    st[7 * (size_t)n + i] = dphi;
+}
+
+__device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& z0, float& z1) {
+    float u1 = u01(a), u2 = u01(b);
+    float rad = sqrtf(-2.f * logf(u1));
+    float s, c;
+    sincosf(TWO_PI_F * u2, &s, &c);
+    z0 = rad * c;
+    z1 = rad * s;
+}
+
+__global__ void __launch_bounds__(64) k_reset(int n, float* __restrict__ st, const uint8_t* __restrict__ mask,
+                                              uint32_t k0, uint32_t k1, uint32_t c1, uint32_t c2,
+                                              float* __restrict__ obs) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    size_t N = n;
+    if (mask == nullptr || mask[i]) {
+        Philox4 a = philox4x32_10((uint32_t)i, c1, c2, 0u, k0, k1);
+        Philox4 b = philox4x32_10((uint32_t)i, c1, c2, 1u, k0, k1);
+        float x = 600.f * u01(a.v[0]);                    // :426
+        float vx = 15.f + 10.f * u01(a.v[1]);             // :434
+        float z0, z1, z2, z3;
+        box_muller(a.v[2], a.v[3], z0, z1);
+        box_muller(b.v[0], b.v[1], z2, z3);
+        float dy = z0;                                     // :428
+        float dphi = z1 * (float)(3.14159265358979323846 / 9.0);   // :431
+        float beta = z2 * 0.15f;                           // :435
+        float r = z3 * 0.3f;                               // :437
+        PathRef p = path_ref(x);
+        float y = dy + p.y;                                // compute_y :222-224
+        float phi = wrap_pi(dphi + p.phi);                 // compute_phi :230-235
+        float vy = vx * tanf(beta);                        // :436
+        st[0 * N + i] = vx;
+        st[1 * N + i] = vy;
+        st[2 * N + i] = r;
+        st[3 * N + i] = y;
+        st[4 * N + i] = phi;
+        st[5 * N + i] = x;
+        st[6 * N + i] = y - p.y;                           // :450
+        st[7 * N + i] = phi - p.phi;                       // :449
+    }
+    float* o = obs + (size_t)i * 6;                        // _get_obs :399-402
+    o[0] = st[0 * N + i] - 20.f;
+    o[1] = st[1 * N + i];
+    o[2] = st[2 * N + i];
+    o[3] = st[6 * N + i];
+    o[4] = st[7 * N + i];
+    o[5] = st[5 * N + i];
+}
+
+__global__ void __launch_bounds__(64) k_step(int n, float* __restrict__ st, const float* __restrict__ action,
+                                             float* __restrict__ obs, float* __restrict__ reward,
+                                             uint8_t* __restrict__ done, uint8_t* __restrict__ done_intended) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const size_t N = n;
+    float vx = st[0 * N + i], vy = st[1 * N + i], r = st[2 * N + i], y = st[3 * N + i], phi = st[4 * N + i],
+          x = st[5 * N + i], dy = st[6 * N + i], dphi = st[7 * N + i];
+    const float2 an = reinterpret_cast<const float2*>(action)[i];
+
+    // step(): scale and clip the action, path_tracking_env.py:457-459
+    const float ACT_HI0 = (float)(1.2 * 3.14159265358979323846 / 9.0), ACT_HI1 = 3.f;
+    float steer = ((an.x * 1.2f) * PI_F) / 9.f;
+    float a_x = an.y * 3.f;
+    steer = fminf(fmaxf(steer, -ACT_HI0), ACT_HI0);
+    a_x = fminf(fmaxf(a_x, -ACT_HI1), ACT_HI1);
+
+    // compute_rewards on the PRE-step veh_state, :181-199
+    {
+        float t = vx - 20.f;
+        float devi_v = -(t * t), devi_y = -(dy * dy), devi_phi = -(dphi * dphi), p_yaw = -(r * r),
+              p_steer = -(steer * steer), p_ax = -(a_x * a_x);
+        reward[i] = 0.01f * devi_v + 0.04f * devi_y + 0.1f * devi_phi + 0.02f * p_yaw + 5.f * p_steer + 0.05f * p_ax;
+    }
+
+    // f_xu pieces that depend on the action only, :95-101,135-136
+    const float F_zf = B_ * MASS * G_ / (A_ + B_), F_zr = A_ * MASS * G_ / (A_ + B_);
+    const float F_xf = a_x < 0.f ? MASS * a_x / 2.f : 0.f;
+    const float F_xr = a_x < 0.f ? MASS * a_x / 2.f : MASS * a_x;
+    const float miu_f = sqrtf((MIU * F_zf) * (MIU * F_zf) - F_xf * F_xf) / F_zf;
+    const float miu_r = sqrtf((MIU * F_zr) * (MIU * F_zr) - F_xr * F_xr) / F_zr;
+
+    const float tau = 0.005f;                  // 1/base_freq as a python float, cast on contact (:141)
+    const float K1 = tau * (A_ * C_f - B_ * C_r);
+    const float K2 = tau * C_f, K3 = tau * MASS, K4 = tau * (C_f + C_r);
+    const float K5 = (tau * A_) * C_f;
+    const float K6 = tau * ((A_ * A_) * C_f + (B_ * B_) * C_r);
+
+    float vx_pre = vx, vy_pre = vy, r_pre = r;  // state entering the LAST sub-step (for `others`)
+    for (int s = 0; s < 20; ++s) {              // simulation(), :144-179
+        vx_pre = vx; vy_pre = vy; r_pre = r;
+        // prediction -> f_xu with tau = 1/200 on (v_x, v_y, r); entries 3-5 are overwritten below
+        float nvx = vx + tau * (a_x + vy * r);
+        float nvy = (((MASS * vy) * vx + K1 * r) - (K2 * steer) * vx - (K3 * (vx * vx)) * r) / (MASS * vx - K4);
+        float nr = ((((-I_z) * r) * vx - K1 * vy) + (K5 * steer) * vx) / (K6 - I_z * vx);
+        nvx = fminf(fmaxf(nvx, 1.f), 35.f);     // :153
+        // world frame, :156-160: phi first, then y and x with the OLD v_x, v_y but the NEW phi (view aliasing)
+        phi = phi + r / 200.f;
+        float sp, cp;
+        sincosf(phi, &sp, &cp);
+        y = y + (vx * sp + vy * cp) / 200.f;
+        x = x + (vx * cp - vy * sp) / 200.f;
+        vx = nvx; vy = nvy; r = nr;             // :161
+        PathRef p = path_ref(x);                // :163-164 (x not yet wrapped)
+        dphi = phi - p.phi;                     // :165
+        dy = y - p.y;                           // :166
+        phi = wrap_pi(phi);                     // :168-169
+        if (x > PERIOD) x = x - PERIOD;         // :171
+        if (x <= 0.f) x = x + PERIOD;           // :172
+        dphi = wrap_pi(dphi);                   // :176-177
+    }
+
+    // `others` of the last sub-step (:100-101,135-138), judge_done :474-487
+    const float alpha_f = atanf((vy_pre + A_ * r_pre) / vx_pre) - steer;
+    const float alpha_r = atanf((vy_pre - B_ * r_pre) / vx_pre);
+    const float afb = 3.f * miu_f * F_zf / C_f, arb = 3.f * miu_r * F_zr / C_r;
+    const float rb = miu_r * G_ / fabsf(vx_pre);
+    const bool geo = (fabsf(dy) > 3.f) | (fabsf(dphi) > PI_F / 4.f) | (vx < 2.f);
+    const bool lit = geo | (alpha_f < -afb) | (alpha_f > afb) | (alpha_r < -arb) | (alpha_r > arb) | (r < -rb) |
+                     (r > rb);
+    done[i] = lit ? 1 : 0;
+    if (done_intended)
+        done_intended[i] = (geo | (fabsf(alpha_f) > fabsf(afb)) | (fabsf(alpha_r) > fabsf(arb)) | (fabsf(r) > rb)) ? 1 : 0;
+
+    st[0 * N + i] = vx; st[1 * N + i] = vy; st[2 * N + i] = r; st[3 * N + i] = y; st[4 * N + i] = phi;
+    st[5 * N + i] = x; st[6 * N + i] = dy; st[7 * N + i] = dphi;
+    float2* o = reinterpret_cast<float2*>(obs + (size_t)i * 6);   // _get_obs :399-402
+    o[0] = make_float2(vx - 20.f, vy);
+    o[1] = make_float2(r, dy);
+    o[2] = make_float2(dphi, x);
+}
+
+}  // namespace
+
+extern "C" int mpg_env_reset_from_obs(int env_kind, int n, float* state, const float* init_obs, mpg_stream_t stream) {
+    MPG_REQUIRE(env_kind == MPG_ENV_PATH_TRACKING, "mpg_env_reset_from_obs: only PathTracking has a real env (kind %d)", env_kind);
+    MPG_REQUIRE(n > 0 && state && init_obs, "mpg_env_reset_from_obs: bad argument");
+    hipLaunchKernelGGL(k_reset_from_obs, dim3((n + 63) / 64), dim3(64), 0, mpg_stream(stream), n, state, init_obs);
+    MPG_CHECK_LAUNCH("mpg_env_reset_from_obs");
+    return MPG_OK;
+}
+
+extern "C" int mpg_env_reset(int env_kind, int n, float* state, const uint8_t* done_mask, uint64_t seed, uint64_t ctr,
+                             float* obs, mpg_stream_t stream) {
+    MPG_REQUIRE(env_kind == MPG_ENV_PATH_TRACKING, "mpg_env_reset: only PathTracking has a real env (kind %d)", env_kind);
+    MPG_REQUIRE(n > 0 && state && obs, "mpg_env_reset: bad argument");
+    hipLaunchKernelGGL(k_reset, dim3((n + 63) / 64), dim3(64), 0, mpg_stream(stream), n, state, done_mask,
+                       (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)ctr, (uint32_t)(ctr >> 32), obs);
+    MPG_CHECK_LAUNCH("mpg_env_reset");
+    return MPG_OK;
+}
+
+extern "C" int mpg_env_step(int env_kind, int n, float* state, const float* action, float* obs, float* reward,
+                            uint8_t* done, uint8_t* done_intended, mpg_stream_t stream) {
+    MPG_REQUIRE(env_kind == MPG_ENV_PATH_TRACKING, "mpg_env_step: only PathTracking has a real env (kind %d)", env_kind);
+    MPG_REQUIRE(n > 0 && state && action && obs && reward && done, "mpg_env_step: bad argument");
+    hipLaunchKernelGGL(k_step, dim3((n + 63) / 64), dim3(64), 0, mpg_stream(stream), n, state, action, obs, reward,
+                       done, done_intended);
+    MPG_CHECK_LAUNCH("mpg_env_step");
+    return MPG_OK;
+}

@@ -1,0 +1,57 @@
+// Shared host/device helpers of libmpg_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/mpg_hip.h"
+
+#define MPG_ABI_VERSION 1
+
+void mpg_set_error(const char* fmt, ...);
+
+#define MPG_REQUIRE(cond, ...)                 \
+    do {                                       \
+        if (!(cond)) {                         \
+            mpg_set_error(__VA_ARGS__);        \
+            return MPG_EINVAL;                 \
+        }                                      \
+    } while (0)
+
+// Kernel launches never synchronise; a launch-configuration error is the only thing visible here.
+#define MPG_CHECK_LAUNCH(name)                                              \
+    do {                                                                    \
+        hipError_t e_ = hipGetLastError();                                  \
+        if (e_ != hipSuccess) {                                             \
+            mpg_set_error("%s: %s", name, hipGetErrorString(e_));           \
+            return -(int)e_;                                                \
+        }                                                                   \
+    } while (0)
+
+static inline hipStream_t mpg_stream(mpg_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+// ---- Philox4x32-10 (Salmon et al. 2011), counter-based: (key, counter) -> 4 x u32 -------------------
+struct Philox4 {
+    uint32_t v[4];
+};
+
+__host__ __device__ static inline Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                        uint32_t k0, uint32_t k1) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)M0 * c0, p1 = (uint64_t)M1 * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += W0; k1 += W1;
+    }
+    Philox4 o;
+    o.v[0] = c0; o.v[1] = c1; o.v[2] = c2; o.v[3] = c3;
+    return o;
+}
+
+// u32 -> float in the open interval (0,1): 24 random mantissa bits, centred.
+__host__ __device__ static inline float u01(uint32_t u) { return ((float)(u >> 8) + 0.5f) * 5.9604644775390625e-08f; }

@@ -1,0 +1,54 @@
+"""CPU-side checks of the drop-in boundary: the library builds for gfx950, loads, and exports every
+symbol include/mpg_hip.h declares.  No compute call is made (no GPU here)."""
+import ctypes
+import os
+import subprocess
+
+import pytest
+
+import mpg_amd._lib as L
+from mpg_amd import build as B
+
+
+@pytest.fixture(scope='module')
+def built():
+    return B.build(verbose=False)
+
+
+def test_library_builds_and_exports_every_declared_symbol(built):
+    assert os.path.exists(built)
+    names = L.declared_symbols()
+    assert 'mpg_env_step' in names and len(names) >= 5
+    lib = ctypes.CDLL(built)
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+    assert lib.mpg_abi_version() >= 1
+
+
+def test_no_undeclared_exports(built):
+    out = subprocess.check_output(['nm', '-D', '--defined-only', built]).decode()
+    exported = sorted(l.split()[-1] for l in out.splitlines() if ' T mpg_' in l)
+    assert exported == L.declared_symbols()
+
+
+def test_code_object_is_gfx950_only(built):
+    import re
+    blob = open(built, 'rb').read()
+    targets = set(re.findall(rb'amdgcn-amd-amdhsa--(gfx[0-9a-z]+)', blob))
+    assert targets == {b'gfx950'}, targets
+
+
+def test_product_path_fails_loudly_without_library(monkeypatch, tmp_path):
+    monkeypatch.setattr(L, '_lib', None)
+    monkeypatch.setattr(L, 'LIB_PATH', str(tmp_path / 'nope.so'))
+    with pytest.raises(L.MpgError):
+        L.lib()
+
+
+def test_product_package_never_imports_the_oracle():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for dp, _, fs in os.walk(os.path.join(root, 'mpg_amd')):
+        for f in fs:
+            if f.endswith('.py'):
+                src = open(os.path.join(dp, f)).read()
+                assert 'import oracle' not in src and 'from oracle' not in src, f

@@ -1,0 +1,103 @@
+"""HIP PathTrackingEnv (mpg_env_*) against the reference's recording, the reference-run fixture and the
+oracle.  Tolerances: the kernel mirrors the reference op-by-op (no FMA contraction); what remains is the
+last-ulp behaviour of sin/cos/atan over 20 sub-steps -> 5e-6 abs on the small entries (the survey's
+figure for mpc_rl.npy) and 4 ulp on x (|x| <= 1200, ulp 1.2e-4)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import mpg_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _close_obs(got, ref, atol=5e-6):
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    err = np.abs(got - ref)
+    tol = np.full(ref.shape, atol)
+    tol[..., 5] = 4 * np.spacing(np.abs(ref[..., 5]).astype(np.float32)).astype(np.float64) + atol
+    assert (err <= tol).all(), (err.max(0), np.argwhere(err > tol)[:5])
+
+
+def test_env_step_vs_reference_recording(golden):
+    from mpg_amd.envs import PathTrackingEnv
+    g = golden('env_step_mpc_rl.npz')
+    for who in ('mpc', 'rl'):
+        obs, act, rew = g[who + '_obs'].copy(), g[who + '_action'], g[who + '_rew']
+        obs[:, 0] -= 20.0
+        env = PathTrackingEnv(num_agent=99)
+        env.reset(init_obs=torch.as_tensor(obs[:-1]))
+        o2, r, done, _ = env.step(torch.as_tensor(act[:-1].astype(np.float32)))
+        _close_obs(o2.cpu().numpy(), obs[1:])
+        np.testing.assert_allclose(r.cpu().numpy(), rew[1:], rtol=2e-6, atol=1e-6)
+        assert bool(done.all())                     # literal reference behaviour (SURVEY B-0)
+
+
+def test_env_multi_step_vs_reference_run(golden):
+    from mpg_amd.envs import PathTrackingEnv
+    g = golden('env_step_ref.npz')
+    env = PathTrackingEnv(num_agent=g['obs0'].shape[0])
+    env.reset(init_obs=torch.as_tensor(g['obs0']))
+    for t in range(g['actions'].shape[0]):
+        o, r, d, _ = env.step(torch.as_tensor(g['actions'][t]))
+        # errors of earlier steps propagate: tolerance grows with t
+        _close_obs(o.cpu().numpy(), g['obs'][t], atol=5e-6 * (t + 1))
+        np.testing.assert_allclose(r.cpu().numpy(), g['reward'][t], rtol=1e-5, atol=2e-6)
+        np.testing.assert_array_equal(d.cpu().numpy(), g['done'][t])
+        full = env.veh_full_state.cpu().numpy()
+        np.testing.assert_allclose(full[:, :5], g['full_state'][t][:, :5], rtol=0, atol=2e-5 * (t + 1))
+
+
+@pytest.mark.parametrize('n', [1, 63, 64, 65, 4096, 100003])
+def test_env_step_vs_oracle_ragged_sizes(n):
+    from mpg_amd.envs import PathTrackingEnv
+    rng = np.random.Generator(np.random.PCG64(n))
+    ora = O.PathTrackingEnvOracle(n)
+    obs0 = ora.reset(rng=rng).copy()
+    act = rng.uniform(-1.2, 1.2, (n, 2)).astype(np.float32)
+    ora.reset(init_obs=obs0.copy())
+    o_ref, r_ref, d_ref, _ = ora.step(act)
+    env = PathTrackingEnv(num_agent=n)
+    env.reset(init_obs=torch.as_tensor(obs0))
+    o, r, d, _ = env.step(torch.as_tensor(act))
+    _close_obs(o.cpu().numpy(), o_ref)
+    np.testing.assert_allclose(r.cpu().numpy(), r_ref, rtol=1e-5, atol=2e-6)
+    np.testing.assert_array_equal(d.cpu().numpy().astype(bool), d_ref)
+
+
+def test_env_reset_law_philox_matches_oracle_and_distribution():
+    from mpg_amd.envs import PathTrackingEnv
+    n = 1 << 16
+    env = PathTrackingEnv(num_agent=n, seed=1234)
+    obs = env.reset().cpu().numpy()
+    full_ref, obs_ref = O.reset_law_philox(n, 1234, 0)
+    np.testing.assert_allclose(env.veh_full_state.cpu().numpy(), full_ref, rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(obs, obs_ref, rtol=2e-5, atol=2e-5)
+    # moments of the reset law (path_tracking_env.py:426-437)
+    assert abs(obs[:, 5].mean() - 300) < 3 and obs[:, 5].min() > 0 and obs[:, 5].max() < 600
+    assert abs(obs[:, 3].std() - 1.0) < 0.02 and abs(obs[:, 4].std() - np.pi / 9) < 0.01
+    assert abs((obs[:, 0] + 20).mean() - 20) < 0.05 and abs(obs[:, 2].std() - 0.3) < 0.01
+    # second call: done is all ones (reference quirk) -> every agent re-drawn with a fresh counter
+    env.step(torch.zeros(n, 2))
+    obs2 = env.reset().cpu().numpy()
+    assert np.abs(obs2 - obs).max() > 1.0
+    _, obs_ref2 = O.reset_law_philox(n, 1234, 1)
+    np.testing.assert_allclose(obs2, obs_ref2, rtol=2e-5, atol=2e-5)
+
+
+def test_env_25_step_rollout_stays_finite_and_matches_oracle_loosely():
+    """Size-independent property at the bench size: 25 consecutive steps (the MPG-v1 n-step sampler) stay
+    finite, x stays in (0, 1200], phi in (-pi, pi]."""
+    from mpg_amd.envs import PathTrackingEnv
+    n = 4096
+    env = PathTrackingEnv(num_agent=n, seed=7)
+    env.reset()
+    g = torch.Generator(device='cpu').manual_seed(0)
+    for _ in range(25):
+        a = (torch.rand(n, 2, generator=g) * 2 - 1) * 0.3
+        o, r, d, _ = env.step(a)
+    full = env.veh_full_state.cpu().numpy()
+    assert np.isfinite(full).all() and np.isfinite(o.cpu().numpy()).all()
+    assert (full[:, 5] > 0).all() and (full[:, 5] <= 1200).all()
+    assert (full[:, 4] > -np.pi - 1e-6).all() and (full[:, 4] <= np.pi + 1e-6).all()
+    assert (full[:, 0] >= 1).all() and (full[:, 0] <= 35).all()
