@@ -74,6 +74,60 @@ int mpg_env_reset(int env_kind, int n, float* state, const uint8_t* done_mask, u
 int mpg_env_step(int env_kind, int n, float* state, const float* action, float* obs, float* reward,
                  uint8_t* done, uint8_t* done_intended, mpg_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Networks (K3), critic targets, losses and gradients (K5, K6)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Hyper-parameters of one config (host memory, read at call time). */
+typedef struct {
+    int obs_dim, act_dim;       /* 6,2 path tracking; 4,1 pendulum */
+    int policy_out_act;         /* MPG_ACT_TANH (train_script.py:267) or MPG_ACT_LINEAR (train_script4mujoco.py:371) */
+    float action_range;         /* <= 0: none; pendulum 3.0 -> a = range*tanh(mean) (policy.py:197-199) */
+    float obs_scale[8];         /* 'scale' preprocessor, preprocessor.py:142-143 */
+    float rew_scale, rew_shift; /* preprocessor.py:155-157 */
+    float gamma;                /* 0.98 */
+    int env_kind;               /* differentiable model used by the rollout: MPG_ENV_* */
+} mpg_cfg_t;
+
+/* MLPNet.call  - model.py:39-43:  y[rows][out_used] = act(ELU(ELU(x W1 + b1) W2 + b2) W3 + b3)[:, :out_used].
+ * x [rows][in_dim] (supported (in_dim, out_used): (6,2) (8,1) (4,1) (5,1) (6,1)); the first n_scaled input
+ * columns are multiplied by in_scale[] (host array, may be NULL). */
+int mpg_mlp_forward(const float* params, int in_dim, int out_dim, int out_used, int out_act, int rows,
+                    const float* x, const float* in_scale, int n_scaled, float* y, mpg_stream_t stream);
+
+/* PolicyWithQs.compute_action / compute_target_action, deterministic branch  - policy.py:193-217:
+ * act[rows][act_dim] = mean half of the policy output on obs*obs_scale (x action_range*tanh if set).
+ * explore_sigma > 0 adds N(0, sigma) per element from Philox(seed, ctr) - OffPolicyWorker.sample,
+ * worker.py:96-98. */
+int mpg_policy_action(const mpg_cfg_t* cfg, const float* policy_params, int rows, const float* obs,
+                      float explore_sigma, uint64_t seed, uint64_t ctr, float* act, mpg_stream_t stream);
+
+/* MPGLearner.compute_clipped_double_q_target  - learners/mpg_learner.py:126-134 (q2t != NULL), the 1-step
+ * target of :148-152 (q2t == NULL), and TD3Learner.compute_clipped_double_q_target learners/td3.py:69-81 when
+ * smooth_eps [rows][act_dim] (standard normal) is given: a' += clip(sigma*eps, -c, c) (no re-clipping).
+ *   y = (rew+shift)*scale + gamma * min_i Qt_i(s~', a'),  a' = pi_t(s~').  No done mask. */
+size_t mpg_q_targets_workspace_bytes(const mpg_cfg_t* cfg, int rows);
+int mpg_q_targets(const mpg_cfg_t* cfg, const float* policy_t, const float* q1t, const float* q2t, int rows,
+                  const float* rew, const float* obs_tp1, const float* smooth_eps, float smooth_sigma,
+                  float smooth_clip, float* y, void* ws, size_t ws_bytes, mpg_stream_t stream);
+
+/* n-step return of MPG-v1 (mpg_learner.py:155-169) once the real-env rollout exists (mpg_env_step x n):
+ *   y = sum_t gamma^t r~_t + gamma^n Q1t(s~_n, pi_t(s~_n)).  rewards [n][rows] RAW, last_obs [rows][obs_dim].
+ * Workspace: mpg_q_targets_workspace_bytes. */
+int mpg_nstep_targets(const mpg_cfg_t* cfg, const float* policy_t, const float* q1t, int rows, int n,
+                      const float* rewards, const float* last_obs, float* y, void* ws, size_t ws_bytes,
+                      mpg_stream_t stream);
+
+/* MPGLearner.q_forward_and_backward  - mpg_learner.py:326-354 (also td3.py:103-118, nadp.py:173-184), ONE critic:
+ *   L = 0.5 * mean_B (Q(s~,a) - y)^2 and dL/dtheta_Q.
+ * inv_b_global = 1/B_global (the mean's divisor; 1/rows on one GPU).  Outputs: loss_sum[0] = this GPU's share
+ * of L, grad = flat gradient (68353 floats path tracking) reduced over this GPU's rows and NOT clipped,
+ * td (nullable) [rows] = Q(s~,a) - y. */
+size_t mpg_q_loss_grad_workspace_bytes(const mpg_cfg_t* cfg, int rows);
+int mpg_q_loss_grad(const mpg_cfg_t* cfg, const float* q_params, int rows, const float* obs, const float* act,
+                    const float* y, float inv_b_global, float* loss_sum, float* grad, float* td, void* ws,
+                    size_t ws_bytes, mpg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,209 @@
+// C-ABI entry points built from the generic network kernels: policy actions, critic targets, critic loss +
+// gradient.  (The fused n-step rollout lives in rollout_kernels.hip, the optimizer in optim_kernels.hip.)
+#include "mlp_launch.h"
+
+using namespace mlp;
+
+namespace {
+
+inline char* align256(char* p) { return reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(p) + 255) & ~uintptr_t(255)); }
+
+struct Carver {   // carves 256-byte aligned float arrays out of the caller's workspace
+    char *p, *end;
+    Carver(void* ws, size_t bytes) : p(align256((char*)ws)), end((char*)ws + bytes) {}
+    float* take(size_t nfloat) {
+        float* r = reinterpret_cast<float*>(p);
+        p = align256(p + nfloat * sizeof(float));
+        return r;
+    }
+    bool ok() const { return p <= end; }
+};
+inline size_t pad256(size_t nfloat) { return ((nfloat * sizeof(float) + 255) & ~size_t(255)) + 256; }
+
+// y = (rew + shift) * scale + gamma * min(q1, q2)      (q2 == nullptr: q1 only)
+__global__ void k_combine_target(int n, const float* __restrict__ rew, const float* __restrict__ q1,
+                                 const float* __restrict__ q2, float shift, float scale, float gamma,
+                                 float* __restrict__ y) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float q = q2 ? fminf(q1[i], q2[i]) : q1[i];
+    y[i] = (rew[i] + shift) * scale + gamma * q;
+}
+
+// a += clip(sigma * eps, -c, c)      (td3.py:74-76)
+__global__ void k_smooth(int n, float* __restrict__ a, const float* __restrict__ eps, float sigma, float c) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    a[i] += fminf(fmaxf(sigma * eps[i], -c), c);
+}
+
+// y = sum_t gamma^t (r_t + shift) * scale + gamma^n q          (mpg_learner.py:165-168)
+__global__ void k_nstep(int rows, int n, const float* __restrict__ rewards, const float* __restrict__ q, float shift,
+                        float scale, float gamma, float* __restrict__ y) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows) return;
+    float acc = 0.f;
+    for (int t = 0; t < n; ++t) acc += powf(gamma, (float)t) * ((rewards[(size_t)t * rows + i] + shift) * scale);
+    y[i] = acc + powf(gamma, (float)n) * q[i];
+}
+
+// err = q - y; dz3 = err * inv_b; td (nullable) = err; loss_sum += 0.5 * inv_b * sum err^2 (one block, fixed order)
+__global__ void __launch_bounds__(1024) k_q_err(int rows, const float* __restrict__ q, const float* __restrict__ y,
+                                                float inv_b, float* __restrict__ dz3, float* __restrict__ td,
+                                                float* __restrict__ loss_sum) {
+    __shared__ float red[1024];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < rows; i += 1024) {
+        const float e = q[i] - y[i];
+        dz3[i] = e * inv_b;
+        if (td) td[i] = e;
+        s += e * e;
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss_sum[0] = 0.5f * inv_b * red[0];
+}
+
+inline OutSpec policy_out(const mpg_cfg_t* c) {
+    OutSpec o;
+    const bool ranged = c->action_range > 0.f;
+    o.out_tanh = (c->policy_out_act == MPG_ACT_TANH || ranged) ? 1 : 0;
+    o.out_scale = ranged ? c->action_range : 1.f;
+    o.sigma = 0.f; o.seed = 0; o.ctr = 0;
+    return o;
+}
+inline OutSpec linear_out() {
+    OutSpec o;
+    o.out_tanh = 0; o.out_scale = 1.f; o.sigma = 0.f; o.seed = 0; o.ctr = 0;
+    return o;
+}
+
+inline bool cfg_ok(const mpg_cfg_t* c) {
+    return c && ((c->obs_dim == 6 && c->act_dim == 2) || (c->obs_dim == 4 && c->act_dim == 1));
+}
+
+}  // namespace
+
+extern "C" int mpg_mlp_forward(const float* params, int in_dim, int out_dim, int out_used, int out_act, int rows,
+                               const float* x, const float* in_scale, int n_scaled, float* y, mpg_stream_t stream) {
+    MPG_REQUIRE(params && x && y && rows > 0, "mpg_mlp_forward: null pointer / rows");
+    OutSpec o = linear_out();
+    o.out_tanh = out_act == MPG_ACT_TANH;
+    return launch_forward(params, in_dim, out_dim, out_used, rows, xspec(x, in_dim, nullptr, 0, in_scale, n_scaled), o, y,
+                          out_used, nullptr, nullptr, mpg_stream(stream));
+}
+
+extern "C" int mpg_policy_action(const mpg_cfg_t* cfg, const float* policy_params, int rows, const float* obs,
+                                 float explore_sigma, uint64_t seed, uint64_t ctr, float* act, mpg_stream_t stream) {
+    MPG_REQUIRE(cfg_ok(cfg) && policy_params && obs && act && rows > 0, "mpg_policy_action: bad argument");
+    OutSpec o = policy_out(cfg);
+    o.sigma = explore_sigma; o.seed = seed; o.ctr = ctr;
+    return launch_forward(policy_params, cfg->obs_dim, 2 * cfg->act_dim, cfg->act_dim, rows,
+                          xspec(obs, cfg->obs_dim, nullptr, 0, cfg->obs_scale, cfg->obs_dim), o, act, cfg->act_dim,
+                          nullptr, nullptr, mpg_stream(stream));
+}
+
+extern "C" size_t mpg_q_targets_workspace_bytes(const mpg_cfg_t* cfg, int rows) {
+    if (!cfg_ok(cfg) || rows <= 0) return 0;
+    return pad256((size_t)rows * cfg->act_dim) + 2 * pad256(rows);
+}
+
+extern "C" int mpg_q_targets(const mpg_cfg_t* cfg, const float* policy_t, const float* q1t, const float* q2t, int rows,
+                             const float* rew, const float* obs_tp1, const float* smooth_eps, float smooth_sigma,
+                             float smooth_clip, float* y, void* ws, size_t ws_bytes, mpg_stream_t stream) {
+    MPG_REQUIRE(cfg_ok(cfg) && policy_t && q1t && rew && obs_tp1 && y && ws && rows > 0, "mpg_q_targets: bad argument");
+    if (ws_bytes < mpg_q_targets_workspace_bytes(cfg, rows)) {
+        mpg_set_error("mpg_q_targets: workspace too small");
+        return MPG_EWORKSPACE;
+    }
+    hipStream_t s = mpg_stream(stream);
+    Carver cv(ws, ws_bytes);
+    float* a = cv.take((size_t)rows * cfg->act_dim);
+    float* q1 = cv.take(rows);
+    float* q2 = cv.take(rows);
+    const int od = cfg->obs_dim, ad = cfg->act_dim;
+    int rc = launch_forward(policy_t, od, 2 * ad, ad, rows, xspec(obs_tp1, od, nullptr, 0, cfg->obs_scale, od),
+                            policy_out(cfg), a, ad, nullptr, nullptr, s);
+    if (rc) return rc;
+    if (smooth_eps) {
+        const int n = rows * ad;
+        hipLaunchKernelGGL(k_smooth, dim3((n + 255) / 256), dim3(256), 0, s, n, a, smooth_eps, smooth_sigma, smooth_clip);
+        MPG_CHECK_LAUNCH("k_smooth");
+    }
+    const XSpec xq = xspec(obs_tp1, od, a, ad, cfg->obs_scale, od);
+    rc = launch_forward(q1t, od + ad, 1, 1, rows, xq, linear_out(), q1, 1, nullptr, nullptr, s);
+    if (rc) return rc;
+    if (q2t) {
+        rc = launch_forward(q2t, od + ad, 1, 1, rows, xq, linear_out(), q2, 1, nullptr, nullptr, s);
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(k_combine_target, dim3((rows + 255) / 256), dim3(256), 0, s, rows, rew, q1, q2t ? q2 : nullptr,
+                       cfg->rew_shift, cfg->rew_scale, cfg->gamma, y);
+    MPG_CHECK_LAUNCH("k_combine_target");
+    return MPG_OK;
+}
+
+extern "C" int mpg_nstep_targets(const mpg_cfg_t* cfg, const float* policy_t, const float* q1t, int rows, int n,
+                                 const float* rewards, const float* last_obs, float* y, void* ws, size_t ws_bytes,
+                                 mpg_stream_t stream) {
+    MPG_REQUIRE(cfg_ok(cfg) && policy_t && q1t && rewards && last_obs && y && ws && rows > 0 && n > 0,
+                "mpg_nstep_targets: bad argument");
+    if (ws_bytes < mpg_q_targets_workspace_bytes(cfg, rows)) {
+        mpg_set_error("mpg_nstep_targets: workspace too small");
+        return MPG_EWORKSPACE;
+    }
+    hipStream_t s = mpg_stream(stream);
+    Carver cv(ws, ws_bytes);
+    float* a = cv.take((size_t)rows * cfg->act_dim);
+    float* q1 = cv.take(rows);
+    const int od = cfg->obs_dim, ad = cfg->act_dim;
+    int rc = launch_forward(policy_t, od, 2 * ad, ad, rows, xspec(last_obs, od, nullptr, 0, cfg->obs_scale, od),
+                            policy_out(cfg), a, ad, nullptr, nullptr, s);
+    if (rc) return rc;
+    rc = launch_forward(q1t, od + ad, 1, 1, rows, xspec(last_obs, od, a, ad, cfg->obs_scale, od), linear_out(), q1, 1,
+                        nullptr, nullptr, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_nstep, dim3((rows + 255) / 256), dim3(256), 0, s, rows, n, rewards, q1, cfg->rew_shift,
+                       cfg->rew_scale, cfg->gamma, y);
+    MPG_CHECK_LAUNCH("k_nstep");
+    return MPG_OK;
+}
+
+extern "C" size_t mpg_q_loss_grad_workspace_bytes(const mpg_cfg_t* cfg, int rows) {
+    if (!cfg_ok(cfg) || rows <= 0) return 0;
+    const int in = cfg->obs_dim + cfg->act_dim;
+    return 4 * pad256(stash_floats(rows)) + 2 * pad256(rows) + pad256(wgrad_workspace_floats(rows, in, 1));
+}
+
+extern "C" int mpg_q_loss_grad(const mpg_cfg_t* cfg, const float* q_params, int rows, const float* obs, const float* act,
+                               const float* y, float inv_b_global, float* loss_sum, float* grad, float* td, void* ws,
+                               size_t ws_bytes, mpg_stream_t stream) {
+    MPG_REQUIRE(cfg_ok(cfg) && q_params && obs && act && y && loss_sum && grad && ws && rows > 0,
+                "mpg_q_loss_grad: bad argument");
+    if (ws_bytes < mpg_q_loss_grad_workspace_bytes(cfg, rows)) {
+        mpg_set_error("mpg_q_loss_grad: workspace too small (%zu < %zu)", ws_bytes, mpg_q_loss_grad_workspace_bytes(cfg, rows));
+        return MPG_EWORKSPACE;
+    }
+    hipStream_t s = mpg_stream(stream);
+    const int od = cfg->obs_dim, ad = cfg->act_dim, in = od + ad;
+    Carver cv(ws, ws_bytes);
+    float* h1 = cv.take(stash_floats(rows));
+    float* h2 = cv.take(stash_floats(rows));
+    float* dz1 = cv.take(stash_floats(rows));
+    float* dz2 = cv.take(stash_floats(rows));
+    float* q = cv.take(rows);
+    float* dz3 = cv.take(rows);
+    float* slabs = cv.take(wgrad_workspace_floats(rows, in, 1));
+    const XSpec xq = xspec(obs, od, act, ad, cfg->obs_scale, od);
+    int rc = launch_forward(q_params, in, 1, 1, rows, xq, linear_out(), q, 1, h1, h2, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_q_err, dim3(1), dim3(1024), 0, s, rows, q, y, inv_b_global, dz3, td, loss_sum);
+    MPG_CHECK_LAUNCH("k_q_err");
+    rc = launch_backward(q_params, in, 1, 1, rows, dz3, 1, nullptr, 0, 0, 1.f, h1, h2, dz1, dz2, nullptr, nullptr, 0, s);
+    if (rc) return rc;
+    return launch_wgrad(in, 1, 1, rows, xq, h1, h2, dz1, dz2, dz3, grad, slabs, s);
+}

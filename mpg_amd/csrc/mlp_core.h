@@ -1,0 +1,263 @@
+// Weight-stationary 2x256 ELU MLP engine for gfx950 (device code shared by every network kernel).
+//
+// Geometry (fixed): one workgroup = 512 threads = 8 waves = 2 waves per SIMD.  A workgroup works on one
+// ROW GROUP of 16 rows at a time.  Wave w owns hidden columns [32w, 32w+32) = 2 column tiles of 16.
+// The 256x256 hidden kernel W2 lives in REGISTERS for the whole kernel: each wave keeps its 256x32 slice as
+// 128 MFMA B-operands (v_mfma_f32_16x16x4_f32: exact fp32, k-ordered fma chain), so the hot loop touches
+// neither HBM nor L2 for weights; activations reach the MFMA A-operand through a 16.6 KB LDS image.
+//
+// Ownership of a 16x256 activation block ("C layout", also the MFMA C/D layout): lane l of wave w holds, for
+// tile t in {0,1} and j in 0..3, element (row = 4*(l>>4) + j, col = 32*w + 16*t + (l&15)).
+//
+// "G16" global layout for stashed activations: float4 index ((group*16 + col/16)*64 + lane), the 4 floats
+// being j = 0..3.  Every lane re-reads exactly the float4 it wrote: 1 KiB coalesced per wave instruction,
+// and the same float4 is directly the A / B fragment of the weight-gradient MFMA (k = batch row).
+#pragma once
+#include "mpg_common.h"
+
+namespace mlp {
+
+constexpr int H = 256;
+constexpr int NTHREAD = 512;
+constexpr int NWAVE = 8;
+constexpr int GROUP = 16;      // rows per row group
+constexpr int LDA = 260;       // row stride (floats) of the LDS A image: 260 = 4 (mod 64) -> conflict-free b128 reads
+constexpr int XS = 8;          // row stride of the small LDS input block
+constexpr int MAXOUT = 2;      // outputs ever *used* (policy mean: act_dim <= 2; critic: 1)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct Net {
+    const float *W1, *b1, *W2, *b2, *W3, *b3;
+    int in_dim, out_dim;
+};
+
+__host__ __device__ inline int net_size(int in_dim, int out_dim) {
+    return in_dim * H + H + H * H + H + H * out_dim + out_dim;
+}
+
+__host__ __device__ inline Net make_net(const float* p, int in_dim, int out_dim) {
+    Net n;
+    n.in_dim = in_dim;
+    n.out_dim = out_dim;
+    n.W1 = p;
+    n.b1 = n.W1 + in_dim * H;
+    n.W2 = n.b1 + H;
+    n.b2 = n.W2 + H * H;
+    n.W3 = n.b2 + H;
+    n.b3 = n.W3 + H * out_dim;
+    return n;
+}
+
+struct Lane {
+    int lane, wave, c, rg;     // c = lane & 15 (column in tile), rg = lane >> 4 (row quad)
+    __device__ Lane() {
+        lane = threadIdx.x & 63;
+        wave = threadIdx.x >> 6;
+        c = lane & 15;
+        rg = lane >> 4;
+    }
+    __device__ int col(int t) const { return 32 * wave + 16 * t + c; }
+    __device__ int row(int j) const { return 4 * rg + j; }
+};
+
+__device__ __forceinline__ float elu(float z) { return z > 0.f ? z : __expf(z) - 1.f; }
+// ELU'(z) expressed through the stored output h = ELU(z): 1 for z > 0, exp(z) = h + 1 otherwise.
+__device__ __forceinline__ float elu_grad_from_out(float h) { return h > 0.f ? 1.f : h + 1.f; }
+
+// ---- cross-lane sum over the 16 lanes of a DPP row (lanes sharing l>>4) -------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row_allreduce16(float v) {
+    v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);   // row_half_mirror
+    v += dpp_mov<0x140>(v);   // row_mirror
+    return v;
+}
+
+// ---- LDS A image --------------------------------------------------------------------------------------
+// element (row, k) lives at row*LDA + (k&3)*64 + (k>>2): the MFMA A fragment of lane (row = l&15, kq = l>>4)
+// for k-steps q..q+3 (k = 4q + kq) is then ONE aligned 16-byte read.
+__device__ __forceinline__ int a_index(int row, int k) { return row * LDA + (k & 3) * 64 + (k >> 2); }
+
+__device__ __forceinline__ void store_c_to_a(float* sA, const Lane& L, const float (&v)[2][4]) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sA[a_index(L.row(j), L.col(t))] = v[t][j];
+}
+
+// ---- stationary hidden kernel -------------------------------------------------------------------------
+// forward:  B[k][n] = W2[k][n];  lane holds, for k-step q and tile t, W2[4q + (l>>4)][32w + 16t + (l&15)]
+__device__ __forceinline__ void load_w2_fwd(const float* __restrict__ W2, const Lane& L, float (&w)[128]) {
+#pragma unroll
+    for (int q = 0; q < 64; ++q)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) w[2 * q + t] = W2[(4 * q + L.rg) * H + L.col(t)];
+}
+// backward: dh1[row][k] = sum_n dz2[row][n] W2[k][n]  ->  B[n][k] = W2[k][n]
+__device__ __forceinline__ void load_w2_bwd(const float* __restrict__ W2, const Lane& L, float (&w)[128]) {
+#pragma unroll
+    for (int q = 0; q < 64; ++q)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) w[2 * q + t] = W2[L.col(t) * H + 4 * q + L.rg];
+}
+
+// 16 x 256 (LDS A image) times the wave's stationary 256 x 32 slice; 128 MFMAs, two independent accumulators.
+__device__ __forceinline__ void mfma_16x256x32(const float* sA, const Lane& L, const float (&w)[128], f32x4& acc0,
+                                               f32x4& acc1) {
+    const float* base = sA + L.c * LDA + L.rg * 64;
+#pragma unroll
+    for (int q4 = 0; q4 < 16; ++q4) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(base + 4 * q4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], w[2 * (4 * q4 + i)], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], w[2 * (4 * q4 + i) + 1], acc1, 0, 0, 0);
+        }
+    }
+}
+
+// ---- small per-lane stationary pieces -----------------------------------------------------------------
+template <int IN, int OU>
+struct SmallRegs {
+    float w1[2][IN];   // W1[i][col(t)]
+    float b1[2], b2[2];
+    float w3[2][OU];   // W3[col(t)][o]
+};
+
+template <int IN, int OU>
+__device__ __forceinline__ void load_small(const Net& n, const Lane& L, SmallRegs<IN, OU>& r) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int col = L.col(t);
+#pragma unroll
+        for (int i = 0; i < IN; ++i) r.w1[t][i] = n.W1[i * H + col];
+        r.b1[t] = n.b1[col];
+        r.b2[t] = n.b2[col];
+#pragma unroll
+        for (int o = 0; o < OU; ++o) r.w3[t][o] = n.W3[col * n.out_dim + o];
+    }
+}
+
+// ---- forward through the two hidden layers + partial output layer for one row group ---------------------
+// sX  [16][XS]  inputs (already scaled), sA the LDS A image, sPart [NWAVE][16][MAXOUT] output partials.
+// On return h1/h2 hold this lane's C-layout activations and sPart the per-wave partial sums of h2*W3 (no bias);
+// the caller must have synchronised sX before the call and may read sPart right after (ends on a barrier).
+template <int IN, int OU>
+__device__ __forceinline__ void forward_group(const float* sX, float* sA, float* sPart, const Lane& L,
+                                              const float (&w2)[128], const SmallRegs<IN, OU>& r,
+                                              float (&h1)[2][4], float (&h2)[2][4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float x[IN];
+#pragma unroll
+        for (int i = 0; i < IN; ++i) x[i] = sX[L.row(j) * XS + i];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            float z = r.b1[t];
+#pragma unroll
+            for (int i = 0; i < IN; ++i) z = fmaf(x[i], r.w1[t][i], z);
+            h1[t][j] = elu(z);
+        }
+    }
+    store_c_to_a(sA, L, h1);
+    __syncthreads();
+    f32x4 acc0 = {r.b2[0], r.b2[0], r.b2[0], r.b2[0]};
+    f32x4 acc1 = {r.b2[1], r.b2[1], r.b2[1], r.b2[1]};
+    mfma_16x256x32(sA, L, w2, acc0, acc1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        h2[0][j] = elu(acc0[j]);
+        h2[1][j] = elu(acc1[j]);
+    }
+#pragma unroll
+    for (int o = 0; o < OU; ++o)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float p = fmaf(h2[1][j], r.w3[1][o], h2[0][j] * r.w3[0][o]);
+            p = row_allreduce16(p);
+            if (L.c == 0) sPart[(L.wave * GROUP + L.row(j)) * MAXOUT + o] = p;
+        }
+    __syncthreads();
+}
+
+// sum of the 8 per-wave partials + bias for (row, o)
+__device__ __forceinline__ float out_preact(const float* sPart, const float* __restrict__ b3, int row, int o) {
+    float z = b3[o];
+#pragma unroll
+    for (int w = 0; w < NWAVE; ++w) z += sPart[(w * GROUP + row) * MAXOUT + o];
+    return z;
+}
+
+// ---- G16 stash ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void stash_store(float* __restrict__ base, long group, const Lane& L, const float (&v)[2][4]) {
+    f32x4* p = reinterpret_cast<f32x4*>(base) + (group * 16 + 2 * L.wave) * 64 + L.lane;
+    p[0] = f32x4{v[0][0], v[0][1], v[0][2], v[0][3]};
+    p[64] = f32x4{v[1][0], v[1][1], v[1][2], v[1][3]};
+}
+__device__ __forceinline__ void stash_load(const float* __restrict__ base, long group, const Lane& L, float (&v)[2][4]) {
+    const f32x4* p = reinterpret_cast<const f32x4*>(base) + (group * 16 + 2 * L.wave) * 64 + L.lane;
+    const f32x4 a = p[0], b = p[64];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        v[0][j] = a[j];
+        v[1][j] = b[j];
+    }
+}
+
+// ---- backward through the hidden layers for one row group ---------------------------------------------
+// sD3 [16][MAXOUT] holds dL/dz3 (pre-activation of the used outputs).  h1/h2: this lane's stashed activations.
+// Produces dz2 and dz1 (C layout).  If WANT_DX, leaves per-wave partial sums of dz1*W1^T in sPartX
+// [NWAVE][16][XS] and ends on a barrier; the caller reduces them.
+template <int IN, int OU, bool WANT_DX>
+__device__ __forceinline__ void backward_group(const float* sD3, float* sA, float* sPartX, const Lane& L,
+                                               const float (&w2t)[128], const SmallRegs<IN, OU>& r,
+                                               const float (&h1)[2][4], const float (&h2)[2][4],
+                                               float (&dz1)[2][4], float (&dz2)[2][4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float d3[OU];
+#pragma unroll
+        for (int o = 0; o < OU; ++o) d3[o] = sD3[L.row(j) * MAXOUT + o];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            float dh = 0.f;
+#pragma unroll
+            for (int o = 0; o < OU; ++o) dh = fmaf(d3[o], r.w3[t][o], dh);
+            dz2[t][j] = dh * elu_grad_from_out(h2[t][j]);
+        }
+    }
+    store_c_to_a(sA, L, dz2);
+    __syncthreads();
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    mfma_16x256x32(sA, L, w2t, acc0, acc1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        dz1[0][j] = acc0[j] * elu_grad_from_out(h1[0][j]);
+        dz1[1][j] = acc1[j] * elu_grad_from_out(h1[1][j]);
+    }
+    if (WANT_DX) {
+#pragma unroll
+        for (int i = 0; i < IN; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float p = fmaf(dz1[1][j], r.w1[1][i], dz1[0][j] * r.w1[0][i]);
+                p = row_allreduce16(p);
+                if (L.c == 0) sPartX[(L.wave * GROUP + L.row(j)) * XS + i] = p;
+            }
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ float dx_reduce(const float* sPartX, int row, int i) {
+    float z = 0.f;
+#pragma unroll
+    for (int w = 0; w < NWAVE; ++w) z += sPartX[(w * GROUP + row) * XS + i];
+    return z;
+}
+
+}  // namespace mlp

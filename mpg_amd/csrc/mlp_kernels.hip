@@ -1,0 +1,354 @@
+// K3/K5: generic network kernels on the weight-stationary engine of mlp_core.h:
+//   forward (optionally stashing hidden activations), input-side backward, weight gradient (+ slab reduce).
+#include "mlp_launch.h"
+
+namespace mlp {
+
+// -------------------------------------------------------------------------------------------------------
+// forward
+// -------------------------------------------------------------------------------------------------------
+struct FwdArgs {
+    const float* params;
+    int in_dim, out_dim, rows;
+    XSpec x;
+    int out_tanh;
+    float out_scale, sigma;
+    uint32_t k0, k1, c1, c2;
+    float* y;
+    int ldy;
+    float *h1, *h2;
+};
+
+// loads one row group of the network input into sX [16][XS] (zero padded)
+template <int IN>
+__device__ __forceinline__ void load_x_group(const XSpec& x, int rows, long g, float* sX) {
+    const int tid = threadIdx.x;
+    if (tid < GROUP * XS) {
+        const int row = tid / XS, i = tid % XS;
+        const long gr = g * GROUP + row;
+        float v = 0.f;
+        if (gr < rows && i < IN) {
+            if (i < x.d0)
+                v = x.x0[gr * x.d0 + i] * x.scale[i];
+            else
+                v = x.x1[gr * x.d1 + (i - x.d0)];
+        }
+        sX[tid] = v;
+    }
+}
+
+template <int IN, int OU>
+__global__ void __launch_bounds__(NTHREAD, 2) k_forward(const FwdArgs a) {
+    __shared__ __attribute__((aligned(16))) float smem[GROUP * LDA + GROUP * XS + NWAVE * GROUP * MAXOUT];
+    float* sA = smem;
+    float* sX = sA + GROUP * LDA;
+    float* sPart = sX + GROUP * XS;
+    const Lane L;
+    const Net net = make_net(a.params, a.in_dim, a.out_dim);
+    float w2[128];
+    SmallRegs<IN, OU> r;
+    load_w2_fwd(net.W2, L, w2);
+    load_small<IN, OU>(net, L, r);
+    const long ngroups = (a.rows + GROUP - 1) / GROUP;
+    for (long g = blockIdx.x; g < ngroups; g += gridDim.x) {
+        load_x_group<IN>(a.x, a.rows, g, sX);
+        __syncthreads();
+        float h1[2][4], h2[2][4];
+        forward_group<IN, OU>(sX, sA, sPart, L, w2, r, h1, h2);
+        if (a.h1) stash_store(a.h1, g, L, h1);
+        if (a.h2) stash_store(a.h2, g, L, h2);
+        const int tid = threadIdx.x;
+        if (tid < GROUP * OU) {
+            const int row = tid / OU, o = tid % OU;
+            const long gr = g * GROUP + row;
+            if (gr < a.rows) {
+                float z = out_preact(sPart, net.b3, row, o);
+                float y = a.out_tanh ? a.out_scale * tanhf(z) : z;
+                if (a.sigma > 0.f) {   // OffPolicyWorker.sample: action += N(0, sigma), worker.py:97-98
+                    Philox4 p = philox4x32_10((uint32_t)gr, a.c1, a.c2, 0x5eedu + (uint32_t)o, a.k0, a.k1);
+                    float u1 = u01(p.v[0]), u2 = u01(p.v[1]);
+                    y += a.sigma * sqrtf(-2.f * logf(u1)) * cosf(6.283185307179586f * u2);
+                }
+                a.y[gr * a.ldy + o] = y;
+            }
+        }
+    }
+}
+
+#define MPG_DISPATCH_NET(in_dim, ou, CALL)                                    \
+    if ((in_dim) == 6 && (ou) == 2) { CALL(6, 2); }                           \
+    else if ((in_dim) == 8 && (ou) == 1) { CALL(8, 1); }                      \
+    else if ((in_dim) == 4 && (ou) == 1) { CALL(4, 1); }                      \
+    else if ((in_dim) == 5 && (ou) == 1) { CALL(5, 1); }                      \
+    else if ((in_dim) == 6 && (ou) == 1) { CALL(6, 1); }                      \
+    else {                                                                    \
+        mpg_set_error("unsupported network shape in=%d used-out=%d", (in_dim), (ou)); \
+        return MPG_EINVAL;                                                    \
+    }
+
+static int grid_for(long ngroups) { return (int)(ngroups < 256 ? ngroups : 256); }
+
+int launch_forward(const float* params, int in_dim, int out_dim, int ou, int rows, const XSpec& x, const OutSpec& o,
+                   float* y, int ldy, float* h1, float* h2, hipStream_t s) {
+    MPG_REQUIRE(params && rows > 0 && y && x.d0 + x.d1 == in_dim && ou <= out_dim, "launch_forward: bad argument");
+    FwdArgs a;
+    a.params = params; a.in_dim = in_dim; a.out_dim = out_dim; a.rows = rows; a.x = x;
+    a.out_tanh = o.out_tanh; a.out_scale = o.out_scale; a.sigma = o.sigma;
+    a.k0 = (uint32_t)o.seed; a.k1 = (uint32_t)(o.seed >> 32); a.c1 = (uint32_t)o.ctr; a.c2 = (uint32_t)(o.ctr >> 32);
+    a.y = y; a.ldy = ldy; a.h1 = h1; a.h2 = h2;
+    const long ngroups = (rows + GROUP - 1) / GROUP;
+#define CALL(I, O) hipLaunchKernelGGL((k_forward<I, O>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, a)
+    MPG_DISPATCH_NET(in_dim, ou, CALL)
+#undef CALL
+    MPG_CHECK_LAUNCH("k_forward");
+    return MPG_OK;
+}
+
+// -------------------------------------------------------------------------------------------------------
+// input-side backward
+// -------------------------------------------------------------------------------------------------------
+struct BwdArgs {
+    const float* params;
+    int in_dim, out_dim, rows;
+    const float* dy;
+    int lddy;
+    const float* yout;
+    int ldyo, out_tanh;
+    float out_scale;
+    const float *h1, *h2;
+    float *dz1, *dz2, *dz3, *dx;
+    int lddx;
+};
+
+template <int IN, int OU, bool WANT_DX>
+__global__ void __launch_bounds__(NTHREAD, 2) k_backward(const BwdArgs a) {
+    __shared__ __attribute__((aligned(16))) float smem[GROUP * LDA + GROUP * MAXOUT + NWAVE * GROUP * XS];
+    float* sA = smem;
+    float* sD3 = sA + GROUP * LDA;
+    float* sPartX = sD3 + GROUP * MAXOUT;
+    const Lane L;
+    const Net net = make_net(a.params, a.in_dim, a.out_dim);
+    float w2t[128];
+    SmallRegs<IN, OU> r;
+    load_w2_bwd(net.W2, L, w2t);
+    load_small<IN, OU>(net, L, r);
+    const long ngroups = (a.rows + GROUP - 1) / GROUP;
+    const int tid = threadIdx.x;
+    for (long g = blockIdx.x; g < ngroups; g += gridDim.x) {
+        if (tid < GROUP * OU) {
+            const int row = tid / OU, o = tid % OU;
+            const long gr = g * GROUP + row;
+            float d = 0.f;
+            if (gr < a.rows) {
+                d = a.dy[gr * a.lddy + o];
+                if (a.out_tanh) {   // a = S*tanh(z): da/dz = S*(1 - (a/S)^2)
+                    const float t = a.yout[gr * a.ldyo + o] / a.out_scale;
+                    d *= a.out_scale * (1.f - t * t);
+                }
+                if (a.dz3) a.dz3[gr * OU + o] = d;
+            }
+            sD3[row * MAXOUT + o] = d;
+        }
+        float h1[2][4], h2[2][4], dz1[2][4], dz2[2][4];
+        stash_load(a.h1, g, L, h1);
+        stash_load(a.h2, g, L, h2);
+        __syncthreads();
+        backward_group<IN, OU, WANT_DX>(sD3, sA, sPartX, L, w2t, r, h1, h2, dz1, dz2);
+        if (a.dz1) stash_store(a.dz1, g, L, dz1);
+        if (a.dz2) stash_store(a.dz2, g, L, dz2);
+        if (WANT_DX) {
+            if (tid < GROUP * IN) {
+                const int row = tid / IN, i = tid % IN;
+                const long gr = g * GROUP + row;
+                if (gr < a.rows) a.dx[gr * a.lddx + i] = dx_reduce(sPartX, row, i);
+            }
+            __syncthreads();   // sPartX / sD3 are rewritten by the next group
+        }
+    }
+}
+
+int launch_backward(const float* params, int in_dim, int out_dim, int ou, int rows, const float* dy, int lddy,
+                    const float* yout, int ldyo, int out_tanh, float out_scale, const float* h1, const float* h2,
+                    float* dz1, float* dz2, float* dz3, float* dx, int lddx, hipStream_t s) {
+    MPG_REQUIRE(params && rows > 0 && dy && h1 && h2 && (!out_tanh || yout), "launch_backward: bad argument");
+    BwdArgs a;
+    a.params = params; a.in_dim = in_dim; a.out_dim = out_dim; a.rows = rows; a.dy = dy; a.lddy = lddy;
+    a.yout = yout; a.ldyo = ldyo; a.out_tanh = out_tanh; a.out_scale = out_scale; a.h1 = h1; a.h2 = h2;
+    a.dz1 = dz1; a.dz2 = dz2; a.dz3 = dz3; a.dx = dx; a.lddx = lddx;
+    const long ngroups = (rows + GROUP - 1) / GROUP;
+    if (dx) {
+#define CALL(I, O) hipLaunchKernelGGL((k_backward<I, O, true>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, a)
+        MPG_DISPATCH_NET(in_dim, ou, CALL)
+#undef CALL
+    } else {
+#define CALL(I, O) hipLaunchKernelGGL((k_backward<I, O, false>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, a)
+        MPG_DISPATCH_NET(in_dim, ou, CALL)
+#undef CALL
+    }
+    MPG_CHECK_LAUNCH("k_backward");
+    return MPG_OK;
+}
+
+// -------------------------------------------------------------------------------------------------------
+// weight gradient:  dW2 = H1^T DZ2 on MFMA straight from the G16 stashes (k = batch row), the thin pieces
+// (dW1, db1, db2, dW3, db3) on VALU.  Each workgroup reduces a contiguous chunk of row groups into one slab;
+// k_reduce_slabs sums the slabs in a fixed order (deterministic, no float atomics).
+// -------------------------------------------------------------------------------------------------------
+struct WgradArgs {
+    int in_dim, out_dim, rows, groups_per_wg;
+    XSpec x;
+    const float *h1, *h2, *dz1, *dz2, *dz3;
+    float* slabs;
+};
+
+template <int IN, int OU>
+__global__ void __launch_bounds__(NTHREAD, 2) k_wgrad(const WgradArgs a) {
+    __shared__ float sX[GROUP * XS];
+    __shared__ float sD3[GROUP * MAXOUT];
+    const Lane L;
+    const int tid = threadIdx.x;
+    const long ngroups = (a.rows + GROUP - 1) / GROUP;
+    const long g0 = (long)blockIdx.x * a.groups_per_wg;
+    const long g1 = (g0 + a.groups_per_wg < ngroups) ? g0 + a.groups_per_wg : ngroups;
+    f32x4 acc[16][2];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) acc[u][0] = acc[u][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float gW1[2][IN], gb1[2] = {0.f, 0.f}, gb2[2] = {0.f, 0.f}, gW3[2][OU], gb3 = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int i = 0; i < IN; ++i) gW1[t][i] = 0.f;
+#pragma unroll
+        for (int o = 0; o < OU; ++o) gW3[t][o] = 0.f;
+    }
+    const f32x4* H1 = reinterpret_cast<const f32x4*>(a.h1);
+    const f32x4* DZ2 = reinterpret_cast<const f32x4*>(a.dz2);
+    for (long g = g0; g < g1; ++g) {
+        load_x_group<IN>(a.x, a.rows, g, sX);
+        if (tid < GROUP * OU) {
+            const int row = tid / OU, o = tid % OU;
+            const long gr = g * GROUP + row;
+            const float d = gr < a.rows ? a.dz3[gr * OU + o] : 0.f;
+            sD3[row * MAXOUT + o] = d;
+            if (tid < OU) {   // db3[o]: one thread per output walks the 16 rows of the group
+                float sum = 0.f;
+                for (int rr = 0; rr < GROUP; ++rr) {
+                    const long g2 = g * GROUP + rr;
+                    if (g2 < a.rows) sum += a.dz3[g2 * OU + tid];
+                }
+                gb3 += sum;
+            }
+        }
+        float h2[2][4], dz1[2][4], dz2[2][4];
+        stash_load(a.h2, g, L, h2);
+        stash_load(a.dz1, g, L, dz1);
+        stash_load(a.dz2, g, L, dz2);
+        // dW2 tile (u, t) += H1[:, 16u:16u+16]^T DZ2[:, col tile]; the float4's 4 entries are 4 k-steps
+#pragma unroll
+        for (int u0 = 0; u0 < 16; u0 += 4) {
+            f32x4 af[4];
+#pragma unroll
+            for (int uu = 0; uu < 4; ++uu) af[uu] = H1[(g * 16 + u0 + uu) * 64 + L.lane];
+#pragma unroll
+            for (int uu = 0; uu < 4; ++uu)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[u0 + uu][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[uu][j], dz2[0][j], acc[u0 + uu][0], 0, 0, 0);
+                    acc[u0 + uu][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[uu][j], dz2[1][j], acc[u0 + uu][1], 0, 0, 0);
+                }
+        }
+        __syncthreads();   // sX, sD3 ready
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = L.row(j);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                gb1[t] += dz1[t][j];
+                gb2[t] += dz2[t][j];
+#pragma unroll
+                for (int i = 0; i < IN; ++i) gW1[t][i] = fmaf(sX[row * XS + i], dz1[t][j], gW1[t][i]);
+#pragma unroll
+                for (int o = 0; o < OU; ++o) gW3[t][o] = fmaf(h2[t][j], sD3[row * MAXOUT + o], gW3[t][o]);
+            }
+        }
+        __syncthreads();   // before the next group overwrites sX / sD3
+    }
+    // ---- write this workgroup's slab ----
+    float* slab = a.slabs + (size_t)blockIdx.x * net_size(a.in_dim, a.out_dim);
+    float* sW1 = slab;
+    float* sb1 = sW1 + a.in_dim * H;
+    float* sW2 = sb1 + H;
+    float* sb2 = sW2 + H * H;
+    float* sW3 = sb2 + H;
+    float* sb3 = sW3 + H * a.out_dim;
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sW2[(16 * u + 4 * L.rg + j) * H + L.col(t)] = acc[u][t][j];
+    // thin pieces: sum the 4 row-quads (lanes l, l^16, l^32, l^48)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        float v1 = gb1[t], v2 = gb2[t];
+        v1 += __shfl_xor(v1, 16); v1 += __shfl_xor(v1, 32);
+        v2 += __shfl_xor(v2, 16); v2 += __shfl_xor(v2, 32);
+        if (L.rg == 0) { sb1[L.col(t)] = v1; sb2[L.col(t)] = v2; }
+#pragma unroll
+        for (int i = 0; i < IN; ++i) {
+            float v = gW1[t][i];
+            v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+            if (L.rg == 0) sW1[i * H + L.col(t)] = v;
+        }
+#pragma unroll
+        for (int o = 0; o < OU; ++o) {
+            float v = gW3[t][o];
+            v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+            if (L.rg == 0) sW3[L.col(t) * a.out_dim + o] = v;
+        }
+        if (L.rg == 0)
+            for (int o = OU; o < a.out_dim; ++o) sW3[L.col(t) * a.out_dim + o] = 0.f;   // unused output columns
+    }
+    if (tid < a.out_dim) sb3[tid] = tid < OU ? gb3 : 0.f;
+}
+
+__global__ void k_reduce_slabs(const float* __restrict__ slabs, int nslab, int n, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int k = 0; k < nslab; ++k) s += slabs[(size_t)k * n + i];
+    out[i] = s;
+}
+
+static int wgrad_groups_per_wg(long ngroups) {
+    long gp = (ngroups + 63) / 64;   // <= 64 slabs
+    return (int)(gp < 1 ? 1 : gp);
+}
+
+size_t wgrad_workspace_floats(int rows, int in_dim, int out_dim) {
+    const long ngroups = (rows + GROUP - 1) / GROUP;
+    const int gp = wgrad_groups_per_wg(ngroups);
+    const long nwg = (ngroups + gp - 1) / gp;
+    return (size_t)nwg * net_size(in_dim, out_dim);
+}
+
+int launch_wgrad(int in_dim, int out_dim, int ou, int rows, const XSpec& x, const float* h1, const float* h2,
+                 const float* dz1, const float* dz2, const float* dz3, float* grad, float* ws, hipStream_t s) {
+    MPG_REQUIRE(rows > 0 && h1 && h2 && dz1 && dz2 && dz3 && grad && ws, "launch_wgrad: bad argument");
+    WgradArgs a;
+    a.in_dim = in_dim; a.out_dim = out_dim; a.rows = rows; a.x = x;
+    a.h1 = h1; a.h2 = h2; a.dz1 = dz1; a.dz2 = dz2; a.dz3 = dz3; a.slabs = ws;
+    const long ngroups = (rows + GROUP - 1) / GROUP;
+    a.groups_per_wg = wgrad_groups_per_wg(ngroups);
+    const int nwg = (int)((ngroups + a.groups_per_wg - 1) / a.groups_per_wg);
+#define CALL(I, O) hipLaunchKernelGGL((k_wgrad<I, O>), dim3(nwg), dim3(NTHREAD), 0, s, a)
+    MPG_DISPATCH_NET(in_dim, ou, CALL)
+#undef CALL
+    MPG_CHECK_LAUNCH("k_wgrad");
+    const int n = net_size(in_dim, out_dim);
+    hipLaunchKernelGGL(k_reduce_slabs, dim3((n + 255) / 256), dim3(256), 0, s, ws, nwg, n, grad);
+    MPG_CHECK_LAUNCH("k_reduce_slabs");
+    return MPG_OK;
+}
+
+}  // namespace mlp

@@ -1,0 +1,132 @@
+"""Thin typed wrappers over the C ABI (include/mpg_hip.h).  Tensors in, tensors out; no arithmetic here."""
+import ctypes
+
+import torch
+
+from . import _lib as L
+
+ACT_LINEAR, ACT_TANH = 0, 1
+HIDDEN = 256
+
+
+class CfgStruct(ctypes.Structure):
+    """mpg_cfg_t"""
+    _fields_ = [('obs_dim', ctypes.c_int), ('act_dim', ctypes.c_int), ('policy_out_act', ctypes.c_int),
+                ('action_range', ctypes.c_float), ('obs_scale', ctypes.c_float * 8),
+                ('rew_scale', ctypes.c_float), ('rew_shift', ctypes.c_float), ('gamma', ctypes.c_float),
+                ('env_kind', ctypes.c_int)]
+
+
+def make_cfg(env_id='PathTracking-v0', obs_scale=None, rew_scale=None, rew_shift=0.0, gamma=0.98,
+             policy_out_activation=None, action_range=None):
+    """Defaults are the reference's (train_script.py:202-306 / train_script4mujoco.py:296-411)."""
+    pt = env_id == 'PathTracking-v0'
+    c = CfgStruct()
+    c.obs_dim, c.act_dim = (6, 2) if pt else (4, 1)
+    if policy_out_activation is None:
+        policy_out_activation = 'tanh' if pt else 'linear'
+    c.policy_out_act = ACT_TANH if policy_out_activation == 'tanh' else ACT_LINEAR
+    if action_range is None:
+        action_range = 0.0 if pt else 3.0
+    c.action_range = float(action_range or 0.0)
+    sc = obs_scale if obs_scale is not None else ([1., 1., 2., 1., 2.4, 1 / 1200] if pt else [0.001, 1 / 3, 0.1, 0.5])
+    for i in range(8):
+        c.obs_scale[i] = float(sc[i]) if i < len(sc) else 1.0
+    c.rew_scale = float(rew_scale if rew_scale is not None else (0.01 if pt else 1.0))
+    c.rew_shift = float(rew_shift)
+    c.gamma = float(gamma)
+    c.env_kind = 0 if pt else 1
+    return c
+
+
+def net_size(in_dim, out_dim):
+    return in_dim * HIDDEN + HIDDEN + HIDDEN * HIDDEN + HIDDEN + HIDDEN * out_dim + out_dim
+
+
+def policy_size(cfg):
+    return net_size(cfg.obs_dim, 2 * cfg.act_dim)
+
+
+def q_size(cfg):
+    return net_size(cfg.obs_dim + cfg.act_dim, 1)
+
+
+class Workspace(object):
+    """Caller-owned scratch the ABI asks for (grown on demand, reused across calls on one stream)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.buf = None
+
+    def get(self, nbytes):
+        if self.buf is None or self.buf.numel() < nbytes:
+            self.buf = torch.empty(int(nbytes) + 256, dtype=torch.uint8, device=self.device)
+        return self.buf
+
+
+_WS = {}
+
+
+def workspace(device, nbytes, slot=0):
+    key = (str(device), slot)
+    if key not in _WS:
+        _WS[key] = Workspace(device)
+    return _WS[key].get(nbytes)
+
+
+def _f32(t):
+    assert t.dtype == torch.float32 and t.is_cuda and t.is_contiguous(), (t.dtype, t.device, t.is_contiguous())
+    return t
+
+
+def mlp_forward(params, in_dim, out_dim, out_used, out_act, x, in_scale=None, n_scaled=0):
+    rows = x.shape[0]
+    y = torch.empty(rows, out_used, dtype=torch.float32, device=x.device)
+    sc = (ctypes.c_float * 8)(*([float(v) for v in in_scale] + [1.0] * (8 - len(in_scale)))) if in_scale is not None else None
+    L.call('mpg_mlp_forward', L.ptr(_f32(params)), L.c_int(in_dim), L.c_int(out_dim), L.c_int(out_used),
+           L.c_int(out_act), L.c_int(rows), L.ptr(_f32(x)), sc, L.c_int(n_scaled), L.ptr(y), L.stream())
+    return y
+
+
+def policy_action(cfg, policy_params, obs, explore_sigma=0.0, seed=0, ctr=0):
+    rows = obs.shape[0]
+    act = torch.empty(rows, cfg.act_dim, dtype=torch.float32, device=obs.device)
+    L.call('mpg_policy_action', ctypes.byref(cfg), L.ptr(_f32(policy_params)), L.c_int(rows), L.ptr(_f32(obs)),
+           L.c_float(explore_sigma), L.c_u64(seed), L.c_u64(ctr), L.ptr(act), L.stream())
+    return act
+
+
+def q_targets(cfg, policy_t, q1t, q2t, rew, obs_tp1, smooth_eps=None, smooth_sigma=0.2, smooth_clip=0.5):
+    rows = obs_tp1.shape[0]
+    y = torch.empty(rows, dtype=torch.float32, device=obs_tp1.device)
+    nb = L.lib().mpg_q_targets_workspace_bytes(ctypes.byref(cfg), L.c_int(rows))
+    ws = workspace(obs_tp1.device, nb)
+    L.call('mpg_q_targets', ctypes.byref(cfg), L.ptr(_f32(policy_t)), L.ptr(_f32(q1t)),
+           L.ptr(_f32(q2t) if q2t is not None else None), L.c_int(rows), L.ptr(_f32(rew)), L.ptr(_f32(obs_tp1)),
+           L.ptr(_f32(smooth_eps) if smooth_eps is not None else None), L.c_float(smooth_sigma),
+           L.c_float(smooth_clip), L.ptr(y), L.ptr(ws), L.c_size_t(ws.numel()), L.stream())
+    return y
+
+
+def nstep_targets(cfg, policy_t, q1t, rewards, last_obs):
+    n, rows = rewards.shape
+    y = torch.empty(rows, dtype=torch.float32, device=last_obs.device)
+    nb = L.lib().mpg_q_targets_workspace_bytes(ctypes.byref(cfg), L.c_int(rows))
+    ws = workspace(last_obs.device, nb)
+    L.call('mpg_nstep_targets', ctypes.byref(cfg), L.ptr(_f32(policy_t)), L.ptr(_f32(q1t)), L.c_int(rows), L.c_int(n),
+           L.ptr(_f32(rewards)), L.ptr(_f32(last_obs)), L.ptr(y), L.ptr(ws), L.c_size_t(ws.numel()), L.stream())
+    return y
+
+
+def q_loss_grad(cfg, q_params, obs, act, y, inv_b_global=None, grad_out=None, loss_out=None, want_td=False):
+    rows = obs.shape[0]
+    dev = obs.device
+    grad = grad_out if grad_out is not None else torch.empty(q_size(cfg), dtype=torch.float32, device=dev)
+    loss = loss_out if loss_out is not None else torch.empty(1, dtype=torch.float32, device=dev)
+    td = torch.empty(rows, dtype=torch.float32, device=dev) if want_td else None
+    nb = L.lib().mpg_q_loss_grad_workspace_bytes(ctypes.byref(cfg), L.c_int(rows))
+    ws = workspace(dev, nb)
+    L.call('mpg_q_loss_grad', ctypes.byref(cfg), L.ptr(_f32(q_params)), L.c_int(rows), L.ptr(_f32(obs)),
+           L.ptr(_f32(act)), L.ptr(_f32(y)), L.c_float(inv_b_global if inv_b_global is not None else 1.0 / rows),
+           L.ptr(loss), L.ptr(grad), L.ptr(td), L.ptr(ws), L.c_size_t(ws.numel()), L.stream())
+    return loss, grad, td

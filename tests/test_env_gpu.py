@@ -1,7 +1,8 @@
 """HIP PathTrackingEnv (mpg_env_*) against the reference's recording, the reference-run fixture and the
 oracle.  Tolerances: the kernel mirrors the reference op-by-op (no FMA contraction); what remains is the
 last-ulp behaviour of sin/cos/atan over 20 sub-steps -> 5e-6 abs on the small entries (the survey's
-figure for mpc_rl.npy) and 4 ulp on x (|x| <= 1200, ulp 1.2e-4)."""
+figure for mpc_rl.npy), 4 ulp on x (|x| <= 1200, ulp 1.2e-4), and on delta_y / delta_phi additionally
+the path slope (<= 0.37) / curvature times that x tolerance."""
 import numpy as np
 import pytest
 import torch
@@ -16,6 +17,9 @@ def _close_obs(got, ref, atol=5e-6):
     err = np.abs(got - ref)
     tol = np.full(ref.shape, atol)
     tol[..., 5] = 4 * np.spacing(np.abs(ref[..., 5]).astype(np.float32)).astype(np.float64) + atol
+    # delta_y = y - path_y(x) and delta_phi inherit an x that may be off by a few ulp: |path slope| <= 0.37
+    tol[..., 3] += 0.4 * tol[..., 5]
+    tol[..., 4] += 0.02 * tol[..., 5]
     assert (err <= tol).all(), (err.max(0), np.argwhere(err > tol)[:5])
 
 

@@ -1,0 +1,173 @@
+"""HIP network kernels (forward / critic targets / critic loss+gradient) through the C ABI against the oracle
+and the reference-generated goldens.
+
+Tolerances (float32 path, exact-fp32 MFMA): <= 1e-4 relative L2 per gradient array, forward
+values <= 2e-5 relative-to-scale; float64 oracle used as the yard-stick where the fixture holds one."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import mpg_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def rel_l2(a, b):
+    a, b = np.asarray(a, np.float64).ravel(), np.asarray(b, np.float64).ravel()
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def dev(x):
+    return torch.as_tensor(np.ascontiguousarray(x), dtype=torch.float32).to(DEV)
+
+
+def rand_net(rng, din, dout):
+    ws = [rng.standard_normal((din, 256)) * 0.4, rng.standard_normal(256) * 0.1,
+          rng.standard_normal((256, 256)) * (1.4 / 16), rng.standard_normal(256) * 0.1,
+          rng.standard_normal((256, dout)) * 0.1, rng.standard_normal(dout) * 0.1]
+    return np.concatenate([w.ravel() for w in ws]).astype(np.float32)
+
+
+@pytest.mark.parametrize('rows', [1, 15, 16, 17, 255, 4096, 4099])
+@pytest.mark.parametrize('shape', [(6, 4, 2, 1), (8, 1, 1, 0), (4, 2, 1, 0), (5, 1, 1, 0)])
+def test_mlp_forward_vs_oracle(rows, shape):
+    from mpg_amd import ops
+    din, dout, used, act = shape
+    rng = np.random.Generator(np.random.PCG64(rows * 31 + din))
+    flat = rand_net(rng, din, dout)
+    x = rng.standard_normal((rows, din)).astype(np.float32)
+    scale = rng.uniform(0.5, 2.0, din)
+    y = ops.mlp_forward(dev(flat), din, dout, used, act, dev(x), in_scale=scale, n_scaled=din).cpu().numpy()
+    ws = O.unflatten(flat, din, 256, dout, dtype=torch.float64)
+    ref = O.mlp(ws, torch.as_tensor(x, dtype=torch.float64) * torch.as_tensor(scale.astype(np.float32)).double(),
+                'tanh' if act else 'linear').numpy()[:, :used]
+    assert np.abs(y - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+
+
+def _cfg_nets(g, names, env='PathTracking-v0'):
+    from mpg_amd import ops
+    cfg = ops.make_cfg(env)
+    online = {k: g['w_' + k] for k in names}
+    targets = {k: (g['w_' + k] * np.float32(g['target_scale'])).astype(np.float32) for k in names}
+    return cfg, online, targets
+
+
+def test_policy_action_and_clipped_double_q_target_vs_golden(golden):
+    from mpg_amd import ops
+    g = golden('mpg_v2_H256_B64.npz')
+    cfg, online, targets = _cfg_nets(g, ['Q1', 'Q2', 'policy'])
+    y = ops.q_targets(cfg, dev(targets['policy']), dev(targets['Q1']), dev(targets['Q2']),
+                      dev(g['batch_rewards']), dev(g['batch_obs_tp1'])).cpu().numpy()
+    np.testing.assert_allclose(y, g['it100_targets'], rtol=2e-5, atol=2e-6)
+    # deterministic action = oracle action
+    ocfg = O.Cfg()
+    nets = O.Nets(ocfg, online, target_scale=g['target_scale'], dtype=torch.float64)
+    a_ref = nets.compute_action(O.process_obses(ocfg, torch.as_tensor(g['batch_obs']).double())).detach().numpy()
+    a = ops.policy_action(cfg, dev(online['policy']), dev(g['batch_obs'])).cpu().numpy()
+    np.testing.assert_allclose(a, a_ref, rtol=0, atol=2e-6)
+
+
+def test_td3_smoothed_target_vs_golden(golden):
+    from mpg_amd import ops
+    g = golden('td3_H256_B64.npz')
+    cfg, online, targets = _cfg_nets(g, ['Q1', 'Q2', 'policy'])
+    y = ops.q_targets(cfg, dev(targets['policy']), dev(targets['Q1']), dev(targets['Q2']), dev(g['batch_rewards']),
+                      dev(g['batch_obs_tp1']), smooth_eps=dev(g['smooth_eps']), smooth_sigma=0.2,
+                      smooth_clip=0.5).cpu().numpy()
+    np.testing.assert_allclose(y, g['targets'], rtol=2e-5, atol=2e-6)
+
+
+def test_exploration_noise_statistics():
+    from mpg_amd import ops
+    cfg = ops.make_cfg()
+    rng = np.random.Generator(np.random.PCG64(3))
+    flat = rand_net(rng, 6, 4)
+    obs = dev(np.zeros((1 << 15, 6), np.float32))
+    a0 = ops.policy_action(cfg, dev(flat), obs)
+    a1 = ops.policy_action(cfg, dev(flat), obs, explore_sigma=0.1, seed=5, ctr=0)
+    a2 = ops.policy_action(cfg, dev(flat), obs, explore_sigma=0.1, seed=5, ctr=1)
+    d = (a1 - a0).cpu().numpy()
+    assert abs(d.mean()) < 3e-3 and abs(d.std() - 0.1) < 3e-3
+    assert np.abs(np.corrcoef(d[:, 0], d[:, 1])[0, 1]) < 0.03
+    assert (a1 - a2).abs().max().item() > 0.05          # a new counter gives a new stream
+    a1b = ops.policy_action(cfg, dev(flat), obs, explore_sigma=0.1, seed=5, ctr=0)
+    assert torch.equal(a1, a1b)                          # counter-based: reproducible
+
+
+def _unclip(flat_clipped, norm, clip=3.0):
+    scale = clip * min(1.0 / float(norm), 1.0 / clip)
+    return flat_clipped / scale
+
+
+@pytest.mark.parametrize('fixture,loss_keys', [('mpg_v2_H256_B64.npz', ('it100_q_loss1', 'it100_q_loss2')),
+                                               ('td3_H256_B64.npz', ('q_loss1', 'q_loss2'))])
+def test_q_loss_grad_vs_golden(golden, fixture, loss_keys):
+    from mpg_amd import ops
+    g = golden(fixture)
+    cfg, online, _ = _cfg_nets(g, ['Q1', 'Q2', 'policy'])
+    pre = 'it100_' if 'mpg' in fixture else ''
+    y = dev(g[pre + 'targets'])
+    nq = ops.q_size(cfg)
+    for i, nm in enumerate(('Q1', 'Q2')):
+        loss, grad, td = ops.q_loss_grad(cfg, dev(online[nm]), dev(g['batch_obs']), dev(g['batch_actions']), y,
+                                         want_td=True)
+        np.testing.assert_allclose(loss.item(), g[loss_keys[i]], rtol=5e-5)
+        norm = g[pre + 'q_gradient_norm%d' % (i + 1)]
+        ref = _unclip(g[pre + 'grads'][i * nq:(i + 1) * nq], norm)
+        got = grad.cpu().numpy()
+        assert abs(np.linalg.norm(got) - norm) <= 1e-4 * norm
+        # per-array check (W1,b1,W2,b2,W3,b3)
+        o = 0
+        for shp in O.mlp_shapes(8, 256, 1):
+            n = int(np.prod(shp))
+            assert rel_l2(got[o:o + n], ref[o:o + n]) <= 1e-4, (nm, shp)
+            o += n
+
+
+@pytest.mark.parametrize('rows', [1, 17, 300, 4096])
+def test_q_loss_grad_vs_oracle_autograd_ragged(rows):
+    from mpg_amd import ops
+    rng = np.random.Generator(np.random.PCG64(rows))
+    cfg = ops.make_cfg()
+    flat = rand_net(rng, 8, 1)
+    obs = (rng.standard_normal((rows, 6)) * np.array([3, 1, .5, 1, .5, 300])).astype(np.float32)
+    act = rng.uniform(-1, 1, (rows, 2)).astype(np.float32)
+    y = rng.standard_normal(rows).astype(np.float32)
+    loss, grad, td = ops.q_loss_grad(cfg, dev(flat), dev(obs), dev(act), dev(y), want_td=True)
+    ocfg = O.Cfg()
+    ws = O.unflatten(flat, 8, 256, 1, dtype=torch.float64, requires_grad=True)
+    po = O.process_obses(ocfg, torch.as_tensor(obs).double())
+    q = O.mlp(ws, torch.cat([po, torch.as_tensor(act).double()], 1), 'linear')[:, 0]
+    l = 0.5 * torch.mean((q - torch.as_tensor(y).double()) ** 2)
+    gs = torch.autograd.grad(l, ws)
+    ref = np.concatenate([x.numpy().ravel() for x in gs])
+    np.testing.assert_allclose(loss.item(), l.item(), rtol=2e-5)
+    np.testing.assert_allclose(td.cpu().numpy(), (q.detach().numpy() - y), rtol=0, atol=3e-5)
+    got = grad.cpu().numpy()
+    o = 0
+    for shp in O.mlp_shapes(8, 256, 1):
+        n = int(np.prod(shp))
+        assert rel_l2(got[o:o + n], ref[o:o + n]) <= 2e-5, (rows, shp, rel_l2(got[o:o + n], ref[o:o + n]))
+        o += n
+
+
+def test_nstep_target_vs_golden(golden):
+    """MPG-v1: real-env 25-step rollout on the HIP env + n-step return (mpg_learner.py:146-169)."""
+    from mpg_amd import ops
+    from mpg_amd.envs import PathTrackingEnv
+    g = golden('mpg_v1_H256_B64.npz')
+    cfg, online, targets = _cfg_nets(g, ['Q1', 'policy'])
+    B = g['batch_obs'].shape[0]
+    env = PathTrackingEnv(num_agent=B)
+    obs = dev(g['batch_obs'])
+    env.reset(init_obs=obs)
+    rewards = []
+    for t in range(25):
+        a = dev(g['batch_actions']) if t == 0 else ops.policy_action(cfg, dev(online['policy']), obs)
+        obs, r, _, _ = env.step(a)
+        rewards.append(r)
+    rewards = torch.stack(rewards).contiguous()
+    np.testing.assert_allclose(rewards.cpu().numpy(), g['nstep_all_rewards'], rtol=2e-3, atol=2e-4)
+    y = ops.nstep_targets(cfg, dev(targets['policy']), dev(targets['Q1']), rewards, obs).cpu().numpy()
+    np.testing.assert_allclose(y, g['it100_targets'], rtol=1e-3, atol=1e-4)
