@@ -128,6 +128,52 @@ int mpg_q_loss_grad(const mpg_cfg_t* cfg, const float* q_params, int rows, const
                     const float* y, float inv_b_global, float* loss_sum, float* grad, float* td, void* ws,
                     size_t ws_bytes, mpg_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * n-step model rollout + mixed policy gradient (K2+K3+K4)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* MPGLearner.model_rollout_for_policy_update + policy_forward_and_backward  - learners/mpg_learner.py:226-286,
+ * :356-365 (default flags: deriv_interval_policy=False - parameter gradients flow only through the step-0
+ * action) and, with all_steps_param_grad != 0, the NADP variant learners/nadp.py:128-171,
+ * :186-194 where every step goes through pi_theta (needs rows*M % 16 == 0).
+ *
+ *   rows   B_local start states obs0 [rows][obs_dim]  (the M copies are tiled inside: trajectory = m*rows + b)
+ *   eps    [n][M*rows] standard-normal draws for the model's injected noise
+ *          (path_tracking_env.py:119: dy += 0.5 + 0.01 eps; inverted_pendulum_model.py:61: p += 0.1 + 0.5 eps)
+ *   select/n_select/w (HOST arrays, n_select <= 4)   slices k whose mean returns R_k = mean(G_k + gamma^k Q1)
+ *          enter the loss  sum_k w_k * (-R_k)   (w = rule_based_weights, mpg_learner.py:384-399, computed by the host)
+ *   inv_b_global   1/B_global: divisor of the batch mean (the M-mean is applied inside); n < 32
+ * Outputs
+ *   ret_sum [n_select], ret_sqsum [n_select]: sum over this GPU's rows of the M-mean return and of its square
+ *   grad    flat policy gradient (68612 floats path tracking) of the loss, reduced over this GPU's rows, NOT clipped. */
+size_t mpg_rollout_pg_workspace_bytes(const mpg_cfg_t* cfg, int rows, int M, int n, int n_select,
+                                      int all_steps_param_grad);
+int mpg_rollout_pg(const mpg_cfg_t* cfg, const float* policy_params, const float* q1_params, int rows, int M,
+                   int n, const int* select, int n_select, const float* w, const float* obs0, const float* eps,
+                   float inv_b_global, int all_steps_param_grad, float* ret_sum, float* ret_sqsum, float* grad,
+                   void* ws, size_t ws_bytes, mpg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * clip_by_global_norm + Keras Adam + Polyak (K7, K8) over the flat [net0 | net1 | ...] vectors
+ * ---------------------------------------------------------------------------------------------- */
+
+/* tf.clip_by_global_norm(g, clip) applied to each of the n_seg (<= 8) consecutive networks of `grad`
+ * (seg_sizes: HOST array of their lengths) - learners/mpg_learner.py:415-431: norms[k] = ||g_k||_2,
+ * g_k *= clip * min(1/norm, 1/clip) in place.  nonfinite_flag (device int, nullable, caller zeroes it) is
+ * raised when a norm is not finite (optimizer.py:357-361 zeroes such gradients).  Must run AFTER the
+ * cross-GPU all-reduce: the clip is not linear. */
+int mpg_clip_by_global_norm(float* grad, const int* seg_sizes, int n_seg, float clip, float* norms,
+                            int* nonfinite_flag, mpg_stream_t stream);
+
+/* PolicyWithQs.apply_gradients + update_*_target  - policy.py:123-171.  For every network k (HOST arrays):
+ * do_adam[k]: one Keras Adam step (beta .9/.999, eps 1e-7 outside the sqrt, TF ApplyAdam form) with the
+ * bias-corrected rate lr_t[k] = lr(step)*sqrt(1-b2^t)/(1-b1^t) computed by the caller from ITS per-optimizer
+ * step counter and PolynomialDecay schedule (policy.py:54-70); do_polyak[k]: target = tau*w + (1-tau)*target
+ * afterwards.  If *skip_flag != 0 the gradient is taken as zeros (NaN guard). */
+int mpg_adam_polyak(float* w, float* m, float* v, float* target, const float* grad, const int* seg_sizes,
+                    int n_seg, const float* lr_t, const int* do_adam, const int* do_polyak, float tau,
+                    const int* skip_flag, mpg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

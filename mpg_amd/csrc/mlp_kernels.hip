@@ -29,9 +29,9 @@ __device__ __forceinline__ void load_x_group(const XSpec& x, int rows, long g, f
         float v = 0.f;
         if (gr < rows && i < IN) {
             if (i < x.d0)
-                v = x.x0[gr * x.d0 + i] * x.scale[i];
+                v = x.x0[gr * x.ld0 + i] * x.scale[i];
             else
-                v = x.x1[gr * x.d1 + (i - x.d0)];
+                v = x.x1[gr * x.ld1 + (i - x.d0)];
         }
         sX[tid] = v;
     }
@@ -222,7 +222,6 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_wgrad(const WgradArgs a) {
         for (int o = 0; o < OU; ++o) gW3[t][o] = 0.f;
     }
     const f32x4* H1 = reinterpret_cast<const f32x4*>(a.h1);
-    const f32x4* DZ2 = reinterpret_cast<const f32x4*>(a.dz2);
     for (long g = g0; g < g1; ++g) {
         load_x_group<IN>(a.x, a.rows, g, sX);
         if (tid < GROUP * OU) {

@@ -1,0 +1,109 @@
+// K7/K8: tf.clip_by_global_norm per network, Keras Adam and Polyak target updates - one launch each over the
+// flat [net0 | net1 | ...] parameter vector.  Deterministic (fixed-order block reductions, no float atomics).
+//
+// Reference: learners/mpg_learner.py:415-431 (clip), policy.py:123-171 (apply_gradients, update_*_target),
+// optimizer.py:357-361 (NaN guard).  Adam follows TensorFlow's ApplyAdam functor:
+//   m += (g - m)(1 - b1);  v += (g^2 - v)(1 - b2);  w -= lr_t * m / (sqrt(v) + eps),  lr_t = lr sqrt(1-b2^t)/(1-b1^t).
+#include "mpg_common.h"
+
+namespace {
+
+constexpr int MAXSEG = 8;
+
+struct Segs {
+    int n_seg;
+    int off[MAXSEG], n[MAXSEG];
+    float lr_t[MAXSEG];
+    int do_adam[MAXSEG], do_polyak[MAXSEG];
+};
+
+// one block per segment: norm = sqrt(sum g^2); g *= clip * min(1/norm, 1/clip)   (tf.clip_by_global_norm)
+__global__ void __launch_bounds__(1024) k_clip(const Segs sg, float* __restrict__ grad, float clip,
+                                               float* __restrict__ norms, int* __restrict__ nonfinite) {
+    __shared__ float red[1024];
+    __shared__ float s_scale;
+    const int k = blockIdx.x;
+    float* g = grad + sg.off[k];
+    const int n = sg.n[k];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 1024) s = fmaf(g[i], g[i], s);
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float nrm = sqrtf(red[0]);
+        norms[k] = nrm;
+        s_scale = clip * fminf(1.f / nrm, 1.f / clip);
+        if (!isfinite(nrm) && nonfinite) atomicOr(nonfinite, 1);
+    }
+    __syncthreads();
+    const float sc = s_scale;
+    for (int i = threadIdx.x; i < n; i += 1024) g[i] *= sc;
+}
+
+__global__ void k_adam_polyak(const Segs sg, float* __restrict__ w, float* __restrict__ m, float* __restrict__ v,
+                              float* __restrict__ target, const float* __restrict__ grad, float tau,
+                              const int* __restrict__ skip) {
+    const int k = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= sg.n[k]) return;
+    const int j = sg.off[k] + i;
+    const float b1 = 0.9f, b2 = 0.999f, eps = 1e-7f;
+    float wj = w[j];
+    if (sg.do_adam[k]) {
+        const float g = (skip && *skip) ? 0.f : grad[j];     // optimizer.py:357-361: a non-finite gradient is zeroed
+        float mj = m[j], vj = v[j];
+        mj += (g - mj) * (1.f - b1);
+        vj += (g * g - vj) * (1.f - b2);
+        wj -= sg.lr_t[k] * mj / (sqrtf(vj) + eps);
+        m[j] = mj; v[j] = vj; w[j] = wj;
+    }
+    if (sg.do_polyak[k] && target) target[j] = tau * wj + (1.f - tau) * target[j];   // policy.py:158-171
+}
+
+int fill(Segs& sg, int n_seg, const int* seg_sizes) {
+    if (n_seg <= 0 || n_seg > MAXSEG || !seg_sizes) return -1;
+    sg.n_seg = n_seg;
+    int off = 0;
+    for (int k = 0; k < MAXSEG; ++k) {
+        sg.off[k] = off;
+        sg.n[k] = k < n_seg ? seg_sizes[k] : 0;
+        off += sg.n[k];
+        sg.lr_t[k] = 0.f;
+        sg.do_adam[k] = sg.do_polyak[k] = 0;
+    }
+    return off;
+}
+
+}  // namespace
+
+extern "C" int mpg_clip_by_global_norm(float* grad, const int* seg_sizes, int n_seg, float clip, float* norms,
+                                       int* nonfinite_flag, mpg_stream_t stream) {
+    Segs sg;
+    MPG_REQUIRE(grad && norms && fill(sg, n_seg, seg_sizes) > 0 && clip > 0.f, "mpg_clip_by_global_norm: bad argument");
+    hipLaunchKernelGGL(k_clip, dim3(n_seg), dim3(1024), 0, mpg_stream(stream), sg, grad, clip, norms, nonfinite_flag);
+    MPG_CHECK_LAUNCH("k_clip");
+    return MPG_OK;
+}
+
+extern "C" int mpg_adam_polyak(float* w, float* m, float* v, float* target, const float* grad, const int* seg_sizes,
+                               int n_seg, const float* lr_t, const int* do_adam, const int* do_polyak, float tau,
+                               const int* skip_flag, mpg_stream_t stream) {
+    Segs sg;
+    MPG_REQUIRE(w && m && v && grad && lr_t && do_adam && do_polyak && fill(sg, n_seg, seg_sizes) > 0,
+                "mpg_adam_polyak: bad argument");
+    int maxn = 0;
+    for (int k = 0; k < n_seg; ++k) {
+        sg.lr_t[k] = lr_t[k];
+        sg.do_adam[k] = do_adam[k];
+        sg.do_polyak[k] = do_polyak[k];
+        if (sg.n[k] > maxn) maxn = sg.n[k];
+    }
+    hipLaunchKernelGGL(k_adam_polyak, dim3((maxn + 255) / 256, n_seg), dim3(256), 0, mpg_stream(stream), sg, w, m, v,
+                       target, grad, tau, skip_flag);
+    MPG_CHECK_LAUNCH("k_adam_polyak");
+    return MPG_OK;
+}

@@ -1,0 +1,543 @@
+// K2+K3+K4: fused n-step model rollout + return accumulation (forward sweep) and its reverse sweep (mixed policy
+// gradient) for gfx950.
+//
+// A workgroup owns 16 trajectories for the WHOLE horizon: the policy's 256x256 kernel stays in registers across all
+// n+1 policy evaluations (mlp_core.h), the vehicle / pendulum state of a trajectory stays in the registers of one
+// lane, and only the hidden activations needed by the reverse sweep are streamed to HBM (G16 layout, 1 KiB coalesced
+// per wave instruction).  No inter-workgroup communication.
+//
+// Reference: MPGLearner.model_rollout_for_policy_update / policy_forward_and_backward
+// (learners/mpg_learner.py:226-286, :356-365), PathTrackingModel.rollout_out (envs_and_models/path_tracking_env.py:
+// 279-297, f_xu :78-138, rewards :181-199), InvertedPendulumModel (envs_and_models/inverted_pendulum_model.py:16-97),
+// NADPLearner (learners/nadp.py:87-194).  The reverse sweep replaces tf.GradientTape; its closed-form model adjoints
+// are pinned against autograd in tests/test_model_vjp.py.
+#include "mlp_launch.h"
+
+using namespace mlp;
+
+namespace {
+
+constexpr int MAXN = 32;      // horizon limit (reference default n = 25)
+constexpr int MAXSEL = 4;     // slices entering the loss (reference default {0, 25})
+constexpr int SAW = 8;        // floats per (step, trajectory) record: obs | action
+
+// ---------------------------------------------------------------------------------------------------------------
+// differentiable models: one lane = one trajectory
+// ---------------------------------------------------------------------------------------------------------------
+struct PathTracking {
+    static constexpr int OBS = 6, ACT = 2;
+    // vehicle parameters, path_tracking_env.py:60-68; tau = 1/10 (:248)
+    static constexpr float C_f = -128915.5f, C_r = -85943.6f, A = 1.06f, B = 1.85f, MASS = 1412.f, I_z = 1536.7f;
+    static constexpr float TAU = 0.1f;
+    static constexpr float K1 = TAU * (A * C_f - B * C_r), K2 = TAU * C_f, K3 = TAU * MASS, K4 = TAU * (C_f + C_r);
+    static constexpr float K5 = TAU * A * C_f, K6 = TAU * (A * A * C_f + B * B * C_r);
+    static constexpr float S0 = (float)(1.2 * 3.14159265358979323846 / 9.0), S1 = 3.f;   // action scaling :282
+    static constexpr float PI_F = 3.14159265358979323846f;
+
+    // obs -> veh state is a shift of entry 0 by 20 (:268-277); we carry obs and add the shift on use.
+    // One model step: obs/act in, new obs + RAW reward out.  eps: standard normal (noise = 0.5 + 0.01 eps, :119).
+    __device__ static void step(const float (&o)[8], const float (&a)[2], float eps, float (&on)[8], float& rew) {
+        const float vx = o[0] + 20.f, vy = o[1], r = o[2], dy = o[3], dphi = o[4], x = o[5];
+        const float de = a[0] * S0, ax = a[1] * S1;
+        const float dv = vx - 20.f;
+        rew = -(0.01f * dv * dv + 0.04f * dy * dy + 0.1f * dphi * dphi + 0.02f * r * r + 5.f * de * de + 0.05f * ax * ax);
+        float nvx = vx + TAU * (ax + vy * r);
+        const float nvy = (MASS * vy * vx + K1 * r - K2 * de * vx - K3 * vx * vx * r) / (MASS * vx - K4);
+        const float nr = (-I_z * r * vx - K1 * vy + K5 * de * vx) / (K6 - I_z * vx);
+        float sp, cp;
+        sincosf(dphi, &sp, &cp);
+        const float ndy = dy + TAU * (vx * sp + vy * cp) + (0.5f + 0.01f * eps);
+        float ndphi = dphi + TAU * r;
+        const float nx = x + TAU * (vx * cp - vy * sp);
+        nvx = fminf(fmaxf(nvx, 1.f), 35.f);                      // :289
+        if (ndphi > PI_F) ndphi -= 2.f * PI_F;                   // :290
+        if (ndphi <= -PI_F) ndphi += 2.f * PI_F;                 // :291
+        on[0] = nvx - 20.f; on[1] = nvy; on[2] = nr; on[3] = ndy; on[4] = ndphi; on[5] = nx;
+    }
+
+    // adjoint of step(): lam = dL/d(new obs), rho = dL/d(raw reward).  Returns dL/d(obs) and dL/d(action).
+    // (oracle/mpg_oracle.py:pt_model_step_vjp is the float64 statement of the same formulas)
+    __device__ static void vjp(const float (&o)[8], const float (&a)[2], const float (&onext)[8], const float (&lam)[8],
+                               float rho, float (&g)[8], float (&ga)[2]) {
+        const float vx = o[0] + 20.f, vy = o[1], r = o[2], dy = o[3], dphi = o[4];
+        const float de = a[0] * S0, ax = a[1] * S1;
+        const float nvx_raw = vx + TAU * (ax + vy * r);
+        const float l_vx = (nvx_raw >= 1.f && nvx_raw <= 35.f) ? lam[0] : 0.f;
+        const float l_vy = lam[1], l_r = lam[2], l_dy = lam[3], l_dphi = lam[4], l_x = lam[5];
+        const float D1 = MASS * vx - K4, D2 = K6 - I_z * vx;
+        const float iD1 = 1.f / D1, iD2 = 1.f / D2;
+        const float nvy = (MASS * vy * vx + K1 * r - K2 * de * vx - K3 * vx * vx * r) * iD1;
+        const float nr = (-I_z * r * vx - K1 * vy + K5 * de * vx) * iD2;
+        float sp, cp;
+        sincosf(dphi, &sp, &cp);
+        const float dvy_vx = (MASS * vy - K2 * de - 2.f * K3 * vx * r - nvy * MASS) * iD1;
+        const float dvy_vy = MASS * vx * iD1;
+        const float dvy_r = (K1 - K3 * vx * vx) * iD1;
+        const float dvy_de = -K2 * vx * iD1;
+        const float dr_vx = (-I_z * r + K5 * de + nr * I_z) * iD2;
+        const float dr_vy = -K1 * iD2;
+        const float dr_r = -I_z * vx * iD2;
+        const float dr_de = K5 * vx * iD2;
+        g[0] = l_vx + l_vy * dvy_vx + l_r * dr_vx + l_dy * TAU * sp + l_x * TAU * cp + rho * (-0.02f * (vx - 20.f));
+        g[1] = l_vx * TAU * r + l_vy * dvy_vy + l_r * dr_vy + l_dy * TAU * cp - l_x * TAU * sp;
+        g[2] = l_vx * TAU * vy + l_vy * dvy_r + l_r * dr_r + l_dphi * TAU + rho * (-0.04f * r);
+        g[3] = l_dy + rho * (-0.08f * dy);
+        g[4] = l_dphi + l_dy * TAU * (vx * cp - vy * sp) - l_x * TAU * (vx * sp + vy * cp) + rho * (-0.2f * dphi);
+        g[5] = l_x;
+        ga[0] = (l_vy * dvy_de + l_r * dr_de + rho * (-10.f * de)) * S0;
+        ga[1] = (l_vx * TAU + rho * (-0.1f * ax)) * S1;
+        (void)onext;
+    }
+};
+
+struct Pendulum {
+    static constexpr int OBS = 4, ACT = 1;
+    // inverted_pendulum_model.py:18-26,38-44: m = 9.42, m1 = 4.89, m2 = 0, l1 = 0.6
+    static constexpr float D1c = 9.42f + 4.89f, D2c = 0.5f * 4.89f * 0.6f, D4c = (1.f / 3.f) * 4.89f * 0.6f * 0.6f;
+    static constexpr float F1c = 0.5f * 4.89f * 0.6f * 9.81f, TAU = 0.04f;
+
+    __device__ static void step(const float (&o)[8], const float (&a)[2], float eps, float (&on)[8], float& rew) {
+        const float p = o[0], th = o[1], pd = o[2], thd = o[3];
+        const float u = 100.f * a[0];                                       // action_trans :96-97
+        float sn, c;
+        sincosf(th, &sn, &c);
+        const float idet = 1.f / (D1c * D4c - D2c * D2c * c * c);          // closed-form 2x2 inverse (:53)
+        const float F1 = D2c * sn * thd * thd + u, F2 = F1c * sn;
+        const float pdd = (D4c * F1 - D2c * c * F2) * idet;
+        const float thdd = (-D2c * c * F1 + D1c * F2) * idet;
+        on[0] = p + TAU * pd + (0.1f + 0.5f * eps);                         // :57,:61
+        on[1] = th + TAU * thd;
+        on[2] = pd + TAU * pdd;
+        on[3] = thd + TAU * thdd;
+        rew = -(0.01f * on[0] * on[0] + on[1] * on[1]) - (1e-3f * on[2] * on[2] + 1e-3f * on[3] * on[3]);   // :66-73,:93
+    }
+
+    __device__ static void vjp(const float (&o)[8], const float (&a)[2], const float (&onext)[8], const float (&lam_in)[8],
+                               float rho, float (&g)[8], float (&ga)[2]) {
+        // the reward is taken on the NEW (noisy) state: fold it into the adjoint of the new state first
+        const float l_p = lam_in[0] + rho * (-0.02f * onext[0]);
+        const float l_th = lam_in[1] + rho * (-2.f * onext[1]);
+        const float l_pd = lam_in[2] + rho * (-2e-3f * onext[2]);
+        const float l_thd = lam_in[3] + rho * (-2e-3f * onext[3]);
+        const float th = o[1], thd = o[3];
+        const float u = 100.f * a[0];
+        float sn, c;
+        sincosf(th, &sn, &c);
+        const float det = D1c * D4c - D2c * D2c * c * c, idet = 1.f / det;
+        const float F1 = D2c * sn * thd * thd + u, F2 = F1c * sn;
+        const float pdd = (D4c * F1 - D2c * c * F2) * idet;
+        const float thdd = (-D2c * c * F1 + D1c * F2) * idet;
+        const float ddet_th = 2.f * D2c * D2c * c * sn;
+        const float dF1_th = D2c * c * thd * thd, dF1_thd = 2.f * D2c * sn * thd, dF2_th = F1c * c;
+        const float dpdd_th = (D4c * dF1_th + D2c * sn * F2 - D2c * c * dF2_th - pdd * ddet_th) * idet;
+        const float dthdd_th = (D2c * sn * F1 - D2c * c * dF1_th + D1c * dF2_th - thdd * ddet_th) * idet;
+        const float dpdd_thd = D4c * dF1_thd * idet, dthdd_thd = -D2c * c * dF1_thd * idet;
+        const float dpdd_u = D4c * idet, dthdd_u = -D2c * c * idet;
+        g[0] = l_p;
+        g[1] = l_th + TAU * (l_pd * dpdd_th + l_thd * dthdd_th);
+        g[2] = l_p * TAU + l_pd;
+        g[3] = l_th * TAU + l_thd + TAU * (l_pd * dpdd_thd + l_thd * dthdd_thd);
+        ga[0] = 100.f * TAU * (l_pd * dpdd_u + l_thd * dthdd_u);
+        ga[1] = 0.f;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// forward sweep
+// ---------------------------------------------------------------------------------------------------------------
+struct RollArgs {
+    const float* policy;
+    int rows, M, n;                     // R = rows * M trajectories, horizon n
+    float obs_scale[8];
+    float rew_scale, rew_shift, gamma;
+    int out_tanh;
+    float out_scale;
+    const float* obs0;                  // [rows][OBS]
+    const float* act0;                  // nullable [rows][ACT]: first action given (NADP Q-target rollout)
+    const float* eps;                   // [n][R]
+    float *H1, *H2;                     // nullable G16 stashes, group index t*ngroups + g
+    float* SA;                          // nullable [(n+1)][R][SAW]: obs | action of every step
+    int sel[MAXSEL], n_sel;
+    float* XQ;                          // [n_sel][R][OBS+ACT] critic inputs (scaled obs | action) at the selected slices
+    float* GK;                          // [n_sel][R] discounted reward sums G_k
+};
+
+template <class ENV>
+__global__ void __launch_bounds__(NTHREAD, 2) k_rollout_fwd(const RollArgs a) {
+    constexpr int OBS = ENV::OBS, ACT = ENV::ACT, QIN = OBS + ACT;
+    __shared__ __attribute__((aligned(16))) float smem[GROUP * LDA + GROUP * XS + NWAVE * GROUP * MAXOUT];
+    float* sA = smem;
+    float* sX = sA + GROUP * LDA;
+    float* sPart = sX + GROUP * XS;
+    const Lane L;
+    const int tid = threadIdx.x;
+    const Net net = make_net(a.policy, OBS, 2 * ACT);
+    float w2[128];
+    SmallRegs<OBS, ACT> r;
+    load_w2_fwd(net.W2, L, w2);
+    load_small<OBS, ACT>(net, L, r);
+    const long R = (long)a.rows * a.M;
+    const long ngroups = (R + GROUP - 1) / GROUP;
+    for (long g = blockIdx.x; g < ngroups; g += gridDim.x) {
+        const long tr = g * GROUP + tid;               // this lane's trajectory (tid < 16 only)
+        const bool own = tid < GROUP, live = own && tr < R;
+        float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        float G = 0.f;
+        if (live) {
+            const float* src = a.obs0 + (tr % a.rows) * OBS;
+#pragma unroll
+            for (int i = 0; i < OBS; ++i) o[i] = src[i];
+        }
+        for (int t = 0; t <= a.n; ++t) {
+            if (own) {
+#pragma unroll
+                for (int i = 0; i < XS; ++i) sX[tid * XS + i] = i < OBS ? o[i] * a.obs_scale[i] : 0.f;
+            }
+            __syncthreads();
+            float h1[2][4], h2[2][4];
+            forward_group<OBS, ACT>(sX, sA, sPart, L, w2, r, h1, h2);
+            if (a.H1) {
+                stash_store(a.H1, (long)t * ngroups + g, L, h1);
+                stash_store(a.H2, (long)t * ngroups + g, L, h2);
+            }
+            if (own) {
+                float act[2] = {0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < ACT; ++k) {
+                    const float z = out_preact(sPart, net.b3, tid, k);
+                    act[k] = a.out_tanh ? a.out_scale * tanhf(z) : z;
+                }
+                if (t == 0 && a.act0 && live) {
+#pragma unroll
+                    for (int k = 0; k < ACT; ++k) act[k] = a.act0[(tr % a.rows) * ACT + k];
+                }
+                if (live) {
+                    if (a.SA) {
+                        float* rec = a.SA + ((long)t * R + tr) * SAW;
+#pragma unroll
+                        for (int i = 0; i < OBS; ++i) rec[i] = o[i];
+#pragma unroll
+                        for (int k = 0; k < ACT; ++k) rec[OBS + k] = act[k];
+                    }
+                    for (int ks = 0; ks < a.n_sel; ++ks)
+                        if (a.sel[ks] == t) {
+                            float* xq = a.XQ + ((long)ks * R + tr) * QIN;
+#pragma unroll
+                            for (int i = 0; i < OBS; ++i) xq[i] = o[i] * a.obs_scale[i];
+#pragma unroll
+                            for (int k = 0; k < ACT; ++k) xq[OBS + k] = act[k];
+                            a.GK[(long)ks * R + tr] = G;
+                        }
+                }
+                if (t < a.n) {
+                    const float e = live ? a.eps[(long)t * R + tr] : 0.f;
+                    float on[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    float rew;
+                    ENV::step(o, act, e, on, rew);
+                    G += powf(a.gamma, (float)t) * ((rew + a.rew_shift) * a.rew_scale);   // mpg_learner.py:245
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) o[i] = on[i];
+                }
+            }
+            // the next iteration's sX write is ordered behind this iteration's reads by forward_group's barriers
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// returns, statistics and the critic-side seeds of the reverse sweep
+// ---------------------------------------------------------------------------------------------------------------
+// per trajectory: ret_k = G_k + gamma^k * Q_k.  M-mean over the tiles, then over this GPU's rows: sum and sum of
+// squares per slice (mpg_learner.py:266-274).  dyq[k][r] = dL/dQ_k = -w_k * gamma^k * inv_b_global / M.
+struct RetCoef {
+    float gpow[MAXSEL];   // gamma^k
+    float coef[MAXSEL];   // -w_k * gamma^k * inv_b_global / M
+};
+__global__ void __launch_bounds__(1024) k_returns(int rows, int M, int n_sel, const RetCoef rc,
+                                                  const float* __restrict__ Q, const float* __restrict__ GK,
+                                                  float* __restrict__ dyq, float* __restrict__ ret_sum,
+                                                  float* __restrict__ ret_sqsum) {
+    __shared__ float red[2][1024];
+    const long R = (long)rows * M;
+    for (int k = 0; k < n_sel; ++k) {
+        float s = 0.f, s2 = 0.f;
+        for (int b = threadIdx.x; b < rows; b += 1024) {
+            float m = 0.f;
+            for (int mm = 0; mm < M; ++mm) {
+                const long tr = (long)mm * rows + b;
+                m += GK[k * R + tr] + rc.gpow[k] * Q[k * R + tr];
+                dyq[k * R + tr] = rc.coef[k];
+            }
+            m /= (float)M;
+            s += m;
+            s2 += m * m;
+        }
+        red[0][threadIdx.x] = s;
+        red[1][threadIdx.x] = s2;
+        __syncthreads();
+        for (int w = 512; w > 0; w >>= 1) {
+            if ((int)threadIdx.x < w) {
+                red[0][threadIdx.x] += red[0][threadIdx.x + w];
+                red[1][threadIdx.x] += red[1][threadIdx.x + w];
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            ret_sum[k] = red[0][0];
+            ret_sqsum[k] = red[1][0];
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// reverse sweep
+// ---------------------------------------------------------------------------------------------------------------
+struct RollBwdArgs {
+    const float* policy;
+    int rows, M, n;
+    float obs_scale[8];
+    int out_tanh;
+    float out_scale;
+    const float *H1, *H2, *SA;
+    int sel[MAXSEL], n_sel;
+    const float* GXQ;                   // [n_sel][R][OBS+ACT] dL/d(critic input) at the selected slices
+    float rho[MAXN];                    // dL/d(raw reward of step t)
+    int stash_all;                      // 0: parameter gradient through step 0 only (MPG); 1: every step (NADP)
+    float *DZ1, *DZ2, *DZ3;             // stashes for the weight gradient: T = stash_all ? n+1 : 1 steps
+};
+
+template <class ENV>
+__global__ void __launch_bounds__(NTHREAD, 2) k_rollout_bwd(const RollBwdArgs a) {
+    constexpr int OBS = ENV::OBS, ACT = ENV::ACT, QIN = OBS + ACT;
+    __shared__ __attribute__((aligned(16))) float smem[GROUP * LDA + GROUP * MAXOUT + NWAVE * GROUP * XS];
+    float* sA = smem;
+    float* sD3 = sA + GROUP * LDA;
+    float* sPartX = sD3 + GROUP * MAXOUT;
+    const Lane L;
+    const int tid = threadIdx.x;
+    const Net net = make_net(a.policy, OBS, 2 * ACT);
+    float w2t[128];
+    SmallRegs<OBS, ACT> r;
+    load_w2_bwd(net.W2, L, w2t);
+    load_small<OBS, ACT>(net, L, r);
+    const long R = (long)a.rows * a.M;
+    const long ngroups = (R + GROUP - 1) / GROUP;
+    for (long g = blockIdx.x; g < ngroups; g += gridDim.x) {
+        const long tr = g * GROUP + tid;
+        const bool own = tid < GROUP, live = own && tr < R;
+        float lam_next[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // dL/d(obs_{t+1})
+        float lam[8];
+        for (int t = a.n; t >= 0; --t) {
+            if (own) {
+                float ga[2] = {0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < 8; ++i) lam[i] = 0.f;
+                float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, act[2] = {0.f, 0.f};
+                if (live) {
+                    const float* rec = a.SA + ((long)t * R + tr) * SAW;
+#pragma unroll
+                    for (int i = 0; i < OBS; ++i) o[i] = rec[i];
+#pragma unroll
+                    for (int k = 0; k < ACT; ++k) act[k] = rec[OBS + k];
+                    if (t < a.n) {
+                        float on[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        const float* recn = a.SA + ((long)(t + 1) * R + tr) * SAW;
+#pragma unroll
+                        for (int i = 0; i < OBS; ++i) on[i] = recn[i];
+                        ENV::vjp(o, act, on, lam_next, a.rho[t], lam, ga);
+                    }
+                    for (int ks = 0; ks < a.n_sel; ++ks)
+                        if (a.sel[ks] == t) {
+                            const float* gx = a.GXQ + ((long)ks * R + tr) * QIN;
+#pragma unroll
+                            for (int i = 0; i < OBS; ++i) lam[i] += gx[i] * a.obs_scale[i];
+#pragma unroll
+                            for (int k = 0; k < ACT; ++k) ga[k] += gx[OBS + k];
+                        }
+                }
+#pragma unroll
+                for (int k = 0; k < ACT; ++k) {
+                    float d = ga[k];
+                    if (a.out_tanh) {
+                        const float th = act[k] / a.out_scale;
+                        d *= a.out_scale * (1.f - th * th);
+                    }
+                    sD3[tid * MAXOUT + k] = d;
+                    if (live && a.DZ3 && (a.stash_all || t == 0))
+                        a.DZ3[((long)(a.stash_all ? t : 0) * R + tr) * ACT + k] = d;
+                }
+            }
+            float h1[2][4], h2[2][4], dz1[2][4], dz2[2][4];
+            stash_load(a.H1, (long)t * ngroups + g, L, h1);
+            stash_load(a.H2, (long)t * ngroups + g, L, h2);
+            __syncthreads();
+            if (t > 0)
+                backward_group<OBS, ACT, true>(sD3, sA, sPartX, L, w2t, r, h1, h2, dz1, dz2);
+            else
+                backward_group<OBS, ACT, false>(sD3, sA, sPartX, L, w2t, r, h1, h2, dz1, dz2);
+            if (a.DZ1 && (a.stash_all || t == 0)) {
+                const long sg = (long)(a.stash_all ? t : 0) * ngroups + g;
+                stash_store(a.DZ1, sg, L, dz1);
+                stash_store(a.DZ2, sg, L, dz2);
+            }
+            if (own) {
+                if (t > 0) {
+#pragma unroll
+                    for (int i = 0; i < OBS; ++i) lam[i] += dx_reduce(sPartX, tid, i) * a.obs_scale[i];
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) lam_next[i] = lam[i];
+            }
+            // next iteration: sD3 is rewritten by wave 0 only after it has passed backward_group's final barrier,
+            // and read by the others only after the __syncthreads above -> no extra barrier needed.
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------
+inline char* align256(char* p) { return reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(p) + 255) & ~uintptr_t(255)); }
+struct Carver {
+    char *p, *end;
+    Carver(void* ws, size_t bytes) : p(align256((char*)ws)), end((char*)ws + bytes) {}
+    float* take(size_t nfloat) {
+        float* r = reinterpret_cast<float*>(p);
+        p = align256(p + nfloat * sizeof(float));
+        return r;
+    }
+};
+inline size_t pad256(size_t nfloat) { return ((nfloat * sizeof(float) + 255) & ~size_t(255)) + 256; }
+
+inline bool cfg_ok(const mpg_cfg_t* c) {
+    return c && ((c->obs_dim == 6 && c->act_dim == 2 && c->env_kind == MPG_ENV_PATH_TRACKING) ||
+                 (c->obs_dim == 4 && c->act_dim == 1 && c->env_kind == MPG_ENV_INVERTED_PENDULUM));
+}
+
+void fill_roll(RollArgs& a, const mpg_cfg_t* cfg, const float* policy, int rows, int M, int n) {
+    a.policy = policy; a.rows = rows; a.M = M; a.n = n;
+    for (int i = 0; i < 8; ++i) a.obs_scale[i] = i < cfg->obs_dim ? cfg->obs_scale[i] : 1.f;
+    a.rew_scale = cfg->rew_scale; a.rew_shift = cfg->rew_shift; a.gamma = cfg->gamma;
+    const bool ranged = cfg->action_range > 0.f;
+    a.out_tanh = (cfg->policy_out_act == MPG_ACT_TANH || ranged) ? 1 : 0;
+    a.out_scale = ranged ? cfg->action_range : 1.f;
+}
+
+int grid_for(long ngroups) { return (int)(ngroups < 256 ? ngroups : 256); }
+
+struct PgLayout {
+    size_t h, sa, xq, gk, q, dyq, hq, gxq, dz, dz3, slabs, small, total;
+};
+
+PgLayout pg_layout(const mpg_cfg_t* cfg, int rows, int M, int n, int n_sel, int stash_all) {
+    PgLayout l;
+    const long R = (long)rows * M;
+    const int qin = cfg->obs_dim + cfg->act_dim;
+    const int T = stash_all ? n + 1 : 1;
+    l.h = (size_t)(n + 1) * stash_floats(R);
+    l.sa = (size_t)(n + 1) * R * SAW;
+    l.xq = (size_t)n_sel * R * qin;
+    l.gk = l.q = l.dyq = (size_t)n_sel * R;
+    l.hq = stash_floats(n_sel * R);
+    l.gxq = (size_t)n_sel * R * qin;
+    l.dz = (size_t)T * stash_floats(R);
+    l.dz3 = (size_t)T * R * cfg->act_dim;
+    l.slabs = wgrad_workspace_floats((int)(T * stash_floats(R) / H), cfg->obs_dim, 2 * cfg->act_dim);
+    l.small = 64;
+    l.total = 2 * pad256(l.h) + pad256(l.sa) + pad256(l.xq) + 3 * pad256(l.gk) + 2 * pad256(l.hq) + pad256(l.gxq) +
+              2 * pad256(l.dz) + pad256(l.dz3) + pad256(l.slabs) + 2 * pad256(l.small);
+    return l;
+}
+
+}  // namespace
+
+extern "C" size_t mpg_rollout_pg_workspace_bytes(const mpg_cfg_t* cfg, int rows, int M, int n, int n_select,
+                                                 int all_steps_param_grad) {
+    if (!cfg_ok(cfg) || rows <= 0 || M <= 0 || n <= 0 || n >= MAXN || n_select <= 0 || n_select > MAXSEL) return 0;
+    return pg_layout(cfg, rows, M, n, n_select, all_steps_param_grad).total;
+}
+
+extern "C" int mpg_rollout_pg(const mpg_cfg_t* cfg, const float* policy_params, const float* q1_params, int rows, int M,
+                              int n, const int* select, int n_select, const float* w, const float* obs0, const float* eps,
+                              float inv_b_global, int all_steps_param_grad, float* ret_sum, float* ret_sqsum, float* grad,
+                              void* ws, size_t ws_bytes, mpg_stream_t stream) {
+    MPG_REQUIRE(cfg_ok(cfg), "mpg_rollout_pg: unsupported cfg (obs/act dims, env_kind)");
+    MPG_REQUIRE(policy_params && q1_params && select && w && obs0 && eps && ret_sum && ret_sqsum && grad && ws,
+                "mpg_rollout_pg: null pointer");
+    MPG_REQUIRE(rows > 0 && M > 0 && n > 0 && n < MAXN && n_select > 0 && n_select <= MAXSEL, "mpg_rollout_pg: bad sizes");
+    const long R = (long)rows * M;
+    MPG_REQUIRE(!all_steps_param_grad || R % GROUP == 0, "mpg_rollout_pg: all_steps_param_grad needs rows*M %% 16 == 0");
+    for (int k = 0; k < n_select; ++k) MPG_REQUIRE(select[k] >= 0 && select[k] <= n, "mpg_rollout_pg: slice out of range");
+    const PgLayout l = pg_layout(cfg, rows, M, n, n_select, all_steps_param_grad);
+    if (ws_bytes < l.total) {
+        mpg_set_error("mpg_rollout_pg: workspace too small (%zu < %zu)", ws_bytes, l.total);
+        return MPG_EWORKSPACE;
+    }
+    hipStream_t s = mpg_stream(stream);
+    const int od = cfg->obs_dim, ad = cfg->act_dim, qin = od + ad;
+    Carver cv(ws, ws_bytes);
+    float* H1 = cv.take(l.h); float* H2 = cv.take(l.h);
+    float* SA = cv.take(l.sa); float* XQ = cv.take(l.xq);
+    float* GK = cv.take(l.gk); float* Q = cv.take(l.q); float* DYQ = cv.take(l.dyq);
+    float* HQ1 = cv.take(l.hq); float* HQ2 = cv.take(l.hq); float* GXQ = cv.take(l.gxq);
+    float* DZ1 = cv.take(l.dz); float* DZ2 = cv.take(l.dz); float* DZ3 = cv.take(l.dz3);
+    float* slabs = cv.take(l.slabs);
+
+    // ---- forward sweep ----
+    RollArgs fa;
+    fill_roll(fa, cfg, policy_params, rows, M, n);
+    fa.obs0 = obs0; fa.act0 = nullptr; fa.eps = eps; fa.H1 = H1; fa.H2 = H2; fa.SA = SA;
+    fa.n_sel = n_select;
+    for (int k = 0; k < MAXSEL; ++k) fa.sel[k] = k < n_select ? select[k] : -1;
+    fa.XQ = XQ; fa.GK = GK;
+    const long ngroups = (R + GROUP - 1) / GROUP;
+    if (cfg->env_kind == MPG_ENV_PATH_TRACKING)
+        hipLaunchKernelGGL((k_rollout_fwd<PathTracking>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, fa);
+    else
+        hipLaunchKernelGGL((k_rollout_fwd<Pendulum>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, fa);
+    MPG_CHECK_LAUNCH("k_rollout_fwd");
+
+    // ---- critic at the selected slices: values, returns, input gradients ----
+    OutSpec lin; lin.out_tanh = 0; lin.out_scale = 1.f; lin.sigma = 0.f; lin.seed = lin.ctr = 0;
+    const int RQ = (int)(n_select * R);
+    int rc = launch_forward(q1_params, qin, 1, 1, RQ, xspec(XQ, qin, nullptr, 0, nullptr, 0), lin, Q, 1, HQ1, HQ2, s);
+    if (rc) return rc;
+    RetCoef rcf;
+    for (int k = 0; k < MAXSEL; ++k) rcf.gpow[k] = rcf.coef[k] = 0.f;
+    const float c = inv_b_global / (float)M;
+    float rho[MAXN];
+    for (int t = 0; t < MAXN; ++t) rho[t] = 0.f;
+    for (int k = 0; k < n_select; ++k) {
+        rcf.gpow[k] = powf(cfg->gamma, (float)select[k]);                 // tf.pow(gamma, k) in float32, mpg_learner.py:251
+        rcf.coef[k] = -w[k] * rcf.gpow[k] * c;
+        for (int t = 0; t < select[k]; ++t) rho[t] += -w[k] * c * powf(cfg->gamma, (float)t) * cfg->rew_scale;
+    }
+    hipLaunchKernelGGL(k_returns, dim3(1), dim3(1024), 0, s, rows, M, n_select, rcf, Q, GK, DYQ, ret_sum, ret_sqsum);
+    MPG_CHECK_LAUNCH("k_returns");
+    rc = launch_backward(q1_params, qin, 1, 1, RQ, DYQ, 1, nullptr, 0, 0, 1.f, HQ1, HQ2, nullptr, nullptr, nullptr, GXQ, qin, s);
+    if (rc) return rc;
+
+    // ---- reverse sweep ----
+    RollBwdArgs ba;
+    ba.policy = policy_params; ba.rows = rows; ba.M = M; ba.n = n;
+    for (int i = 0; i < 8; ++i) ba.obs_scale[i] = fa.obs_scale[i];
+    ba.out_tanh = fa.out_tanh; ba.out_scale = fa.out_scale;
+    ba.H1 = H1; ba.H2 = H2; ba.SA = SA; ba.n_sel = n_select;
+    for (int k = 0; k < MAXSEL; ++k) ba.sel[k] = fa.sel[k];
+    ba.GXQ = GXQ;
+    for (int t = 0; t < MAXN; ++t) ba.rho[t] = rho[t];
+    ba.stash_all = all_steps_param_grad ? 1 : 0;
+    ba.DZ1 = DZ1; ba.DZ2 = DZ2; ba.DZ3 = DZ3;
+    if (cfg->env_kind == MPG_ENV_PATH_TRACKING)
+        hipLaunchKernelGGL((k_rollout_bwd<PathTracking>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, ba);
+    else
+        hipLaunchKernelGGL((k_rollout_bwd<Pendulum>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, ba);
+    MPG_CHECK_LAUNCH("k_rollout_bwd");
+
+    // ---- policy weight gradient from the stashes (step 0 only, or every step for NADP) ----
+    const int T = all_steps_param_grad ? n + 1 : 1;
+    XSpec xs = xspec(SA, od, nullptr, 0, cfg->obs_scale, od);
+    xs.ld0 = SAW;
+    return launch_wgrad(od, 2 * ad, ad, (int)(T * R), xs, H1, H2, DZ1, DZ2, DZ3, grad, slabs, s);
+}

@@ -130,3 +130,46 @@ def q_loss_grad(cfg, q_params, obs, act, y, inv_b_global=None, grad_out=None, lo
            L.ptr(_f32(act)), L.ptr(_f32(y)), L.c_float(inv_b_global if inv_b_global is not None else 1.0 / rows),
            L.ptr(loss), L.ptr(grad), L.ptr(td), L.ptr(ws), L.c_size_t(ws.numel()), L.stream())
     return loss, grad, td
+
+
+def rollout_pg(cfg, policy_params, q1_params, obs0, eps, select, w, M=1, inv_b_global=None, all_steps_param_grad=False,
+               grad_out=None, stats_out=None):
+    """mpg_rollout_pg: n-step model rollout + (mixed) policy gradient.  Returns (ret_sum, ret_sqsum, grad)."""
+    rows = obs0.shape[0]
+    n = eps.shape[0]
+    assert eps.shape[1] == rows * M
+    dev = obs0.device
+    ns = len(select)
+    grad = grad_out if grad_out is not None else torch.empty(policy_size(cfg), dtype=torch.float32, device=dev)
+    stats = stats_out if stats_out is not None else torch.empty(2 * ns, dtype=torch.float32, device=dev)
+    sel = (ctypes.c_int * ns)(*[int(k) for k in select])
+    wv = (ctypes.c_float * ns)(*[float(x) for x in w])
+    nb = L.lib().mpg_rollout_pg_workspace_bytes(ctypes.byref(cfg), L.c_int(rows), L.c_int(M), L.c_int(n), L.c_int(ns),
+                                                L.c_int(int(all_steps_param_grad)))
+    if nb == 0:
+        raise L.MpgError('mpg_rollout_pg_workspace_bytes: unsupported configuration')
+    ws = workspace(dev, nb, slot=1)
+    L.call('mpg_rollout_pg', ctypes.byref(cfg), L.ptr(_f32(policy_params)), L.ptr(_f32(q1_params)), L.c_int(rows),
+           L.c_int(M), L.c_int(n), sel, L.c_int(ns), wv, L.ptr(_f32(obs0)), L.ptr(_f32(eps)),
+           L.c_float(inv_b_global if inv_b_global is not None else 1.0 / rows), L.c_int(int(all_steps_param_grad)),
+           L.ptr(stats[:ns]), L.ptr(stats[ns:]), L.ptr(grad), L.ptr(ws), L.c_size_t(ws.numel()), L.stream())
+    return stats[:ns], stats[ns:], grad
+
+
+def clip_by_global_norm(grad, seg_sizes, clip, norms_out=None, nonfinite=None):
+    ns = len(seg_sizes)
+    norms = norms_out if norms_out is not None else torch.empty(ns, dtype=torch.float32, device=grad.device)
+    segs = (ctypes.c_int * ns)(*[int(s) for s in seg_sizes])
+    L.call('mpg_clip_by_global_norm', L.ptr(_f32(grad)), segs, L.c_int(ns), L.c_float(clip), L.ptr(norms),
+           L.ptr(nonfinite), L.stream())
+    return norms
+
+
+def adam_polyak(w, m, v, target, grad, seg_sizes, lr_t, do_adam, do_polyak, tau, skip_flag=None):
+    ns = len(seg_sizes)
+    segs = (ctypes.c_int * ns)(*[int(s) for s in seg_sizes])
+    lr = (ctypes.c_float * ns)(*[float(x) for x in lr_t])
+    da = (ctypes.c_int * ns)(*[int(x) for x in do_adam])
+    dp = (ctypes.c_int * ns)(*[int(x) for x in do_polyak])
+    L.call('mpg_adam_polyak', L.ptr(_f32(w)), L.ptr(_f32(m)), L.ptr(_f32(v)), L.ptr(target), L.ptr(_f32(grad)), segs,
+           L.c_int(ns), lr, da, dp, L.c_float(tau), L.ptr(skip_flag), L.stream())
