@@ -174,6 +174,27 @@ int mpg_adam_polyak(float* w, float* m, float* v, float* target, const float* gr
                     int n_seg, const float* lr_t, const int* do_adam, const int* do_polyak, float tau,
                     const int* skip_flag, mpg_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * On-device replay ring (K9, uniform part)  - buffer.py:21-91
+ * ---------------------------------------------------------------------------------------------- */
+
+/* ReplayBuffer.add_batch (buffer.py:46-55,80-82): writes n transitions at ring positions
+ * (next_idx + i) % capacity.  Ring arrays: obs [cap][obs_dim], act [cap][act_dim], rew [cap],
+ * obs2 [cap][obs_dim], done [cap] bytes - RAW observations and rewards. */
+int mpg_replay_add(int capacity, int next_idx, int n, int obs_dim, int act_dim, const float* s_obs,
+                   const float* s_act, const float* s_rew, const float* s_obs2, const uint8_t* s_done,
+                   float* obs, float* act, float* rew, float* obs2, uint8_t* done, mpg_stream_t stream);
+
+/* ReplayBuffer._encode_sample (buffer.py:57-68): gathers rows idx[i] of the ring; o_done (nullable) is
+ * written as float32 like the learners' cast (mpg_learner.py:71). */
+int mpg_replay_gather(int n, const int* idx, int obs_dim, int act_dim, const float* obs, const float* act,
+                      const float* rew, const float* obs2, const uint8_t* done, float* o_obs, float* o_act,
+                      float* o_rew, float* o_obs2, float* o_done, mpg_stream_t stream);
+
+/* ReplayBuffer.sample_idxes (buffer.py:70-71): n indices uniform in [0, n_storage), with replacement,
+ * from Philox(seed, ctr). */
+int mpg_uniform_indices(int n_storage, int n, uint64_t seed, uint64_t ctr, int* idx, mpg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -48,10 +48,12 @@ class PathTrackingEnv(object):
             self._initialised = True
             return self.obs
         mask = self.done if self._initialised else None
+        obs = torch.empty_like(self.obs)        # never write into a tensor already handed to the caller
         L.call('mpg_env_reset', L.c_int(0), L.c_int(self.num_agent), L.ptr(self._state), L.ptr(mask),
-               L.c_u64(self.seed), L.c_u64(self._ctr), L.ptr(self.obs), L.stream())
+               L.c_u64(self.seed), L.c_u64(self._ctr), L.ptr(obs), L.stream())
         self._ctr += 1
         self._initialised = True
+        self.obs = obs
         return self.obs
 
     def step(self, action):

@@ -1,0 +1,195 @@
+"""Learners - device mirrors of learners/mpg_learner.py (MPGLearner), learners/nadp.py (NADPLearner) and
+learners/td3.py (TD3Learner): same constructor signature `(policy_cls, args)`, same methods the optimizer calls
+(`set_weights`, `compute_gradient(batch5, rb, indexes, iteration)`, `get_stats`, `get_info_for_buffer`), same
+output order `q1 (+q2) + policy`.
+
+Data-parallel form: each process computes sum-reduced, UN-clipped gradient partials already scaled
+by 1/B_global into one flat buffer [grads | stats]; ONE all-reduce; then per-network tf.clip_by_global_norm
+(non-linear, must follow the reduce).  On one process this is exactly the reference computation."""
+import numpy as np
+import torch
+
+from . import dist as D
+from . import ops
+from .envs import PathTrackingEnv
+
+
+def rule_based_weights(ite, total_ite, eta, select):
+    """MPGLearner.rule_based_weights, mpg_learner.py:384-399 (float32 like the TF graph)."""
+    f = np.float32
+    lam = f(1. - eta) + f(2. * eta / total_ite) * f(ite)
+    lam = f(min(max(lam, f(0.)), f(1.5)))
+    if lam < 1.:
+        biases = np.array([np.power(lam, f(i)) for i in select], dtype=f)
+    else:
+        mx = max(select)
+        biases = np.array([np.power(f(2.) - lam, f(mx - i)) for i in select], dtype=f)
+    inv = (f(1.) / (biases + f(1e-8))).astype(f)
+    e = np.exp(inv - inv.max()).astype(f)
+    return (e / e.sum()).astype(f)
+
+
+N_STATS = 16     # floats appended to the gradient buffer and summed by the same all-reduce
+
+
+class _LearnerBase(object):
+    def __init__(self, policy_cls, args, device='cuda'):
+        self.args = args
+        self.device = torch.device(device)
+        self.batch_size = args.replay_batch_size
+        self.policy_with_value = policy_cls(**vars(args), device=device)
+        self.cfg = self.policy_with_value.cfg
+        self.batch_data = {}
+        self.counter = 0
+        self.num_batch_reuse = getattr(args, 'num_batch_reuse', 1)
+        self.stats = {}
+        self.info_for_buffer = {}
+        pw = self.policy_with_value
+        self.n_grad = int(pw.offsets[-1])
+        self.flat = torch.zeros(self.n_grad + N_STATS, dtype=torch.float32, device=self.device)
+        self.norms = torch.zeros(len(pw.names), dtype=torch.float32, device=self.device)
+        self._noise_gen = torch.Generator(device=self.device)
+        self._noise_gen.manual_seed(int(getattr(args, 'seed', 0)) + 12345)
+
+    # ---- optimizer-facing API ----
+    def get_stats(self):
+        return {k: (v.item() if isinstance(v, torch.Tensor) and v.numel() == 1 else
+                    (v.tolist() if isinstance(v, torch.Tensor) else v)) for k, v in self.stats.items()}
+
+    def get_info_for_buffer(self):
+        return self.info_for_buffer
+
+    def get_weights(self):
+        return self.policy_with_value.get_weights()
+
+    def set_weights(self, weights):
+        if weights is self.policy_with_value or weights is None:
+            return
+        return self.policy_with_value.set_weights(weights)
+
+    def share_policy(self, policy):
+        """Single-process mode: learner and worker use ONE PolicyWithQs instead of copying 1.6 MB of weights every
+        iteration (optimizer.py:345 `learner.set_weights(worker.get_weights())` becomes a no-op)."""
+        self.policy_with_value = policy
+        self.cfg = policy.cfg
+
+    def set_ppc_params(self, params):
+        pass
+
+    def grad(self, name):
+        pw = self.policy_with_value
+        i = pw.names.index(name)
+        return self.flat[pw.offsets[i]:pw.offsets[i + 1]]
+
+    def _get_batch(self, batch_data):
+        self.batch_data = {k: batch_data[i].to(self.device, torch.float32).contiguous()
+                           for i, k in enumerate(('batch_obs', 'batch_actions', 'batch_rewards', 'batch_obs_tp1', 'batch_dones'))}
+
+    def _finish(self, iteration, clip):
+        """all-reduce, clip per network, expose the reference's list view."""
+        pw = self.policy_with_value
+        D.all_reduce_sum_(self.flat)
+        pw.nonfinite.zero_()
+        ops.clip_by_global_norm(self.flat[:self.n_grad], pw.sizes, clip, norms_out=self.norms, nonfinite=pw.nonfinite)
+        self.flat_grad = self.flat[:self.n_grad]
+        out = []
+        for i, n in enumerate(pw.names):
+            out += pw._as_list(self.flat[pw.offsets[i]:pw.offsets[i + 1]], n)
+        self.stats.update(iteration=iteration)
+        return out
+
+
+class MPGLearner(_LearnerBase):
+    def __init__(self, policy_cls, args, device='cuda'):
+        super().__init__(policy_cls, args, device)
+        self.sample_num_in_learner = args.sample_num_in_learner
+        self.M = args.M
+        self.num_rollout_list_for_policy_update = list(args.num_rollout_list_for_policy_update)
+        assert not getattr(args, 'deriv_interval_policy', False), 'deriv_interval_policy=True is a "next" row (SURVEY §8 f4)'
+        self.env = None
+        if args.learner_version == 'MPG-v1':
+            self.env = PathTrackingEnv(num_agent=self.batch_size, num_future_data=args.num_future_data, device=device)
+
+    # ---- targets ----
+    def compute_clipped_double_q_target(self):
+        """mpg_learner.py:126-134"""
+        pw, b = self.policy_with_value, self.batch_data
+        return ops.q_targets(self.cfg, pw.net('policy', True), pw.net('Q1', True), pw.net('Q2', True),
+                             b['batch_rewards'], b['batch_obs_tp1'])
+
+    def sample(self, start_obs, start_action):
+        """mpg_learner.py:109-124: n real-env steps; first action from replay, then the ONLINE policy, no noise."""
+        pw = self.policy_with_value
+        obs = start_obs
+        self.env.reset(init_obs=obs)
+        rewards = []
+        for t in range(self.sample_num_in_learner):
+            action = start_action if t == 0 else ops.policy_action(self.cfg, pw.net('policy'), obs)
+            obs, r, _, _ = self.env.step(action)
+            rewards.append(r)
+        return {'all_rewards': torch.stack(rewards).contiguous(), 'last_obs': obs}
+
+    def compute_n_step_target(self):
+        """mpg_learner.py:146-169"""
+        pw, b = self.policy_with_value, self.batch_data
+        ro = self.sample(b['batch_obs'], b['batch_actions'])
+        return ops.nstep_targets(self.cfg, pw.net('policy', True), pw.net('Q1', True), ro['all_rewards'], ro['last_obs'])
+
+    def compute_td_error(self):
+        """mpg_learner.py:136-144 (signed)."""
+        pw, b = self.policy_with_value, self.batch_data
+        y1 = ops.q_targets(self.cfg, pw.net('policy', True), pw.net('Q1', True), None, b['batch_rewards'], b['batch_obs_tp1'])
+        return y1 - pw.compute_Q1(b['batch_obs'], b['batch_actions'])
+
+    def get_batch_data(self, batch_data, rb, indexes):
+        self._get_batch(batch_data)
+        if self.args.learner_version == 'MPG-v1':
+            target = self.compute_n_step_target()
+        elif self.args.learner_version == 'MPG-v2':
+            target = self.compute_clipped_double_q_target()
+        else:
+            raise ValueError(self.args.learner_version)
+        self.batch_data['batch_targets'] = target
+        if self.args.buffer_type != 'normal':
+            self.info_for_buffer.update(dict(td_error=self.compute_td_error(), rb=rb, indexes=indexes))
+
+    def draw_model_noise(self, n, cols):
+        return torch.randn(n, cols, generator=self._noise_gen, device=self.device, dtype=torch.float32)
+
+    def compute_gradient(self, batch_data, rb, indexes, iteration, eps=None):
+        """mpg_learner.py:401-455.  Returns the list [q1 (6 arrays) (+ q2) + policy (6 arrays)] of device tensors
+        (views of one flat buffer, also available as `self.flat_grad`)."""
+        if self.counter % self.num_batch_reuse == 0:
+            self.get_batch_data(batch_data, rb, indexes)
+        self.counter += 1
+        pw, b = self.policy_with_value, self.batch_data
+        rows = b['batch_obs'].shape[0]
+        world = D.world_size()
+        inv_b = 1.0 / (rows * world)
+        ng = self.n_grad
+        stats = self.flat[ng:]
+        stats.zero_()
+        qnames = [n for n in pw.names if n != 'policy']
+        for i, nm in enumerate(qnames):
+            ops.q_loss_grad(self.cfg, pw.net(nm), b['batch_obs'], b['batch_actions'], b['batch_targets'], inv_b_global=inv_b,
+                            grad_out=self.grad(nm), loss_out=stats[i:i + 1])
+        select = self.num_rollout_list_for_policy_update
+        n = max(select)
+        ws = rule_based_weights(iteration, self.args.rule_based_bias_total_ite, self.args.eta, select)
+        if eps is None:
+            eps = self.draw_model_noise(n, rows * self.M)
+        ns = len(select)
+        ops.rollout_pg(self.cfg, pw.net('policy'), pw.net('Q1'), b['batch_obs'], eps, select, ws, M=self.M,
+                       inv_b_global=inv_b, grad_out=self.grad('policy'), stats_out=stats[2:2 + 2 * ns])
+        out = self._finish(iteration, float(self.args.gradient_clip_norm))
+        # ---- stats (mpg_learner.py:433-452); device scalars, converted lazily in get_stats() ----
+        B = rows * world
+        mean_ret = stats[2:2 + ns] / B
+        self.stats.update(dict(
+            value_mean=mean_ret[select.index(0)] if 0 in select else None,
+            policy_total_loss=-(torch.as_tensor(ws, device=self.device) * mean_ret).sum(),
+            policy_gradient_norm=self.norms[len(qnames)], q_loss1=stats[0], q_gradient_norm1=self.norms[0],
+            num_rollout_list=select, w_list=list(map(float, ws)), all_losses=-mean_ret))
+        if len(qnames) == 2:
+            self.stats.update(dict(q_loss2=stats[1], q_gradient_norm2=self.norms[1]))
+        return out

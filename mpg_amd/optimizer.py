@@ -1,0 +1,45 @@
+"""SingleProcessOffPolicyOptimizer - mirror of optimizer.py:286-397: the per-iteration order
+(sample every 10th iteration -> replay -> set_weights -> compute_gradient -> (priorities) -> NaN guard ->
+apply_gradients) is the contract; Ray / TensorBoard plumbing is out of scope.  One instance per GPU process."""
+import logging
+
+logger = logging.getLogger(__name__)
+
+
+class SingleProcessOffPolicyOptimizer(object):
+    def __init__(self, worker, learner, replay_buffer, evaluator, args, sampling_interval=10):
+        self.args = args
+        self.worker, self.learner, self.replay_buffer, self.evaluator = worker, learner, replay_buffer, evaluator
+        self.num_sampled_steps = 0
+        self.iteration = 0
+        self.sampling_interval = sampling_interval
+        self.stats = {}
+        # single process: share one PolicyWithQs between worker and learner (no 1.6 MB weight copy per iteration)
+        self.learner.share_policy(self.worker.policy_with_value)
+        while not len(self.replay_buffer) >= self.args.replay_starts:      # optimizer.py:310-313
+            sample_batch, count = self.worker.sample_with_count()
+            self.num_sampled_steps += count
+            self.replay_buffer.add_batch(sample_batch)
+
+    def get_stats(self):
+        self.stats.update(dict(num_sampled_steps=self.num_sampled_steps, iteration=self.iteration))
+        return self.stats
+
+    def step(self):
+        if self.iteration % self.sampling_interval == 0:                   # optimizer.py:332-337
+            sample_batch, count = self.worker.sample_with_count()
+            self.num_sampled_steps += count
+            self.replay_buffer.add_batch(sample_batch)
+        samples = self.replay_buffer.replay()                              # :340-341
+        self.learner.set_weights(self.worker.policy_with_value)            # :345 (shared object: no copy)
+        grads = self.learner.compute_gradient(samples[:5], self.replay_buffer, samples[-1], self.iteration)   # :349
+        if getattr(self.args, 'buffer_type', 'normal') == 'priority':     # :351-353
+            info = self.learner.get_info_for_buffer()
+            info['rb'].update_priorities(info['indexes'], info['td_error'])
+        # NaN guard (:357-361) lives on the device: the clip kernel raises a flag that makes Adam see zero gradients
+        self.worker.apply_gradients(self.iteration, self.learner.flat_grad)   # :362
+        self.get_stats()
+        self.iteration += 1
+
+    def stop(self):
+        pass

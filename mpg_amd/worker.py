@@ -1,0 +1,76 @@
+"""OffPolicyWorker - device mirror of worker.py:25-123: the env-step producer that also owns the master weights and
+the optimizer state (`apply_gradients`).  `sample()` keeps the reference's loop (policy -> + N(0, sigma) ->
+env.step -> env.reset, worker.py:91-119) but every stage is one HIP launch over all `num_agent` agents."""
+import torch
+
+from .envs import PathTrackingEnv
+from . import ops
+
+
+class OffPolicyWorker(object):
+    def __init__(self, policy_cls, env_id, args, worker_id, device='cuda'):
+        self.worker_id = worker_id
+        self.args = args
+        self.device = torch.device(device)
+        self.num_agent = int(args.num_agent)
+        assert env_id == 'PathTracking-v0', 'only PathTracking has a real vectorised env on the hot path'
+        seed = int(getattr(args, 'seed', 0)) * 1000003 + int(worker_id)
+        self.env = PathTrackingEnv(num_agent=self.num_agent, num_future_data=args.num_future_data, device=device, seed=seed)
+        self.policy_with_value = policy_cls(**vars(args), device=device)
+        self.batch_size = int(args.batch_size)
+        self.obs = self.env.reset()
+        self.explore_sigma = args.explore_sigma
+        self.seed = seed
+        self.iteration = 0
+        self.num_sample = 0
+        self.sample_times = 0
+        self._noise_ctr = 0
+        self.stats = {}
+
+    def get_stats(self):
+        self.stats.update(dict(worker_id=self.worker_id, num_sample=self.num_sample))
+        return self.stats
+
+    def get_weights(self):
+        return self.policy_with_value.get_weights()
+
+    def set_weights(self, weights):
+        return self.policy_with_value.set_weights(weights)
+
+    def save_weights(self, save_dir, iteration):
+        self.policy_with_value.save_weights(save_dir, iteration)
+
+    def load_weights(self, load_dir, iteration):
+        self.policy_with_value.load_weights(load_dir, iteration)
+
+    def apply_gradients(self, iteration, grads):
+        self.iteration = iteration
+        self.policy_with_value.apply_gradients(iteration, grads)
+
+    def get_ppc_params(self):
+        return {}
+
+    def set_ppc_params(self, params):
+        pass
+
+    def sample(self):
+        """-> (obs, act, RAW reward, obs', done) stacked over batch_size/num_agent env steps (worker.py:91-119)."""
+        pw = self.policy_with_value
+        out = [[], [], [], [], []]
+        for _ in range(max(1, self.batch_size // self.num_agent)):
+            obs = self.obs
+            action = ops.policy_action(pw.cfg, pw.net('policy'), obs, explore_sigma=float(self.explore_sigma or 0.),
+                                       seed=self.seed, ctr=self._noise_ctr)
+            self._noise_ctr += 1
+            obs_tp1, reward, done, _ = self.env.step(action)
+            for lst, x in zip(out, (obs, action, reward, obs_tp1, done.clone())):
+                lst.append(x)
+            self.obs = self.env.reset()          # done is always 1: every agent is re-drawn
+        batch = tuple(torch.cat(x, 0) for x in out)
+        self.num_sample += batch[0].shape[0]
+        self.sample_times += 1
+        return batch
+
+    def sample_with_count(self):
+        batch = self.sample()
+        return batch, batch[0].shape[0]

@@ -1,0 +1,128 @@
+"""End-to-end: the device learner / worker / buffer / optimizer classes (reference class and method names) against
+the goldens produced by the reference's own MPGLearner.compute_gradient, plus a short training run."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import mpg_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def rel_l2(a, b):
+    a, b = np.asarray(a, np.float64).ravel(), np.asarray(b, np.float64).ravel()
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def dev(x):
+    return torch.as_tensor(np.ascontiguousarray(x), dtype=torch.float32).to(DEV)
+
+
+def _learner(g, version, B=64):
+    from mpg_amd.config import default_args
+    from mpg_amd.learners import MPGLearner
+    from mpg_amd.policy import PolicyWithQs
+    args = default_args('MPG-' + version, replay_batch_size=B, num_batch_reuse=1)
+    learner = MPGLearner(PolicyWithQs, args)
+    pw = learner.policy_with_value
+    flat = np.concatenate([g['w_' + n] for n in pw.names])
+    pw.set_flat(flat, (flat * np.float32(g['target_scale'])).astype(np.float32))
+    return learner
+
+
+@pytest.mark.parametrize('version', ['v2', 'v1'])
+def test_compute_gradient_vs_reference_golden(golden, version):
+    """The full list the reference's MPGLearner.compute_gradient returns (clipped q1, (q2), policy gradients) and its
+    stats, on the same minibatch, weights and model noise.  <= 1e-4 relative L2 per array."""
+    g = golden('mpg_%s_H256_B64.npz' % version)
+    learner = _learner(g, version)
+    pw = learner.policy_with_value
+    batch = [dev(g[k]) for k in ('batch_obs', 'batch_actions', 'batch_rewards', 'batch_obs_tp1', 'batch_dones')]
+    for it in (100, 9000):
+        learner.counter = 0
+        grads = learner.compute_gradient(batch, None, None, it, eps=dev(g['eps']))
+        assert len(grads) == (18 if version == 'v2' else 12)
+        got = torch.cat([x.reshape(-1) for x in grads]).cpu().numpy()
+        ref = g['it%d_grads' % it]
+        o = 0
+        for name in pw.names:
+            din, dout = pw.dims[name]
+            for shp in O.mlp_shapes(din, 256, dout):
+                n = int(np.prod(shp))
+                if np.linalg.norm(ref[o:o + n]) > 0:
+                    # MPG-v1: the target comes from 25 chaotic-free but long real-env steps -> slightly looser
+                    tol = 1e-4 if version == 'v2' or name == 'policy' else 5e-4
+                    assert rel_l2(got[o:o + n], ref[o:o + n]) <= tol, (it, name, shp, rel_l2(got[o:o + n], ref[o:o + n]))
+                o += n
+        st = learner.get_stats()
+        p = 'it%d_' % it
+        rt = 1e-4 if version == 'v2' else 1e-3
+        for k in ('value_mean', 'policy_total_loss', 'policy_gradient_norm', 'q_loss1', 'q_gradient_norm1', 'q_loss2',
+                  'q_gradient_norm2'):
+            if p + k in g:
+                np.testing.assert_allclose(st[k], g[p + k], rtol=rt, atol=1e-6, err_msg=k)
+        np.testing.assert_allclose(st['w_list'], g[p + 'w_list'], rtol=1e-5, atol=1e-9)
+        np.testing.assert_allclose(st['all_losses'], g[p + 'all_losses'], rtol=1e-4, atol=1e-6)
+        tol_t = dict(rtol=2e-5, atol=2e-6) if version == 'v2' else dict(rtol=1e-3, atol=1e-4)
+        np.testing.assert_allclose(learner.batch_data['batch_targets'].cpu().numpy(), g[p + 'targets'], **tol_t)
+    np.testing.assert_allclose(learner.compute_td_error().cpu().numpy(), g['td_error'], rtol=1e-3, atol=1e-4)
+
+
+def test_replay_buffer_ring_and_gather_bit_exact():
+    from mpg_amd.buffer import ReplayBuffer
+    from mpg_amd.config import default_args
+    args = default_args(max_buffer_size=1000, replay_starts=300, replay_batch_size=256)
+    rb = ReplayBuffer(args, 0)
+    rng = np.random.Generator(np.random.PCG64(0))
+    mirror = {k: np.zeros(s, np.float32) for k, s in (('o', (1000, 6)), ('a', (1000, 2)), ('r', 1000), ('o2', (1000, 6)))}
+    nxt, size = 0, 0
+    assert rb.replay() is None                                     # buffer.py:85-86
+    for n in (300, 512, 512):                                      # wraps around the 1000-slot ring
+        o, a, r, o2 = [rng.standard_normal(s).astype(np.float32) for s in ((n, 6), (n, 2), n, (n, 6))]
+        rb.add_batch((dev(o), dev(a), dev(r), dev(o2), torch.ones(n, dtype=torch.uint8, device=DEV)))
+        pos = (nxt + np.arange(n)) % 1000
+        mirror['o'][pos], mirror['a'][pos], mirror['r'][pos], mirror['o2'][pos] = o, a, r, o2
+        nxt, size = (nxt + n) % 1000, min(size + n, 1000)
+    assert len(rb) == 1000
+    s = rb.replay()
+    idx = s[-1].cpu().numpy()
+    assert idx.min() >= 0 and idx.max() < 1000 and len(np.unique(idx)) > 200
+    np.testing.assert_array_equal(s[0].cpu().numpy(), mirror['o'][idx])       # gather is a copy: bit-exact
+    np.testing.assert_array_equal(s[1].cpu().numpy(), mirror['a'][idx])
+    np.testing.assert_array_equal(s[2].cpu().numpy(), mirror['r'][idx])
+    np.testing.assert_array_equal(s[3].cpu().numpy(), mirror['o2'][idx])
+    assert bool((s[4] == 1).all())
+    big = rb.sample_idxes(1 << 16).cpu().numpy()                               # uniformity of the index draw
+    hist = np.bincount(big, minlength=1000)
+    assert hist.min() > 20 and abs(hist.mean() - 65.536) < 1e-6 and hist.std() < 12
+
+
+@pytest.mark.parametrize('alg', ['MPG-v2', 'MPG-v1'])
+def test_single_process_training_loop_runs_and_learns_the_critic(alg):
+    """SingleProcessOffPolicyOptimizer.step order (optimizer.py:330-362) for a few dozen iterations: finite, the
+    policy optimizer ticks every 2nd iteration (delay_update), targets move by Polyak, critic loss goes down."""
+    from mpg_amd.buffer import ReplayBuffer
+    from mpg_amd.config import default_args
+    from mpg_amd.learners import MPGLearner
+    from mpg_amd.optimizer import SingleProcessOffPolicyOptimizer
+    from mpg_amd.policy import PolicyWithQs
+    from mpg_amd.worker import OffPolicyWorker
+    args = default_args(alg, num_agent=64, batch_size=512, replay_batch_size=256, replay_starts=1024,
+                        max_buffer_size=8192, value_lr_schedule=[1e-3, 100000, 1e-4])
+    worker = OffPolicyWorker(PolicyWithQs, args.env_id, args, 0)
+    learner = MPGLearner(PolicyWithQs, args)
+    rb = ReplayBuffer(args, 0)
+    opt = SingleProcessOffPolicyOptimizer(worker, learner, rb, None, args)
+    assert len(rb) >= 1024
+    pw = worker.policy_with_value
+    t0 = pw.targets.clone()
+    losses = []
+    for i in range(40):
+        opt.step()
+        losses.append(learner.get_stats()['q_loss1'])
+    assert all(np.isfinite(losses)) and torch.isfinite(pw.params).all()
+    assert pw.opt_steps['Q1'] == 40 and pw.opt_steps['policy'] == 20
+    assert (pw.targets - t0).abs().max().item() > 0
+    assert np.mean(losses[-5:]) < np.mean(losses[:5])
+    assert pw.nonfinite.item() == 0
