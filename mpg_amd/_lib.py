@@ -36,6 +36,8 @@ def lib():
             fn = getattr(_lib, name)            # AttributeError here = header/library out of sync
             if name.endswith('_workspace_bytes'):
                 fn.restype = ctypes.c_size_t
+            elif name == 'mpg_prof_slot_name':
+                fn.restype = ctypes.c_char_p
             elif name != 'mpg_last_error':
                 fn.restype = ctypes.c_int
     return _lib

@@ -97,9 +97,11 @@ int launch_forward(const float* params, int in_dim, int out_dim, int ou, int row
     a.k0 = (uint32_t)o.seed; a.k1 = (uint32_t)(o.seed >> 32); a.c1 = (uint32_t)o.ctr; a.c2 = (uint32_t)(o.ctr >> 32);
     a.y = y; a.ldy = ldy; a.h1 = h1; a.h2 = h2;
     const long ngroups = (rows + GROUP - 1) / GROUP;
+    mpg_prof_begin(3, s);
 #define CALL(I, O) hipLaunchKernelGGL((k_forward<I, O>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, a)
     MPG_DISPATCH_NET(in_dim, ou, CALL)
 #undef CALL
+    mpg_prof_end(3, s);
     MPG_CHECK_LAUNCH("k_forward");
     return MPG_OK;
 }
@@ -176,6 +178,7 @@ int launch_backward(const float* params, int in_dim, int out_dim, int ou, int ro
     a.yout = yout; a.ldyo = ldyo; a.out_tanh = out_tanh; a.out_scale = out_scale; a.h1 = h1; a.h2 = h2;
     a.dz1 = dz1; a.dz2 = dz2; a.dz3 = dz3; a.dx = dx; a.lddx = lddx;
     const long ngroups = (rows + GROUP - 1) / GROUP;
+    mpg_prof_begin(4, s);
     if (dx) {
 #define CALL(I, O) hipLaunchKernelGGL((k_backward<I, O, true>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, a)
         MPG_DISPATCH_NET(in_dim, ou, CALL)
@@ -185,6 +188,7 @@ int launch_backward(const float* params, int in_dim, int out_dim, int ou, int ro
         MPG_DISPATCH_NET(in_dim, ou, CALL)
 #undef CALL
     }
+    mpg_prof_end(4, s);
     MPG_CHECK_LAUNCH("k_backward");
     return MPG_OK;
 }
@@ -340,9 +344,11 @@ int launch_wgrad(int in_dim, int out_dim, int ou, int rows, const XSpec& x, cons
     const long ngroups = (rows + GROUP - 1) / GROUP;
     a.groups_per_wg = wgrad_groups_per_wg(ngroups);
     const int nwg = (int)((ngroups + a.groups_per_wg - 1) / a.groups_per_wg);
+    mpg_prof_begin(5, s);
 #define CALL(I, O) hipLaunchKernelGGL((k_wgrad<I, O>), dim3(nwg), dim3(NTHREAD), 0, s, a)
     MPG_DISPATCH_NET(in_dim, ou, CALL)
 #undef CALL
+    mpg_prof_end(5, s);
     MPG_CHECK_LAUNCH("k_wgrad");
     const int n = net_size(in_dim, out_dim);
     hipLaunchKernelGGL(k_reduce_slabs, dim3((n + 255) / 256), dim3(256), 0, s, ws, nwg, n, grad);

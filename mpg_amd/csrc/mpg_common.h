@@ -28,6 +28,10 @@ void mpg_set_error(const char* fmt, ...);
         }                                                                   \
     } while (0)
 
+// optional HIP-event timing of a launch (no-ops unless mpg_prof_enable(1)); slots: see mpg_api.cpp
+void mpg_prof_begin(int slot, hipStream_t s);
+void mpg_prof_end(int slot, hipStream_t s);
+
 static inline hipStream_t mpg_stream(mpg_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
 // ---- Philox4x32-10 (Salmon et al. 2011), counter-based: (key, counter) -> 4 x u32 -------------------

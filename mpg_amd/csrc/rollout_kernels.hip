@@ -492,10 +492,12 @@ extern "C" int mpg_rollout_pg(const mpg_cfg_t* cfg, const float* policy_params, 
     for (int k = 0; k < MAXSEL; ++k) fa.sel[k] = k < n_select ? select[k] : -1;
     fa.XQ = XQ; fa.GK = GK;
     const long ngroups = (R + GROUP - 1) / GROUP;
+    mpg_prof_begin(0, s);
     if (cfg->env_kind == MPG_ENV_PATH_TRACKING)
         hipLaunchKernelGGL((k_rollout_fwd<PathTracking>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, fa);
     else
         hipLaunchKernelGGL((k_rollout_fwd<Pendulum>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, fa);
+    mpg_prof_end(0, s);
     MPG_CHECK_LAUNCH("k_rollout_fwd");
 
     // ---- critic at the selected slices: values, returns, input gradients ----
@@ -529,10 +531,12 @@ extern "C" int mpg_rollout_pg(const mpg_cfg_t* cfg, const float* policy_params, 
     for (int t = 0; t < MAXN; ++t) ba.rho[t] = rho[t];
     ba.stash_all = all_steps_param_grad ? 1 : 0;
     ba.DZ1 = DZ1; ba.DZ2 = DZ2; ba.DZ3 = DZ3;
+    mpg_prof_begin(1, s);
     if (cfg->env_kind == MPG_ENV_PATH_TRACKING)
         hipLaunchKernelGGL((k_rollout_bwd<PathTracking>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, ba);
     else
         hipLaunchKernelGGL((k_rollout_bwd<Pendulum>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, ba);
+    mpg_prof_end(1, s);
     MPG_CHECK_LAUNCH("k_rollout_bwd");
 
     // ---- policy weight gradient from the stashes (step 0 only, or every step for NADP) ----
