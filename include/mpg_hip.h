@@ -162,6 +162,23 @@ int mpg_rollout_pg(const mpg_cfg_t* cfg, const float* policy_params, const float
                    float inv_b_global, int all_steps_param_grad, float* ret_sum, float* ret_sqsum, float* grad,
                    void* ws, size_t ws_bytes, mpg_stream_t stream);
 
+/* NADPLearner.model_rollout_for_q_estimation  - learners/nadp.py:87-126: from (s, a_replay) roll n model steps,
+ * later actions from pi_theta, y = G_n + gamma^n * Q1_target(s~_n, pi_theta(s~_n)) (no gradient).
+ * eps [n][rows] standard normal. */
+size_t mpg_rollout_q_target_workspace_bytes(const mpg_cfg_t* cfg, int rows);
+int mpg_rollout_q_target(const mpg_cfg_t* cfg, const float* policy_params, const float* q1t, int rows, int n,
+                         const float* obs0, const float* act0, const float* eps, float* y, void* ws, size_t ws_bytes,
+                         mpg_stream_t stream);
+
+/* TD3Learner.policy_forward_and_backward  - learners/td3.py:120-134:
+ *   loss = -mean_B min(Q1,Q2)(s~, pi(s~)); grad = flat policy gradient (unclipped, reduced over this GPU's rows,
+ *   divisor B_global through inv_b_global); qmin_sum / qmin_sqsum: sum and sum of squares of min-Q over the rows
+ *   (value_mean / value_var, td3.py:130-132).  The gradient flows through whichever critic is smaller per row. */
+size_t mpg_td3_policy_grad_workspace_bytes(const mpg_cfg_t* cfg, int rows);
+int mpg_td3_policy_grad(const mpg_cfg_t* cfg, const float* policy_params, const float* q1, const float* q2,
+                        int rows, const float* obs, float inv_b_global, float* qmin_sum, float* qmin_sqsum,
+                        float* grad, void* ws, size_t ws_bytes, mpg_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * clip_by_global_norm + Keras Adam + Polyak (K7, K8) over the flat [net0 | net1 | ...] vectors
  * ---------------------------------------------------------------------------------------------- */
@@ -203,6 +220,33 @@ int mpg_replay_gather(int n, const int* idx, int obs_dim, int act_dim, const flo
 /* ReplayBuffer.sample_idxes (buffer.py:70-71): n indices uniform in [0, n_storage), with replacement,
  * from Philox(seed, ctr). */
 int mpg_uniform_indices(int n_storage, int n, uint64_t seed, uint64_t ctr, int* idx, mpg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * On-device prioritized replay (K9, proportional part)  - buffer.py:94-189, utils/segment_tree.py:13-151
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Each tree is ONE float64 array of 2*capacity nodes in the reference's heap order (node 1 = root, leaves at
+ * [capacity, 2*capacity), capacity a power of two, segment_tree.py:40-44); float64 because the reference keeps
+ * python floats.  stamp: int scratch [capacity] owned by the caller (duplicate-index resolution). */
+
+/* SegmentTree.__init__: neutral elements 0.0 / +inf (segment_tree.py:106,146); stamp = -1. */
+int mpg_per_init(double* sum_tree, double* min_tree, int* stamp, int capacity, mpg_stream_t stream);
+
+/* Batched SegmentTree.__setitem__ (segment_tree.py:90-97) = PrioritizedReplayBuffer.update_priorities / add
+ * (buffer.py:127-136,166-189): leaf[idx[i]] = (|prio[i]| + eps)^alpha in both trees (the reference asserts
+ * priority > 0; learners hand signed td errors, SURVEY.md B-3, hence |.| + eps), then every internal node is
+ * recomputed as left + right / min(left, right).  Duplicates: the last entry of the batch wins, like the
+ * reference's sequential loop.  max_priority (device float, nullable) tracks max(|prio| + eps) (buffer.py:189). */
+int mpg_per_update(double* sum_tree, double* min_tree, int* stamp, int capacity, int n, const int* idx,
+                   const float* prio, double alpha, double eps, float* max_priority, mpg_stream_t stream);
+
+/* PrioritizedReplayBuffer._sample_proportional + IS weights (buffer.py:138-160):
+ *   mass_i = u_i * sum(0, n_storage)  (inclusive end, buffer.py:141);  idx_i = find_prefixsum_idx(mass_i)
+ *   (segment_tree.py:114-140);  w_i = (p_i/sum * n_storage)^-beta / max_w  with max_w from the min tree.
+ * u [n] uniform(0,1) float64 draws supplied by the caller (NULL: 53-bit Philox(seed, ctr) draws). */
+int mpg_per_sample(const double* sum_tree, const double* min_tree, int capacity, int n_storage, int n,
+                   const double* u, uint64_t seed, uint64_t ctr, double beta, int* idx, float* is_weight,
+                   mpg_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -64,4 +64,4 @@ def call(name, *args):
     check(getattr(lib(), name)(*args), name)
 
 
-c_int, c_float, c_u64, c_size_t = ctypes.c_int, ctypes.c_float, ctypes.c_uint64, ctypes.c_size_t
+c_int, c_float, c_double, c_u64, c_size_t = ctypes.c_int, ctypes.c_float, ctypes.c_double, ctypes.c_uint64, ctypes.c_size_t

@@ -75,3 +75,52 @@ class ReplayBuffer(object):
             return None
         self.replay_times += 1
         return self.sample(self.replay_batch_size)
+
+
+class PrioritizedReplayBuffer(ReplayBuffer):
+    """buffer.py:94-189 on device (sum / min segment trees in the reference's heap layout, float64).  The shipped
+    constructor is dead code (asserts args.alpha > 0 with alpha None and reads args.size); this is the
+    canonical PER it evidently intends: new transitions enter at max priority, p = (|td| + eps)^alpha with
+    replay_alpha 0.6, IS weights with replay_beta 0.4 (train_script.py:239-240)."""
+
+    def __init__(self, args, buffer_id, device='cuda', obs_dim=None, act_dim=None, eps=1e-6):
+        super().__init__(args, buffer_id, device, obs_dim, act_dim)
+        self._alpha, self._beta, self._eps = float(args.replay_alpha), float(args.replay_beta), float(eps)
+        cap = 1
+        while cap < self._maxsize:                                       # buffer.py:119-121
+            cap *= 2
+        self._cap = cap
+        self._it_sum = torch.empty(2 * cap, dtype=torch.float64, device=self.device)
+        self._it_min = torch.empty(2 * cap, dtype=torch.float64, device=self.device)
+        self._stamp = torch.empty(cap, dtype=torch.int32, device=self.device)
+        self._max_priority = torch.ones(1, dtype=torch.float32, device=self.device)          # buffer.py:125
+        L.call('mpg_per_init', L.ptr(self._it_sum), L.ptr(self._it_min), L.ptr(self._stamp), L.c_int(cap), L.stream())
+
+    def _set(self, idx, prio, eps):
+        L.call('mpg_per_update', L.ptr(self._it_sum), L.ptr(self._it_min), L.ptr(self._stamp), L.c_int(self._cap),
+               L.c_int(idx.shape[0]), L.ptr(idx), L.ptr(prio), L.c_double(self._alpha), L.c_double(eps),
+               L.ptr(self._max_priority), L.stream())
+
+    def add_batch(self, batch):
+        n = batch[0].shape[0]
+        idx = ((torch.arange(n, device=self.device, dtype=torch.int64) + self._next_idx) % self._maxsize).to(torch.int32)
+        super().add_batch(batch)
+        self._set(idx, self._max_priority.expand(n).contiguous(), 0.0)   # weight = max priority (buffer.py:133-136)
+
+    def sample_idxes(self, batch_size, u=None, want_weights=True):
+        idx = torch.empty(batch_size, dtype=torch.int32, device=self.device)
+        w = torch.empty(batch_size, dtype=torch.float32, device=self.device) if want_weights else None
+        L.call('mpg_per_sample', L.ptr(self._it_sum), L.ptr(self._it_min), L.c_int(self._cap), L.c_int(self._size),
+               L.c_int(batch_size), L.ptr(u), L.c_u64(self.seed), L.c_u64(self.replay_times), L.c_double(self._beta),
+               L.ptr(idx), L.ptr(w), L.stream())
+        self._last_weights = w
+        return idx
+
+    def sample(self, batch_size):
+        """[obs, act, rew, obs', done, weights, idx] (buffer.py:146-164)."""
+        idx = self.sample_idxes(batch_size)
+        return list(self._encode_sample(idx)) + [self._last_weights, idx]
+
+    def update_priorities(self, idxes, priorities):
+        """buffer.py:166-189; priorities may be signed td errors (|.| + eps is taken on the device)."""
+        self._set(idxes.to(torch.int32).contiguous(), priorities.to(torch.float32).contiguous(), self._eps)

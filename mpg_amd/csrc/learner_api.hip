@@ -68,6 +68,46 @@ __global__ void __launch_bounds__(1024) k_q_err(int rows, const float* __restric
     if (threadIdx.x == 0) loss_sum[0] = 0.5f * inv_b * red[0];
 }
 
+// TD3 policy loss pieces (td3.py:120-134): qmin = min(q1, q2); dL/dq_i = -inv_b where q_i is the smaller one
+// (tf.reduce_min routes the gradient to the minimum; exact ties go to Q1).  One block, fixed-order sums.
+__global__ void __launch_bounds__(1024) k_td3_dy(int rows, const float* __restrict__ q1, const float* __restrict__ q2,
+                                                 float inv_b, float* __restrict__ dy1, float* __restrict__ dy2,
+                                                 float* __restrict__ qmin_sum, float* __restrict__ qmin_sqsum) {
+    __shared__ float red[2][1024];
+    float s = 0.f, s2 = 0.f;
+    for (int i = threadIdx.x; i < rows; i += 1024) {
+        const bool first = q1[i] <= q2[i];
+        const float m = first ? q1[i] : q2[i];
+        dy1[i] = first ? -inv_b : 0.f;
+        dy2[i] = first ? 0.f : -inv_b;
+        s += m;
+        s2 += m * m;
+    }
+    red[0][threadIdx.x] = s;
+    red[1][threadIdx.x] = s2;
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + w];
+            red[1][threadIdx.x] += red[1][threadIdx.x + w];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        qmin_sum[0] = red[0][0];
+        qmin_sqsum[0] = red[1][0];
+    }
+}
+
+// ga[row][k] = dx1[row][od + k] + dx2[row][od + k]
+__global__ void k_sum_action_grad(int rows, int od, int ad, const float* __restrict__ dx1, const float* __restrict__ dx2,
+                                  float* __restrict__ ga) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * ad) return;
+    const int row = i / ad, k = i % ad;
+    ga[i] = dx1[(long)row * (od + ad) + od + k] + dx2[(long)row * (od + ad) + od + k];
+}
+
 inline OutSpec policy_out(const mpg_cfg_t* c) {
     OutSpec o;
     const bool ranged = c->action_range > 0.f;
@@ -206,4 +246,55 @@ extern "C" int mpg_q_loss_grad(const mpg_cfg_t* cfg, const float* q_params, int 
     rc = launch_backward(q_params, in, 1, 1, rows, dz3, 1, nullptr, 0, 0, 1.f, h1, h2, dz1, dz2, nullptr, nullptr, 0, s);
     if (rc) return rc;
     return launch_wgrad(in, 1, 1, rows, xq, h1, h2, dz1, dz2, dz3, grad, slabs, s);
+}
+
+extern "C" size_t mpg_td3_policy_grad_workspace_bytes(const mpg_cfg_t* cfg, int rows) {
+    if (!cfg_ok(cfg) || rows <= 0) return 0;
+    const int od = cfg->obs_dim, ad = cfg->act_dim, qin = od + ad;
+    return 8 * pad256(stash_floats(rows)) + 2 * pad256((size_t)rows * ad) + 4 * pad256(rows) +
+           2 * pad256((size_t)rows * qin) + pad256((size_t)rows * ad) + pad256(wgrad_workspace_floats(rows, od, 2 * ad));
+}
+
+extern "C" int mpg_td3_policy_grad(const mpg_cfg_t* cfg, const float* policy_params, const float* q1, const float* q2,
+                                   int rows, const float* obs, float inv_b_global, float* qmin_sum, float* qmin_sqsum,
+                                   float* grad, void* ws, size_t ws_bytes, mpg_stream_t stream) {
+    MPG_REQUIRE(cfg_ok(cfg) && policy_params && q1 && q2 && obs && qmin_sum && qmin_sqsum && grad && ws && rows > 0,
+                "mpg_td3_policy_grad: bad argument");
+    if (ws_bytes < mpg_td3_policy_grad_workspace_bytes(cfg, rows)) {
+        mpg_set_error("mpg_td3_policy_grad: workspace too small");
+        return MPG_EWORKSPACE;
+    }
+    hipStream_t s = mpg_stream(stream);
+    const int od = cfg->obs_dim, ad = cfg->act_dim, qin = od + ad;
+    Carver cv(ws, ws_bytes);
+    float* hp1 = cv.take(stash_floats(rows)); float* hp2 = cv.take(stash_floats(rows));
+    float* h11 = cv.take(stash_floats(rows)); float* h12 = cv.take(stash_floats(rows));
+    float* h21 = cv.take(stash_floats(rows)); float* h22 = cv.take(stash_floats(rows));
+    float* dz1 = cv.take(stash_floats(rows)); float* dz2 = cv.take(stash_floats(rows));
+    float* a = cv.take((size_t)rows * ad); float* dz3 = cv.take((size_t)rows * ad);
+    float* qv1 = cv.take(rows); float* qv2 = cv.take(rows); float* dy1 = cv.take(rows); float* dy2 = cv.take(rows);
+    float* dx1 = cv.take((size_t)rows * qin); float* dx2 = cv.take((size_t)rows * qin);
+    float* ga = cv.take((size_t)rows * ad);
+    float* slabs = cv.take(wgrad_workspace_floats(rows, od, 2 * ad));
+    const OutSpec po = policy_out(cfg);
+    const XSpec xp = xspec(obs, od, nullptr, 0, cfg->obs_scale, od);
+    int rc = launch_forward(policy_params, od, 2 * ad, ad, rows, xp, po, a, ad, hp1, hp2, s);        // td3.py:123
+    if (rc) return rc;
+    const XSpec xq = xspec(obs, od, a, ad, cfg->obs_scale, od);
+    rc = launch_forward(q1, qin, 1, 1, rows, xq, linear_out(), qv1, 1, h11, h12, s);                  // :124
+    if (rc) return rc;
+    rc = launch_forward(q2, qin, 1, 1, rows, xq, linear_out(), qv2, 1, h21, h22, s);                  // :125
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_td3_dy, dim3(1), dim3(1024), 0, s, rows, qv1, qv2, inv_b_global, dy1, dy2, qmin_sum, qmin_sqsum);
+    MPG_CHECK_LAUNCH("k_td3_dy");
+    rc = launch_backward(q1, qin, 1, 1, rows, dy1, 1, nullptr, 0, 0, 1.f, h11, h12, nullptr, nullptr, nullptr, dx1, qin, s);
+    if (rc) return rc;
+    rc = launch_backward(q2, qin, 1, 1, rows, dy2, 1, nullptr, 0, 0, 1.f, h21, h22, nullptr, nullptr, nullptr, dx2, qin, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_sum_action_grad, dim3((rows * ad + 255) / 256), dim3(256), 0, s, rows, od, ad, dx1, dx2, ga);
+    MPG_CHECK_LAUNCH("k_sum_action_grad");
+    rc = launch_backward(policy_params, od, 2 * ad, ad, rows, ga, ad, a, ad, po.out_tanh, po.out_scale, hp1, hp2, dz1, dz2, dz3,
+                         nullptr, 0, s);
+    if (rc) return rc;
+    return launch_wgrad(od, 2 * ad, ad, rows, xp, hp1, hp2, dz1, dz2, dz3, grad, slabs, s);
 }

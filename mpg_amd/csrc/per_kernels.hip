@@ -1,0 +1,157 @@
+// K9 (part 2): on-device prioritized replay - sum / min segment trees, proportional sampling, IS weights.
+// Reference: utils/segment_tree.py:13-151 (SegmentTree, SumSegmentTree.find_prefixsum_idx, MinSegmentTree) and
+// buffer.py:94-189 (PrioritizedReplayBuffer).  The trees keep the reference's heap layout (node 1 = root, leaves at
+// [capacity, 2*capacity)) and its float64 values (python floats), every internal node being left (+|min) right, so the
+// tree CONTENT is bit-identical to the reference's whatever the update order; sampling indices are therefore exact.
+//
+// Batched update = (1) set the leaves, last occurrence of a duplicate index wins like the sequential python loop,
+// (2) rebuild the internal nodes: bottom 10 levels per 1024-leaf subtree inside one workgroup, top levels by one
+// workgroup.  No float atomics.
+#include "mpg_common.h"
+
+namespace {
+
+constexpr int SUB = 1024;   // leaves per subtree handled by one workgroup
+
+__global__ void k_stamp(int n, const int* __restrict__ idx, int* __restrict__ stamp) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) atomicMax(&stamp[idx[i]], i);
+}
+
+__global__ void k_set_leaves(int n, int capacity, const int* __restrict__ idx, const float* __restrict__ prio,
+                             double alpha, double eps, int* __restrict__ stamp, double* __restrict__ sum_tree,
+                             double* __restrict__ min_tree, float* __restrict__ max_prio) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int leaf = idx[i];
+    if (stamp[leaf] != i) return;                      // a later entry of the batch overrides this one
+    const double p = fabs((double)prio[i]) + eps;      // canonical PER: |td| + eps (the shipped ctor is dead code, SURVEY B-3)
+    const double v = pow(p, alpha);                    // buffer.py:185-187
+    sum_tree[capacity + leaf] = v;
+    min_tree[capacity + leaf] = v;
+    if (max_prio) atomicMax(reinterpret_cast<unsigned int*>(max_prio), __float_as_uint((float)p));   // p > 0: bit order == value order
+}
+
+__global__ void k_unstamp(int n, const int* __restrict__ idx, int* __restrict__ stamp) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) stamp[idx[i]] = -1;
+}
+
+// rebuild nodes of one 1024-leaf subtree (levels below the subtree root), SegmentTree.__setitem__ :90-97 semantics
+__global__ void __launch_bounds__(512) k_rebuild_bottom(int capacity, double* __restrict__ sum_tree, double* __restrict__ min_tree) {
+    const int nsub_leaves = capacity < SUB ? capacity : SUB;
+    const int sub = blockIdx.x;                         // subtree index
+    // node ids of level with `w` nodes inside this subtree: first = (capacity / nsub_leaves * w') ... compute per level
+    for (int w = nsub_leaves / 2; w >= 1; w >>= 1) {    // w = nodes of this subtree on the level being written
+        const int level_first = (capacity / nsub_leaves) * w;        // first node id of that level in the whole tree
+        for (int j = threadIdx.x; j < w; j += blockDim.x) {
+            const int node = level_first + sub * w + j;
+            sum_tree[node] = sum_tree[2 * node] + sum_tree[2 * node + 1];
+            min_tree[node] = fmin(min_tree[2 * node], min_tree[2 * node + 1]);
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(512) k_rebuild_top(int ntop, double* __restrict__ sum_tree, double* __restrict__ min_tree) {
+    // ntop = number of subtree roots (a power of two); rebuild levels above them
+    for (int w = ntop / 2; w >= 1; w >>= 1) {
+        for (int j = threadIdx.x; j < w; j += blockDim.x) {
+            const int node = w + j;
+            sum_tree[node] = sum_tree[2 * node] + sum_tree[2 * node + 1];
+            min_tree[node] = fmin(min_tree[2 * node], min_tree[2 * node + 1]);
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void k_sample(int capacity, int n_storage, int n, const double* __restrict__ sum_tree,
+                         const double* __restrict__ min_tree, const double* __restrict__ u, uint32_t k0, uint32_t k1,
+                         uint32_t c1, uint32_t c2, double beta, int* __restrict__ idx, float* __restrict__ is_w) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double ui;
+    if (u) {
+        ui = u[i];
+    } else {
+        const Philox4 p = philox4x32_10((uint32_t)i, c1, c2, 0x9e4u, k0, k1);
+        ui = ((double)(((uint64_t)p.v[0] << 21) ^ (uint64_t)(p.v[1] >> 11)) + 0.5) * (1.0 / 9007199254740992.0);   // 53-bit uniform in (0,1)
+    }
+    const double total = sum_tree[1];                    // == sum(0, len(storage)) bit for bit (unfilled leaves are exact zeros)
+    double prefix = ui * total;                          // buffer.py:141
+    int node = 1;
+    while (node < capacity) {                            // find_prefixsum_idx, segment_tree.py:133-140
+        const double left = sum_tree[2 * node];
+        if (left > prefix) {
+            node = 2 * node;
+        } else {
+            prefix -= left;
+            node = 2 * node + 1;
+        }
+    }
+    const int leaf = node - capacity;
+    idx[i] = leaf;
+    if (is_w) {                                          // buffer.py:146-158
+        const double p_min = min_tree[1] / total;
+        const double max_w = pow(p_min * (double)n_storage, -beta);
+        const double p_s = sum_tree[capacity + leaf] / total;
+        is_w[i] = (float)(pow(p_s * (double)n_storage, -beta) / max_w);
+    }
+}
+
+__global__ void k_tree_init(int capacity, double* __restrict__ sum_tree, double* __restrict__ min_tree, int* __restrict__ stamp) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 2 * capacity) {
+        sum_tree[i] = 0.0;                               // neutral elements, segment_tree.py:106,146
+        min_tree[i] = __builtin_huge_val();
+    }
+    if (i < capacity) stamp[i] = -1;
+}
+
+int rebuild(int capacity, double* sum_tree, double* min_tree, hipStream_t s) {
+    const int nsub = capacity < SUB ? 1 : capacity / SUB;
+    hipLaunchKernelGGL(k_rebuild_bottom, dim3(nsub), dim3(512), 0, s, capacity, sum_tree, min_tree);
+    MPG_CHECK_LAUNCH("k_rebuild_bottom");
+    if (nsub > 1) {
+        hipLaunchKernelGGL(k_rebuild_top, dim3(1), dim3(512), 0, s, nsub, sum_tree, min_tree);
+        MPG_CHECK_LAUNCH("k_rebuild_top");
+    }
+    return MPG_OK;
+}
+
+inline bool pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
+
+}  // namespace
+
+extern "C" int mpg_per_init(double* sum_tree, double* min_tree, int* stamp, int capacity, mpg_stream_t stream) {
+    MPG_REQUIRE(sum_tree && min_tree && stamp && pow2(capacity), "mpg_per_init: capacity must be a power of two (segment_tree.py:40)");
+    hipLaunchKernelGGL(k_tree_init, dim3((2 * capacity + 255) / 256), dim3(256), 0, mpg_stream(stream), capacity, sum_tree,
+                       min_tree, stamp);
+    MPG_CHECK_LAUNCH("k_tree_init");
+    return MPG_OK;
+}
+
+extern "C" int mpg_per_update(double* sum_tree, double* min_tree, int* stamp, int capacity, int n, const int* idx,
+                              const float* prio, double alpha, double eps, float* max_priority, mpg_stream_t stream) {
+    MPG_REQUIRE(sum_tree && min_tree && stamp && idx && prio && pow2(capacity) && n > 0, "mpg_per_update: bad argument");
+    hipStream_t s = mpg_stream(stream);
+    const dim3 g((n + 255) / 256), b(256);
+    hipLaunchKernelGGL(k_stamp, g, b, 0, s, n, idx, stamp);
+    hipLaunchKernelGGL(k_set_leaves, g, b, 0, s, n, capacity, idx, prio, alpha, eps, stamp, sum_tree, min_tree,
+                       max_priority);
+    hipLaunchKernelGGL(k_unstamp, g, b, 0, s, n, idx, stamp);
+    MPG_CHECK_LAUNCH("mpg_per_update");
+    return rebuild(capacity, sum_tree, min_tree, s);
+}
+
+extern "C" int mpg_per_sample(const double* sum_tree, const double* min_tree, int capacity, int n_storage, int n,
+                              const double* u, uint64_t seed, uint64_t ctr, double beta, int* idx, float* is_weight,
+                              mpg_stream_t stream) {
+    MPG_REQUIRE(sum_tree && min_tree && idx && pow2(capacity) && n > 0 && n_storage > 0 && n_storage <= capacity,
+                "mpg_per_sample: bad argument");
+    hipLaunchKernelGGL(k_sample, dim3((n + 255) / 256), dim3(256), 0, mpg_stream(stream), capacity, n_storage, n, sum_tree,
+                       min_tree, u, (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)ctr, (uint32_t)(ctr >> 32), beta,
+                       idx, is_weight);
+    MPG_CHECK_LAUNCH("k_sample");
+    return MPG_OK;
+}

@@ -290,6 +290,12 @@ __global__ void __launch_bounds__(1024) k_returns(int rows, int M, int n_sel, co
     }
 }
 
+// y = G_n + gamma^n * Q   (nadp.py:117-126)
+__global__ void k_gq(int n, const float* __restrict__ G, const float* __restrict__ Q, float gpow, float* __restrict__ y) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = G[i] + gpow * Q[i];
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // reverse sweep
 // ---------------------------------------------------------------------------------------------------------------
@@ -544,4 +550,42 @@ extern "C" int mpg_rollout_pg(const mpg_cfg_t* cfg, const float* policy_params, 
     XSpec xs = xspec(SA, od, nullptr, 0, cfg->obs_scale, od);
     xs.ld0 = SAW;
     return launch_wgrad(od, 2 * ad, ad, (int)(T * R), xs, H1, H2, DZ1, DZ2, DZ3, grad, slabs, s);
+}
+
+extern "C" size_t mpg_rollout_q_target_workspace_bytes(const mpg_cfg_t* cfg, int rows) {
+    if (!cfg_ok(cfg) || rows <= 0) return 0;
+    return pad256((size_t)rows * (cfg->obs_dim + cfg->act_dim)) + 2 * pad256(rows);
+}
+
+extern "C" int mpg_rollout_q_target(const mpg_cfg_t* cfg, const float* policy_params, const float* q1t, int rows, int n,
+                                    const float* obs0, const float* act0, const float* eps, float* y, void* ws,
+                                    size_t ws_bytes, mpg_stream_t stream) {
+    MPG_REQUIRE(cfg_ok(cfg) && policy_params && q1t && obs0 && act0 && eps && y && ws && rows > 0 && n > 0 && n < MAXN,
+                "mpg_rollout_q_target: bad argument");
+    if (ws_bytes < mpg_rollout_q_target_workspace_bytes(cfg, rows)) {
+        mpg_set_error("mpg_rollout_q_target: workspace too small");
+        return MPG_EWORKSPACE;
+    }
+    hipStream_t s = mpg_stream(stream);
+    const int qin = cfg->obs_dim + cfg->act_dim;
+    Carver cv(ws, ws_bytes);
+    float* XQ = cv.take((size_t)rows * qin); float* GK = cv.take(rows); float* Q = cv.take(rows);
+    RollArgs fa;
+    fill_roll(fa, cfg, policy_params, rows, 1, n);
+    fa.obs0 = obs0; fa.act0 = act0; fa.eps = eps; fa.H1 = fa.H2 = nullptr; fa.SA = nullptr;
+    fa.n_sel = 1;
+    for (int k = 0; k < MAXSEL; ++k) fa.sel[k] = k == 0 ? n : -1;
+    fa.XQ = XQ; fa.GK = GK;
+    const long ngroups = (rows + GROUP - 1) / GROUP;
+    if (cfg->env_kind == MPG_ENV_PATH_TRACKING)
+        hipLaunchKernelGGL((k_rollout_fwd<PathTracking>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, fa);
+    else
+        hipLaunchKernelGGL((k_rollout_fwd<Pendulum>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, fa);
+    MPG_CHECK_LAUNCH("k_rollout_fwd (q target)");
+    OutSpec lin; lin.out_tanh = 0; lin.out_scale = 1.f; lin.sigma = 0.f; lin.seed = lin.ctr = 0;
+    int rc = launch_forward(q1t, qin, 1, 1, rows, xspec(XQ, qin, nullptr, 0, nullptr, 0), lin, Q, 1, nullptr, nullptr, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_gq, dim3((rows + 255) / 256), dim3(256), 0, s, rows, GK, Q, powf(cfg->gamma, (float)n), y);
+    MPG_CHECK_LAUNCH("k_gq");
+    return MPG_OK;
 }

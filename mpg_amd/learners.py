@@ -193,3 +193,97 @@ class MPGLearner(_LearnerBase):
         if len(qnames) == 2:
             self.stats.update(dict(q_loss2=stats[1], q_gradient_norm2=self.norms[1]))
         return out
+
+
+class NADPLearner(_LearnerBase):
+    """n-step ADP (learners/nadp.py:23-241), config 3: the Q target AND the policy loss come from 25-step MODEL rollouts;
+    every rollout step goes through pi_theta, so parameter gradients accumulate at all 26 policy evaluations."""
+
+    def __init__(self, policy_cls, args, device='cuda'):
+        super().__init__(policy_cls, args, device)
+        self.M = args.M
+        assert self.M == 1
+        self.n_q = max(args.num_rollout_list_for_q_estimation)
+        self.n_pi = args.num_rollout_list_for_policy_update[0]
+
+    def get_batch_data(self, batch_data, rb, indexes):
+        self._get_batch(batch_data)
+
+    def compute_gradient(self, batch_data, rb, indexes, iteration, eps_q=None, eps_pi=None):
+        """nadp.py:209-241"""
+        if self.counter % self.num_batch_reuse == 0:
+            self.get_batch_data(batch_data, rb, indexes)
+        self.counter += 1
+        pw, b = self.policy_with_value, self.batch_data
+        rows = b['batch_obs'].shape[0]
+        world = D.world_size()
+        inv_b = 1.0 / (rows * world)
+        stats = self.flat[self.n_grad:]
+        stats.zero_()
+        if eps_q is None:
+            eps_q = torch.randn(self.n_q, rows, generator=self._noise_gen, device=self.device)
+        if eps_pi is None:
+            eps_pi = torch.randn(self.n_pi, rows, generator=self._noise_gen, device=self.device)
+        targets = ops.rollout_q_target(self.cfg, pw.net('policy'), pw.net('Q1', True), b['batch_obs'], b['batch_actions'],
+                                       eps_q)                                                       # nadp.py:87-126
+        self.batch_data['batch_targets'] = targets
+        ops.q_loss_grad(self.cfg, pw.net('Q1'), b['batch_obs'], b['batch_actions'], targets, inv_b_global=inv_b,
+                        grad_out=self.grad('Q1'), loss_out=stats[0:1])                               # :173-184
+        # slice 0 only feeds value_mean (weight 0); the loss is -R_n (nadp.py:168-171)
+        ops.rollout_pg(self.cfg, pw.net('policy'), pw.net('Q1'), b['batch_obs'], eps_pi, [0, self.n_pi], [0.0, 1.0], M=1,
+                       inv_b_global=inv_b, all_steps_param_grad=True, grad_out=self.grad('policy'), stats_out=stats[2:6])
+        out = self._finish(iteration, float(self.args.gradient_clip_norm))
+        B = rows * world
+        self.stats.update(dict(q_loss=stats[0], policy_loss=-stats[3] / B, value_mean=stats[2] / B,
+                               q_gradient_norm=self.norms[0], policy_gradient_norm=self.norms[1]))
+        return out
+
+
+class TD3Learner(_LearnerBase):
+    """learners/td3.py:22-188, config 4."""
+
+    def compute_clipped_double_q_target(self, smooth_eps=None):
+        """td3.py:69-81"""
+        pw, b = self.policy_with_value, self.batch_data
+        rows = b['batch_obs'].shape[0]
+        if smooth_eps is None:
+            smooth_eps = torch.randn(rows, self.cfg.act_dim, generator=self._noise_gen, device=self.device)
+        return ops.q_targets(self.cfg, pw.net('policy', True), pw.net('Q1', True), pw.net('Q2', True), b['batch_rewards'],
+                             b['batch_obs_tp1'], smooth_eps=smooth_eps, smooth_sigma=self.args.policy_smoothing_sigma,
+                             smooth_clip=self.args.policy_smoothing_clip)
+
+    def compute_td_error(self):
+        """td3.py:83-92 (signed)."""
+        pw, b = self.policy_with_value, self.batch_data
+        y1 = ops.q_targets(self.cfg, pw.net('policy', True), pw.net('Q1', True), None, b['batch_rewards'], b['batch_obs_tp1'])
+        return y1 - pw.compute_Q1(b['batch_obs'], b['batch_actions'])
+
+    def get_batch_data(self, batch_data, rb, indexes, smooth_eps=None):
+        self._get_batch(batch_data)
+        self.batch_data['batch_targets'] = self.compute_clipped_double_q_target(smooth_eps)
+        if self.args.buffer_type != 'normal':
+            self.info_for_buffer.update(dict(td_error=self.compute_td_error(), rb=rb, indexes=indexes))
+
+    def compute_gradient(self, batch_data, rb, indexes, iteration, smooth_eps=None):
+        """td3.py:150-188"""
+        if self.counter % self.num_batch_reuse == 0:
+            self.get_batch_data(batch_data, rb, indexes, smooth_eps)
+        self.counter += 1
+        pw, b = self.policy_with_value, self.batch_data
+        rows = b['batch_obs'].shape[0]
+        world = D.world_size()
+        inv_b = 1.0 / (rows * world)
+        stats = self.flat[self.n_grad:]
+        stats.zero_()
+        for i, nm in enumerate(('Q1', 'Q2')):
+            ops.q_loss_grad(self.cfg, pw.net(nm), b['batch_obs'], b['batch_actions'], b['batch_targets'], inv_b_global=inv_b,
+                            grad_out=self.grad(nm), loss_out=stats[i:i + 1])
+        ops.td3_policy_grad(self.cfg, pw.net('policy'), pw.net('Q1'), pw.net('Q2'), b['batch_obs'], inv_b_global=inv_b,
+                            grad_out=self.grad('policy'), stats_out=stats[2:4])
+        out = self._finish(iteration, float(self.args.gradient_clip_norm))
+        B = rows * world
+        mean = stats[2] / B
+        self.stats.update(dict(q_loss1=stats[0], q_loss2=stats[1], policy_loss=-mean, value_mean=mean,
+                               value_var=stats[3] / B - mean * mean, q_gradient_norm1=self.norms[0],
+                               q_gradient_norm2=self.norms[1], policy_gradient_norm=self.norms[2]))
+        return out

@@ -173,3 +173,25 @@ def adam_polyak(w, m, v, target, grad, seg_sizes, lr_t, do_adam, do_polyak, tau,
     dp = (ctypes.c_int * ns)(*[int(x) for x in do_polyak])
     L.call('mpg_adam_polyak', L.ptr(_f32(w)), L.ptr(_f32(m)), L.ptr(_f32(v)), L.ptr(target), L.ptr(_f32(grad)), segs,
            L.c_int(ns), lr, da, dp, L.c_float(tau), L.ptr(skip_flag), L.stream())
+
+
+def rollout_q_target(cfg, policy_params, q1t, obs0, act0, eps):
+    rows, n = obs0.shape[0], eps.shape[0]
+    y = torch.empty(rows, dtype=torch.float32, device=obs0.device)
+    nb = L.lib().mpg_rollout_q_target_workspace_bytes(ctypes.byref(cfg), L.c_int(rows))
+    ws = workspace(obs0.device, nb)
+    L.call('mpg_rollout_q_target', ctypes.byref(cfg), L.ptr(_f32(policy_params)), L.ptr(_f32(q1t)), L.c_int(rows), L.c_int(n),
+           L.ptr(_f32(obs0)), L.ptr(_f32(act0)), L.ptr(_f32(eps)), L.ptr(y), L.ptr(ws), L.c_size_t(ws.numel()), L.stream())
+    return y
+
+
+def td3_policy_grad(cfg, policy_params, q1, q2, obs, inv_b_global=None, grad_out=None, stats_out=None):
+    rows, dev = obs.shape[0], obs.device
+    grad = grad_out if grad_out is not None else torch.empty(policy_size(cfg), dtype=torch.float32, device=dev)
+    stats = stats_out if stats_out is not None else torch.empty(2, dtype=torch.float32, device=dev)
+    nb = L.lib().mpg_td3_policy_grad_workspace_bytes(ctypes.byref(cfg), L.c_int(rows))
+    ws = workspace(dev, nb, slot=1)
+    L.call('mpg_td3_policy_grad', ctypes.byref(cfg), L.ptr(_f32(policy_params)), L.ptr(_f32(q1)), L.ptr(_f32(q2)),
+           L.c_int(rows), L.ptr(_f32(obs)), L.c_float(inv_b_global if inv_b_global is not None else 1.0 / rows),
+           L.ptr(stats[0:1]), L.ptr(stats[1:2]), L.ptr(grad), L.ptr(ws), L.c_size_t(ws.numel()), L.stream())
+    return stats, grad
