@@ -60,6 +60,19 @@ int mpg_prof_enable(int on);
 int mpg_prof_read(int slot, double* total_ms, int* count);
 const char* mpg_prof_slot_name(int slot);
 
+/* Weight cache (acceleration only, no reference counterpart): pre-packed register images of the 256x256 hidden
+ * kernels of the networks stored in `params` = [net0 | net1 | ...] (Keras order each, in_dims/out_dims HOST arrays,
+ * n_nets <= 8).  Once bound, every entry point that receives a pointer into `params` loads its stationary weights
+ * with coalesced 1 KiB reads instead of strided ones; results are bit-identical with and without the cache.
+ * The binding is process-wide state keyed by the pointer: unbind before freeing `params`; after writing `params`
+ * by any means other than mpg_adam_polyak (which refreshes bound buffers itself) call mpg_weight_cache_refresh.
+ * cache: caller-owned device array of mpg_weight_cache_floats(n_nets) floats. */
+size_t mpg_weight_cache_floats(int n_nets);
+int mpg_weight_cache_bind(const float* params, const int* in_dims, const int* out_dims, int n_nets, float* cache,
+                          mpg_stream_t stream);
+int mpg_weight_cache_refresh(const float* params, mpg_stream_t stream);
+int mpg_weight_cache_unbind(const float* params);
+
 /* ------------------------------------------------------------------------------------------------
  * Vectorised real environment (K1)
  * ---------------------------------------------------------------------------------------------- */

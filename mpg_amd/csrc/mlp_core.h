@@ -106,6 +106,24 @@ __device__ __forceinline__ void load_w2_bwd(const float* __restrict__ W2, const 
         for (int t = 0; t < 2; ++t) w[2 * q + t] = W2[L.col(t) * H + 4 * q + L.rg];
 }
 
+// Same register images from the pre-packed copy kept by the weight cache (weight_cache.hip): float4 index
+// ((wave*16 + q/4)*2 + t)*64 + lane, entry q%4 -> 32 fully coalesced 1 KiB loads per wave instead of 128 strided ones.
+__device__ __forceinline__ void load_w2_packed(const float* __restrict__ pack, const Lane& L, float (&w)[128]) {
+    const f32x4* p = reinterpret_cast<const f32x4*>(pack) + (L.wave * 32) * 64 + L.lane;
+#pragma unroll
+    for (int q4 = 0; q4 < 16; ++q4)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const f32x4 v = p[(q4 * 2 + t) * 64];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[2 * (4 * q4 + e) + t] = v[e];
+        }
+}
+
+// host side: packed copy of W2 for direction dir (0 forward, 1 backward) if `W2` belongs to a bound parameter
+// buffer (mpg_weight_cache_bind), else nullptr.
+const float* weight_cache_lookup(const float* W2, int dir);
+
 // 16 x 256 (LDS A image) times the wave's stationary 256 x 32 slice; 128 MFMAs, two independent accumulators.
 __device__ __forceinline__ void mfma_16x256x32(const float* sA, const Lane& L, const float (&w)[128], f32x4& acc0,
                                                f32x4& acc1) {

@@ -17,6 +17,7 @@ struct FwdArgs {
     float* y;
     int ldy;
     float *h1, *h2;
+    const float* pack;   // nullable: packed forward image of W2 (weight cache)
 };
 
 // loads one row group of the network input into sX [16][XS] (zero padded)
@@ -47,7 +48,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_forward(const FwdArgs a) {
     const Net net = make_net(a.params, a.in_dim, a.out_dim);
     float w2[128];
     SmallRegs<IN, OU> r;
-    load_w2_fwd(net.W2, L, w2);
+    if (a.pack) load_w2_packed(a.pack, L, w2); else load_w2_fwd(net.W2, L, w2);
     load_small<IN, OU>(net, L, r);
     const long ngroups = (a.rows + GROUP - 1) / GROUP;
     for (long g = blockIdx.x; g < ngroups; g += gridDim.x) {
@@ -96,6 +97,7 @@ int launch_forward(const float* params, int in_dim, int out_dim, int ou, int row
     a.out_tanh = o.out_tanh; a.out_scale = o.out_scale; a.sigma = o.sigma;
     a.k0 = (uint32_t)o.seed; a.k1 = (uint32_t)(o.seed >> 32); a.c1 = (uint32_t)o.ctr; a.c2 = (uint32_t)(o.ctr >> 32);
     a.y = y; a.ldy = ldy; a.h1 = h1; a.h2 = h2;
+    a.pack = weight_cache_lookup(make_net(params, in_dim, out_dim).W2, 0);
     const long ngroups = (rows + GROUP - 1) / GROUP;
     mpg_prof_begin(3, s);
 #define CALL(I, O) hipLaunchKernelGGL((k_forward<I, O>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, a)
@@ -120,6 +122,7 @@ struct BwdArgs {
     const float *h1, *h2;
     float *dz1, *dz2, *dz3, *dx;
     int lddx;
+    const float* pack;   // nullable: packed backward image of W2
 };
 
 template <int IN, int OU, bool WANT_DX>
@@ -132,7 +135,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_backward(const BwdArgs a) {
     const Net net = make_net(a.params, a.in_dim, a.out_dim);
     float w2t[128];
     SmallRegs<IN, OU> r;
-    load_w2_bwd(net.W2, L, w2t);
+    if (a.pack) load_w2_packed(a.pack, L, w2t); else load_w2_bwd(net.W2, L, w2t);
     load_small<IN, OU>(net, L, r);
     const long ngroups = (a.rows + GROUP - 1) / GROUP;
     const int tid = threadIdx.x;
@@ -177,6 +180,7 @@ int launch_backward(const float* params, int in_dim, int out_dim, int ou, int ro
     a.params = params; a.in_dim = in_dim; a.out_dim = out_dim; a.rows = rows; a.dy = dy; a.lddy = lddy;
     a.yout = yout; a.ldyo = ldyo; a.out_tanh = out_tanh; a.out_scale = out_scale; a.h1 = h1; a.h2 = h2;
     a.dz1 = dz1; a.dz2 = dz2; a.dz3 = dz3; a.dx = dx; a.lddx = lddx;
+    a.pack = weight_cache_lookup(make_net(params, in_dim, out_dim).W2, 1);
     const long ngroups = (rows + GROUP - 1) / GROUP;
     mpg_prof_begin(4, s);
     if (dx) {
@@ -195,29 +199,36 @@ int launch_backward(const float* params, int in_dim, int out_dim, int ou, int ro
 
 // -------------------------------------------------------------------------------------------------------
 // weight gradient:  dW2 = H1^T DZ2 on MFMA straight from the G16 stashes (k = batch row), the thin pieces
-// (dW1, db1, db2, dW3, db3) on VALU.  Each workgroup reduces a contiguous chunk of row groups into one slab;
-// k_reduce_slabs sums the slabs in a fixed order (deterministic, no float atomics).
+// (dW1, db1, db2, dW3, db3) on VALU.  Grid = (8 column slices, chunks of row groups): a workgroup accumulates the
+// 256 x 32 column slice of dW2 over its chunk (wave w: feature tiles 2w, 2w+1), so a chunk's slab is written once
+// by 8 workgroups; k_reduce_slabs sums the <= 32 chunk slabs in a fixed order (deterministic, no float atomics).
 // -------------------------------------------------------------------------------------------------------
 struct WgradArgs {
-    int in_dim, out_dim, rows, groups_per_wg;
+    int in_dim, out_dim, rows, groups_per_chunk;
     XSpec x;
     const float *h1, *h2, *dz1, *dz2, *dz3;
     float* slabs;
 };
 
+template <int IN>
+__device__ __forceinline__ float x_value(const XSpec& x, long gr, int i) {
+    return i < x.d0 ? x.x0[gr * x.ld0 + i] * x.scale[i] : x.x1[gr * x.ld1 + (i - x.d0)];
+}
+
 template <int IN, int OU>
 __global__ void __launch_bounds__(NTHREAD, 2) k_wgrad(const WgradArgs a) {
-    __shared__ float sX[GROUP * XS];
-    __shared__ float sD3[GROUP * MAXOUT];
+    constexpr int NQ = 2 * IN + 4 + 2 * OU + OU;      // thin quantities per lane
+    __shared__ float sRed[NWAVE * NQ * 64];
     const Lane L;
     const int tid = threadIdx.x;
+    const int sl = blockIdx.x;                         // column slice: hidden columns [32 sl, 32 sl + 32)
     const long ngroups = (a.rows + GROUP - 1) / GROUP;
-    const long g0 = (long)blockIdx.x * a.groups_per_wg;
-    const long g1 = (g0 + a.groups_per_wg < ngroups) ? g0 + a.groups_per_wg : ngroups;
-    f32x4 acc[16][2];
+    const long g0 = (long)blockIdx.y * a.groups_per_chunk;
+    const long g1 = (g0 + a.groups_per_chunk < ngroups) ? g0 + a.groups_per_chunk : ngroups;
+    f32x4 acc[2][2];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) acc[u][0] = acc[u][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float gW1[2][IN], gb1[2] = {0.f, 0.f}, gb2[2] = {0.f, 0.f}, gW3[2][OU], gb3 = 0.f;
+    for (int u = 0; u < 2; ++u) acc[u][0] = acc[u][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float gW1[2][IN], gb1[2] = {0.f, 0.f}, gb2[2] = {0.f, 0.f}, gW3[2][OU], gb3[OU];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
 #pragma unroll
@@ -225,59 +236,51 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_wgrad(const WgradArgs a) {
 #pragma unroll
         for (int o = 0; o < OU; ++o) gW3[t][o] = 0.f;
     }
+#pragma unroll
+    for (int o = 0; o < OU; ++o) gb3[o] = 0.f;
     const f32x4* H1 = reinterpret_cast<const f32x4*>(a.h1);
+    const f32x4* H2 = reinterpret_cast<const f32x4*>(a.h2);
+    const f32x4* DZ1 = reinterpret_cast<const f32x4*>(a.dz1);
+    const f32x4* DZ2 = reinterpret_cast<const f32x4*>(a.dz2);
     for (long g = g0; g < g1; ++g) {
-        load_x_group<IN>(a.x, a.rows, g, sX);
-        if (tid < GROUP * OU) {
-            const int row = tid / OU, o = tid % OU;
-            const long gr = g * GROUP + row;
-            const float d = gr < a.rows ? a.dz3[gr * OU + o] : 0.f;
-            sD3[row * MAXOUT + o] = d;
-            if (tid < OU) {   // db3[o]: one thread per output walks the 16 rows of the group
-                float sum = 0.f;
-                for (int rr = 0; rr < GROUP; ++rr) {
-                    const long g2 = g * GROUP + rr;
-                    if (g2 < a.rows) sum += a.dz3[g2 * OU + tid];
+        const f32x4 b0 = DZ2[(g * 16 + 2 * sl) * 64 + L.lane], b1 = DZ2[(g * 16 + 2 * sl + 1) * 64 + L.lane];
+        const f32x4 a0 = H1[(g * 16 + 2 * L.wave) * 64 + L.lane], a1 = H1[(g * 16 + 2 * L.wave + 1) * 64 + L.lane];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {   // the float4's 4 entries are 4 k-steps (k = batch row)
+            acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], b0[j], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], b1[j], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], b0[j], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], b1[j], acc[1][1], 0, 0, 0);
+        }
+        if ((int)((g - g0) & 7) == L.wave) {   // thin pieces: the chunk's groups are dealt round-robin to the 8 waves
+            const f32x4 d10 = DZ1[(g * 16 + 2 * sl) * 64 + L.lane], d11 = DZ1[(g * 16 + 2 * sl + 1) * 64 + L.lane];
+            const f32x4 h20 = H2[(g * 16 + 2 * sl) * 64 + L.lane], h21 = H2[(g * 16 + 2 * sl + 1) * 64 + L.lane];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const long gr = g * GROUP + L.row(j);
+                const bool live = gr < a.rows;
+                float d3[OU];
+#pragma unroll
+                for (int o = 0; o < OU; ++o) d3[o] = live ? a.dz3[gr * OU + o] : 0.f;
+                gb1[0] += d10[j]; gb1[1] += d11[j];
+                gb2[0] += b0[j];  gb2[1] += b1[j];
+#pragma unroll
+                for (int i = 0; i < IN; ++i) {
+                    const float xv = live ? x_value<IN>(a.x, gr, i) : 0.f;
+                    gW1[0][i] = fmaf(xv, d10[j], gW1[0][i]);
+                    gW1[1][i] = fmaf(xv, d11[j], gW1[1][i]);
                 }
-                gb3 += sum;
+#pragma unroll
+                for (int o = 0; o < OU; ++o) {
+                    gW3[0][o] = fmaf(h20[j], d3[o], gW3[0][o]);
+                    gW3[1][o] = fmaf(h21[j], d3[o], gW3[1][o]);
+                    if (L.c == 0) gb3[o] += d3[o];
+                }
             }
         }
-        float h2[2][4], dz1[2][4], dz2[2][4];
-        stash_load(a.h2, g, L, h2);
-        stash_load(a.dz1, g, L, dz1);
-        stash_load(a.dz2, g, L, dz2);
-        // dW2 tile (u, t) += H1[:, 16u:16u+16]^T DZ2[:, col tile]; the float4's 4 entries are 4 k-steps
-#pragma unroll
-        for (int u0 = 0; u0 < 16; u0 += 4) {
-            f32x4 af[4];
-#pragma unroll
-            for (int uu = 0; uu < 4; ++uu) af[uu] = H1[(g * 16 + u0 + uu) * 64 + L.lane];
-#pragma unroll
-            for (int uu = 0; uu < 4; ++uu)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    acc[u0 + uu][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[uu][j], dz2[0][j], acc[u0 + uu][0], 0, 0, 0);
-                    acc[u0 + uu][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[uu][j], dz2[1][j], acc[u0 + uu][1], 0, 0, 0);
-                }
-        }
-        __syncthreads();   // sX, sD3 ready
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int row = L.row(j);
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                gb1[t] += dz1[t][j];
-                gb2[t] += dz2[t][j];
-#pragma unroll
-                for (int i = 0; i < IN; ++i) gW1[t][i] = fmaf(sX[row * XS + i], dz1[t][j], gW1[t][i]);
-#pragma unroll
-                for (int o = 0; o < OU; ++o) gW3[t][o] = fmaf(h2[t][j], sD3[row * MAXOUT + o], gW3[t][o]);
-            }
-        }
-        __syncthreads();   // before the next group overwrites sX / sD3
     }
-    // ---- write this workgroup's slab ----
-    float* slab = a.slabs + (size_t)blockIdx.x * net_size(a.in_dim, a.out_dim);
+    // ---- this workgroup's part of the chunk slab ----
+    float* slab = a.slabs + (size_t)blockIdx.y * net_size(a.in_dim, a.out_dim);
     float* sW1 = slab;
     float* sb1 = sW1 + a.in_dim * H;
     float* sW2 = sb1 + H;
@@ -285,34 +288,55 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_wgrad(const WgradArgs a) {
     float* sW3 = sb2 + H;
     float* sb3 = sW3 + H * a.out_dim;
 #pragma unroll
-    for (int u = 0; u < 16; ++u)
+    for (int u = 0; u < 2; ++u)
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) sW2[(16 * u + 4 * L.rg + j) * H + L.col(t)] = acc[u][t][j];
-    // thin pieces: sum the 4 row-quads (lanes l, l^16, l^32, l^48)
+            for (int j = 0; j < 4; ++j)
+                sW2[(16 * (2 * L.wave + u) + 4 * L.rg + j) * H + 32 * sl + 16 * t + L.c] = acc[u][t][j];
+    // thin pieces: sum over the 8 waves and the 4 row quads through LDS in a fixed order
+    {
+        float* dst = sRed + (L.wave * NQ) * 64 + L.lane;
+        int q = 0;
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        float v1 = gb1[t], v2 = gb2[t];
-        v1 += __shfl_xor(v1, 16); v1 += __shfl_xor(v1, 32);
-        v2 += __shfl_xor(v2, 16); v2 += __shfl_xor(v2, 32);
-        if (L.rg == 0) { sb1[L.col(t)] = v1; sb2[L.col(t)] = v2; }
+        for (int t = 0; t < 2; ++t) {
 #pragma unroll
-        for (int i = 0; i < IN; ++i) {
-            float v = gW1[t][i];
-            v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
-            if (L.rg == 0) sW1[i * H + L.col(t)] = v;
+            for (int i = 0; i < IN; ++i) dst[(q++) * 64] = gW1[t][i];
+            dst[(q++) * 64] = gb1[t];
+            dst[(q++) * 64] = gb2[t];
+#pragma unroll
+            for (int o = 0; o < OU; ++o) dst[(q++) * 64] = gW3[t][o];
         }
 #pragma unroll
-        for (int o = 0; o < OU; ++o) {
-            float v = gW3[t][o];
-            v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
-            if (L.rg == 0) sW3[L.col(t) * a.out_dim + o] = v;
-        }
-        if (L.rg == 0)
-            for (int o = OU; o < a.out_dim; ++o) sW3[L.col(t) * a.out_dim + o] = 0.f;   // unused output columns
+        for (int o = 0; o < OU; ++o) dst[(q++) * 64] = gb3[o];
     }
-    if (tid < a.out_dim) sb3[tid] = tid < OU ? gb3 : 0.f;
+    __syncthreads();
+    for (int item = tid; item < NQ * 16; item += NTHREAD) {
+        const int q = item / 16, c = item % 16;
+        float sum = 0.f;
+        for (int w = 0; w < NWAVE; ++w)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) sum += sRed[(w * NQ + q) * 64 + rg * 16 + c];
+        constexpr int PER_T = IN + 2 + OU;
+        if (q < 2 * PER_T) {
+            const int t = q / PER_T, r = q % PER_T, col = 32 * sl + 16 * t + c;
+            if (r < IN) sW1[r * H + col] = sum;
+            else if (r == IN) sb1[col] = sum;
+            else if (r == IN + 1) sb2[col] = sum;
+            else sW3[col * a.out_dim + (r - IN - 2)] = sum;
+        } else if (sl == 0) {
+            // db3[o]: lanes with c == 0 carried it; summing over c adds exact zeros
+            float tot = sum;
+            tot += __shfl_xor(tot, 1, 16); tot += __shfl_xor(tot, 2, 16); tot += __shfl_xor(tot, 4, 16); tot += __shfl_xor(tot, 8, 16);
+            if (c == 0) sb3[q - 2 * PER_T] = tot;
+        }
+    }
+    // unused output columns of W3 / b3 (the log-std half of the policy head, SURVEY B-5) have zero gradient
+    for (int item = tid; item < 32 * (a.out_dim - OU); item += NTHREAD) {
+        const int col = 32 * sl + item / (a.out_dim - OU), o = OU + item % (a.out_dim - OU);
+        sW3[col * a.out_dim + o] = 0.f;
+    }
+    if (sl == 0 && tid < a.out_dim - OU) sb3[OU + tid] = 0.f;
 }
 
 __global__ void k_reduce_slabs(const float* __restrict__ slabs, int nslab, int n, float* __restrict__ out) {
@@ -323,16 +347,16 @@ __global__ void k_reduce_slabs(const float* __restrict__ slabs, int nslab, int n
     out[i] = s;
 }
 
-static int wgrad_groups_per_wg(long ngroups) {
-    long gp = (ngroups + 63) / 64;   // <= 64 slabs
+static int wgrad_groups_per_chunk(long ngroups) {
+    long gp = (ngroups + 31) / 32;   // <= 32 chunk slabs
     return (int)(gp < 1 ? 1 : gp);
 }
 
 size_t wgrad_workspace_floats(int rows, int in_dim, int out_dim) {
     const long ngroups = (rows + GROUP - 1) / GROUP;
-    const int gp = wgrad_groups_per_wg(ngroups);
-    const long nwg = (ngroups + gp - 1) / gp;
-    return (size_t)nwg * net_size(in_dim, out_dim);
+    const int gp = wgrad_groups_per_chunk(ngroups);
+    const long nch = (ngroups + gp - 1) / gp;
+    return (size_t)nch * net_size(in_dim, out_dim);
 }
 
 int launch_wgrad(int in_dim, int out_dim, int ou, int rows, const XSpec& x, const float* h1, const float* h2,
@@ -342,16 +366,16 @@ int launch_wgrad(int in_dim, int out_dim, int ou, int rows, const XSpec& x, cons
     a.in_dim = in_dim; a.out_dim = out_dim; a.rows = rows; a.x = x;
     a.h1 = h1; a.h2 = h2; a.dz1 = dz1; a.dz2 = dz2; a.dz3 = dz3; a.slabs = ws;
     const long ngroups = (rows + GROUP - 1) / GROUP;
-    a.groups_per_wg = wgrad_groups_per_wg(ngroups);
-    const int nwg = (int)((ngroups + a.groups_per_wg - 1) / a.groups_per_wg);
+    a.groups_per_chunk = wgrad_groups_per_chunk(ngroups);
+    const int nch = (int)((ngroups + a.groups_per_chunk - 1) / a.groups_per_chunk);
     mpg_prof_begin(5, s);
-#define CALL(I, O) hipLaunchKernelGGL((k_wgrad<I, O>), dim3(nwg), dim3(NTHREAD), 0, s, a)
+#define CALL(I, O) hipLaunchKernelGGL((k_wgrad<I, O>), dim3(8, nch), dim3(NTHREAD), 0, s, a)
     MPG_DISPATCH_NET(in_dim, ou, CALL)
 #undef CALL
     mpg_prof_end(5, s);
     MPG_CHECK_LAUNCH("k_wgrad");
     const int n = net_size(in_dim, out_dim);
-    hipLaunchKernelGGL(k_reduce_slabs, dim3((n + 255) / 256), dim3(256), 0, s, ws, nwg, n, grad);
+    hipLaunchKernelGGL(k_reduce_slabs, dim3((n + 255) / 256), dim3(256), 0, s, ws, nch, n, grad);
     MPG_CHECK_LAUNCH("k_reduce_slabs");
     return MPG_OK;
 }

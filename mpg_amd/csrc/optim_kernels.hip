@@ -6,6 +6,8 @@
 //   m += (g - m)(1 - b1);  v += (g^2 - v)(1 - b2);  w -= lr_t * m / (sqrt(v) + eps),  lr_t = lr sqrt(1-b2^t)/(1-b1^t).
 #include "mpg_common.h"
 
+int weight_cache_refresh_if_bound(const float* params, hipStream_t s);   // weight_cache.hip
+
 namespace {
 
 constexpr int MAXSEG = 8;
@@ -18,6 +20,8 @@ struct Segs {
 };
 
 // one block per segment: norm = sqrt(sum g^2); g *= clip * min(1/norm, 1/clip)   (tf.clip_by_global_norm)
+// 8 independent accumulators / float4 loads keep ~8 loads in flight per lane (a serial fma chain on one load per
+// iteration is L2-latency bound: 35 us for 68 k floats).
 __global__ void __launch_bounds__(1024) k_clip(const Segs sg, float* __restrict__ grad, float clip,
                                                float* __restrict__ norms, int* __restrict__ nonfinite) {
     __shared__ float red[1024];
@@ -25,9 +29,17 @@ __global__ void __launch_bounds__(1024) k_clip(const Segs sg, float* __restrict_
     const int k = blockIdx.x;
     float* g = grad + sg.off[k];
     const int n = sg.n[k];
-    float s = 0.f;
-    for (int i = threadIdx.x; i < n; i += 1024) s = fmaf(g[i], g[i], s);
-    red[threadIdx.x] = s;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int i = threadIdx.x;
+    for (; i + 7 * 1024 < n; i += 8 * 1024) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = g[i + u * 1024];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc[u] = fmaf(v[u], v[u], acc[u]);
+    }
+    for (; i < n; i += 1024) acc[0] = fmaf(g[i], g[i], acc[0]);
+    red[threadIdx.x] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
     __syncthreads();
     for (int w = 512; w > 0; w >>= 1) {
         if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
@@ -41,7 +53,15 @@ __global__ void __launch_bounds__(1024) k_clip(const Segs sg, float* __restrict_
     }
     __syncthreads();
     const float sc = s_scale;
-    for (int i = threadIdx.x; i < n; i += 1024) g[i] *= sc;
+    i = threadIdx.x;
+    for (; i + 7 * 1024 < n; i += 8 * 1024) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = g[i + u * 1024];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) g[i + u * 1024] = v[u] * sc;
+    }
+    for (; i < n; i += 1024) g[i] *= sc;
 }
 
 __global__ void k_adam_polyak(const Segs sg, float* __restrict__ w, float* __restrict__ m, float* __restrict__ v,
@@ -105,5 +125,8 @@ extern "C" int mpg_adam_polyak(float* w, float* m, float* v, float* target, cons
     hipLaunchKernelGGL(k_adam_polyak, dim3((maxn + 255) / 256, n_seg), dim3(256), 0, mpg_stream(stream), sg, w, m, v,
                        target, grad, tau, skip_flag);
     MPG_CHECK_LAUNCH("k_adam_polyak");
-    return MPG_OK;
+    // keep the packed register images of bound buffers in sync with what was just written
+    int rc = weight_cache_refresh_if_bound(w, mpg_stream(stream));
+    if (rc == MPG_OK && target) rc = weight_cache_refresh_if_bound(target, mpg_stream(stream));
+    return rc;
 }

@@ -160,6 +160,7 @@ struct RollArgs {
     int sel[MAXSEL], n_sel;
     float* XQ;                          // [n_sel][R][OBS+ACT] critic inputs (scaled obs | action) at the selected slices
     float* GK;                          // [n_sel][R] discounted reward sums G_k
+    const float* pack;                  // nullable: packed forward image of the policy's W2
 };
 
 template <class ENV>
@@ -174,7 +175,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_fwd(const RollArgs a) {
     const Net net = make_net(a.policy, OBS, 2 * ACT);
     float w2[128];
     SmallRegs<OBS, ACT> r;
-    load_w2_fwd(net.W2, L, w2);
+    if (a.pack) load_w2_packed(a.pack, L, w2); else load_w2_fwd(net.W2, L, w2);
     load_small<OBS, ACT>(net, L, r);
     const long R = (long)a.rows * a.M;
     const long ngroups = (R + GROUP - 1) / GROUP;
@@ -311,6 +312,7 @@ struct RollBwdArgs {
     float rho[MAXN];                    // dL/d(raw reward of step t)
     int stash_all;                      // 0: parameter gradient through step 0 only (MPG); 1: every step (NADP)
     float *DZ1, *DZ2, *DZ3;             // stashes for the weight gradient: T = stash_all ? n+1 : 1 steps
+    const float* pack;                  // nullable: packed backward image of the policy's W2
 };
 
 template <class ENV>
@@ -325,7 +327,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_bwd(const RollBwdArgs a)
     const Net net = make_net(a.policy, OBS, 2 * ACT);
     float w2t[128];
     SmallRegs<OBS, ACT> r;
-    load_w2_bwd(net.W2, L, w2t);
+    if (a.pack) load_w2_packed(a.pack, L, w2t); else load_w2_bwd(net.W2, L, w2t);
     load_small<OBS, ACT>(net, L, r);
     const long R = (long)a.rows * a.M;
     const long ngroups = (R + GROUP - 1) / GROUP;
@@ -428,6 +430,7 @@ void fill_roll(RollArgs& a, const mpg_cfg_t* cfg, const float* policy, int rows,
     const bool ranged = cfg->action_range > 0.f;
     a.out_tanh = (cfg->policy_out_act == MPG_ACT_TANH || ranged) ? 1 : 0;
     a.out_scale = ranged ? cfg->action_range : 1.f;
+    a.pack = weight_cache_lookup(make_net(policy, cfg->obs_dim, 2 * cfg->act_dim).W2, 0);
 }
 
 int grid_for(long ngroups) { return (int)(ngroups < 256 ? ngroups : 256); }
@@ -537,6 +540,7 @@ extern "C" int mpg_rollout_pg(const mpg_cfg_t* cfg, const float* policy_params, 
     for (int t = 0; t < MAXN; ++t) ba.rho[t] = rho[t];
     ba.stash_all = all_steps_param_grad ? 1 : 0;
     ba.DZ1 = DZ1; ba.DZ2 = DZ2; ba.DZ3 = DZ3;
+    ba.pack = weight_cache_lookup(make_net(policy_params, od, 2 * ad).W2, 1);
     mpg_prof_begin(1, s);
     if (cfg->env_kind == MPG_ENV_PATH_TRACKING)
         hipLaunchKernelGGL((k_rollout_bwd<PathTracking>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, ba);

@@ -6,9 +6,12 @@ likewise.  Per-optimizer step counters and the PolynomialDecay schedules (policy
 """
 import math
 
+import ctypes
+
 import numpy as np
 import torch
 
+from . import _lib as L
 from . import ops
 
 
@@ -66,6 +69,30 @@ class PolicyWithQs(object):
         self.schedules = {n: (tuple(policy_lr_schedule) if n == 'policy' else tuple(value_lr_schedule)) for n in self.names}
         self.opt_steps = {n: 0 for n in self.names}
         self.nonfinite = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._bind_weight_cache()
+
+    # ---- weight cache (packed register images of the hidden kernels; see include/mpg_hip.h) ----
+    def _bind_weight_cache(self):
+        k = len(self.names)
+        nf = L.lib().mpg_weight_cache_floats(L.c_int(k))
+        ind = (ctypes.c_int * k)(*[self.dims[n][0] for n in self.names])
+        outd = (ctypes.c_int * k)(*[self.dims[n][1] for n in self.names])
+        self._cache = [torch.empty(nf, dtype=torch.float32, device=self.device) for _ in range(2)]
+        self._bound = [self.params.data_ptr(), self.targets.data_ptr()]
+        for buf, cache in zip((self.params, self.targets), self._cache):
+            L.call('mpg_weight_cache_bind', L.ptr(buf), ind, outd, L.c_int(k), L.ptr(cache), L.stream())
+
+    def refresh_weight_cache(self):
+        """call after writing params/targets by anything other than apply_gradients"""
+        for buf in (self.params, self.targets):
+            L.call('mpg_weight_cache_refresh', L.ptr(buf), L.stream())
+
+    def __del__(self):
+        try:
+            for p in getattr(self, '_bound', []):
+                L.lib().mpg_weight_cache_unbind(ctypes.c_void_p(p))
+        except Exception:
+            pass
 
     # ---- views ----
     def net(self, name, target=False):
@@ -94,11 +121,13 @@ class PolicyWithQs(object):
             flat = torch.cat([torch.as_tensor(np.asarray(a.cpu() if isinstance(a, torch.Tensor) else a),
                                               dtype=torch.float32).reshape(-1) for a in w])
             dst.copy_(flat.to(self.device))
+        self.refresh_weight_cache()
 
     def set_flat(self, params, targets=None):
         self.params.copy_(torch.as_tensor(params, dtype=torch.float32).to(self.device))
         if targets is not None:
             self.targets.copy_(torch.as_tensor(targets, dtype=torch.float32).to(self.device))
+        self.refresh_weight_cache()
 
     # ---- forward helpers ----
     def compute_action(self, obs):
@@ -158,6 +187,7 @@ class PolicyWithQs(object):
         for k in ('params', 'targets', 'm', 'v'):
             getattr(self, k).copy_(sd[k].to(self.device))
         self.opt_steps = dict(sd['opt_steps'])
+        self.refresh_weight_cache()
 
     def save_weights(self, save_dir, iteration):
         torch.save(self.state_dict(), '%s/ckpt_ite%d.pt' % (save_dir, iteration))
