@@ -129,7 +129,7 @@ def main():
     lib.mpg_prof_enable(0)
     assert fwd_n == a.steps and bwd_n == a.steps, (fwd_n, bwd_n)
     finite = bool(torch.isfinite(worker.policy_with_value.params).all().item())
-    assert finite and worker.policy_with_value.nonfinite.item() == 0, 'non-finite parameters after the timed region'
+    assert finite and int(worker.policy_with_value.nonfinite.sum().item()) == 0, 'non-finite parameters after the timed region'
 
     if rank != 0:
         return

@@ -161,7 +161,8 @@ int mpg_q_loss_grad(const mpg_cfg_t* cfg, const float* q_params, int rows, const
  *
  *   rows   B_local start states obs0 [rows][obs_dim]  (the M copies are tiled inside: trajectory = m*rows + b)
  *   eps    [n][M*rows] standard-normal draws for the model's injected noise
- *          (path_tracking_env.py:119: dy += 0.5 + 0.01 eps; inverted_pendulum_model.py:61: p += 0.1 + 0.5 eps)
+ *          (path_tracking_env.py:119: dy += 0.5 + 0.01 eps; inverted_pendulum_model.py:61: p += 0.1 + 0.5 eps);
+ *          NULL: drawn inside the kernel from Philox4x32-10 keyed by (noise_seed, noise_ctr, step, trajectory)
  *   select/n_select/w (HOST arrays, n_select <= 4)   slices k whose mean returns R_k = mean(G_k + gamma^k Q1)
  *          enter the loss  sum_k w_k * (-R_k)   (w = rule_based_weights, mpg_learner.py:384-399, computed by the host)
  *   inv_b_global   1/B_global: divisor of the batch mean (the M-mean is applied inside); n < 32
@@ -172,16 +173,16 @@ size_t mpg_rollout_pg_workspace_bytes(const mpg_cfg_t* cfg, int rows, int M, int
                                       int all_steps_param_grad);
 int mpg_rollout_pg(const mpg_cfg_t* cfg, const float* policy_params, const float* q1_params, int rows, int M,
                    int n, const int* select, int n_select, const float* w, const float* obs0, const float* eps,
-                   float inv_b_global, int all_steps_param_grad, float* ret_sum, float* ret_sqsum, float* grad,
+                   uint64_t noise_seed, uint64_t noise_ctr, float inv_b_global, int all_steps_param_grad, float* ret_sum, float* ret_sqsum, float* grad,
                    void* ws, size_t ws_bytes, mpg_stream_t stream);
 
 /* NADPLearner.model_rollout_for_q_estimation  - learners/nadp.py:87-126: from (s, a_replay) roll n model steps,
  * later actions from pi_theta, y = G_n + gamma^n * Q1_target(s~_n, pi_theta(s~_n)) (no gradient).
- * eps [n][rows] standard normal. */
+ * eps [n][rows] standard normal, or NULL for in-kernel Philox(noise_seed, noise_ctr) draws. */
 size_t mpg_rollout_q_target_workspace_bytes(const mpg_cfg_t* cfg, int rows);
 int mpg_rollout_q_target(const mpg_cfg_t* cfg, const float* policy_params, const float* q1t, int rows, int n,
-                         const float* obs0, const float* act0, const float* eps, float* y, void* ws, size_t ws_bytes,
-                         mpg_stream_t stream);
+                         const float* obs0, const float* act0, const float* eps, uint64_t noise_seed,
+                         uint64_t noise_ctr, float* y, void* ws, size_t ws_bytes, mpg_stream_t stream);
 
 /* TD3Learner.policy_forward_and_backward  - learners/td3.py:120-134:
  *   loss = -mean_B min(Q1,Q2)(s~, pi(s~)); grad = flat policy gradient (unclipped, reduced over this GPU's rows,
@@ -198,20 +199,21 @@ int mpg_td3_policy_grad(const mpg_cfg_t* cfg, const float* policy_params, const 
 
 /* tf.clip_by_global_norm(g, clip) applied to each of the n_seg (<= 8) consecutive networks of `grad`
  * (seg_sizes: HOST array of their lengths) - learners/mpg_learner.py:415-431: norms[k] = ||g_k||_2,
- * g_k *= clip * min(1/norm, 1/clip) in place.  nonfinite_flag (device int, nullable, caller zeroes it) is
- * raised when a norm is not finite (optimizer.py:357-361 zeroes such gradients).  Must run AFTER the
- * cross-GPU all-reduce: the clip is not linear. */
+ * g_k *= clip * min(1/norm, 1/clip) in place.  nonfinite_flags (device int[n_seg], nullable) receives 1 for
+ * every network whose norm is not finite, else 0 (optimizer.py:357-361 zeroes such gradient lists).  Must run
+ * AFTER the cross-GPU all-reduce: the clip is not linear. */
 int mpg_clip_by_global_norm(float* grad, const int* seg_sizes, int n_seg, float clip, float* norms,
-                            int* nonfinite_flag, mpg_stream_t stream);
+                            int* nonfinite_flags, mpg_stream_t stream);
 
 /* PolicyWithQs.apply_gradients + update_*_target  - policy.py:123-171.  For every network k (HOST arrays):
  * do_adam[k]: one Keras Adam step (beta .9/.999, eps 1e-7 outside the sqrt, TF ApplyAdam form) with the
  * bias-corrected rate lr_t[k] = lr(step)*sqrt(1-b2^t)/(1-b1^t) computed by the caller from ITS per-optimizer
  * step counter and PolynomialDecay schedule (policy.py:54-70); do_polyak[k]: target = tau*w + (1-tau)*target
- * afterwards.  If *skip_flag != 0 the gradient is taken as zeros (NaN guard). */
+ * afterwards.  If any of skip_flags[0..n_skip_flags) (device ints, nullable) is non-zero the gradient is taken as
+ * zeros (NaN guard, optimizer.py:357-361). */
 int mpg_adam_polyak(float* w, float* m, float* v, float* target, const float* grad, const int* seg_sizes,
                     int n_seg, const float* lr_t, const int* do_adam, const int* do_polyak, float tau,
-                    const int* skip_flag, mpg_stream_t stream);
+                    const int* skip_flags, int n_skip_flags, mpg_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * On-device replay ring (K9, uniform part)  - buffer.py:21-91

@@ -39,10 +39,11 @@ class ReplayBuffer(object):
         """batch = (obs [n,od], act [n,ad], rew [n], obs2 [n,od], done [n] uint8) device tensors (buffer.py:80-82)."""
         obs, act, rew, obs2, done = batch
         n = obs.shape[0]
-        done = done.to(torch.uint8).contiguous()
+        if done.dtype != torch.uint8:
+            done = done.to(torch.uint8)
         L.call('mpg_replay_add', L.c_int(self._maxsize), L.c_int(self._next_idx), L.c_int(n), L.c_int(self.obs_dim),
-               L.c_int(self.act_dim), L.ptr(obs.contiguous()), L.ptr(act.contiguous()), L.ptr(rew.contiguous()),
-               L.ptr(obs2.contiguous()), L.ptr(done), L.ptr(self.obs), L.ptr(self.act), L.ptr(self.rew),
+               L.c_int(self.act_dim), L.ptr(obs), L.ptr(act), L.ptr(rew),
+               L.ptr(obs2), L.ptr(done), L.ptr(self.obs), L.ptr(self.act), L.ptr(self.rew),
                L.ptr(self.obs2), L.ptr(self.done), L.stream())
         self._next_idx = (self._next_idx + n) % self._maxsize
         self._size = min(self._size + n, self._maxsize)

@@ -49,7 +49,7 @@ __global__ void __launch_bounds__(1024) k_clip(const Segs sg, float* __restrict_
         const float nrm = sqrtf(red[0]);
         norms[k] = nrm;
         s_scale = clip * fminf(1.f / nrm, 1.f / clip);
-        if (!isfinite(nrm) && nonfinite) atomicOr(nonfinite, 1);
+        if (nonfinite) nonfinite[k] = isfinite(nrm) ? 0 : 1;
     }
     __syncthreads();
     const float sc = s_scale;
@@ -66,7 +66,7 @@ __global__ void __launch_bounds__(1024) k_clip(const Segs sg, float* __restrict_
 
 __global__ void k_adam_polyak(const Segs sg, float* __restrict__ w, float* __restrict__ m, float* __restrict__ v,
                               float* __restrict__ target, const float* __restrict__ grad, float tau,
-                              const int* __restrict__ skip) {
+                              const int* __restrict__ skip, int n_skip) {
     const int k = blockIdx.y;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= sg.n[k]) return;
@@ -74,7 +74,10 @@ __global__ void k_adam_polyak(const Segs sg, float* __restrict__ w, float* __res
     const float b1 = 0.9f, b2 = 0.999f, eps = 1e-7f;
     float wj = w[j];
     if (sg.do_adam[k]) {
-        const float g = (skip && *skip) ? 0.f : grad[j];     // optimizer.py:357-361: a non-finite gradient is zeroed
+        bool bad = false;                                     // optimizer.py:357-361: if ANY gradient is non-finite,
+        if (skip)                                             // the whole list is replaced by zeros
+            for (int q = 0; q < n_skip; ++q) bad |= skip[q] != 0;
+        const float g = bad ? 0.f : grad[j];
         float mj = m[j], vj = v[j];
         mj += (g - mj) * (1.f - b1);
         vj += (g * g - vj) * (1.f - b2);
@@ -111,7 +114,7 @@ extern "C" int mpg_clip_by_global_norm(float* grad, const int* seg_sizes, int n_
 
 extern "C" int mpg_adam_polyak(float* w, float* m, float* v, float* target, const float* grad, const int* seg_sizes,
                                int n_seg, const float* lr_t, const int* do_adam, const int* do_polyak, float tau,
-                               const int* skip_flag, mpg_stream_t stream) {
+                               const int* skip_flags, int n_skip_flags, mpg_stream_t stream) {
     Segs sg;
     MPG_REQUIRE(w && m && v && grad && lr_t && do_adam && do_polyak && fill(sg, n_seg, seg_sizes) > 0,
                 "mpg_adam_polyak: bad argument");
@@ -123,7 +126,7 @@ extern "C" int mpg_adam_polyak(float* w, float* m, float* v, float* target, cons
         if (sg.n[k] > maxn) maxn = sg.n[k];
     }
     hipLaunchKernelGGL(k_adam_polyak, dim3((maxn + 255) / 256, n_seg), dim3(256), 0, mpg_stream(stream), sg, w, m, v,
-                       target, grad, tau, skip_flag);
+                       target, grad, tau, skip_flags, skip_flags ? n_skip_flags : 0);
     MPG_CHECK_LAUNCH("k_adam_polyak");
     // keep the packed register images of bound buffers in sync with what was just written
     int rc = weight_cache_refresh_if_bound(w, mpg_stream(stream));

@@ -154,7 +154,8 @@ struct RollArgs {
     float out_scale;
     const float* obs0;                  // [rows][OBS]
     const float* act0;                  // nullable [rows][ACT]: first action given (NADP Q-target rollout)
-    const float* eps;                   // [n][R]
+    const float* eps;                   // [n][R] standard normal, or nullptr: Philox4x32-10(noise_seed, noise_ctr, t, trajectory)
+    uint32_t nk0, nk1, nc0, nc1;
     float *H1, *H2;                     // nullable G16 stashes, group index t*ngroups + g
     float* SA;                          // nullable [(n+1)][R][SAW]: obs | action of every step
     int sel[MAXSEL], n_sel;
@@ -166,10 +167,11 @@ struct RollArgs {
 template <class ENV>
 __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_fwd(const RollArgs a) {
     constexpr int OBS = ENV::OBS, ACT = ENV::ACT, QIN = OBS + ACT;
-    __shared__ __attribute__((aligned(16))) float smem[GROUP * LDA + GROUP * XS + NWAVE * GROUP * MAXOUT];
+    __shared__ __attribute__((aligned(16))) float smem[GROUP * LDA + GROUP * XS + NWAVE * GROUP * MAXOUT + MAXN * GROUP];
     float* sA = smem;
     float* sX = sA + GROUP * LDA;
     float* sPart = sX + GROUP * XS;
+    float* sEps = sPart + NWAVE * GROUP * MAXOUT;
     const Lane L;
     const int tid = threadIdx.x;
     const Net net = make_net(a.policy, OBS, 2 * ACT);
@@ -188,6 +190,15 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_fwd(const RollArgs a) {
             const float* src = a.obs0 + (tr % a.rows) * OBS;
 #pragma unroll
             for (int i = 0; i < OBS; ++i) o[i] = src[i];
+        }
+        if (!a.eps) {   // draw the whole group's model noise up front, off the serial chain (one value per thread)
+            for (int idx = tid; idx < a.n * GROUP; idx += NTHREAD) {
+                const int t = idx / GROUP;
+                const long trj = g * GROUP + (idx % GROUP);
+                const Philox4 p = philox4x32_10((uint32_t)trj, (uint32_t)t, a.nc0, a.nc1 ^ 0x6e6f6973u, a.nk0, a.nk1);
+                sEps[idx] = sqrtf(-2.f * logf(u01(p.v[0]))) * cosf(6.283185307179586f * u01(p.v[1]));
+            }
+            // visible to the dynamics lanes after the first barrier of the step loop
         }
         for (int t = 0; t <= a.n; ++t) {
             if (own) {
@@ -231,7 +242,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_fwd(const RollArgs a) {
                         }
                 }
                 if (t < a.n) {
-                    const float e = live ? a.eps[(long)t * R + tr] : 0.f;
+                    const float e = a.eps ? (live ? a.eps[(long)t * R + tr] : 0.f) : sEps[t * GROUP + tid];
                     float on[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                     float rew;
                     ENV::step(o, act, e, on, rew);
@@ -469,10 +480,10 @@ extern "C" size_t mpg_rollout_pg_workspace_bytes(const mpg_cfg_t* cfg, int rows,
 
 extern "C" int mpg_rollout_pg(const mpg_cfg_t* cfg, const float* policy_params, const float* q1_params, int rows, int M,
                               int n, const int* select, int n_select, const float* w, const float* obs0, const float* eps,
-                              float inv_b_global, int all_steps_param_grad, float* ret_sum, float* ret_sqsum, float* grad,
+                              uint64_t noise_seed, uint64_t noise_ctr, float inv_b_global, int all_steps_param_grad, float* ret_sum, float* ret_sqsum, float* grad,
                               void* ws, size_t ws_bytes, mpg_stream_t stream) {
     MPG_REQUIRE(cfg_ok(cfg), "mpg_rollout_pg: unsupported cfg (obs/act dims, env_kind)");
-    MPG_REQUIRE(policy_params && q1_params && select && w && obs0 && eps && ret_sum && ret_sqsum && grad && ws,
+    MPG_REQUIRE(policy_params && q1_params && select && w && obs0 && ret_sum && ret_sqsum && grad && ws,
                 "mpg_rollout_pg: null pointer");
     MPG_REQUIRE(rows > 0 && M > 0 && n > 0 && n < MAXN && n_select > 0 && n_select <= MAXSEL, "mpg_rollout_pg: bad sizes");
     const long R = (long)rows * M;
@@ -497,6 +508,7 @@ extern "C" int mpg_rollout_pg(const mpg_cfg_t* cfg, const float* policy_params, 
     RollArgs fa;
     fill_roll(fa, cfg, policy_params, rows, M, n);
     fa.obs0 = obs0; fa.act0 = nullptr; fa.eps = eps; fa.H1 = H1; fa.H2 = H2; fa.SA = SA;
+    fa.nk0 = (uint32_t)noise_seed; fa.nk1 = (uint32_t)(noise_seed >> 32); fa.nc0 = (uint32_t)noise_ctr; fa.nc1 = (uint32_t)(noise_ctr >> 32);
     fa.n_sel = n_select;
     for (int k = 0; k < MAXSEL; ++k) fa.sel[k] = k < n_select ? select[k] : -1;
     fa.XQ = XQ; fa.GK = GK;
@@ -562,9 +574,9 @@ extern "C" size_t mpg_rollout_q_target_workspace_bytes(const mpg_cfg_t* cfg, int
 }
 
 extern "C" int mpg_rollout_q_target(const mpg_cfg_t* cfg, const float* policy_params, const float* q1t, int rows, int n,
-                                    const float* obs0, const float* act0, const float* eps, float* y, void* ws,
-                                    size_t ws_bytes, mpg_stream_t stream) {
-    MPG_REQUIRE(cfg_ok(cfg) && policy_params && q1t && obs0 && act0 && eps && y && ws && rows > 0 && n > 0 && n < MAXN,
+                                    const float* obs0, const float* act0, const float* eps, uint64_t noise_seed,
+                                    uint64_t noise_ctr, float* y, void* ws, size_t ws_bytes, mpg_stream_t stream) {
+    MPG_REQUIRE(cfg_ok(cfg) && policy_params && q1t && obs0 && act0 && y && ws && rows > 0 && n > 0 && n < MAXN,
                 "mpg_rollout_q_target: bad argument");
     if (ws_bytes < mpg_rollout_q_target_workspace_bytes(cfg, rows)) {
         mpg_set_error("mpg_rollout_q_target: workspace too small");
@@ -577,6 +589,7 @@ extern "C" int mpg_rollout_q_target(const mpg_cfg_t* cfg, const float* policy_pa
     RollArgs fa;
     fill_roll(fa, cfg, policy_params, rows, 1, n);
     fa.obs0 = obs0; fa.act0 = act0; fa.eps = eps; fa.H1 = fa.H2 = nullptr; fa.SA = nullptr;
+    fa.nk0 = (uint32_t)noise_seed; fa.nk1 = (uint32_t)(noise_seed >> 32); fa.nc0 = (uint32_t)noise_ctr; fa.nc1 = (uint32_t)(noise_ctr >> 32);
     fa.n_sel = 1;
     for (int k = 0; k < MAXSEL; ++k) fa.sel[k] = k == 0 ? n : -1;
     fa.XQ = XQ; fa.GK = GK;

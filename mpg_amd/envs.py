@@ -58,11 +58,13 @@ class PathTrackingEnv(object):
 
     def step(self, action):
         """action [num_agent, 2] in [-1, 1] -> (obs, reward, done, info) (:456-472)."""
-        action = action.to(self.device, torch.float32).contiguous()
+        if not (action.dtype == torch.float32 and action.device == self.device and action.is_contiguous()):
+            action = action.to(self.device, torch.float32).contiguous()
         assert action.shape == (self.num_agent, 2)
         obs = torch.empty_like(self.obs)
         reward = torch.empty_like(self.reward)
+        done = torch.empty_like(self.done)      # fresh outputs: callers keep them (replay batches)
         L.call('mpg_env_step', L.c_int(0), L.c_int(self.num_agent), L.ptr(self._state), L.ptr(action),
-               L.ptr(obs), L.ptr(reward), L.ptr(self.done), L.ptr(self.done_intended), L.stream())
-        self.obs, self.reward = obs, reward
+               L.ptr(obs), L.ptr(reward), L.ptr(done), L.ptr(self.done_intended), L.stream())
+        self.obs, self.reward, self.done = obs, reward, done
         return self.obs, self.reward, self.done, {}

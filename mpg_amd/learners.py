@@ -48,11 +48,18 @@ class _LearnerBase(object):
         self.n_grad = int(pw.offsets[-1])
         self.flat = torch.zeros(self.n_grad + N_STATS, dtype=torch.float32, device=self.device)
         self.norms = torch.zeros(len(pw.names), dtype=torch.float32, device=self.device)
+        self.seed = int(getattr(args, 'seed', 0)) + 12345
         self._noise_gen = torch.Generator(device=self.device)
-        self._noise_gen.manual_seed(int(getattr(args, 'seed', 0)) + 12345)
+        self._noise_gen.manual_seed(self.seed)
+        self._views = None
+        self._lazy_stats = None
 
     # ---- optimizer-facing API ----
     def get_stats(self):
+        """Host copy of the stats of the last compute_gradient (device scalars are only read here, so the training
+        loop itself never synchronises)."""
+        if self._lazy_stats is not None:
+            self.stats.update(self._lazy_stats())
         return {k: (v.item() if isinstance(v, torch.Tensor) and v.numel() == 1 else
                     (v.tolist() if isinstance(v, torch.Tensor) else v)) for k, v in self.stats.items()}
 
@@ -72,6 +79,7 @@ class _LearnerBase(object):
         iteration (optimizer.py:345 `learner.set_weights(worker.get_weights())` becomes a no-op)."""
         self.policy_with_value = policy
         self.cfg = policy.cfg
+        self._views = None
 
     def set_ppc_params(self, params):
         pass
@@ -82,21 +90,25 @@ class _LearnerBase(object):
         return self.flat[pw.offsets[i]:pw.offsets[i + 1]]
 
     def _get_batch(self, batch_data):
-        self.batch_data = {k: batch_data[i].to(self.device, torch.float32).contiguous()
+        def f32(t):
+            if t.dtype == torch.float32 and t.device == self.device and t.is_contiguous():
+                return t
+            return t.to(self.device, torch.float32).contiguous()
+        self.batch_data = {k: f32(batch_data[i])
                            for i, k in enumerate(('batch_obs', 'batch_actions', 'batch_rewards', 'batch_obs_tp1', 'batch_dones'))}
 
     def _finish(self, iteration, clip):
         """all-reduce, clip per network, expose the reference's list view."""
         pw = self.policy_with_value
         D.all_reduce_sum_(self.flat)
-        pw.nonfinite.zero_()
-        ops.clip_by_global_norm(self.flat[:self.n_grad], pw.sizes, clip, norms_out=self.norms, nonfinite=pw.nonfinite)
-        self.flat_grad = self.flat[:self.n_grad]
-        out = []
-        for i, n in enumerate(pw.names):
-            out += pw._as_list(self.flat[pw.offsets[i]:pw.offsets[i + 1]], n)
-        self.stats.update(iteration=iteration)
-        return out
+        if self._views is None:
+            self.flat_grad = self.flat[:self.n_grad]
+            self._views = []
+            for i, n in enumerate(pw.names):
+                self._views += pw._as_list(self.flat[pw.offsets[i]:pw.offsets[i + 1]], n)
+        ops.clip_by_global_norm(self.flat_grad, pw.sizes, clip, norms_out=self.norms, nonfinite=pw.nonfinite)
+        self.stats['iteration'] = iteration
+        return self._views
 
 
 class MPGLearner(_LearnerBase):
@@ -158,7 +170,8 @@ class MPGLearner(_LearnerBase):
 
     def compute_gradient(self, batch_data, rb, indexes, iteration, eps=None):
         """mpg_learner.py:401-455.  Returns the list [q1 (6 arrays) (+ q2) + policy (6 arrays)] of device tensors
-        (views of one flat buffer, also available as `self.flat_grad`)."""
+        (views of one flat buffer, also available as `self.flat_grad`).  eps: optional [n, M*B] standard-normal model
+        noise (parity tests); by default it is drawn inside the rollout kernel."""
         if self.counter % self.num_batch_reuse == 0:
             self.get_batch_data(batch_data, rb, indexes)
         self.counter += 1
@@ -166,32 +179,30 @@ class MPGLearner(_LearnerBase):
         rows = b['batch_obs'].shape[0]
         world = D.world_size()
         inv_b = 1.0 / (rows * world)
-        ng = self.n_grad
-        stats = self.flat[ng:]
-        stats.zero_()
+        stats = self.flat[self.n_grad:]
         qnames = [n for n in pw.names if n != 'policy']
         for i, nm in enumerate(qnames):
             ops.q_loss_grad(self.cfg, pw.net(nm), b['batch_obs'], b['batch_actions'], b['batch_targets'], inv_b_global=inv_b,
                             grad_out=self.grad(nm), loss_out=stats[i:i + 1])
         select = self.num_rollout_list_for_policy_update
-        n = max(select)
         ws = rule_based_weights(iteration, self.args.rule_based_bias_total_ite, self.args.eta, select)
-        if eps is None:
-            eps = self.draw_model_noise(n, rows * self.M)
         ns = len(select)
         ops.rollout_pg(self.cfg, pw.net('policy'), pw.net('Q1'), b['batch_obs'], eps, select, ws, M=self.M,
-                       inv_b_global=inv_b, grad_out=self.grad('policy'), stats_out=stats[2:2 + 2 * ns])
+                       inv_b_global=inv_b, grad_out=self.grad('policy'), stats_out=stats[2:2 + 2 * ns], n=max(select),
+                       noise_seed=self.seed, noise_ctr=self.counter)
         out = self._finish(iteration, float(self.args.gradient_clip_norm))
-        # ---- stats (mpg_learner.py:433-452); device scalars, converted lazily in get_stats() ----
         B = rows * world
-        mean_ret = stats[2:2 + ns] / B
-        self.stats.update(dict(
-            value_mean=mean_ret[select.index(0)] if 0 in select else None,
-            policy_total_loss=-(torch.as_tensor(ws, device=self.device) * mean_ret).sum(),
-            policy_gradient_norm=self.norms[len(qnames)], q_loss1=stats[0], q_gradient_norm1=self.norms[0],
-            num_rollout_list=select, w_list=list(map(float, ws)), all_losses=-mean_ret))
-        if len(qnames) == 2:
-            self.stats.update(dict(q_loss2=stats[1], q_gradient_norm2=self.norms[1]))
+
+        def lazy():   # mpg_learner.py:433-452
+            mean_ret = stats[2:2 + ns] / B
+            d = dict(value_mean=mean_ret[select.index(0)] if 0 in select else None,
+                     policy_total_loss=-(torch.as_tensor(ws, device=self.device) * mean_ret).sum(),
+                     policy_gradient_norm=self.norms[len(qnames)], q_loss1=stats[0], q_gradient_norm1=self.norms[0],
+                     num_rollout_list=select, w_list=list(map(float, ws)), all_losses=-mean_ret)
+            if len(qnames) == 2:
+                d.update(q_loss2=stats[1], q_gradient_norm2=self.norms[1])
+            return d
+        self._lazy_stats = lazy
         return out
 
 
@@ -219,19 +230,15 @@ class NADPLearner(_LearnerBase):
         world = D.world_size()
         inv_b = 1.0 / (rows * world)
         stats = self.flat[self.n_grad:]
-        stats.zero_()
-        if eps_q is None:
-            eps_q = torch.randn(self.n_q, rows, generator=self._noise_gen, device=self.device)
-        if eps_pi is None:
-            eps_pi = torch.randn(self.n_pi, rows, generator=self._noise_gen, device=self.device)
         targets = ops.rollout_q_target(self.cfg, pw.net('policy'), pw.net('Q1', True), b['batch_obs'], b['batch_actions'],
-                                       eps_q)                                                       # nadp.py:87-126
+                                       eps_q, n=self.n_q, noise_seed=self.seed, noise_ctr=2 * self.counter)   # nadp.py:87-126
         self.batch_data['batch_targets'] = targets
         ops.q_loss_grad(self.cfg, pw.net('Q1'), b['batch_obs'], b['batch_actions'], targets, inv_b_global=inv_b,
                         grad_out=self.grad('Q1'), loss_out=stats[0:1])                               # :173-184
         # slice 0 only feeds value_mean (weight 0); the loss is -R_n (nadp.py:168-171)
         ops.rollout_pg(self.cfg, pw.net('policy'), pw.net('Q1'), b['batch_obs'], eps_pi, [0, self.n_pi], [0.0, 1.0], M=1,
-                       inv_b_global=inv_b, all_steps_param_grad=True, grad_out=self.grad('policy'), stats_out=stats[2:6])
+                       inv_b_global=inv_b, all_steps_param_grad=True, grad_out=self.grad('policy'), stats_out=stats[2:6],
+                       n=self.n_pi, noise_seed=self.seed, noise_ctr=2 * self.counter + 1)
         out = self._finish(iteration, float(self.args.gradient_clip_norm))
         B = rows * world
         self.stats.update(dict(q_loss=stats[0], policy_loss=-stats[3] / B, value_mean=stats[2] / B,
@@ -274,7 +281,6 @@ class TD3Learner(_LearnerBase):
         world = D.world_size()
         inv_b = 1.0 / (rows * world)
         stats = self.flat[self.n_grad:]
-        stats.zero_()
         for i, nm in enumerate(('Q1', 'Q2')):
             ops.q_loss_grad(self.cfg, pw.net(nm), b['batch_obs'], b['batch_actions'], b['batch_targets'], inv_b_global=inv_b,
                             grad_out=self.grad(nm), loss_out=stats[i:i + 1])

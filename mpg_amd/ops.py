@@ -133,11 +133,13 @@ def q_loss_grad(cfg, q_params, obs, act, y, inv_b_global=None, grad_out=None, lo
 
 
 def rollout_pg(cfg, policy_params, q1_params, obs0, eps, select, w, M=1, inv_b_global=None, all_steps_param_grad=False,
-               grad_out=None, stats_out=None):
-    """mpg_rollout_pg: n-step model rollout + (mixed) policy gradient.  Returns (ret_sum, ret_sqsum, grad)."""
+               grad_out=None, stats_out=None, n=None, noise_seed=0, noise_ctr=0):
+    """mpg_rollout_pg: n-step model rollout + (mixed) policy gradient.  Returns (ret_sum, ret_sqsum, grad).
+    eps=None draws the model noise inside the kernel (Philox(noise_seed, noise_ctr)); then pass n."""
     rows = obs0.shape[0]
-    n = eps.shape[0]
-    assert eps.shape[1] == rows * M
+    if eps is not None:
+        n = eps.shape[0]
+        assert eps.shape[1] == rows * M
     dev = obs0.device
     ns = len(select)
     grad = grad_out if grad_out is not None else torch.empty(policy_size(cfg), dtype=torch.float32, device=dev)
@@ -150,8 +152,8 @@ def rollout_pg(cfg, policy_params, q1_params, obs0, eps, select, w, M=1, inv_b_g
         raise L.MpgError('mpg_rollout_pg_workspace_bytes: unsupported configuration')
     ws = workspace(dev, nb, slot=1)
     L.call('mpg_rollout_pg', ctypes.byref(cfg), L.ptr(_f32(policy_params)), L.ptr(_f32(q1_params)), L.c_int(rows),
-           L.c_int(M), L.c_int(n), sel, L.c_int(ns), wv, L.ptr(_f32(obs0)), L.ptr(_f32(eps)),
-           L.c_float(inv_b_global if inv_b_global is not None else 1.0 / rows), L.c_int(int(all_steps_param_grad)),
+           L.c_int(M), L.c_int(n), sel, L.c_int(ns), wv, L.ptr(_f32(obs0)), L.ptr(_f32(eps) if eps is not None else None),
+           L.c_u64(noise_seed), L.c_u64(noise_ctr), L.c_float(inv_b_global if inv_b_global is not None else 1.0 / rows), L.c_int(int(all_steps_param_grad)),
            L.ptr(stats[:ns]), L.ptr(stats[ns:]), L.ptr(grad), L.ptr(ws), L.c_size_t(ws.numel()), L.stream())
     return stats[:ns], stats[ns:], grad
 
@@ -172,16 +174,19 @@ def adam_polyak(w, m, v, target, grad, seg_sizes, lr_t, do_adam, do_polyak, tau,
     da = (ctypes.c_int * ns)(*[int(x) for x in do_adam])
     dp = (ctypes.c_int * ns)(*[int(x) for x in do_polyak])
     L.call('mpg_adam_polyak', L.ptr(_f32(w)), L.ptr(_f32(m)), L.ptr(_f32(v)), L.ptr(target), L.ptr(_f32(grad)), segs,
-           L.c_int(ns), lr, da, dp, L.c_float(tau), L.ptr(skip_flag), L.stream())
+           L.c_int(ns), lr, da, dp, L.c_float(tau), L.ptr(skip_flag),
+           L.c_int(skip_flag.numel() if skip_flag is not None else 0), L.stream())
 
 
-def rollout_q_target(cfg, policy_params, q1t, obs0, act0, eps):
-    rows, n = obs0.shape[0], eps.shape[0]
+def rollout_q_target(cfg, policy_params, q1t, obs0, act0, eps, n=None, noise_seed=0, noise_ctr=0):
+    rows = obs0.shape[0]
+    n = eps.shape[0] if eps is not None else n
     y = torch.empty(rows, dtype=torch.float32, device=obs0.device)
     nb = L.lib().mpg_rollout_q_target_workspace_bytes(ctypes.byref(cfg), L.c_int(rows))
     ws = workspace(obs0.device, nb)
     L.call('mpg_rollout_q_target', ctypes.byref(cfg), L.ptr(_f32(policy_params)), L.ptr(_f32(q1t)), L.c_int(rows), L.c_int(n),
-           L.ptr(_f32(obs0)), L.ptr(_f32(act0)), L.ptr(_f32(eps)), L.ptr(y), L.ptr(ws), L.c_size_t(ws.numel()), L.stream())
+           L.ptr(_f32(obs0)), L.ptr(_f32(act0)), L.ptr(_f32(eps) if eps is not None else None), L.c_u64(noise_seed),
+           L.c_u64(noise_ctr), L.ptr(y), L.ptr(ws), L.c_size_t(ws.numel()), L.stream())
     return y
 
 

@@ -68,7 +68,7 @@ class PolicyWithQs(object):
         self.v = torch.zeros_like(self.params)
         self.schedules = {n: (tuple(policy_lr_schedule) if n == 'policy' else tuple(value_lr_schedule)) for n in self.names}
         self.opt_steps = {n: 0 for n in self.names}
-        self.nonfinite = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.nonfinite = torch.zeros(len(self.names), dtype=torch.int32, device=self.device)
         self._bind_weight_cache()
 
     # ---- weight cache (packed register images of the hidden kernels; see include/mpg_hip.h) ----

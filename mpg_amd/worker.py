@@ -57,16 +57,17 @@ class OffPolicyWorker(object):
         """-> (obs, act, RAW reward, obs', done) stacked over batch_size/num_agent env steps (worker.py:91-119)."""
         pw = self.policy_with_value
         out = [[], [], [], [], []]
-        for _ in range(max(1, self.batch_size // self.num_agent)):
+        iters = max(1, self.batch_size // self.num_agent)
+        for _ in range(iters):
             obs = self.obs
             action = ops.policy_action(pw.cfg, pw.net('policy'), obs, explore_sigma=float(self.explore_sigma or 0.),
                                        seed=self.seed, ctr=self._noise_ctr)
             self._noise_ctr += 1
-            obs_tp1, reward, done, _ = self.env.step(action)
-            for lst, x in zip(out, (obs, action, reward, obs_tp1, done.clone())):
+            obs_tp1, reward, done, _ = self.env.step(action)          # fresh tensors every call (never aliased later)
+            for lst, x in zip(out, (obs, action, reward, obs_tp1, done)):
                 lst.append(x)
             self.obs = self.env.reset()          # done is always 1 (SURVEY.md B-0): every agent is re-drawn
-        batch = tuple(torch.cat(x, 0) for x in out)
+        batch = tuple(x[0] for x in out) if iters == 1 else tuple(torch.cat(x, 0) for x in out)
         self.num_sample += batch[0].shape[0]
         self.sample_times += 1
         return batch
