@@ -142,18 +142,22 @@ __device__ __forceinline__ void mfma_16x256x32(const float* sA, const Lane& L, c
 // ---- small per-lane stationary pieces -----------------------------------------------------------------
 template <int IN, int OU>
 struct SmallRegs {
-    float w1[2][IN];   // W1[i][col(t)]
+    float w1p[2][2];   // layer-1 MFMA B operand: W1[4q + rg][col(t)] (0 beyond IN), index [q][t]
+    float w1t[8];      // dx MFMA B operand: W1[c][32w + 4q + rg] (0 for c >= IN), q = 0..7
     float b1[2], b2[2];
     float w3[2][OU];   // W3[col(t)][o]
 };
 
 template <int IN, int OU>
 __device__ __forceinline__ void load_small(const Net& n, const Lane& L, SmallRegs<IN, OU>& r) {
+    static_assert(IN <= 8, "layer-1 MFMA covers K <= 8");
+#pragma unroll
+    for (int q = 0; q < 8; ++q) r.w1t[q] = L.c < IN ? n.W1[L.c * H + 32 * L.wave + 4 * q + L.rg] : 0.f;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int col = L.col(t);
 #pragma unroll
-        for (int i = 0; i < IN; ++i) r.w1[t][i] = n.W1[i * H + col];
+        for (int q = 0; q < 2; ++q) r.w1p[q][t] = (4 * q + L.rg) < IN ? n.W1[(4 * q + L.rg) * H + col] : 0.f;
         r.b1[t] = n.b1[col];
         r.b2[t] = n.b2[col];
 #pragma unroll
@@ -169,17 +173,18 @@ template <int IN, int OU>
 __device__ __forceinline__ void forward_group(const float* sX, float* sA, float* sPart, const Lane& L,
                                               const float (&w2)[128], const SmallRegs<IN, OU>& r,
                                               float (&h1)[2][4], float (&h2)[2][4]) {
+    {   // layer 1 on the matrix pipe too: K = IN <= 8 zero-padded = 2 k-steps (sX rows are zero beyond IN)
+        f32x4 z0 = {r.b1[0], r.b1[0], r.b1[0], r.b1[0]}, z1 = {r.b1[1], r.b1[1], r.b1[1], r.b1[1]};
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        float x[IN];
+        for (int q = 0; q < 2; ++q) {
+            const float xa = sX[L.c * XS + 4 * q + L.rg];
+            z0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, r.w1p[q][0], z0, 0, 0, 0);
+            z1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, r.w1p[q][1], z1, 0, 0, 0);
+        }
 #pragma unroll
-        for (int i = 0; i < IN; ++i) x[i] = sX[L.row(j) * XS + i];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            float z = r.b1[t];
-#pragma unroll
-            for (int i = 0; i < IN; ++i) z = fmaf(x[i], r.w1[t][i], z);
-            h1[t][j] = elu(z);
+        for (int j = 0; j < 4; ++j) {
+            h1[0][j] = elu(z0[j]);
+            h1[1][j] = elu(z1[j]);
         }
     }
     store_c_to_a(sA, L, h1);
@@ -259,14 +264,23 @@ __device__ __forceinline__ void backward_group(const float* sD3, float* sA, floa
         dz1[1][j] = acc1[j] * elu_grad_from_out(h1[1][j]);
     }
     if (WANT_DX) {
+        // dx partial of this wave's 32 hidden columns on the matrix pipe: A = dz1 (this wave's own columns of the
+        // LDS A image), B = W1^T.  The barrier orders the image rewrite behind every wave's reads of dz2.
+        __syncthreads();
+        store_c_to_a(sA, L, dz1);
+        __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): this wave reads back only what it wrote itself
+        __builtin_amdgcn_wave_barrier();
+        const float* base = sA + L.c * LDA + L.rg * 64 + 8 * L.wave;
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(base), a1 = *reinterpret_cast<const f32x4*>(base + 4);
+        f32x4 dx = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < IN; ++i)
+        for (int q = 0; q < 4; ++q) dx = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[q], r.w1t[q], dx, 0, 0, 0);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float p = fmaf(dz1[1][j], r.w1[1][i], dz1[0][j] * r.w1[0][i]);
-                p = row_allreduce16(p);
-                if (L.c == 0) sPartX[(L.wave * GROUP + L.row(j)) * XS + i] = p;
-            }
+        for (int q = 0; q < 4; ++q) dx = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[q], r.w1t[4 + q], dx, 0, 0, 0);
+        if (L.c < IN) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sPartX[(L.wave * GROUP + L.row(j)) * XS + L.c] = dx[j];
+        }
     }
     __syncthreads();
 }

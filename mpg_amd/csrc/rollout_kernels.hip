@@ -24,6 +24,18 @@ constexpr int SAW = 8;        // floats per (step, trajectory) record: obs | act
 // ---------------------------------------------------------------------------------------------------------------
 // differentiable models: one lane = one trajectory
 // ---------------------------------------------------------------------------------------------------------------
+// The model step sits on the serial chain of the rollout (16 lanes work, 496 wait), so it uses the hardware
+// reciprocal / exp / sin / cos (<= 1-2 ulp, far inside the stated 1e-4 gradient tolerance) instead of the
+// correctly-rounded library routines.
+__device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ void fast_sincos(float x, float* s, float* c) {   // |x| <= pi here
+    *s = __sinf(x);
+    *c = __cosf(x);
+}
+__device__ __forceinline__ float fast_tanh(float z) {                       // 1 - 2/(e^{2z} + 1); exact limits +-1
+    return 1.f - 2.f * frcp(__expf(2.f * z) + 1.f);
+}
+
 struct PathTracking {
     static constexpr int OBS = 6, ACT = 2;
     // vehicle parameters, path_tracking_env.py:60-68; tau = 1/10 (:248)
@@ -42,10 +54,10 @@ struct PathTracking {
         const float dv = vx - 20.f;
         rew = -(0.01f * dv * dv + 0.04f * dy * dy + 0.1f * dphi * dphi + 0.02f * r * r + 5.f * de * de + 0.05f * ax * ax);
         float nvx = vx + TAU * (ax + vy * r);
-        const float nvy = (MASS * vy * vx + K1 * r - K2 * de * vx - K3 * vx * vx * r) / (MASS * vx - K4);
-        const float nr = (-I_z * r * vx - K1 * vy + K5 * de * vx) / (K6 - I_z * vx);
+        const float nvy = (MASS * vy * vx + K1 * r - K2 * de * vx - K3 * vx * vx * r) * frcp(MASS * vx - K4);
+        const float nr = (-I_z * r * vx - K1 * vy + K5 * de * vx) * frcp(K6 - I_z * vx);
         float sp, cp;
-        sincosf(dphi, &sp, &cp);
+        fast_sincos(dphi, &sp, &cp);
         const float ndy = dy + TAU * (vx * sp + vy * cp) + (0.5f + 0.01f * eps);
         float ndphi = dphi + TAU * r;
         const float nx = x + TAU * (vx * cp - vy * sp);
@@ -65,11 +77,11 @@ struct PathTracking {
         const float l_vx = (nvx_raw >= 1.f && nvx_raw <= 35.f) ? lam[0] : 0.f;
         const float l_vy = lam[1], l_r = lam[2], l_dy = lam[3], l_dphi = lam[4], l_x = lam[5];
         const float D1 = MASS * vx - K4, D2 = K6 - I_z * vx;
-        const float iD1 = 1.f / D1, iD2 = 1.f / D2;
+        const float iD1 = frcp(D1), iD2 = frcp(D2);
         const float nvy = (MASS * vy * vx + K1 * r - K2 * de * vx - K3 * vx * vx * r) * iD1;
         const float nr = (-I_z * r * vx - K1 * vy + K5 * de * vx) * iD2;
         float sp, cp;
-        sincosf(dphi, &sp, &cp);
+        fast_sincos(dphi, &sp, &cp);
         const float dvy_vx = (MASS * vy - K2 * de - 2.f * K3 * vx * r - nvy * MASS) * iD1;
         const float dvy_vy = MASS * vx * iD1;
         const float dvy_r = (K1 - K3 * vx * vx) * iD1;
@@ -100,8 +112,8 @@ struct Pendulum {
         const float p = o[0], th = o[1], pd = o[2], thd = o[3];
         const float u = 100.f * a[0];                                       // action_trans :96-97
         float sn, c;
-        sincosf(th, &sn, &c);
-        const float idet = 1.f / (D1c * D4c - D2c * D2c * c * c);          // closed-form 2x2 inverse (:53)
+        sincosf(th, &sn, &c);                                               // theta is not range-limited: keep the library routine
+        const float idet = frcp(D1c * D4c - D2c * D2c * c * c);             // closed-form 2x2 inverse (:53)
         const float F1 = D2c * sn * thd * thd + u, F2 = F1c * sn;
         const float pdd = (D4c * F1 - D2c * c * F2) * idet;
         const float thdd = (-D2c * c * F1 + D1c * F2) * idet;
@@ -123,7 +135,7 @@ struct Pendulum {
         const float u = 100.f * a[0];
         float sn, c;
         sincosf(th, &sn, &c);
-        const float det = D1c * D4c - D2c * D2c * c * c, idet = 1.f / det;
+        const float det = D1c * D4c - D2c * D2c * c * c, idet = frcp(det);
         const float F1 = D2c * sn * thd * thd + u, F2 = F1c * sn;
         const float pdd = (D4c * F1 - D2c * c * F2) * idet;
         const float thdd = (-D2c * c * F1 + D1c * F2) * idet;
@@ -172,8 +184,10 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_fwd(const RollArgs a) {
     float* sX = sA + GROUP * LDA;
     float* sPart = sX + GROUP * XS;
     float* sEps = sPart + NWAVE * GROUP * MAXOUT;
+    __shared__ float sGp[MAXN];
     const Lane L;
     const int tid = threadIdx.x;
+    if (tid <= a.n) sGp[tid] = powf(a.gamma, (float)tid);     // tf.pow(gamma, ri) in float32, mpg_learner.py:245
     const Net net = make_net(a.policy, OBS, 2 * ACT);
     float w2[128];
     SmallRegs<OBS, ACT> r;
@@ -217,7 +231,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_fwd(const RollArgs a) {
 #pragma unroll
                 for (int k = 0; k < ACT; ++k) {
                     const float z = out_preact(sPart, net.b3, tid, k);
-                    act[k] = a.out_tanh ? a.out_scale * tanhf(z) : z;
+                    act[k] = a.out_tanh ? a.out_scale * fast_tanh(z) : z;
                 }
                 if (t == 0 && a.act0 && live) {
 #pragma unroll
@@ -246,7 +260,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_fwd(const RollArgs a) {
                     float on[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                     float rew;
                     ENV::step(o, act, e, on, rew);
-                    G += powf(a.gamma, (float)t) * ((rew + a.rew_shift) * a.rew_scale);   // mpg_learner.py:245
+                    G += sGp[t] * ((rew + a.rew_shift) * a.rew_scale);                     // mpg_learner.py:245
 #pragma unroll
                     for (int i = 0; i < 8; ++i) o[i] = on[i];
                 }
