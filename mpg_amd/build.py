@@ -14,7 +14,8 @@ OBJ = os.path.join(HERE, 'build')
 LIB = os.path.join(HERE, 'libmpg_hip.so')
 ARCH = 'gfx950'
 
-COMMON = ['-O3', '-fPIC', '-std=c++17', '--offload-arch=' + ARCH, '-Wall', '-Wno-unused-function', '-Wno-bitwise-instead-of-logical',
+# MPG_EXTRA_CFLAGS: ablation / diagnostic builds only (e.g. -DMPG_AB_NODYN); never set in the product build
+COMMON = os.environ.get('MPG_EXTRA_CFLAGS', '').split() + ['-O3', '-fPIC', '-std=c++17', '--offload-arch=' + ARCH, '-Wall', '-Wno-unused-function', '-Wno-bitwise-instead-of-logical',
           '-I' + os.path.join(HERE, '..', 'include')]
 # per-file extras: the real-env kernel mirrors the reference op-by-op, so no fused multiply-adds there
 EXTRA = {'env_path_tracking.hip': ['-ffp-contract=off']}

@@ -61,6 +61,12 @@ struct Lane {
     __device__ int row(int j) const { return 4 * rg + j; }
 };
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding GLOBAL store
+// (s_waitcnt vmcnt(0)), which puts the HBM write latency of the activation stash on the serial chain of every
+// rollout step; nothing inside the engine kernels communicates through global memory, so LDS ordering is all that
+// is needed.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ float elu(float z) { return z > 0.f ? z : __expf(z) - 1.f; }
 // ELU'(z) expressed through the stored output h = ELU(z): 1 for z > 0, exp(z) = h + 1 otherwise.
 __device__ __forceinline__ float elu_grad_from_out(float h) { return h > 0.f ? 1.f : h + 1.f; }
@@ -128,8 +134,13 @@ const float* weight_cache_lookup(const float* W2, int dir);
 __device__ __forceinline__ void mfma_16x256x32(const float* sA, const Lane& L, const float (&w)[128], f32x4& acc0,
                                                f32x4& acc1) {
     const float* base = sA + L.c * LDA + L.rg * 64;
+#ifdef MPG_AB_NOMFMA   // ablation build: one k-block instead of 16 (timing only)
+#pragma unroll
+    for (int q4 = 0; q4 < 1; ++q4) {
+#else
 #pragma unroll
     for (int q4 = 0; q4 < 16; ++q4) {
+#endif
         const f32x4 a = *reinterpret_cast<const f32x4*>(base + 4 * q4);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -188,7 +199,7 @@ __device__ __forceinline__ void forward_group(const float* sX, float* sA, float*
         }
     }
     store_c_to_a(sA, L, h1);
-    __syncthreads();
+    lds_barrier();
     f32x4 acc0 = {r.b2[0], r.b2[0], r.b2[0], r.b2[0]};
     f32x4 acc1 = {r.b2[1], r.b2[1], r.b2[1], r.b2[1]};
     mfma_16x256x32(sA, L, w2, acc0, acc1);
@@ -205,7 +216,7 @@ __device__ __forceinline__ void forward_group(const float* sX, float* sA, float*
             p = row_allreduce16(p);
             if (L.c == 0) sPart[(L.wave * GROUP + L.row(j)) * MAXOUT + o] = p;
         }
-    __syncthreads();
+    lds_barrier();
 }
 
 // sum of the 8 per-wave partials + bias for (row, o)
@@ -255,7 +266,7 @@ __device__ __forceinline__ void backward_group(const float* sD3, float* sA, floa
         }
     }
     store_c_to_a(sA, L, dz2);
-    __syncthreads();
+    lds_barrier();
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     mfma_16x256x32(sA, L, w2t, acc0, acc1);
 #pragma unroll
@@ -266,7 +277,7 @@ __device__ __forceinline__ void backward_group(const float* sD3, float* sA, floa
     if (WANT_DX) {
         // dx partial of this wave's 32 hidden columns on the matrix pipe: A = dz1 (this wave's own columns of the
         // LDS A image), B = W1^T.  The barrier orders the image rewrite behind every wave's reads of dz2.
-        __syncthreads();
+        lds_barrier();
         store_c_to_a(sA, L, dz1);
         __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): this wave reads back only what it wrote itself
         __builtin_amdgcn_wave_barrier();
@@ -282,7 +293,7 @@ __device__ __forceinline__ void backward_group(const float* sD3, float* sA, floa
             for (int j = 0; j < 4; ++j) sPartX[(L.wave * GROUP + L.row(j)) * XS + L.c] = dx[j];
         }
     }
-    __syncthreads();
+    lds_barrier();
 }
 
 __device__ __forceinline__ float dx_reduce(const float* sPartX, int row, int i) {

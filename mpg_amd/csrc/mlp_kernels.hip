@@ -53,7 +53,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_forward(const FwdArgs a) {
     const long ngroups = (a.rows + GROUP - 1) / GROUP;
     for (long g = blockIdx.x; g < ngroups; g += gridDim.x) {
         load_x_group<IN>(a.x, a.rows, g, sX);
-        __syncthreads();
+        lds_barrier();
         float h1[2][4], h2[2][4];
         forward_group<IN, OU>(sX, sA, sPart, L, w2, r, h1, h2);
         if (a.h1) stash_store(a.h1, g, L, h1);
@@ -157,7 +157,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_backward(const BwdArgs a) {
         float h1[2][4], h2[2][4], dz1[2][4], dz2[2][4];
         stash_load(a.h1, g, L, h1);
         stash_load(a.h2, g, L, h2);
-        __syncthreads();
+        lds_barrier();
         backward_group<IN, OU, WANT_DX>(sD3, sA, sPartX, L, w2t, r, h1, h2, dz1, dz2);
         if (a.dz1) stash_store(a.dz1, g, L, dz1);
         if (a.dz2) stash_store(a.dz2, g, L, dz2);
@@ -167,7 +167,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_backward(const BwdArgs a) {
                 const long gr = g * GROUP + row;
                 if (gr < a.rows) a.dx[gr * a.lddx + i] = dx_reduce(sPartX, row, i);
             }
-            __syncthreads();   // sPartX / sD3 are rewritten by the next group
+            lds_barrier();   // sPartX / sD3 are rewritten by the next group
         }
     }
 }

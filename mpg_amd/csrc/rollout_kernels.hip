@@ -219,7 +219,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_fwd(const RollArgs a) {
 #pragma unroll
                 for (int i = 0; i < XS; ++i) sX[tid * XS + i] = i < OBS ? o[i] * a.obs_scale[i] : 0.f;
             }
-            __syncthreads();
+            lds_barrier();
             float h1[2][4], h2[2][4];
             forward_group<OBS, ACT>(sX, sA, sPart, L, w2, r, h1, h2);
             if (a.H1) {
@@ -259,7 +259,11 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_fwd(const RollArgs a) {
                     const float e = a.eps ? (live ? a.eps[(long)t * R + tr] : 0.f) : sEps[t * GROUP + tid];
                     float on[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                     float rew;
+#ifdef MPG_AB_NODYN   // ablation build: skip the model step (timing only, results meaningless)
+                    rew = e; for (int i = 0; i < 8; ++i) on[i] = o[i] + act[0];
+#else
                     ENV::step(o, act, e, on, rew);
+#endif
                     G += sGp[t] * ((rew + a.rew_shift) * a.rew_scale);                     // mpg_learner.py:245
 #pragma unroll
                     for (int i = 0; i < 8; ++i) o[i] = on[i];
@@ -404,7 +408,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_bwd(const RollBwdArgs a)
             float h1[2][4], h2[2][4], dz1[2][4], dz2[2][4];
             stash_load(a.H1, (long)t * ngroups + g, L, h1);
             stash_load(a.H2, (long)t * ngroups + g, L, h2);
-            __syncthreads();
+            lds_barrier();
             if (t > 0)
                 backward_group<OBS, ACT, true>(sD3, sA, sPartX, L, w2t, r, h1, h2, dz1, dz2);
             else
