@@ -263,6 +263,61 @@ int mpg_per_sample(const double* sum_tree, const double* min_tree, int capacity,
                    const double* u, uint64_t seed, uint64_t ctr, double beta, int* idx, float* is_weight,
                    mpg_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Native step driver  - SingleProcessOffPolicyOptimizer.step, optimizer.py:330-362
+ * ---------------------------------------------------------------------------------------------- */
+
+/* One training iteration of the MPG learner enqueued by native code, so that the ~45 kernel launches of a step are
+ * not paced by the Python interpreter.  It calls exactly the entry points above, in the reference's order:
+ *   mpg_step_begin:  [every sampling_interval-th iteration: sample_iters x (policy + N(0,sigma) -> env.step ->
+ *                    ring add -> env.reset)]  (worker.py:91-119, optimizer.py:332-337);  replay (uniform indices +
+ *                    gather, buffer.py:70-91);  target (MPG-v2: mpg_learner.py:126-134; MPG-v1: 25 real-env steps +
+ *                    n-step return, :146-169);  Q loss/gradients (:326-354);  model rollout + mixed policy gradient
+ *                    (:226-286,356-365).  Leaves UN-clipped partials scaled by 1/(batch*world_size) in grad[].
+ *   (the caller all-reduces grad[0 .. n_grad+16) across GPUs here)
+ *   mpg_step_end:    per-network clip_by_global_norm (:415-431) + Adam/Polyak (policy.py:123-171).
+ * All pointers are device buffers owned by the caller; counters are advanced in place (host fields). */
+typedef struct {
+    mpg_cfg_t cfg;
+    int learner_version;              /* 1: MPG-v1 (n-step real-env target), 2: MPG-v2 (clipped double-Q target) */
+    int num_agent, sample_iters;      /* worker: sample_iters env steps of num_agent agents per sampling call */
+    int sampling_interval;            /* optimizer.py:331 (10 in the reference) */
+    int batch, n, M, n_select, select[4];
+    float eta;                        /* rule_based_weights, mpg_learner.py:384-399 */
+    int total_ite;
+    float clip, tau;
+    int delay_update, num_batch_reuse, world_size;
+    float explore_sigma;
+    float value_lr[3], policy_lr[3];  /* PolynomialDecay(lr0, steps, lr_end), policy.py:54-70 */
+    /* counters */
+    uint64_t worker_seed, noise_ctr, env_seed, env_ctr, replay_seed, replay_times, learner_seed, learner_counter;
+    int ring_capacity, ring_next, ring_size;
+    long long opt_steps[3];           /* per-optimizer step counters in network order Q1,(Q2),policy */
+    /* worker / env */
+    float *env_state, *w_obs, *w_act, *w_rew, *w_obs2;
+    uint8_t *w_done, *w_done_intended;
+    /* replay ring and the sampled minibatch */
+    float *ring_obs, *ring_act, *ring_rew, *ring_obs2;
+    uint8_t* ring_done;
+    int* idx;
+    float *b_obs, *b_act, *b_rew, *b_obs2, *b_done, *b_targets;
+    /* networks [Q1 | (Q2) | policy], their targets, Adam moments */
+    float *params, *targets, *adam_m, *adam_v;
+    float* grad;                      /* n_grad + 16 floats: gradients then statistics (q losses, return sums) */
+    float* norms;                     /* n_nets */
+    int* nonfinite;                   /* n_nets */
+    /* MPG-v1 only: the learner's own env for the n-step sampler (batch agents) */
+    float *l_env_state, *l_obs, *l_act, *l_rewards;
+    uint8_t *l_done, *l_done_intended;
+    void *ws0, *ws1;
+    size_t ws0_bytes, ws1_bytes;
+} mpg_train_ctx_t;
+
+/* workspace requirements of a context (ws0: targets / critic; ws1: rollout) */
+int mpg_step_workspace_bytes(const mpg_train_ctx_t* ctx, size_t* ws0_bytes, size_t* ws1_bytes);
+int mpg_step_begin(mpg_train_ctx_t* ctx, int iteration, mpg_stream_t stream);
+int mpg_step_end(mpg_train_ctx_t* ctx, int iteration, mpg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,160 @@
+// Native step driver: SingleProcessOffPolicyOptimizer.step (optimizer.py:330-362) for the MPG learner, built purely
+// from the public entry points of this library so that Python is not on the launch path.
+#include <algorithm>
+#include <cmath>
+
+#include "mpg_common.h"
+
+namespace {
+
+constexpr int H = MPG_HIDDEN;
+inline int net_size(int in_dim, int out_dim) { return in_dim * H + H + H * H + H + H * out_dim + out_dim; }
+
+struct Layout {
+    int n_nets, q_size, p_size, n_grad;
+    int sizes[3], off[3];   // Q1, (Q2), policy
+};
+
+Layout layout(const mpg_train_ctx_t* c) {
+    Layout l;
+    l.q_size = net_size(c->cfg.obs_dim + c->cfg.act_dim, 1);
+    l.p_size = net_size(c->cfg.obs_dim, 2 * c->cfg.act_dim);
+    l.n_nets = c->learner_version == 2 ? 3 : 2;
+    int o = 0;
+    for (int k = 0; k < l.n_nets; ++k) {
+        l.sizes[k] = k == l.n_nets - 1 ? l.p_size : l.q_size;
+        l.off[k] = o;
+        o += l.sizes[k];
+    }
+    l.n_grad = o;
+    return l;
+}
+
+// MPGLearner.rule_based_weights, mpg_learner.py:384-399, in float32 like the TF graph
+void rule_based_weights(int ite, int total_ite, float eta, const int* select, int ns, float* w) {
+    float lam = (1.f - eta) + (2.f * eta / (float)total_ite) * (float)ite;
+    lam = std::min(std::max(lam, 0.f), 1.5f);
+    int mx = 0;
+    for (int k = 0; k < ns; ++k) mx = std::max(mx, select[k]);
+    float inv[4], m = -INFINITY;
+    for (int k = 0; k < ns; ++k) {
+        const float bias = lam < 1.f ? powf(lam, (float)select[k]) : powf(2.f - lam, (float)(mx - select[k]));
+        inv[k] = 1.f / (bias + 1e-8f);
+        m = std::max(m, inv[k]);
+    }
+    float sum = 0.f;
+    for (int k = 0; k < ns; ++k) { w[k] = expf(inv[k] - m); sum += w[k]; }
+    for (int k = 0; k < ns; ++k) w[k] /= sum;
+}
+
+double polynomial_decay(const float* sched, long long step) {       // policy.py:54,62
+    const double lr0 = sched[0], S = sched[1], lr_end = sched[2];
+    const double s = std::min((double)step, S);
+    return (lr0 - lr_end) * (1.0 - s / S) + lr_end;
+}
+
+#define TRY(call)            \
+    do {                     \
+        int rc_ = (call);    \
+        if (rc_) return rc_; \
+    } while (0)
+
+bool ctx_ok(const mpg_train_ctx_t* c) {
+    return c && (c->learner_version == 1 || c->learner_version == 2) && c->num_agent > 0 && c->batch > 0 && c->n > 0 &&
+           c->M > 0 && c->n_select > 0 && c->n_select <= 4 && c->world_size > 0 && c->sampling_interval > 0 &&
+           c->num_batch_reuse > 0 && c->ring_capacity > 0 && c->params && c->targets && c->grad && c->ws0 && c->ws1;
+}
+
+}  // namespace
+
+extern "C" int mpg_step_workspace_bytes(const mpg_train_ctx_t* c, size_t* ws0, size_t* ws1) {
+    MPG_REQUIRE(c && ws0 && ws1, "mpg_step_workspace_bytes: null pointer");
+    *ws0 = std::max(mpg_q_targets_workspace_bytes(&c->cfg, c->batch), mpg_q_loss_grad_workspace_bytes(&c->cfg, c->batch));
+    *ws1 = mpg_rollout_pg_workspace_bytes(&c->cfg, c->batch, c->M, c->n, c->n_select, 0);
+    MPG_REQUIRE(*ws0 && *ws1, "mpg_step_workspace_bytes: unsupported configuration");
+    return MPG_OK;
+}
+
+extern "C" int mpg_step_begin(mpg_train_ctx_t* c, int iteration, mpg_stream_t s) {
+    MPG_REQUIRE(ctx_ok(c), "mpg_step_begin: incomplete context");
+    const Layout l = layout(c);
+    const int od = c->cfg.obs_dim, ad = c->cfg.act_dim, kind = c->cfg.env_kind;
+    const float* policy = c->params + l.off[l.n_nets - 1];
+    const float* policy_t = c->targets + l.off[l.n_nets - 1];
+    // ---- worker.sample + replay_buffer.add_batch (optimizer.py:332-337, worker.py:91-119) ----
+    if (iteration % c->sampling_interval == 0) {
+        for (int it = 0; it < c->sample_iters; ++it) {
+            TRY(mpg_policy_action(&c->cfg, policy, c->num_agent, c->w_obs, c->explore_sigma, c->worker_seed, c->noise_ctr++,
+                                  c->w_act, s));
+            TRY(mpg_env_step(kind, c->num_agent, c->env_state, c->w_act, c->w_obs2, c->w_rew, c->w_done, c->w_done_intended, s));
+            MPG_REQUIRE(c->num_agent <= c->ring_capacity, "mpg_step_begin: ring smaller than one sample");
+            // a batch that wraps the ring is added in two pieces by the kernel's modulo addressing
+            TRY(mpg_replay_add(c->ring_capacity, c->ring_next, c->num_agent, od, ad, c->w_obs, c->w_act, c->w_rew, c->w_obs2,
+                               c->w_done, c->ring_obs, c->ring_act, c->ring_rew, c->ring_obs2, c->ring_done, s));
+            c->ring_next = (c->ring_next + c->num_agent) % c->ring_capacity;
+            c->ring_size = std::min(c->ring_size + c->num_agent, c->ring_capacity);
+            TRY(mpg_env_reset(kind, c->num_agent, c->env_state, c->w_done, c->env_seed, c->env_ctr++, c->w_obs, s));
+        }
+    }
+    // ---- replay_buffer.replay (optimizer.py:340-341; buffer.py:70-91) ----
+    MPG_REQUIRE(c->ring_size > 0, "mpg_step_begin: empty replay ring");
+    c->replay_times++;
+    if (c->learner_counter % c->num_batch_reuse == 0) {       // get_batch_data, mpg_learner.py:402-403
+        TRY(mpg_uniform_indices(c->ring_size, c->batch, c->replay_seed, c->replay_times, c->idx, s));
+        TRY(mpg_replay_gather(c->batch, c->idx, od, ad, c->ring_obs, c->ring_act, c->ring_rew, c->ring_obs2, c->ring_done,
+                              c->b_obs, c->b_act, c->b_rew, c->b_obs2, c->b_done, s));
+        if (c->learner_version == 2) {
+            TRY(mpg_q_targets(&c->cfg, policy_t, c->targets + l.off[0], c->targets + l.off[1], c->batch, c->b_rew, c->b_obs2,
+                              nullptr, 0.f, 0.f, c->b_targets, c->ws0, c->ws0_bytes, s));
+        } else {   // MPGLearner.sample + compute_n_step_target, mpg_learner.py:109-124,146-169
+            MPG_REQUIRE(c->l_env_state && c->l_obs && c->l_act && c->l_rewards && c->l_done, "mpg_step_begin: MPG-v1 needs the learner env buffers");
+            TRY(mpg_env_reset_from_obs(kind, c->batch, c->l_env_state, c->b_obs, s));
+            for (int t = 0; t < c->n; ++t) {
+                const float* act = c->b_act;
+                if (t > 0) {
+                    TRY(mpg_policy_action(&c->cfg, policy, c->batch, c->l_obs, 0.f, 0, 0, c->l_act, s));
+                    act = c->l_act;
+                }
+                TRY(mpg_env_step(kind, c->batch, c->l_env_state, act, c->l_obs, c->l_rewards + (size_t)t * c->batch, c->l_done,
+                                 c->l_done_intended, s));
+            }
+            TRY(mpg_nstep_targets(&c->cfg, policy_t, c->targets + l.off[0], c->batch, c->n, c->l_rewards, c->l_obs, c->b_targets,
+                                  c->ws0, c->ws0_bytes, s));
+        }
+    }
+    c->learner_counter++;
+    // ---- learner.compute_gradient (mpg_learner.py:401-431), un-clipped partials scaled by 1/B_global ----
+    const float inv_b = 1.f / ((float)c->batch * (float)c->world_size);
+    float* stats = c->grad + l.n_grad;
+    for (int k = 0; k < l.n_nets - 1; ++k)
+        TRY(mpg_q_loss_grad(&c->cfg, c->params + l.off[k], c->batch, c->b_obs, c->b_act, c->b_targets, inv_b, stats + k,
+                            c->grad + l.off[k], nullptr, c->ws0, c->ws0_bytes, s));
+    float w[4];
+    rule_based_weights(iteration, c->total_ite, c->eta, c->select, c->n_select, w);
+    TRY(mpg_rollout_pg(&c->cfg, policy, c->params + l.off[0], c->batch, c->M, c->n, c->select, c->n_select, w, c->b_obs, nullptr,
+                       c->learner_seed, c->learner_counter, inv_b, 0, stats + 2, stats + 2 + c->n_select,
+                       c->grad + l.off[l.n_nets - 1], c->ws1, c->ws1_bytes, s));
+    return MPG_OK;
+}
+
+extern "C" int mpg_step_end(mpg_train_ctx_t* c, int iteration, mpg_stream_t s) {
+    MPG_REQUIRE(ctx_ok(c) && c->norms && c->nonfinite && c->adam_m && c->adam_v, "mpg_step_end: incomplete context");
+    const Layout l = layout(c);
+    TRY(mpg_clip_by_global_norm(c->grad, l.sizes, l.n_nets, c->clip, c->norms, c->nonfinite, s));   // mpg_learner.py:415-431
+    // PolicyWithQs.apply_gradients, policy.py:123-156
+    const bool delayed = iteration % c->delay_update == 0;
+    float lr_t[3];
+    int do_adam[3], do_polyak[3];
+    for (int k = 0; k < l.n_nets; ++k) {
+        const bool is_policy = k == l.n_nets - 1;
+        const bool upd = !is_policy || delayed;
+        const long long t = c->opt_steps[k] + 1;
+        const double lr = polynomial_decay(is_policy ? c->policy_lr : c->value_lr, c->opt_steps[k]);
+        lr_t[k] = (float)(lr * std::sqrt(1.0 - std::pow(0.999, (double)t)) / (1.0 - std::pow(0.9, (double)t)));
+        do_adam[k] = upd ? 1 : 0;
+        do_polyak[k] = delayed ? 1 : 0;
+        if (upd) c->opt_steps[k] = t;
+    }
+    return mpg_adam_polyak(c->params, c->adam_m, c->adam_v, c->targets, c->grad, l.sizes, l.n_nets, lr_t, do_adam, do_polyak,
+                           c->tau, c->nonfinite, l.n_nets, s);
+}

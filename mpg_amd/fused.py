@@ -1,0 +1,121 @@
+"""Native step driver binding (mpg_step_begin / mpg_step_end): one optimizer iteration enqueued from C++ so that the
+Python interpreter is not on the launch path.  Built from - and kept in sync with - the stock worker / buffer / learner
+objects, whose methods remain usable at any time (counters are written back after every step)."""
+import ctypes
+
+import torch
+
+from . import _lib as L
+from . import dist as D
+from .ops import CfgStruct
+
+_P = ctypes.c_void_p
+
+
+class TrainCtx(ctypes.Structure):
+    """mpg_train_ctx_t (include/mpg_hip.h)"""
+    _fields_ = [
+        ('cfg', CfgStruct), ('learner_version', ctypes.c_int), ('num_agent', ctypes.c_int), ('sample_iters', ctypes.c_int),
+        ('sampling_interval', ctypes.c_int), ('batch', ctypes.c_int), ('n', ctypes.c_int), ('M', ctypes.c_int),
+        ('n_select', ctypes.c_int), ('select', ctypes.c_int * 4), ('eta', ctypes.c_float), ('total_ite', ctypes.c_int),
+        ('clip', ctypes.c_float), ('tau', ctypes.c_float), ('delay_update', ctypes.c_int), ('num_batch_reuse', ctypes.c_int),
+        ('world_size', ctypes.c_int), ('explore_sigma', ctypes.c_float), ('value_lr', ctypes.c_float * 3),
+        ('policy_lr', ctypes.c_float * 3),
+        ('worker_seed', ctypes.c_uint64), ('noise_ctr', ctypes.c_uint64), ('env_seed', ctypes.c_uint64),
+        ('env_ctr', ctypes.c_uint64), ('replay_seed', ctypes.c_uint64), ('replay_times', ctypes.c_uint64),
+        ('learner_seed', ctypes.c_uint64), ('learner_counter', ctypes.c_uint64),
+        ('ring_capacity', ctypes.c_int), ('ring_next', ctypes.c_int), ('ring_size', ctypes.c_int),
+        ('opt_steps', ctypes.c_longlong * 3),
+        ('env_state', _P), ('w_obs', _P), ('w_act', _P), ('w_rew', _P), ('w_obs2', _P), ('w_done', _P), ('w_done_intended', _P),
+        ('ring_obs', _P), ('ring_act', _P), ('ring_rew', _P), ('ring_obs2', _P), ('ring_done', _P),
+        ('idx', _P), ('b_obs', _P), ('b_act', _P), ('b_rew', _P), ('b_obs2', _P), ('b_done', _P), ('b_targets', _P),
+        ('params', _P), ('targets', _P), ('adam_m', _P), ('adam_v', _P), ('grad', _P), ('norms', _P), ('nonfinite', _P),
+        ('l_env_state', _P), ('l_obs', _P), ('l_act', _P), ('l_rewards', _P), ('l_done', _P), ('l_done_intended', _P),
+        ('ws0', _P), ('ws1', _P), ('ws0_bytes', ctypes.c_size_t), ('ws1_bytes', ctypes.c_size_t)]
+
+
+class FusedMPGStep(object):
+    """step(iteration) == SingleProcessOffPolicyOptimizer.step for (OffPolicyWorker, ReplayBuffer, MPGLearner) sharing
+    one PolicyWithQs."""
+
+    def __init__(self, worker, learner, rb, sampling_interval):
+        from .buffer import PrioritizedReplayBuffer
+        assert not isinstance(rb, PrioritizedReplayBuffer) and learner.args.buffer_type == 'normal'
+        assert learner.policy_with_value is worker.policy_with_value
+        self.worker, self.learner, self.rb = worker, learner, rb
+        pw, a, dev = worker.policy_with_value, learner.args, worker.device
+        self.pw = pw
+        c = self.c = TrainCtx()
+        c.cfg = pw.cfg
+        c.learner_version = 1 if a.learner_version == 'MPG-v1' else 2
+        c.num_agent, c.sample_iters = worker.num_agent, max(1, worker.batch_size // worker.num_agent)
+        c.sampling_interval = sampling_interval
+        sel = list(learner.num_rollout_list_for_policy_update)
+        c.batch, c.n, c.M, c.n_select = learner.batch_size, max(sel), learner.M, len(sel)
+        for i, k in enumerate(sel):
+            c.select[i] = k
+        c.eta, c.total_ite = a.eta, a.rule_based_bias_total_ite
+        c.clip, c.tau, c.delay_update = float(a.gradient_clip_norm), pw.tau, pw.delay_update
+        c.num_batch_reuse, c.world_size = learner.num_batch_reuse, D.world_size()
+        c.explore_sigma = float(worker.explore_sigma or 0.)
+        for i in range(3):
+            c.value_lr[i], c.policy_lr[i] = pw.schedules['Q1'][i], pw.schedules['policy'][i]
+        c.worker_seed, c.env_seed, c.replay_seed, c.learner_seed = worker.seed, worker.env.seed, rb.seed, learner.seed
+        n, B, od, ad = worker.num_agent, learner.batch_size, pw.obs_dim, pw.act_dim
+        f = dict(dtype=torch.float32, device=dev)
+        u8 = dict(dtype=torch.uint8, device=dev)
+        self.t = t = dict(
+            w_obs=worker.obs.clone(), w_act=torch.empty(n, ad, **f), w_rew=torch.empty(n, **f), w_obs2=torch.empty(n, od, **f),
+            w_done=torch.ones(n, **u8), w_done_intended=torch.zeros(n, **u8),
+            idx=torch.empty(B, dtype=torch.int32, device=dev), b_obs=torch.empty(B, od, **f), b_act=torch.empty(B, ad, **f),
+            b_rew=torch.empty(B, **f), b_obs2=torch.empty(B, od, **f), b_done=torch.empty(B, **f), b_targets=torch.empty(B, **f))
+        if c.learner_version == 1:
+            t.update(l_obs=torch.empty(B, od, **f), l_act=torch.empty(B, ad, **f), l_rewards=torch.empty(c.n, B, **f),
+                     l_done=torch.ones(B, **u8), l_done_intended=torch.zeros(B, **u8))
+            c.l_env_state = L.ptr(learner.env._state)
+        for k, v in t.items():
+            setattr(c, k, L.ptr(v))
+        c.env_state = L.ptr(worker.env._state)
+        c.ring_capacity = rb._maxsize
+        for k, v in (('ring_obs', rb.obs), ('ring_act', rb.act), ('ring_rew', rb.rew), ('ring_obs2', rb.obs2), ('ring_done', rb.done)):
+            setattr(c, k, L.ptr(v))
+        c.params, c.targets, c.adam_m, c.adam_v = L.ptr(pw.params), L.ptr(pw.targets), L.ptr(pw.m), L.ptr(pw.v)
+        c.grad, c.norms, c.nonfinite = L.ptr(learner.flat), L.ptr(learner.norms), L.ptr(pw.nonfinite)
+        w0, w1 = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        L.call('mpg_step_workspace_bytes', ctypes.byref(c), ctypes.byref(w0), ctypes.byref(w1))
+        self.ws0 = torch.empty(w0.value + 256, dtype=torch.uint8, device=dev)
+        self.ws1 = torch.empty(w1.value + 256, dtype=torch.uint8, device=dev)
+        c.ws0, c.ws1, c.ws0_bytes, c.ws1_bytes = L.ptr(self.ws0), L.ptr(self.ws1), self.ws0.numel(), self.ws1.numel()
+        self._lib = L.lib()
+        self._ref = ctypes.byref(c)
+        # the python objects now look at the driver's buffers
+        learner.batch_data = {'batch_obs': t['b_obs'], 'batch_actions': t['b_act'], 'batch_rewards': t['b_rew'],
+                              'batch_obs_tp1': t['b_obs2'], 'batch_dones': t['b_done'], 'batch_targets': t['b_targets']}
+        learner._views = None
+        self.pull()
+
+    def pull(self):
+        """python objects -> context counters"""
+        c, w, rb, ln, pw = self.c, self.worker, self.rb, self.learner, self.pw
+        c.noise_ctr, c.env_ctr, c.replay_times, c.learner_counter = w._noise_ctr, w.env._ctr, rb.replay_times, ln.counter
+        c.ring_next, c.ring_size = rb._next_idx, rb._size
+        for i, n in enumerate(pw.names):
+            c.opt_steps[i] = pw.opt_steps[n]
+
+    def push(self):
+        """context counters -> python objects (so their own methods can be mixed with fused steps)"""
+        c, w, rb, ln, pw = self.c, self.worker, self.rb, self.learner, self.pw
+        w._noise_ctr, w.env._ctr, rb.replay_times, ln.counter = c.noise_ctr, c.env_ctr, c.replay_times, c.learner_counter
+        rb._next_idx, rb._size = c.ring_next, c.ring_size
+        for i, n in enumerate(pw.names):
+            pw.opt_steps[n] = c.opt_steps[i]
+        w.obs = w.env.obs = self.t['w_obs']
+        w.env.done = self.t['w_done']
+        w.env._initialised = True
+
+    def step(self, iteration):
+        s = L.stream()
+        L.check(self._lib.mpg_step_begin(self._ref, ctypes.c_int(iteration), s), 'mpg_step_begin')
+        D.all_reduce_sum_(self.learner.flat)                     # the ONE exchange step (no-op on a single GPU)
+        L.check(self._lib.mpg_step_end(self._ref, ctypes.c_int(iteration), s), 'mpg_step_end')
+        self.push()

@@ -191,19 +191,28 @@ class MPGLearner(_LearnerBase):
                        inv_b_global=inv_b, grad_out=self.grad('policy'), stats_out=stats[2:2 + 2 * ns], n=max(select),
                        noise_seed=self.seed, noise_ctr=self.counter)
         out = self._finish(iteration, float(self.args.gradient_clip_norm))
-        B = rows * world
+        self._lazy_stats = self._mpg_lazy_stats(iteration)
+        return out
 
-        def lazy():   # mpg_learner.py:433-452
+    def _mpg_lazy_stats(self, iteration):
+        """stats of mpg_learner.py:433-452, evaluated only when get_stats() is called"""
+        pw = self.policy_with_value
+        select = self.num_rollout_list_for_policy_update
+        ns, nq = len(select), len(pw.names) - 1
+        stats = self.flat[self.n_grad:]
+        B = self.batch_size * D.world_size()
+
+        def lazy():
+            ws = rule_based_weights(iteration, self.args.rule_based_bias_total_ite, self.args.eta, select)
             mean_ret = stats[2:2 + ns] / B
-            d = dict(value_mean=mean_ret[select.index(0)] if 0 in select else None,
+            d = dict(iteration=iteration, value_mean=mean_ret[select.index(0)] if 0 in select else None,
                      policy_total_loss=-(torch.as_tensor(ws, device=self.device) * mean_ret).sum(),
-                     policy_gradient_norm=self.norms[len(qnames)], q_loss1=stats[0], q_gradient_norm1=self.norms[0],
+                     policy_gradient_norm=self.norms[nq], q_loss1=stats[0], q_gradient_norm1=self.norms[0],
                      num_rollout_list=select, w_list=list(map(float, ws)), all_losses=-mean_ret)
-            if len(qnames) == 2:
+            if nq == 2:
                 d.update(q_loss2=stats[1], q_gradient_norm2=self.norms[1])
             return d
-        self._lazy_stats = lazy
-        return out
+        return lazy
 
 
 class NADPLearner(_LearnerBase):

@@ -7,7 +7,7 @@ logger = logging.getLogger(__name__)
 
 
 class SingleProcessOffPolicyOptimizer(object):
-    def __init__(self, worker, learner, replay_buffer, evaluator, args, sampling_interval=10):
+    def __init__(self, worker, learner, replay_buffer, evaluator, args, sampling_interval=10, fused=True):
         self.args = args
         self.worker, self.learner, self.replay_buffer, self.evaluator = worker, learner, replay_buffer, evaluator
         self.num_sampled_steps = 0
@@ -20,12 +20,29 @@ class SingleProcessOffPolicyOptimizer(object):
             sample_batch, count = self.worker.sample_with_count()
             self.num_sampled_steps += count
             self.replay_buffer.add_batch(sample_batch)
+        # native step driver (mpg_step_begin/_end) when the stock MPG components are plugged in; otherwise the
+        # method-by-method path below, which computes the same thing
+        self._fused = None
+        if fused:
+            from .buffer import PrioritizedReplayBuffer
+            from .learners import MPGLearner
+            if type(learner) is MPGLearner and not isinstance(replay_buffer, PrioritizedReplayBuffer) and \
+                    getattr(args, 'buffer_type', 'normal') == 'normal':
+                from .fused import FusedMPGStep
+                self._fused = FusedMPGStep(worker, learner, replay_buffer, sampling_interval)
 
     def get_stats(self):
         self.stats.update(dict(num_sampled_steps=self.num_sampled_steps, iteration=self.iteration))
         return self.stats
 
     def step(self):
+        if self._fused is not None:
+            if self.iteration % self.sampling_interval == 0:
+                self.num_sampled_steps += self.worker.num_agent * self._fused.c.sample_iters
+            self._fused.step(self.iteration)
+            self.learner._lazy_stats = self.learner._mpg_lazy_stats(self.iteration)
+            self.iteration += 1
+            return
         if self.iteration % self.sampling_interval == 0:                   # optimizer.py:332-337
             sample_batch, count = self.worker.sample_with_count()
             self.num_sampled_steps += count

@@ -126,3 +126,42 @@ def test_single_process_training_loop_runs_and_learns_the_critic(alg):
     assert (pw.targets - t0).abs().max().item() > 0
     assert np.mean(losses[-5:]) < np.mean(losses[:5])
     assert int(pw.nonfinite.sum().item()) == 0
+
+
+@pytest.mark.parametrize('alg', ['MPG-v2', 'MPG-v1'])
+def test_native_step_driver_equals_method_by_method_path(alg):
+    """mpg_step_begin/_end enqueue the same launches as the python classes: after the same number of iterations the
+    counters and the replay ring are identical, and parameters / Adam moments / targets agree to float32 rounding (the
+    host-side scalars - rule-based weights, bias-corrected learning rates - are evaluated by libm in one path and by
+    numpy in the other, which may differ in the last bit)."""
+    from mpg_amd.buffer import ReplayBuffer
+    from mpg_amd.config import default_args
+    from mpg_amd.learners import MPGLearner
+    from mpg_amd.optimizer import SingleProcessOffPolicyOptimizer
+    from mpg_amd.policy import PolicyWithQs
+    from mpg_amd.worker import OffPolicyWorker
+
+    def run(fused):
+        args = default_args(alg, num_agent=64, batch_size=128, replay_batch_size=96, replay_starts=512, max_buffer_size=1000,
+                            num_batch_reuse=2 if alg == 'MPG-v1' else 1)
+        worker = OffPolicyWorker(PolicyWithQs, args.env_id, args, 0)
+        learner = MPGLearner(PolicyWithQs, args)
+        rb = ReplayBuffer(args, 0)
+        opt = SingleProcessOffPolicyOptimizer(worker, learner, rb, None, args, sampling_interval=3, fused=fused)
+        assert (opt._fused is not None) == fused
+        for _ in range(9):
+            opt.step()
+        pw = worker.policy_with_value
+        st = learner.get_stats()
+        return [pw.params.clone(), pw.targets.clone(), pw.m.clone(), pw.v.clone(), rb.obs.clone(), rb.rew.clone(),
+                learner.flat.clone()], (dict(pw.opt_steps), rb._next_idx, len(rb), worker._noise_ctr, st['q_loss1'])
+    a, ca = run(True)
+    b, cb = run(False)
+    assert ca[:4] == cb[:4], (ca, cb)
+    assert abs(ca[4] - cb[4]) <= 1e-6 * abs(cb[4])
+    assert torch.equal(a[4], b[4])                    # ring: same reset-law draws in the same slots
+    assert (a[5] - b[5]).abs().max().item() < 1e-4    # rewards depend on the (rounding-different) policy
+    for x, y in zip(a[:4], b[:4]):
+        assert (x - y).abs().max().item() <= 1e-6 * max(1.0, y.abs().max().item())
+    g1, g2 = a[6], b[6]
+    assert ((g1 - g2).norm() / g2.norm()).item() < 1e-5
