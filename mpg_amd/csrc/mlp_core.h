@@ -220,8 +220,8 @@ __device__ __forceinline__ void forward_group(const float* sX, float* sA, float*
 }
 
 // sum of the 8 per-wave partials + bias for (row, o)
-__device__ __forceinline__ float out_preact(const float* sPart, const float* __restrict__ b3, int row, int o) {
-    float z = b3[o];
+__device__ __forceinline__ float out_preact(const float* sPart, float bias, int row, int o) {
+    float z = bias;
 #pragma unroll
     for (int w = 0; w < NWAVE; ++w) z += sPart[(w * GROUP + row) * MAXOUT + o];
     return z;

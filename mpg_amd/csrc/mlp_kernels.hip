@@ -63,7 +63,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_forward(const FwdArgs a) {
             const int row = tid / OU, o = tid % OU;
             const long gr = g * GROUP + row;
             if (gr < a.rows) {
-                float z = out_preact(sPart, net.b3, row, o);
+                float z = out_preact(sPart, net.b3[o], row, o);
                 float y = a.out_tanh ? a.out_scale * tanhf(z) : z;
                 if (a.sigma > 0.f) {   // OffPolicyWorker.sample: action += N(0, sigma), worker.py:97-98
                     Philox4 p = philox4x32_10((uint32_t)gr, a.c1, a.c2, 0x5eedu + (uint32_t)o, a.k0, a.k1);

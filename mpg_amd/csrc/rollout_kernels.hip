@@ -193,6 +193,9 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_fwd(const RollArgs a) {
     SmallRegs<OBS, ACT> r;
     if (a.pack) load_w2_packed(a.pack, L, w2); else load_w2_fwd(net.W2, L, w2);
     load_small<OBS, ACT>(net, L, r);
+    float b3r[2] = {0.f, 0.f};                         // output bias in registers: no global load on the serial chain
+#pragma unroll
+    for (int k = 0; k < ACT; ++k) b3r[k] = net.b3[k];
     const long R = (long)a.rows * a.M;
     const long ngroups = (R + GROUP - 1) / GROUP;
     for (long g = blockIdx.x; g < ngroups; g += gridDim.x) {
@@ -200,19 +203,29 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_fwd(const RollArgs a) {
         const bool own = tid < GROUP, live = own && tr < R;
         float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         float G = 0.f;
+        float act_first[2] = {0.f, 0.f};
         if (live) {
             const float* src = a.obs0 + (tr % a.rows) * OBS;
 #pragma unroll
             for (int i = 0; i < OBS; ++i) o[i] = src[i];
-        }
-        if (!a.eps) {   // draw the whole group's model noise up front, off the serial chain (one value per thread)
-            for (int idx = tid; idx < a.n * GROUP; idx += NTHREAD) {
-                const int t = idx / GROUP;
-                const long trj = g * GROUP + (idx % GROUP);
-                const Philox4 p = philox4x32_10((uint32_t)trj, (uint32_t)t, a.nc0, a.nc1 ^ 0x6e6f6973u, a.nk0, a.nk1);
-                sEps[idx] = sqrtf(-2.f * logf(u01(p.v[0]))) * cosf(6.283185307179586f * u01(p.v[1]));
+            if (a.act0) {
+#pragma unroll
+                for (int k = 0; k < ACT; ++k) act_first[k] = a.act0[(tr % a.rows) * ACT + k];
             }
-            // visible to the dynamics lanes after the first barrier of the step loop
+        }
+        // the whole group's model noise goes to LDS up front (one value per thread), off the serial chain: either the
+        // caller's eps or Philox draws.  Visible to the dynamics lanes after the first barrier of the step loop.
+        for (int idx = tid; idx < a.n * GROUP; idx += NTHREAD) {
+            const int t = idx / GROUP;
+            const long trj = g * GROUP + (idx % GROUP);
+            float z = 0.f;
+            if (a.eps) {
+                if (trj < R) z = a.eps[(long)t * R + trj];
+            } else {
+                const Philox4 p = philox4x32_10((uint32_t)trj, (uint32_t)t, a.nc0, a.nc1 ^ 0x6e6f6973u, a.nk0, a.nk1);
+                z = sqrtf(-2.f * logf(u01(p.v[0]))) * cosf(6.283185307179586f * u01(p.v[1]));
+            }
+            sEps[idx] = z;
         }
         for (int t = 0; t <= a.n; ++t) {
             if (own) {
@@ -230,12 +243,12 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_fwd(const RollArgs a) {
                 float act[2] = {0.f, 0.f};
 #pragma unroll
                 for (int k = 0; k < ACT; ++k) {
-                    const float z = out_preact(sPart, net.b3, tid, k);
+                    const float z = out_preact(sPart, b3r[k], tid, k);
                     act[k] = a.out_tanh ? a.out_scale * fast_tanh(z) : z;
                 }
-                if (t == 0 && a.act0 && live) {
+                if (t == 0 && a.act0) {
 #pragma unroll
-                    for (int k = 0; k < ACT; ++k) act[k] = a.act0[(tr % a.rows) * ACT + k];
+                    for (int k = 0; k < ACT; ++k) act[k] = act_first[k];
                 }
                 if (live) {
                     if (a.SA) {
@@ -256,7 +269,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_fwd(const RollArgs a) {
                         }
                 }
                 if (t < a.n) {
-                    const float e = a.eps ? (live ? a.eps[(long)t * R + tr] : 0.f) : sEps[t * GROUP + tid];
+                    const float e = sEps[t * GROUP + tid];
                     float on[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                     float rew;
 #ifdef MPG_AB_NODYN   // ablation build: skip the model step (timing only, results meaningless)
@@ -365,23 +378,44 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_bwd(const RollBwdArgs a)
         const bool own = tid < GROUP, live = own && tr < R;
         float lam_next[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // dL/d(obs_{t+1})
         float lam[8];
+        // Software pipeline over the steps: the (obs | action) record and the h2 stash of step t-1 are requested while
+        // step t computes, so that no HBM / L2 latency sits on the serial chain.
+        float rec_cur[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, rec_next[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        float rec_pre[8];
+        float h2_cur[2][4], h2_pre[2][4];
+        if (live) {
+            const f32x4* rp = reinterpret_cast<const f32x4*>(a.SA + ((long)a.n * R + tr) * SAW);
+            const f32x4 r0 = rp[0], r1 = rp[1];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { rec_cur[i] = r0[i]; rec_cur[4 + i] = r1[i]; }
+        }
+        stash_load(a.H2, (long)a.n * ngroups + g, L, h2_cur);
         for (int t = a.n; t >= 0; --t) {
+            if (t > 0) {   // prefetch step t-1
+                if (live) {
+                    const f32x4* rp = reinterpret_cast<const f32x4*>(a.SA + ((long)(t - 1) * R + tr) * SAW);
+                    const f32x4 r0 = rp[0], r1 = rp[1];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { rec_pre[i] = r0[i]; rec_pre[4 + i] = r1[i]; }
+                }
+                stash_load(a.H2, (long)(t - 1) * ngroups + g, L, h2_pre);
+            }
+            float h1[2][4];
+            stash_load(a.H1, (long)t * ngroups + g, L, h1);          // consumed after the MFMA block
             if (own) {
                 float ga[2] = {0.f, 0.f};
 #pragma unroll
                 for (int i = 0; i < 8; ++i) lam[i] = 0.f;
                 float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, act[2] = {0.f, 0.f};
                 if (live) {
-                    const float* rec = a.SA + ((long)t * R + tr) * SAW;
 #pragma unroll
-                    for (int i = 0; i < OBS; ++i) o[i] = rec[i];
+                    for (int i = 0; i < OBS; ++i) o[i] = rec_cur[i];
 #pragma unroll
-                    for (int k = 0; k < ACT; ++k) act[k] = rec[OBS + k];
+                    for (int k = 0; k < ACT; ++k) act[k] = rec_cur[OBS + k];
                     if (t < a.n) {
                         float on[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                        const float* recn = a.SA + ((long)(t + 1) * R + tr) * SAW;
 #pragma unroll
-                        for (int i = 0; i < OBS; ++i) on[i] = recn[i];
+                        for (int i = 0; i < OBS; ++i) on[i] = rec_next[i];
                         ENV::vjp(o, act, on, lam_next, a.rho[t], lam, ga);
                     }
                     for (int ks = 0; ks < a.n_sel; ++ks)
@@ -405,14 +439,12 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_bwd(const RollBwdArgs a)
                         a.DZ3[((long)(a.stash_all ? t : 0) * R + tr) * ACT + k] = d;
                 }
             }
-            float h1[2][4], h2[2][4], dz1[2][4], dz2[2][4];
-            stash_load(a.H1, (long)t * ngroups + g, L, h1);
-            stash_load(a.H2, (long)t * ngroups + g, L, h2);
+            float dz1[2][4], dz2[2][4];
             lds_barrier();
             if (t > 0)
-                backward_group<OBS, ACT, true>(sD3, sA, sPartX, L, w2t, r, h1, h2, dz1, dz2);
+                backward_group<OBS, ACT, true>(sD3, sA, sPartX, L, w2t, r, h1, h2_cur, dz1, dz2);
             else
-                backward_group<OBS, ACT, false>(sD3, sA, sPartX, L, w2t, r, h1, h2, dz1, dz2);
+                backward_group<OBS, ACT, false>(sD3, sA, sPartX, L, w2t, r, h1, h2_cur, dz1, dz2);
             if (a.DZ1 && (a.stash_all || t == 0)) {
                 const long sg = (long)(a.stash_all ? t : 0) * ngroups + g;
                 stash_store(a.DZ1, sg, L, dz1);
@@ -424,8 +456,16 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_bwd(const RollBwdArgs a)
                     for (int i = 0; i < OBS; ++i) lam[i] += dx_reduce(sPartX, tid, i) * a.obs_scale[i];
                 }
 #pragma unroll
-                for (int i = 0; i < 8; ++i) lam_next[i] = lam[i];
+                for (int i = 0; i < 8; ++i) {
+                    lam_next[i] = lam[i];
+                    rec_next[i] = rec_cur[i];
+                    rec_cur[i] = rec_pre[i];
+                }
             }
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) h2_cur[tt][j] = h2_pre[tt][j];
             // next iteration: sD3 is rewritten by wave 0 only after it has passed backward_group's final barrier,
             // and read by the others only after the __syncthreads above -> no extra barrier needed.
         }
