@@ -21,7 +21,8 @@ constexpr int H = 256;
 constexpr int NTHREAD = 512;
 constexpr int NWAVE = 8;
 constexpr int GROUP = 16;      // rows per row group
-constexpr int LDA = 260;       // row stride (floats) of the LDS A image: 260 = 4 (mod 64) -> conflict-free b128 reads
+constexpr int LDA = 280;       // row stride (floats) of the LDS A image
+constexpr int KS = 68;         // stride between the 4 k-phases of a row; (LDA, KS) = (280, 68): b128 reads conflict-free, b32 writes 2-way (free)
 constexpr int XS = 8;          // row stride of the small LDS input block
 constexpr int MAXOUT = 2;      // outputs ever *used* (policy mean: act_dim <= 2; critic: 1)
 
@@ -67,6 +68,24 @@ struct Lane {
 // is needed.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+#ifdef MPG_STAMP   // diagnostic build only: per-wave cycle accounting of the step phases (see scratch/stamps.md)
+__shared__ unsigned long long g_st_acc[NWAVE][10];
+__shared__ unsigned long long g_st_prev[NWAVE];
+__device__ __forceinline__ void mpg_stamp(int k) {
+    __builtin_amdgcn_sched_barrier(0);
+    if ((threadIdx.x & 63) == 0) {
+        const unsigned long long now = __builtin_amdgcn_s_memtime();
+        const int w = threadIdx.x >> 6;
+        g_st_acc[w][k] += now - g_st_prev[w];
+        g_st_prev[w] = now;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+#define MPG_STAMP_AT(k) mpg_stamp(k)
+#else
+#define MPG_STAMP_AT(k)
+#endif
+
 __device__ __forceinline__ float elu(float z) { return z > 0.f ? z : __expf(z) - 1.f; }
 // ELU'(z) expressed through the stored output h = ELU(z): 1 for z > 0, exp(z) = h + 1 otherwise.
 __device__ __forceinline__ float elu_grad_from_out(float h) { return h > 0.f ? 1.f : h + 1.f; }
@@ -85,9 +104,9 @@ __device__ __forceinline__ float row_allreduce16(float v) {
 }
 
 // ---- LDS A image --------------------------------------------------------------------------------------
-// element (row, k) lives at row*LDA + (k&3)*64 + (k>>2): the MFMA A fragment of lane (row = l&15, kq = l>>4)
+// element (row, k) lives at row*LDA + (k&3)*KS + (k>>2): the MFMA A fragment of lane (row = l&15, kq = l>>4)
 // for k-steps q..q+3 (k = 4q + kq) is then ONE aligned 16-byte read.
-__device__ __forceinline__ int a_index(int row, int k) { return row * LDA + (k & 3) * 64 + (k >> 2); }
+__device__ __forceinline__ int a_index(int row, int k) { return row * LDA + (k & 3) * KS + (k >> 2); }
 
 __device__ __forceinline__ void store_c_to_a(float* sA, const Lane& L, const float (&v)[2][4]) {
 #pragma unroll
@@ -133,20 +152,25 @@ const float* weight_cache_lookup(const float* W2, int dir);
 // 16 x 256 (LDS A image) times the wave's stationary 256 x 32 slice; 128 MFMAs, two independent accumulators.
 __device__ __forceinline__ void mfma_16x256x32(const float* sA, const Lane& L, const float (&w)[128], f32x4& acc0,
                                                f32x4& acc1) {
-    const float* base = sA + L.c * LDA + L.rg * 64;
+    const float* base = sA + L.c * LDA + L.rg * KS;
 #ifdef MPG_AB_NOMFMA   // ablation build: one k-block instead of 16 (timing only)
-#pragma unroll
-    for (int q4 = 0; q4 < 1; ++q4) {
+    constexpr int NQ4 = 1;
 #else
-#pragma unroll
-    for (int q4 = 0; q4 < 16; ++q4) {
+    constexpr int NQ4 = 16;
 #endif
-        const f32x4 a = *reinterpret_cast<const f32x4*>(base + 4 * q4);
+    // explicit one-block-ahead prefetch of the A fragments: the LDS latency of block q4+1 hides under the 8 MFMAs
+    // (256 cycles) of block q4 instead of stalling the first MFMA of every block
+    f32x4 a = *reinterpret_cast<const f32x4*>(base);
+#pragma unroll
+    for (int q4 = 0; q4 < NQ4; ++q4) {
+        f32x4 nxt = a;
+        if (q4 + 1 < NQ4) nxt = *reinterpret_cast<const f32x4*>(base + 4 * (q4 + 1));
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], w[2 * (4 * q4 + i)], acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], w[2 * (4 * q4 + i) + 1], acc1, 0, 0, 0);
         }
+        a = nxt;
     }
 }
 
@@ -199,24 +223,39 @@ __device__ __forceinline__ void forward_group(const float* sX, float* sA, float*
         }
     }
     store_c_to_a(sA, L, h1);
+    MPG_STAMP_AT(1);
     lds_barrier();
+    MPG_STAMP_AT(2);
     f32x4 acc0 = {r.b2[0], r.b2[0], r.b2[0], r.b2[0]};
     f32x4 acc1 = {r.b2[1], r.b2[1], r.b2[1], r.b2[1]};
     mfma_16x256x32(sA, L, w2, acc0, acc1);
+    MPG_STAMP_AT(3);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         h2[0][j] = elu(acc0[j]);
         h2[1][j] = elu(acc1[j]);
     }
+    {   // output-layer partials: all 4*OU row sums advance stage by stage so that the DPP latencies interleave
+        float p[OU][4];
 #pragma unroll
-    for (int o = 0; o < OU; ++o)
+        for (int o = 0; o < OU; ++o)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float p = fmaf(h2[1][j], r.w3[1][o], h2[0][j] * r.w3[0][o]);
-            p = row_allreduce16(p);
-            if (L.c == 0) sPart[(L.wave * GROUP + L.row(j)) * MAXOUT + o] = p;
+            for (int j = 0; j < 4; ++j) p[o][j] = fmaf(h2[1][j], r.w3[1][o], h2[0][j] * r.w3[0][o]);
+#define MPG_DPP_STAGE(CTRL)                                     \
+        _Pragma("unroll") for (int o = 0; o < OU; ++o)           \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) p[o][j] += dpp_mov<CTRL>(p[o][j]);
+        MPG_DPP_STAGE(0xB1) MPG_DPP_STAGE(0x4E) MPG_DPP_STAGE(0x141) MPG_DPP_STAGE(0x140)
+#undef MPG_DPP_STAGE
+        if (L.c == 0) {
+#pragma unroll
+            for (int o = 0; o < OU; ++o)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sPart[(L.wave * GROUP + L.row(j)) * MAXOUT + o] = p[o][j];
         }
+    }
+    MPG_STAMP_AT(4);
     lds_barrier();
+    MPG_STAMP_AT(5);
 }
 
 // sum of the 8 per-wave partials + bias for (row, o)
@@ -281,7 +320,7 @@ __device__ __forceinline__ void backward_group(const float* sD3, float* sA, floa
         store_c_to_a(sA, L, dz1);
         __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): this wave reads back only what it wrote itself
         __builtin_amdgcn_wave_barrier();
-        const float* base = sA + L.c * LDA + L.rg * 64 + 8 * L.wave;
+        const float* base = sA + L.c * LDA + L.rg * KS + 8 * L.wave;
         const f32x4 a0 = *reinterpret_cast<const f32x4*>(base), a1 = *reinterpret_cast<const f32x4*>(base + 4);
         f32x4 dx = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll

@@ -174,6 +174,7 @@ struct RollArgs {
     float* XQ;                          // [n_sel][R][OBS+ACT] critic inputs (scaled obs | action) at the selected slices
     float* GK;                          // [n_sel][R] discounted reward sums G_k
     const float* pack;                  // nullable: packed forward image of the policy's W2
+    float* dbg;                         // diagnostic builds only
 };
 
 template <class ENV>
@@ -198,6 +199,12 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_fwd(const RollArgs a) {
     for (int k = 0; k < ACT; ++k) b3r[k] = net.b3[k];
     const long R = (long)a.rows * a.M;
     const long ngroups = (R + GROUP - 1) / GROUP;
+#ifdef MPG_STAMP
+    if ((tid & 63) == 0) {
+        for (int k = 0; k < 10; ++k) g_st_acc[tid >> 6][k] = 0;
+        g_st_prev[tid >> 6] = __builtin_amdgcn_s_memtime();
+    }
+#endif
     for (long g = blockIdx.x; g < ngroups; g += gridDim.x) {
         const long tr = g * GROUP + tid;               // this lane's trajectory (tid < 16 only)
         const bool own = tid < GROUP, live = own && tr < R;
@@ -233,12 +240,14 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_fwd(const RollArgs a) {
                 for (int i = 0; i < XS; ++i) sX[tid * XS + i] = i < OBS ? o[i] * a.obs_scale[i] : 0.f;
             }
             lds_barrier();
+            MPG_STAMP_AT(0);
             float h1[2][4], h2[2][4];
             forward_group<OBS, ACT>(sX, sA, sPart, L, w2, r, h1, h2);
             if (a.H1) {
                 stash_store(a.H1, (long)t * ngroups + g, L, h1);
                 stash_store(a.H2, (long)t * ngroups + g, L, h2);
             }
+            MPG_STAMP_AT(6);
             if (own) {
                 float act[2] = {0.f, 0.f};
 #pragma unroll
@@ -283,7 +292,12 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_fwd(const RollArgs a) {
                 }
             }
             // the next iteration's sX write is ordered behind this iteration's reads by forward_group's barriers
+            MPG_STAMP_AT(7);
         }
+#ifdef MPG_STAMP
+        if ((tid & 63) == 0 && a.dbg)
+            for (int k = 0; k < 8; ++k) a.dbg[((long)blockIdx.x * NWAVE + (tid >> 6)) * 8 + k] = (float)g_st_acc[tid >> 6][k];
+#endif
     }
 }
 
@@ -571,6 +585,13 @@ extern "C" int mpg_rollout_pg(const mpg_cfg_t* cfg, const float* policy_params, 
     for (int k = 0; k < MAXSEL; ++k) fa.sel[k] = k < n_select ? select[k] : -1;
     fa.XQ = XQ; fa.GK = GK;
     const long ngroups = (R + GROUP - 1) / GROUP;
+    fa.dbg = nullptr;
+#ifdef MPG_STAMP
+    static float* s_dbg = nullptr;
+    static int s_calls = 0;
+    if (!s_dbg) (void)hipMalloc(&s_dbg, 256 * 8 * 8 * sizeof(float));
+    fa.dbg = s_dbg;
+#endif
     mpg_prof_begin(0, s);
     if (cfg->env_kind == MPG_ENV_PATH_TRACKING)
         hipLaunchKernelGGL((k_rollout_fwd<PathTracking>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, fa);
@@ -578,6 +599,22 @@ extern "C" int mpg_rollout_pg(const mpg_cfg_t* cfg, const float* policy_params, 
         hipLaunchKernelGGL((k_rollout_fwd<Pendulum>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, fa);
     mpg_prof_end(0, s);
     MPG_CHECK_LAUNCH("k_rollout_fwd");
+#ifdef MPG_STAMP
+    if (++s_calls % 50 == 0) {
+        static float h[256 * 8 * 8];
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(h, s_dbg, sizeof(h), hipMemcpyDeviceToHost);
+        const int nwg = grid_for(ngroups);
+        for (int w = 0; w < 8; w += 7) {
+            double acc[8] = {0};
+            for (int b = 0; b < nwg; ++b) for (int k = 0; k < 8; ++k) acc[k] += h[(b * 8 + w) * 8 + k];
+            fprintf(stderr, "[stamp fwd] wave %d cycles/step:", w);
+            double tot = 0;
+            for (int k = 0; k < 8; ++k) { fprintf(stderr, " p%d=%.0f", k, acc[k] / nwg / (n + 1)); tot += acc[k] / nwg / (n + 1); }
+            fprintf(stderr, " total=%.0f\n", tot);
+        }
+    }
+#endif
 
     // ---- critic at the selected slices: values, returns, input gradients ----
     OutSpec lin; lin.out_tanh = 0; lin.out_scale = 1.f; lin.sigma = 0.f; lin.seed = lin.ctr = 0;
@@ -646,7 +683,7 @@ extern "C" int mpg_rollout_q_target(const mpg_cfg_t* cfg, const float* policy_pa
     float* XQ = cv.take((size_t)rows * qin); float* GK = cv.take(rows); float* Q = cv.take(rows);
     RollArgs fa;
     fill_roll(fa, cfg, policy_params, rows, 1, n);
-    fa.obs0 = obs0; fa.act0 = act0; fa.eps = eps; fa.H1 = fa.H2 = nullptr; fa.SA = nullptr;
+    fa.obs0 = obs0; fa.act0 = act0; fa.eps = eps; fa.H1 = fa.H2 = nullptr; fa.SA = nullptr; fa.dbg = nullptr;
     fa.nk0 = (uint32_t)noise_seed; fa.nk1 = (uint32_t)(noise_seed >> 32); fa.nc0 = (uint32_t)noise_ctr; fa.nc1 = (uint32_t)(noise_ctr >> 32);
     fa.n_sel = 1;
     for (int k = 0; k < MAXSEL; ++k) fa.sel[k] = k == 0 ? n : -1;
