@@ -55,7 +55,7 @@ def build_stack(dev, seed):
     return args, worker, learner, rb, opt
 
 
-def cpu_baseline(budget_s=20.0):
+def cpu_baseline(budget_s=15.0):
     """The oracle ("port": torch-CPU/numpy restatement of the reference, op by op) timed on the host cores on a bounded
     sample of the SAME workload: steps of [4096-agent worker sample + MPG-v2 compute_gradient at B = 4096 + Adam]."""
     from oracle import mpg_oracle as O
@@ -80,7 +80,7 @@ def cpu_baseline(budget_s=20.0):
         grads, _ = O.mpg_compute_gradient(cfg, nets, batch, eps, 100 + n_done, 'MPG-v2')
         n_done += 1
         el = time.perf_counter() - t0
-        if el > budget_s or n_done >= 8:
+        if el > budget_s or n_done >= 200:
             break
     return {'value': n_done * B_PER_GPU / el, 'unit': 'env-steps/s', 'cores': cores, 'kind': 'port',
             'grad_steps_per_sec': n_done / el,

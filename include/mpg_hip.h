@@ -176,6 +176,22 @@ int mpg_rollout_pg(const mpg_cfg_t* cfg, const float* policy_params, const float
                    uint64_t noise_seed, uint64_t noise_ctr, float inv_b_global, int all_steps_param_grad, float* ret_sum, float* ret_sqsum, float* grad,
                    void* ws, size_t ws_bytes, mpg_stream_t stream);
 
+/* MPGLearner.compute_gradient without the clip, as one entry point  - learners/mpg_learner.py:401-431:
+ * target (when y_in == NULL: clipped double-Q target from target_params, :126-134), critic losses and gradients of
+ * the n_q (1: MPG-v1, 2: MPG-v2) critics (:326-354), n-step model rollout + mixed policy gradient (:226-286,356-365).
+ * params / target_params / grad: flat [Q1 | (Q2) | policy] like PolicyWithQs.models (policy.py:72-86); y_in: optional
+ * precomputed targets [rows] (MPG-v1's real-env n-step return); y_out [rows] receives the targets used.
+ * stats (16 floats): [0..n_q) critic losses, [2..2+n_select) return sums, [2+n_select..2+2 n_select) sums of squares.
+ * Everything is this GPU's UN-clipped partial, scaled by inv_b_global = 1/B_global: all-reduce, then
+ * mpg_clip_by_global_norm.  Same results as mpg_q_targets + mpg_q_loss_grad + mpg_rollout_pg (up to the association
+ * of the slab sums) in 7 launches instead of 22 when rows % 16 == 0 and M == 1; otherwise it calls those. */
+size_t mpg_mpg_gradients_workspace_bytes(const mpg_cfg_t* cfg, int rows, int M, int n, int n_select, int n_q);
+int mpg_mpg_gradients(const mpg_cfg_t* cfg, int n_q, const float* params, const float* target_params, int rows,
+                      const float* obs, const float* act, const float* rew, const float* obs_tp1, const float* y_in,
+                      int M, int n, const int* select, int n_select, const float* w, const float* eps,
+                      uint64_t noise_seed, uint64_t noise_ctr, float inv_b_global, float* grad, float* stats,
+                      float* y_out, void* ws, size_t ws_bytes, mpg_stream_t stream);
+
 /* NADPLearner.model_rollout_for_q_estimation  - learners/nadp.py:87-126: from (s, a_replay) roll n model steps,
  * later actions from pi_theta, y = G_n + gamma^n * Q1_target(s~_n, pi_theta(s~_n)) (no gradient).
  * eps [n][rows] standard normal, or NULL for in-kernel Philox(noise_seed, noise_ctr) draws. */

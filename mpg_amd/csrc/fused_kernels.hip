@@ -1,0 +1,381 @@
+// Fused critic-side kernels: the clipped double-Q target, the critics' forward + error + backward, and the critic's
+// value + input gradient at the rollout slices - each ONE launch in which a workgroup takes one 16-row group through
+// several networks / directions, re-loading its register-stationary weights between phases.  At B = 4096 (one group
+// per CU) every separate launch costs a prologue + ~3.5 us boundary for ~3.4 us of MFMA work; fusing removes 14 of the
+// 22 launches of a gradient step.  Results are bit-identical to the unfused launchers (same device functions).
+#include "mlp_wgrad.h"
+
+namespace mlp {
+
+namespace {
+
+__device__ __forceinline__ void load_w2(const float* pack, const float* W2, bool bwd, const Lane& L, float (&w)[128]) {
+    if (pack) load_w2_packed(pack, L, w);
+    else if (bwd) load_w2_bwd(W2, L, w);
+    else load_w2_fwd(W2, L, w);
+}
+
+constexpr int SMEM_FLOATS = GROUP * LDA + GROUP * XS + NWAVE * GROUP * MAXOUT + GROUP * MAXOUT + NWAVE * GROUP * XS + 4 * GROUP;
+struct Smem {
+    float *sA, *sX, *sPart, *sD3, *sPartX, *sQ;
+    __device__ explicit Smem(float* base) {
+        sA = base;
+        sX = sA + GROUP * LDA;
+        sPart = sX + GROUP * XS;
+        sD3 = sPart + NWAVE * GROUP * MAXOUT;
+        sPartX = sD3 + GROUP * MAXOUT;
+        sQ = sPartX + NWAVE * GROUP * XS;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+struct TargetArgs {
+    const float *pol, *q1, *q2;                 // target networks (q2 nullable)
+    const float *pk_pol, *pk_q1, *pk_q2;        // packed forward images (nullable)
+    int rows;
+    const float *obs2, *rew, *smooth_eps;
+    float scale[8];
+    int out_tanh;
+    float out_scale, sigma, clipc, rshift, rscale, gamma;
+    float* y;
+};
+
+template <int OBS, int ACT>
+__global__ void __launch_bounds__(NTHREAD, 2) k_target_fused(const TargetArgs a) {
+    constexpr int QIN = OBS + ACT;
+    __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
+    const Smem m(smem);
+    const Lane L;
+    const int tid = threadIdx.x;
+    const long g = blockIdx.x;
+    if (tid < GROUP * XS) {
+        const int row = tid / XS, i = tid % XS;
+        const long gr = g * GROUP + row;
+        m.sX[tid] = (gr < a.rows && i < OBS) ? a.obs2[gr * OBS + i] * a.scale[i] : 0.f;
+    }
+    lds_barrier();
+    float w2[128], h1[2][4], h2[2][4];
+    {   // a' = pi_target(s~')  (+ clip(sigma*eps, +-c), td3.py:74-76)
+        const Net net = make_net(a.pol, OBS, 2 * ACT);
+        SmallRegs<OBS, ACT> r;
+        load_w2(a.pk_pol, net.W2, false, L, w2);
+        load_small<OBS, ACT>(net, L, r);
+        forward_group<OBS, ACT>(m.sX, m.sA, m.sPart, L, w2, r, h1, h2);
+        if (tid < GROUP * ACT) {
+            const int row = tid / ACT, k = tid % ACT;
+            const long gr = g * GROUP + row;
+            const float z = out_preact(m.sPart, net.b3[k], row, k);
+            float act = a.out_tanh ? a.out_scale * tanhf(z) : z;
+            if (a.smooth_eps && gr < a.rows) act += fminf(fmaxf(a.sigma * a.smooth_eps[gr * ACT + k], -a.clipc), a.clipc);
+            m.sX[row * XS + OBS + k] = act;
+        }
+        lds_barrier();
+    }
+    for (int qi = 0; qi < 2; ++qi) {
+        const float* qp = qi == 0 ? a.q1 : a.q2;
+        if (!qp) break;
+        const Net net = make_net(qp, QIN, 1);
+        SmallRegs<QIN, 1> r;
+        load_w2(qi == 0 ? a.pk_q1 : a.pk_q2, net.W2, false, L, w2);
+        load_small<QIN, 1>(net, L, r);
+        forward_group<QIN, 1>(m.sX, m.sA, m.sPart, L, w2, r, h1, h2);
+        if (tid < GROUP) m.sQ[qi * GROUP + tid] = out_preact(m.sPart, net.b3[0], tid, 0);
+        lds_barrier();
+    }
+    if (tid < GROUP) {
+        const long gr = g * GROUP + tid;
+        if (gr < a.rows) {
+            const float q = a.q2 ? fminf(m.sQ[tid], m.sQ[GROUP + tid]) : m.sQ[tid];
+            a.y[gr] = (a.rew[gr] + a.rshift) * a.rscale + a.gamma * q;      // mpg_learner.py:132-133
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+struct QlossArgs {
+    const float* q[2];
+    const float *pkf[2], *pkb[2];
+    int rows;
+    XSpec x;
+    const float* y;
+    float inv_b;
+    CriticStash st[2];
+    float* loss_part;          // [n_q][ngroups]
+    float* td;
+};
+
+template <int QIN>
+__global__ void __launch_bounds__(NTHREAD, 2) k_qloss_fused(const QlossArgs a) {
+    __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
+    const Smem m(smem);
+    const Lane L;
+    const int tid = threadIdx.x;
+    const long g = blockIdx.x;
+    const int qi = blockIdx.y;
+    const long ngroups = gridDim.x;
+    const Net net = make_net(a.q[qi], QIN, 1);
+    const CriticStash st = a.st[qi];
+    load_x_group<QIN>(a.x, a.rows, g, m.sX);
+    lds_barrier();
+    float w2[128], h1[2][4], h2[2][4], dz1[2][4], dz2[2][4];
+    SmallRegs<QIN, 1> r;
+    load_w2(a.pkf[qi], net.W2, false, L, w2);
+    load_small<QIN, 1>(net, L, r);
+    forward_group<QIN, 1>(m.sX, m.sA, m.sPart, L, w2, r, h1, h2);
+    stash_store(st.h1, g, L, h1);
+    stash_store(st.h2, g, L, h2);
+    if (tid < GROUP) {   // err = Q(s~,a) - y; dL/dq = err / B_global   (mpg_learner.py:331-336)
+        const long gr = g * GROUP + tid;
+        float e = 0.f;
+        if (gr < a.rows) {
+            e = out_preact(m.sPart, net.b3[0], tid, 0) - a.y[gr];
+            st.dz3[gr] = e * a.inv_b;
+            if (a.td && qi == 0) a.td[gr] = e;
+        }
+        m.sD3[tid * MAXOUT] = e * a.inv_b;
+        m.sQ[tid] = e * e;
+    }
+    load_w2(a.pkb[qi], net.W2, true, L, w2);     // same registers, backward image
+    lds_barrier();
+    if (tid == 0) {
+        float s2 = 0.f;
+        for (int i = 0; i < GROUP; ++i) s2 += m.sQ[i];
+        a.loss_part[qi * ngroups + g] = 0.5f * a.inv_b * s2;
+    }
+    backward_group<QIN, 1, false>(m.sD3, m.sA, m.sPartX, L, w2, r, h1, h2, dz1, dz2);
+    stash_store(st.dz1, g, L, dz1);
+    stash_store(st.dz2, g, L, dz2);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+struct QsliceArgs {
+    const float* q;
+    const float *pkf, *pkb;
+    int R, n_sel;              // rows per slice, slices; total rows n_sel * R, one group per workgroup
+    const float *xq, *gk;
+    float gpow[4], coef[4];
+    float* ret_part;           // [ngroups_total][2]: sum and sum of squares of G + gpow*q over the group's rows
+    float* gxq;
+};
+
+template <int QIN>
+__global__ void __launch_bounds__(NTHREAD, 2) k_qslice_fused(const QsliceArgs a) {
+    __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
+    const Smem m(smem);
+    const Lane L;
+    const int tid = threadIdx.x;
+    const long g = blockIdx.x;
+    const long total = (long)a.n_sel * a.R;
+    const Net net = make_net(a.q, QIN, 1);
+    if (tid < GROUP * XS) {
+        const int row = tid / XS, i = tid % XS;
+        const long gr = g * GROUP + row;
+        m.sX[tid] = (gr < total && i < QIN) ? a.xq[gr * QIN + i] : 0.f;
+    }
+    lds_barrier();
+    float w2[128], h1[2][4], h2[2][4], dz1[2][4], dz2[2][4];
+    SmallRegs<QIN, 1> r;
+    load_w2(a.pkf, net.W2, false, L, w2);
+    load_small<QIN, 1>(net, L, r);
+    forward_group<QIN, 1>(m.sX, m.sA, m.sPart, L, w2, r, h1, h2);
+    if (tid < GROUP) {
+        const long gr = g * GROUP + tid;
+        float ret = 0.f, d = 0.f;
+        if (gr < total) {
+            const int k = (int)(gr / a.R);                               // slice of this row (R % 16 == 0 is not required)
+            ret = a.gk[gr] + a.gpow[k] * out_preact(m.sPart, net.b3[0], tid, 0);   // mpg_learner.py:266
+            d = a.coef[k];
+        }
+        m.sD3[tid * MAXOUT] = d;
+        m.sQ[tid] = ret;
+        m.sQ[GROUP + tid] = (gr < total) ? (float)(gr / a.R) : -1.f;
+    }
+    load_w2(a.pkb, net.W2, true, L, w2);
+    lds_barrier();
+    if (tid == 0) {   // a group may straddle two slices only when R % 16 != 0; the launcher requires R % 16 == 0
+        float s1 = 0.f, s2 = 0.f;
+        for (int i = 0; i < GROUP; ++i) { s1 += m.sQ[i]; s2 += m.sQ[i] * m.sQ[i]; }
+        a.ret_part[g * 2] = s1;
+        a.ret_part[g * 2 + 1] = s2;
+    }
+    backward_group<QIN, 1, true>(m.sD3, m.sA, m.sPartX, L, w2, r, h1, h2, dz1, dz2);
+    if (tid < GROUP * QIN) {
+        const int row = tid / QIN, i = tid % QIN;
+        const long gr = g * GROUP + row;
+        if (gr < total) a.gxq[gr * QIN + i] = dx_reduce(m.sPartX, row, i);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+struct WgradMulti {
+    int n_jobs;
+    WgradArgs a[3];
+    int type[3];               // 0: template pair A, 1: template pair B
+    int chunk_off[4];          // blockIdx.y ranges of the jobs
+};
+
+template <int IA, int OA, int IB, int OB>
+__global__ void __launch_bounds__(NTHREAD, 2) k_wgrad_multi(const WgradMulti m) {
+    constexpr int NQA = wgrad_nq<IA, OA>(), NQB = wgrad_nq<IB, OB>();
+    __shared__ float sRed[NWAVE * (NQA > NQB ? NQA : NQB) * 64];
+    int j = 0;
+    while (j + 1 < m.n_jobs && (int)blockIdx.y >= m.chunk_off[j + 1]) ++j;
+    const int chunk = blockIdx.y - m.chunk_off[j];
+    if (m.type[j] == 0) wgrad_body<IA, OA>(m.a[j], blockIdx.x, chunk, sRed);
+    else wgrad_body<IB, OB>(m.a[j], blockIdx.x, chunk, sRed);
+}
+
+struct ReduceMulti {
+    int n_jobs;
+    const float* slabs[3];
+    int nslab[3], n[3];
+    float* out[3];
+    int n_sums;
+    SumJob sums[8];
+};
+
+// blockIdx.y < n_jobs: out = sum of the chunk slabs (fixed order); blockIdx.y == n_jobs: the scalar sums, one per block
+__global__ void __launch_bounds__(256) k_reduce_multi(const ReduceMulti m) {
+    const int j = blockIdx.y;
+    if (j < m.n_jobs) {
+        const int i = blockIdx.x * blockDim.x + threadIdx.x;
+        if (i >= m.n[j]) return;
+        const float* sl = m.slabs[j];
+        const int n = m.n[j], ns = m.nslab[j];
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        int k = 0;
+        for (; k + 3 < ns; k += 4) {      // 4 loads in flight; the association ((s0+s4+..)+(s1+s5+..))+... is fixed
+            acc[0] += sl[(size_t)k * n + i];
+            acc[1] += sl[(size_t)(k + 1) * n + i];
+            acc[2] += sl[(size_t)(k + 2) * n + i];
+            acc[3] += sl[(size_t)(k + 3) * n + i];
+        }
+        for (; k < ns; ++k) acc[0] += sl[(size_t)k * n + i];
+        m.out[j][i] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    } else if ((int)blockIdx.x < m.n_sums) {
+        __shared__ float red[256];
+        const SumJob sj = m.sums[blockIdx.x];
+        float s = 0.f;
+        for (int i = threadIdx.x; i < sj.n; i += 256) s += sj.src[(size_t)i * sj.stride];
+        red[threadIdx.x] = s;
+        __syncthreads();
+        for (int w = 128; w > 0; w >>= 1) {
+            if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) sj.dst[0] = red[0];
+    }
+}
+
+inline void fill_scale(float (&dst)[8], const mpg_cfg_t* cfg) {
+    for (int i = 0; i < 8; ++i) dst[i] = i < cfg->obs_dim ? cfg->obs_scale[i] : 1.f;
+}
+
+}  // namespace
+
+int launch_target_fused(const mpg_cfg_t* cfg, const float* policy_t, const float* q1t, const float* q2t, int rows,
+                        const float* rew, const float* obs_tp1, const float* smooth_eps, float sigma, float clipc, float* y,
+                        hipStream_t s) {
+    const int od = cfg->obs_dim, ad = cfg->act_dim;
+    TargetArgs a;
+    a.pol = policy_t; a.q1 = q1t; a.q2 = q2t;
+    a.pk_pol = weight_cache_lookup(make_net(policy_t, od, 2 * ad).W2, 0);
+    a.pk_q1 = weight_cache_lookup(make_net(q1t, od + ad, 1).W2, 0);
+    a.pk_q2 = q2t ? weight_cache_lookup(make_net(q2t, od + ad, 1).W2, 0) : nullptr;
+    a.rows = rows; a.obs2 = obs_tp1; a.rew = rew; a.smooth_eps = smooth_eps;
+    fill_scale(a.scale, cfg);
+    const bool ranged = cfg->action_range > 0.f;
+    a.out_tanh = (cfg->policy_out_act == MPG_ACT_TANH || ranged) ? 1 : 0;
+    a.out_scale = ranged ? cfg->action_range : 1.f;
+    a.sigma = sigma; a.clipc = clipc; a.rshift = cfg->rew_shift; a.rscale = cfg->rew_scale; a.gamma = cfg->gamma; a.y = y;
+    const int ngroups = (rows + GROUP - 1) / GROUP;
+    if (od == 6 && ad == 2) hipLaunchKernelGGL((k_target_fused<6, 2>), dim3(ngroups), dim3(NTHREAD), 0, s, a);
+    else if (od == 4 && ad == 1) hipLaunchKernelGGL((k_target_fused<4, 1>), dim3(ngroups), dim3(NTHREAD), 0, s, a);
+    else { mpg_set_error("launch_target_fused: unsupported dims"); return MPG_EINVAL; }
+    MPG_CHECK_LAUNCH("k_target_fused");
+    return MPG_OK;
+}
+
+int launch_qloss_fused(const mpg_cfg_t* cfg, const float* const* q_params, int n_q, int rows, const float* obs,
+                       const float* act, const float* y, float inv_b, const CriticStash* st, float* loss_part, float* td,
+                       hipStream_t s) {
+    MPG_REQUIRE(n_q == 1 || n_q == 2, "launch_qloss_fused: n_q");
+    const int od = cfg->obs_dim, ad = cfg->act_dim, qin = od + ad;
+    QlossArgs a;
+    for (int k = 0; k < 2; ++k) {
+        a.q[k] = k < n_q ? q_params[k] : nullptr;
+        a.pkf[k] = k < n_q ? weight_cache_lookup(make_net(q_params[k], qin, 1).W2, 0) : nullptr;
+        a.pkb[k] = k < n_q ? weight_cache_lookup(make_net(q_params[k], qin, 1).W2, 1) : nullptr;
+        if (k < n_q) a.st[k] = st[k];
+    }
+    a.rows = rows; a.x = xspec(obs, od, act, ad, cfg->obs_scale, od); a.y = y; a.inv_b = inv_b; a.loss_part = loss_part; a.td = td;
+    const int ngroups = (rows + GROUP - 1) / GROUP;
+    if (qin == 8) hipLaunchKernelGGL((k_qloss_fused<8>), dim3(ngroups, n_q), dim3(NTHREAD), 0, s, a);
+    else if (qin == 5) hipLaunchKernelGGL((k_qloss_fused<5>), dim3(ngroups, n_q), dim3(NTHREAD), 0, s, a);
+    else { mpg_set_error("launch_qloss_fused: unsupported dims"); return MPG_EINVAL; }
+    MPG_CHECK_LAUNCH("k_qloss_fused");
+    return MPG_OK;
+}
+
+int launch_qslice_fused(const float* q_params, int qin, int R, int n_sel, const float* xq, const float* gk, const float* gpow,
+                        const float* coef, float* ret_part, float* gxq, hipStream_t s) {
+    MPG_REQUIRE(R % GROUP == 0 && n_sel >= 1 && n_sel <= 4, "launch_qslice_fused: needs rows %% 16 == 0");
+    QsliceArgs a;
+    a.q = q_params;
+    a.pkf = weight_cache_lookup(make_net(q_params, qin, 1).W2, 0);
+    a.pkb = weight_cache_lookup(make_net(q_params, qin, 1).W2, 1);
+    a.R = R; a.n_sel = n_sel; a.xq = xq; a.gk = gk; a.ret_part = ret_part; a.gxq = gxq;
+    for (int k = 0; k < 4; ++k) { a.gpow[k] = k < n_sel ? gpow[k] : 0.f; a.coef[k] = k < n_sel ? coef[k] : 0.f; }
+    const int ngroups = n_sel * (R / GROUP);
+    if (qin == 8) hipLaunchKernelGGL((k_qslice_fused<8>), dim3(ngroups), dim3(NTHREAD), 0, s, a);
+    else if (qin == 5) hipLaunchKernelGGL((k_qslice_fused<5>), dim3(ngroups), dim3(NTHREAD), 0, s, a);
+    else { mpg_set_error("launch_qslice_fused: unsupported dims"); return MPG_EINVAL; }
+    MPG_CHECK_LAUNCH("k_qslice_fused");
+    return MPG_OK;
+}
+
+int launch_wgrad_multi(const WgradJob* jobs, int n_jobs, const SumJob* sums, int n_sums, hipStream_t s) {
+    MPG_REQUIRE(jobs && n_jobs >= 1 && n_jobs <= 3 && n_sums >= 0 && n_sums <= 8, "launch_wgrad_multi: bad argument");
+    WgradMulti m;
+    ReduceMulti rm;
+    m.n_jobs = rm.n_jobs = n_jobs;
+    int off = 0, maxn = 0;
+    bool pendulum = false;
+    for (int j = 0; j < n_jobs; ++j) {
+        const WgradJob& jb = jobs[j];
+        WgradArgs& a = m.a[j];
+        a.in_dim = jb.in_dim; a.out_dim = jb.out_dim; a.rows = jb.rows; a.x = jb.x;
+        a.h1 = jb.h1; a.h2 = jb.h2; a.dz1 = jb.dz1; a.dz2 = jb.dz2; a.dz3 = jb.dz3; a.slabs = jb.slabs;
+        const long ngroups = (jb.rows + GROUP - 1) / GROUP;
+        a.groups_per_chunk = wgrad_groups_per_chunk(ngroups);
+        const int nch = (int)((ngroups + a.groups_per_chunk - 1) / a.groups_per_chunk);
+        m.chunk_off[j] = off;
+        off += nch;
+        if (jb.in_dim == 8 && jb.ou == 1) m.type[j] = 0;
+        else if (jb.in_dim == 6 && jb.ou == 2) m.type[j] = 1;
+        else if (jb.in_dim == 5 && jb.ou == 1) { m.type[j] = 0; pendulum = true; }
+        else if (jb.in_dim == 4 && jb.ou == 1) { m.type[j] = 1; pendulum = true; }
+        else { mpg_set_error("launch_wgrad_multi: unsupported network shape"); return MPG_EINVAL; }
+        rm.slabs[j] = jb.slabs; rm.nslab[j] = nch; rm.n[j] = net_size(jb.in_dim, jb.out_dim); rm.out[j] = jb.grad;
+        if (rm.n[j] > maxn) maxn = rm.n[j];
+    }
+    m.chunk_off[n_jobs] = off;
+    for (int j = n_jobs; j < 3; ++j) { m.type[j] = 0; m.chunk_off[j + 1] = off; rm.slabs[j] = nullptr; rm.nslab[j] = rm.n[j] = 0; rm.out[j] = nullptr; }
+    mpg_prof_begin(5, s);
+    if (!pendulum) hipLaunchKernelGGL((k_wgrad_multi<8, 1, 6, 2>), dim3(8, off), dim3(NTHREAD), 0, s, m);
+    else hipLaunchKernelGGL((k_wgrad_multi<5, 1, 4, 1>), dim3(8, off), dim3(NTHREAD), 0, s, m);
+    mpg_prof_end(5, s);
+    MPG_CHECK_LAUNCH("k_wgrad_multi");
+    rm.n_sums = n_sums;
+    for (int k = 0; k < 8; ++k) {
+        if (k < n_sums) rm.sums[k] = sums[k];
+        else { rm.sums[k].src = nullptr; rm.sums[k].n = 0; rm.sums[k].stride = 1; rm.sums[k].dst = nullptr; }
+    }
+    int gx = (maxn + 255) / 256;
+    if (gx < n_sums) gx = n_sums;
+    hipLaunchKernelGGL(k_reduce_multi, dim3(gx, n_jobs + (n_sums ? 1 : 0)), dim3(256), 0, s, rm);
+    MPG_CHECK_LAUNCH("k_reduce_multi");
+    return MPG_OK;
+}
+
+}  // namespace mlp

@@ -20,6 +20,27 @@ inline XSpec xspec(const float* x0, int d0, const float* x1, int d1, const float
     return s;
 }
 
+#ifdef __HIPCC__
+// loads one row group of the network input into sX [16][XS] (zero padded)
+template <int IN>
+__device__ __forceinline__ void load_x_group(const XSpec& x, int rows, long g, float* sX) {
+    const int tid = threadIdx.x;
+    if (tid < GROUP * XS) {
+        const int row = tid / XS, i = tid % XS;
+        const long gr = g * GROUP + row;
+        float v = 0.f;
+        if (gr < rows && i < IN) {
+            if (i < x.d0)
+                v = x.x0[gr * x.ld0 + i] * x.scale[i];
+            else
+                v = x.x1[gr * x.ld1 + (i - x.d0)];
+        }
+        sX[tid] = v;
+    }
+}
+
+#endif
+
 struct OutSpec {            // y = out_scale * tanh(z) (out_tanh) or z; optional Philox N(0, sigma) exploration noise
     int out_tanh;
     float out_scale;
@@ -43,6 +64,48 @@ int launch_backward(const float* params, int in_dim, int out_dim, int ou, int ro
 size_t wgrad_workspace_floats(int rows, int in_dim, int out_dim);
 int launch_wgrad(int in_dim, int out_dim, int ou, int rows, const XSpec& x, const float* h1, const float* h2,
                  const float* dz1, const float* dz2, const float* dz3, float* grad, float* ws, hipStream_t s);
+
+// ---- fused critic-side kernels (one 16-row group per workgroup; callers fall back to the unfused launchers when a
+// configuration is not covered) ----------------------------------------------------------------------------------
+struct NetRef {            // one network: Keras-ordered parameters (+ optional packed images resolved by the launcher)
+    const float* params;
+    int in_dim, out_dim;
+};
+
+// y = (rew + shift) * scale + gamma * min_i Qt_i(s~', a'),  a' = pi_t(s~') (+ clipped smoothing noise): ONE launch.
+int launch_target_fused(const mpg_cfg_t* cfg, const float* policy_t, const float* q1t, const float* q2t, int rows,
+                        const float* rew, const float* obs_tp1, const float* smooth_eps, float sigma, float clipc, float* y,
+                        hipStream_t s);
+
+struct CriticStash {       // G16 stashes + dz3 of one critic, kept for the weight-gradient launch
+    float *h1, *h2, *dz1, *dz2, *dz3;
+};
+// forward + error + input-side backward of n_q (1 or 2) critics in ONE launch.  loss_part [n_q][ngroups] receives
+// 0.5*inv_b*sum(err^2) per row group; td (nullable) = Q1(s~,a) - y.
+int launch_qloss_fused(const mpg_cfg_t* cfg, const float* const* q_params, int n_q, int rows, const float* obs,
+                       const float* act, const float* y, float inv_b, const CriticStash* st, float* loss_part, float* td,
+                       hipStream_t s);
+
+// critic value + input gradient at the selected rollout slices in ONE launch: q = Q(xq), per-group partial sums of
+// the returns G + gpow*q and of their squares (ret_part [n_sel][ngroups][2]), dx = coef_k * dQ/dxq.  xq [n_sel*R][qin].
+int launch_qslice_fused(const float* q_params, int qin, int R, int n_sel, const float* xq, const float* gk, const float* gpow,
+                        const float* coef, float* ret_part, float* gxq, hipStream_t s);
+
+// weight gradients of up to 3 networks in one launch + one reduce launch.  Also folds the fixed-order sums of the
+// per-group loss / return partials (sum_src[i] has sum_n[i] floats -> sum_dst[i]), up to 8 of them.
+struct WgradJob {
+    int in_dim, out_dim, ou, rows;
+    XSpec x;
+    const float *h1, *h2, *dz1, *dz2, *dz3;
+    float* grad;
+    float* slabs;          // wgrad_workspace_floats(rows, in_dim, out_dim)
+};
+struct SumJob {
+    const float* src;
+    int n, stride;         // sums src[0], src[stride], ... (n terms)
+    float* dst;
+};
+int launch_wgrad_multi(const WgradJob* jobs, int n_jobs, const SumJob* sums, int n_sums, hipStream_t s);
 
 inline size_t stash_floats(int rows) { return (size_t)((rows + GROUP - 1) / GROUP) * GROUP * H; }
 

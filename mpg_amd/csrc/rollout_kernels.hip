@@ -11,6 +11,8 @@
 // 279-297, f_xu :78-138, rewards :181-199), InvertedPendulumModel (envs_and_models/inverted_pendulum_model.py:16-97),
 // NADPLearner (learners/nadp.py:87-194).  The reverse sweep replaces tf.GradientTape; its closed-form model adjoints
 // are pinned against autograd in tests/test_model_vjp.py.
+#include <algorithm>
+
 #include "mlp_launch.h"
 
 using namespace mlp;
@@ -542,40 +544,30 @@ PgLayout pg_layout(const mpg_cfg_t* cfg, int rows, int M, int n, int n_sel, int 
     return l;
 }
 
-}  // namespace
 
-extern "C" size_t mpg_rollout_pg_workspace_bytes(const mpg_cfg_t* cfg, int rows, int M, int n, int n_select,
-                                                 int all_steps_param_grad) {
-    if (!cfg_ok(cfg) || rows <= 0 || M <= 0 || n <= 0 || n >= MAXN || n_select <= 0 || n_select > MAXSEL) return 0;
-    return pg_layout(cfg, rows, M, n, n_select, all_steps_param_grad).total;
+// ---- launch helpers shared by mpg_rollout_pg and mpg_mpg_gradients ---------------------------------------------------
+struct Coefs {
+    float gpow[MAXSEL], coef[MAXSEL], rho[MAXN];
+};
+
+// gamma^k, dL/dQ_k and dL/d(raw reward_t) for the loss sum_k w_k * (-mean return_k)   (mpg_learner.py:251,360-361)
+Coefs make_coefs(const mpg_cfg_t* cfg, const int* select, int n_select, const float* w, float inv_b_global, int M) {
+    Coefs c;
+    for (int k = 0; k < MAXSEL; ++k) c.gpow[k] = c.coef[k] = 0.f;
+    for (int t = 0; t < MAXN; ++t) c.rho[t] = 0.f;
+    const float cc = inv_b_global / (float)M;
+    for (int k = 0; k < n_select; ++k) {
+        c.gpow[k] = powf(cfg->gamma, (float)select[k]);                   // tf.pow(gamma, k) in float32
+        c.coef[k] = -w[k] * c.gpow[k] * cc;
+        for (int t = 0; t < select[k]; ++t) c.rho[t] += -w[k] * cc * powf(cfg->gamma, (float)t) * cfg->rew_scale;
+    }
+    return c;
 }
 
-extern "C" int mpg_rollout_pg(const mpg_cfg_t* cfg, const float* policy_params, const float* q1_params, int rows, int M,
-                              int n, const int* select, int n_select, const float* w, const float* obs0, const float* eps,
-                              uint64_t noise_seed, uint64_t noise_ctr, float inv_b_global, int all_steps_param_grad, float* ret_sum, float* ret_sqsum, float* grad,
-                              void* ws, size_t ws_bytes, mpg_stream_t stream) {
-    MPG_REQUIRE(cfg_ok(cfg), "mpg_rollout_pg: unsupported cfg (obs/act dims, env_kind)");
-    MPG_REQUIRE(policy_params && q1_params && select && w && obs0 && ret_sum && ret_sqsum && grad && ws,
-                "mpg_rollout_pg: null pointer");
-    MPG_REQUIRE(rows > 0 && M > 0 && n > 0 && n < MAXN && n_select > 0 && n_select <= MAXSEL, "mpg_rollout_pg: bad sizes");
+int run_rollout_fwd(const mpg_cfg_t* cfg, const float* policy_params, int rows, int M, int n, const int* select, int n_select,
+                    const float* obs0, const float* eps, uint64_t noise_seed, uint64_t noise_ctr, float* H1, float* H2,
+                    float* SA, float* XQ, float* GK, hipStream_t s) {
     const long R = (long)rows * M;
-    MPG_REQUIRE(!all_steps_param_grad || R % GROUP == 0, "mpg_rollout_pg: all_steps_param_grad needs rows*M %% 16 == 0");
-    for (int k = 0; k < n_select; ++k) MPG_REQUIRE(select[k] >= 0 && select[k] <= n, "mpg_rollout_pg: slice out of range");
-    const PgLayout l = pg_layout(cfg, rows, M, n, n_select, all_steps_param_grad);
-    if (ws_bytes < l.total) {
-        mpg_set_error("mpg_rollout_pg: workspace too small (%zu < %zu)", ws_bytes, l.total);
-        return MPG_EWORKSPACE;
-    }
-    hipStream_t s = mpg_stream(stream);
-    const int od = cfg->obs_dim, ad = cfg->act_dim, qin = od + ad;
-    Carver cv(ws, ws_bytes);
-    float* H1 = cv.take(l.h); float* H2 = cv.take(l.h);
-    float* SA = cv.take(l.sa); float* XQ = cv.take(l.xq);
-    float* GK = cv.take(l.gk); float* Q = cv.take(l.q); float* DYQ = cv.take(l.dyq);
-    float* HQ1 = cv.take(l.hq); float* HQ2 = cv.take(l.hq); float* GXQ = cv.take(l.gxq);
-    float* DZ1 = cv.take(l.dz); float* DZ2 = cv.take(l.dz); float* DZ3 = cv.take(l.dz3);
-    float* slabs = cv.take(l.slabs);
-
     // ---- forward sweep ----
     RollArgs fa;
     fill_roll(fa, cfg, policy_params, rows, M, n);
@@ -615,27 +607,18 @@ extern "C" int mpg_rollout_pg(const mpg_cfg_t* cfg, const float* policy_params, 
         }
     }
 #endif
+    return MPG_OK;
+}
 
-    // ---- critic at the selected slices: values, returns, input gradients ----
-    OutSpec lin; lin.out_tanh = 0; lin.out_scale = 1.f; lin.sigma = 0.f; lin.seed = lin.ctr = 0;
-    const int RQ = (int)(n_select * R);
-    int rc = launch_forward(q1_params, qin, 1, 1, RQ, xspec(XQ, qin, nullptr, 0, nullptr, 0), lin, Q, 1, HQ1, HQ2, s);
-    if (rc) return rc;
-    RetCoef rcf;
-    for (int k = 0; k < MAXSEL; ++k) rcf.gpow[k] = rcf.coef[k] = 0.f;
-    const float c = inv_b_global / (float)M;
-    float rho[MAXN];
-    for (int t = 0; t < MAXN; ++t) rho[t] = 0.f;
-    for (int k = 0; k < n_select; ++k) {
-        rcf.gpow[k] = powf(cfg->gamma, (float)select[k]);                 // tf.pow(gamma, k) in float32, mpg_learner.py:251
-        rcf.coef[k] = -w[k] * rcf.gpow[k] * c;
-        for (int t = 0; t < select[k]; ++t) rho[t] += -w[k] * c * powf(cfg->gamma, (float)t) * cfg->rew_scale;
-    }
-    hipLaunchKernelGGL(k_returns, dim3(1), dim3(1024), 0, s, rows, M, n_select, rcf, Q, GK, DYQ, ret_sum, ret_sqsum);
-    MPG_CHECK_LAUNCH("k_returns");
-    rc = launch_backward(q1_params, qin, 1, 1, RQ, DYQ, 1, nullptr, 0, 0, 1.f, HQ1, HQ2, nullptr, nullptr, nullptr, GXQ, qin, s);
-    if (rc) return rc;
-
+int run_rollout_bwd(const mpg_cfg_t* cfg, const float* policy_params, int rows, int M, int n, const int* select, int n_select,
+                    const float* rho, const float* H1, const float* H2, const float* SA, const float* GXQ,
+                    int all_steps_param_grad, float* DZ1, float* DZ2, float* DZ3, hipStream_t s) {
+    const long R = (long)rows * M;
+    const long ngroups = (R + GROUP - 1) / GROUP;
+    const int od = cfg->obs_dim, ad = cfg->act_dim;
+    RollArgs fa;
+    fill_roll(fa, cfg, policy_params, rows, M, n);
+    for (int k = 0; k < MAXSEL; ++k) fa.sel[k] = k < n_select ? select[k] : -1;
     // ---- reverse sweep ----
     RollBwdArgs ba;
     ba.policy = policy_params; ba.rows = rows; ba.M = M; ba.n = n;
@@ -655,6 +638,67 @@ extern "C" int mpg_rollout_pg(const mpg_cfg_t* cfg, const float* policy_params, 
         hipLaunchKernelGGL((k_rollout_bwd<Pendulum>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, ba);
     mpg_prof_end(1, s);
     MPG_CHECK_LAUNCH("k_rollout_bwd");
+    return MPG_OK;
+}
+
+}  // namespace
+
+extern "C" size_t mpg_rollout_pg_workspace_bytes(const mpg_cfg_t* cfg, int rows, int M, int n, int n_select,
+                                                 int all_steps_param_grad) {
+    if (!cfg_ok(cfg) || rows <= 0 || M <= 0 || n <= 0 || n >= MAXN || n_select <= 0 || n_select > MAXSEL) return 0;
+    return pg_layout(cfg, rows, M, n, n_select, all_steps_param_grad).total;
+}
+
+extern "C" int mpg_rollout_pg(const mpg_cfg_t* cfg, const float* policy_params, const float* q1_params, int rows, int M,
+                              int n, const int* select, int n_select, const float* w, const float* obs0, const float* eps,
+                              uint64_t noise_seed, uint64_t noise_ctr, float inv_b_global, int all_steps_param_grad, float* ret_sum, float* ret_sqsum, float* grad,
+                              void* ws, size_t ws_bytes, mpg_stream_t stream) {
+    MPG_REQUIRE(cfg_ok(cfg), "mpg_rollout_pg: unsupported cfg (obs/act dims, env_kind)");
+    MPG_REQUIRE(policy_params && q1_params && select && w && obs0 && ret_sum && ret_sqsum && grad && ws,
+                "mpg_rollout_pg: null pointer");
+    MPG_REQUIRE(rows > 0 && M > 0 && n > 0 && n < MAXN && n_select > 0 && n_select <= MAXSEL, "mpg_rollout_pg: bad sizes");
+    const long R = (long)rows * M;
+    MPG_REQUIRE(!all_steps_param_grad || R % GROUP == 0, "mpg_rollout_pg: all_steps_param_grad needs rows*M %% 16 == 0");
+    for (int k = 0; k < n_select; ++k) MPG_REQUIRE(select[k] >= 0 && select[k] <= n, "mpg_rollout_pg: slice out of range");
+    const PgLayout l = pg_layout(cfg, rows, M, n, n_select, all_steps_param_grad);
+    if (ws_bytes < l.total) {
+        mpg_set_error("mpg_rollout_pg: workspace too small (%zu < %zu)", ws_bytes, l.total);
+        return MPG_EWORKSPACE;
+    }
+    hipStream_t s = mpg_stream(stream);
+    const int od = cfg->obs_dim, ad = cfg->act_dim, qin = od + ad;
+    Carver cv(ws, ws_bytes);
+    float* H1 = cv.take(l.h); float* H2 = cv.take(l.h);
+    float* SA = cv.take(l.sa); float* XQ = cv.take(l.xq);
+    float* GK = cv.take(l.gk); float* Q = cv.take(l.q); float* DYQ = cv.take(l.dyq);
+    float* HQ1 = cv.take(l.hq); float* HQ2 = cv.take(l.hq); float* GXQ = cv.take(l.gxq);
+    float* DZ1 = cv.take(l.dz); float* DZ2 = cv.take(l.dz); float* DZ3 = cv.take(l.dz3);
+    float* slabs = cv.take(l.slabs);
+
+    // ---- forward sweep ----
+    int rc = run_rollout_fwd(cfg, policy_params, rows, M, n, select, n_select, obs0, eps, noise_seed, noise_ctr, H1, H2, SA, XQ,
+                             GK, s);
+    if (rc) return rc;
+    const long ngroups = (R + GROUP - 1) / GROUP;
+    (void)ngroups;
+
+    // ---- critic at the selected slices: values, returns, input gradients ----
+    OutSpec lin; lin.out_tanh = 0; lin.out_scale = 1.f; lin.sigma = 0.f; lin.seed = lin.ctr = 0;
+    const int RQ = (int)(n_select * R);
+    rc = launch_forward(q1_params, qin, 1, 1, RQ, xspec(XQ, qin, nullptr, 0, nullptr, 0), lin, Q, 1, HQ1, HQ2, s);
+    if (rc) return rc;
+    const Coefs cf = make_coefs(cfg, select, n_select, w, inv_b_global, M);
+    RetCoef rcf;
+    for (int k = 0; k < MAXSEL; ++k) { rcf.gpow[k] = cf.gpow[k]; rcf.coef[k] = cf.coef[k]; }
+    hipLaunchKernelGGL(k_returns, dim3(1), dim3(1024), 0, s, rows, M, n_select, rcf, Q, GK, DYQ, ret_sum, ret_sqsum);
+    MPG_CHECK_LAUNCH("k_returns");
+    rc = launch_backward(q1_params, qin, 1, 1, RQ, DYQ, 1, nullptr, 0, 0, 1.f, HQ1, HQ2, nullptr, nullptr, nullptr, GXQ, qin, s);
+    if (rc) return rc;
+
+    // ---- reverse sweep ----
+    rc = run_rollout_bwd(cfg, policy_params, rows, M, n, select, n_select, cf.rho, H1, H2, SA, GXQ, all_steps_param_grad, DZ1, DZ2,
+                         DZ3, s);
+    if (rc) return rc;
 
     // ---- policy weight gradient from the stashes (step 0 only, or every step for NADP) ----
     const int T = all_steps_param_grad ? n + 1 : 1;
@@ -700,4 +744,150 @@ extern "C" int mpg_rollout_q_target(const mpg_cfg_t* cfg, const float* policy_pa
     hipLaunchKernelGGL(k_gq, dim3((rows + 255) / 256), dim3(256), 0, s, rows, GK, Q, powf(cfg->gamma, (float)n), y);
     MPG_CHECK_LAUNCH("k_gq");
     return MPG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// MPGLearner.compute_gradient minus the clip, as ONE entry point (mpg_learner.py:401-431): 7 launches
+//   target (fused)  ->  critics fwd+err+bwd (fused)  ->  rollout forward  ->  critic at the slices fwd+bwd (fused)
+//   ->  rollout reverse  ->  weight gradients of all networks  ->  slab + statistic reduction
+// Falls back to the fine-grained entry points (same results up to summation order) when rows % 16 != 0 or M > 1.
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct MgLayout {
+    size_t stash, dz3, loss_part, h, sa, xq, gk, gxq, ret_part, dz3p, slab_q, slab_p, fused_total, fallback0, fallback1;
+};
+
+MgLayout mg_layout(const mpg_cfg_t* cfg, int rows, int M, int n, int n_sel, int n_q) {
+    MgLayout l;
+    const long R = (long)rows * M;
+    const int od = cfg->obs_dim, ad = cfg->act_dim, qin = od + ad;
+    const long ngroups = (rows + GROUP - 1) / GROUP;
+    l.stash = stash_floats(rows);
+    l.dz3 = rows;
+    l.loss_part = 2 * ngroups;
+    l.h = (size_t)(n + 1) * stash_floats(R);
+    l.sa = (size_t)(n + 1) * R * SAW;
+    l.xq = l.gxq = (size_t)n_sel * R * qin;
+    l.gk = (size_t)n_sel * R;
+    l.ret_part = (size_t)n_sel * ((R + GROUP - 1) / GROUP) * 2;
+    l.dz3p = (size_t)R * ad;
+    l.slab_q = wgrad_workspace_floats(rows, qin, 1);
+    l.slab_p = wgrad_workspace_floats((int)R, od, 2 * ad);
+    l.fused_total = (size_t)n_q * (4 * pad256(l.stash) + pad256(l.dz3) + pad256(l.slab_q)) + pad256(l.loss_part) +
+                    2 * pad256(l.h) + pad256(l.sa) + pad256(l.xq) + pad256(l.gk) + pad256(l.gxq) + pad256(l.ret_part) +
+                    2 * pad256(stash_floats(R)) + pad256(l.dz3p) + pad256(l.slab_p);
+    l.fallback0 = std::max(mpg_q_targets_workspace_bytes(cfg, rows), mpg_q_loss_grad_workspace_bytes(cfg, rows));
+    l.fallback1 = mpg_rollout_pg_workspace_bytes(cfg, rows, M, n, n_sel, 0);
+    return l;
+}
+
+}  // namespace
+
+extern "C" size_t mpg_mpg_gradients_workspace_bytes(const mpg_cfg_t* cfg, int rows, int M, int n, int n_select, int n_q) {
+    if (!cfg_ok(cfg) || rows <= 0 || M <= 0 || n <= 0 || n >= MAXN || n_select <= 0 || n_select > MAXSEL || n_q < 1 || n_q > 2)
+        return 0;
+    const MgLayout l = mg_layout(cfg, rows, M, n, n_select, n_q);
+    return std::max(l.fused_total, l.fallback0 + l.fallback1 + 512);
+}
+
+extern "C" int mpg_mpg_gradients(const mpg_cfg_t* cfg, int n_q, const float* params, const float* target_params, int rows,
+                                 const float* obs, const float* act, const float* rew, const float* obs_tp1,
+                                 const float* y_in, int M, int n, const int* select, int n_select, const float* w,
+                                 const float* eps, uint64_t noise_seed, uint64_t noise_ctr, float inv_b_global, float* grad,
+                                 float* stats, float* y_out, void* ws, size_t ws_bytes, mpg_stream_t stream) {
+    MPG_REQUIRE(cfg_ok(cfg) && (n_q == 1 || n_q == 2), "mpg_mpg_gradients: unsupported cfg / n_q");
+    MPG_REQUIRE(params && obs && act && select && w && grad && stats && y_out && ws, "mpg_mpg_gradients: null pointer");
+    MPG_REQUIRE(y_in || (target_params && rew && obs_tp1), "mpg_mpg_gradients: either y_in or the target inputs are required");
+    MPG_REQUIRE(rows > 0 && M > 0 && n > 0 && n < MAXN && n_select > 0 && n_select <= MAXSEL, "mpg_mpg_gradients: bad sizes");
+    for (int k = 0; k < n_select; ++k) MPG_REQUIRE(select[k] >= 0 && select[k] <= n, "mpg_mpg_gradients: slice out of range");
+    if (ws_bytes < mpg_mpg_gradients_workspace_bytes(cfg, rows, M, n, n_select, n_q)) {
+        mpg_set_error("mpg_mpg_gradients: workspace too small");
+        return MPG_EWORKSPACE;
+    }
+    hipStream_t s = mpg_stream(stream);
+    const int od = cfg->obs_dim, ad = cfg->act_dim, qin = od + ad;
+    const int q_size = net_size(qin, 1);
+    const float* qp[2] = {params, n_q == 2 ? params + q_size : nullptr};
+    const float* policy = params + (size_t)n_q * q_size;
+    const float* qt[2] = {target_params, (target_params && n_q == 2) ? target_params + q_size : nullptr};
+    const float* policy_t = target_params ? target_params + (size_t)n_q * q_size : nullptr;
+    float* gq[2] = {grad, grad + q_size};
+    float* gp = grad + (size_t)n_q * q_size;
+    const MgLayout l = mg_layout(cfg, rows, M, n, n_select, n_q);
+
+    if (rows % GROUP != 0 || M != 1) {   // ---- fallback: the fine-grained entry points ----
+        char* w0 = align256((char*)ws);
+        char* w1 = align256(w0 + l.fallback0);
+        const float* y = y_in;
+        if (!y) {
+            int rc = mpg_q_targets(cfg, policy_t, qt[0], qt[1], rows, rew, obs_tp1, nullptr, 0.f, 0.f, y_out, w0, l.fallback0, stream);
+            if (rc) return rc;
+            y = y_out;
+        }
+        for (int k = 0; k < n_q; ++k) {
+            int rc = mpg_q_loss_grad(cfg, qp[k], rows, obs, act, y, inv_b_global, stats + k, gq[k], nullptr, w0, l.fallback0, stream);
+            if (rc) return rc;
+        }
+        return mpg_rollout_pg(cfg, policy, qp[0], rows, M, n, select, n_select, w, obs, eps, noise_seed, noise_ctr, inv_b_global, 0,
+                              stats + 2, stats + 2 + n_select, gp, w1, l.fallback1, stream);
+    }
+
+    Carver cv(ws, ws_bytes);
+    CriticStash st[2];
+    float* slab_q[2] = {nullptr, nullptr};
+    for (int k = 0; k < n_q; ++k) {
+        st[k].h1 = cv.take(l.stash); st[k].h2 = cv.take(l.stash); st[k].dz1 = cv.take(l.stash); st[k].dz2 = cv.take(l.stash);
+        st[k].dz3 = cv.take(l.dz3);
+        slab_q[k] = cv.take(l.slab_q);
+    }
+    float* loss_part = cv.take(l.loss_part);
+    float* H1 = cv.take(l.h); float* H2 = cv.take(l.h);
+    float* SA = cv.take(l.sa); float* XQ = cv.take(l.xq); float* GK = cv.take(l.gk); float* GXQ = cv.take(l.gxq);
+    float* ret_part = cv.take(l.ret_part);
+    float* DZ1 = cv.take(stash_floats(rows)); float* DZ2 = cv.take(stash_floats(rows)); float* DZ3 = cv.take(l.dz3p);
+    float* slab_p = cv.take(l.slab_p);
+
+    const float* y = y_in;
+    if (!y) {   // 1. clipped double-Q (or single-Q) target, mpg_learner.py:126-134
+        int rc = launch_target_fused(cfg, policy_t, qt[0], qt[1], rows, rew, obs_tp1, nullptr, 0.f, 0.f, y_out, s);
+        if (rc) return rc;
+        y = y_out;
+    }
+    // 2. critics: forward, error, input-side backward (mpg_learner.py:326-354)
+    int rc = launch_qloss_fused(cfg, qp, n_q, rows, obs, act, y, inv_b_global, st, loss_part, nullptr, s);
+    if (rc) return rc;
+    // 3. rollout forward sweep
+    rc = run_rollout_fwd(cfg, policy, rows, 1, n, select, n_select, obs, eps, noise_seed, noise_ctr, H1, H2, SA, XQ, GK, s);
+    if (rc) return rc;
+    // 4. critic at the selected slices: returns and input gradients
+    const Coefs cf = make_coefs(cfg, select, n_select, w, inv_b_global, 1);
+    rc = launch_qslice_fused(qp[0], qin, rows, n_select, XQ, GK, cf.gpow, cf.coef, ret_part, GXQ, s);
+    if (rc) return rc;
+    // 5. reverse sweep
+    rc = run_rollout_bwd(cfg, policy, rows, 1, n, select, n_select, cf.rho, H1, H2, SA, GXQ, 0, DZ1, DZ2, DZ3, s);
+    if (rc) return rc;
+    // 6./7. weight gradients of every network + all scalar statistics, two launches
+    WgradJob jobs[3];
+    const XSpec xq = xspec(obs, od, act, ad, cfg->obs_scale, od);
+    for (int k = 0; k < n_q; ++k) {
+        jobs[k].in_dim = qin; jobs[k].out_dim = 1; jobs[k].ou = 1; jobs[k].rows = rows; jobs[k].x = xq;
+        jobs[k].h1 = st[k].h1; jobs[k].h2 = st[k].h2; jobs[k].dz1 = st[k].dz1; jobs[k].dz2 = st[k].dz2; jobs[k].dz3 = st[k].dz3;
+        jobs[k].grad = gq[k]; jobs[k].slabs = slab_q[k];
+    }
+    WgradJob& jp = jobs[n_q];
+    jp.in_dim = od; jp.out_dim = 2 * ad; jp.ou = ad; jp.rows = rows;
+    jp.x = xspec(SA, od, nullptr, 0, cfg->obs_scale, od);
+    jp.x.ld0 = SAW;
+    jp.h1 = H1; jp.h2 = H2; jp.dz1 = DZ1; jp.dz2 = DZ2; jp.dz3 = DZ3; jp.grad = gp; jp.slabs = slab_p;
+    const int ngroups = rows / GROUP;
+    SumJob sums[8];
+    int ns = 0;
+    for (int k = 0; k < n_q; ++k) { sums[ns].src = loss_part + (size_t)k * ngroups; sums[ns].n = ngroups; sums[ns].stride = 1; sums[ns].dst = stats + k; ++ns; }
+    for (int k = 0; k < n_select && ns + 1 < 8; ++k) {
+        sums[ns].src = ret_part + (size_t)k * ngroups * 2; sums[ns].n = ngroups; sums[ns].stride = 2; sums[ns].dst = stats + 2 + k; ++ns;
+        sums[ns].src = ret_part + (size_t)k * ngroups * 2 + 1; sums[ns].n = ngroups; sums[ns].stride = 2; sums[ns].dst = stats + 2 + n_select + k; ++ns;
+    }
+    MPG_REQUIRE(n_q + 2 * n_select <= 8, "mpg_mpg_gradients: too many statistics (n_select <= 3 with two critics)");
+    return launch_wgrad_multi(jobs, n_q + 1, sums, ns, s);
 }

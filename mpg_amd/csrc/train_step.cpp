@@ -70,7 +70,7 @@ bool ctx_ok(const mpg_train_ctx_t* c) {
 extern "C" int mpg_step_workspace_bytes(const mpg_train_ctx_t* c, size_t* ws0, size_t* ws1) {
     MPG_REQUIRE(c && ws0 && ws1, "mpg_step_workspace_bytes: null pointer");
     *ws0 = std::max(mpg_q_targets_workspace_bytes(&c->cfg, c->batch), mpg_q_loss_grad_workspace_bytes(&c->cfg, c->batch));
-    *ws1 = mpg_rollout_pg_workspace_bytes(&c->cfg, c->batch, c->M, c->n, c->n_select, 0);
+    *ws1 = mpg_mpg_gradients_workspace_bytes(&c->cfg, c->batch, c->M, c->n, c->n_select, c->learner_version == 2 ? 2 : 1);
     MPG_REQUIRE(*ws0 && *ws1, "mpg_step_workspace_bytes: unsupported configuration");
     return MPG_OK;
 }
@@ -104,8 +104,7 @@ extern "C" int mpg_step_begin(mpg_train_ctx_t* c, int iteration, mpg_stream_t s)
         TRY(mpg_replay_gather(c->batch, c->idx, od, ad, c->ring_obs, c->ring_act, c->ring_rew, c->ring_obs2, c->ring_done,
                               c->b_obs, c->b_act, c->b_rew, c->b_obs2, c->b_done, s));
         if (c->learner_version == 2) {
-            TRY(mpg_q_targets(&c->cfg, policy_t, c->targets + l.off[0], c->targets + l.off[1], c->batch, c->b_rew, c->b_obs2,
-                              nullptr, 0.f, 0.f, c->b_targets, c->ws0, c->ws0_bytes, s));
+            // the clipped double-Q target is computed inside mpg_mpg_gradients below
         } else {   // MPGLearner.sample + compute_n_step_target, mpg_learner.py:109-124,146-169
             MPG_REQUIRE(c->l_env_state && c->l_obs && c->l_act && c->l_rewards && c->l_done, "mpg_step_begin: MPG-v1 needs the learner env buffers");
             TRY(mpg_env_reset_from_obs(kind, c->batch, c->l_env_state, c->b_obs, s));
@@ -125,15 +124,14 @@ extern "C" int mpg_step_begin(mpg_train_ctx_t* c, int iteration, mpg_stream_t s)
     c->learner_counter++;
     // ---- learner.compute_gradient (mpg_learner.py:401-431), un-clipped partials scaled by 1/B_global ----
     const float inv_b = 1.f / ((float)c->batch * (float)c->world_size);
-    float* stats = c->grad + l.n_grad;
-    for (int k = 0; k < l.n_nets - 1; ++k)
-        TRY(mpg_q_loss_grad(&c->cfg, c->params + l.off[k], c->batch, c->b_obs, c->b_act, c->b_targets, inv_b, stats + k,
-                            c->grad + l.off[k], nullptr, c->ws0, c->ws0_bytes, s));
     float w[4];
     rule_based_weights(iteration, c->total_ite, c->eta, c->select, c->n_select, w);
-    TRY(mpg_rollout_pg(&c->cfg, policy, c->params + l.off[0], c->batch, c->M, c->n, c->select, c->n_select, w, c->b_obs, nullptr,
-                       c->learner_seed, c->learner_counter, inv_b, 0, stats + 2, stats + 2 + c->n_select,
-                       c->grad + l.off[l.n_nets - 1], c->ws1, c->ws1_bytes, s));
+    // MPG-v2 with num_batch_reuse > 1 keeps the targets of the batch they were computed for (mpg_learner.py:402-403)
+    const bool fresh = (c->learner_counter - 1) % c->num_batch_reuse == 0;
+    const float* y_in = (c->learner_version == 2 && fresh) ? nullptr : c->b_targets;
+    TRY(mpg_mpg_gradients(&c->cfg, l.n_nets - 1, c->params, c->targets, c->batch, c->b_obs, c->b_act, c->b_rew, c->b_obs2, y_in,
+                          c->M, c->n, c->select, c->n_select, w, nullptr, c->learner_seed, c->learner_counter, inv_b, c->grad,
+                          c->grad + l.n_grad, c->b_targets, c->ws1, c->ws1_bytes, s));
     return MPG_OK;
 }
 

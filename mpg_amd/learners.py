@@ -179,17 +179,14 @@ class MPGLearner(_LearnerBase):
         rows = b['batch_obs'].shape[0]
         world = D.world_size()
         inv_b = 1.0 / (rows * world)
-        stats = self.flat[self.n_grad:]
-        qnames = [n for n in pw.names if n != 'policy']
-        for i, nm in enumerate(qnames):
-            ops.q_loss_grad(self.cfg, pw.net(nm), b['batch_obs'], b['batch_actions'], b['batch_targets'], inv_b_global=inv_b,
-                            grad_out=self.grad(nm), loss_out=stats[i:i + 1])
         select = self.num_rollout_list_for_policy_update
         ws = rule_based_weights(iteration, self.args.rule_based_bias_total_ite, self.args.eta, select)
-        ns = len(select)
-        ops.rollout_pg(self.cfg, pw.net('policy'), pw.net('Q1'), b['batch_obs'], eps, select, ws, M=self.M,
-                       inv_b_global=inv_b, grad_out=self.grad('policy'), stats_out=stats[2:2 + 2 * ns], n=max(select),
-                       noise_seed=self.seed, noise_ctr=self.counter)
+        # one native call: critic losses/gradients + model rollout + mixed policy gradient (7 launches); the targets
+        # were computed by get_batch_data (the reference caches them per batch, mpg_learner.py:402-403)
+        ops.mpg_gradients(self.cfg, len(pw.names) - 1, pw.params, pw.targets, b['batch_obs'], b['batch_actions'],
+                          b['batch_rewards'], b['batch_obs_tp1'], b['batch_targets'], select, ws, self.flat[:self.n_grad],
+                          self.flat[self.n_grad:], b['batch_targets'], M=self.M, n=max(select), eps=eps, noise_seed=self.seed,
+                          noise_ctr=self.counter, inv_b_global=inv_b)
         out = self._finish(iteration, float(self.args.gradient_clip_norm))
         self._lazy_stats = self._mpg_lazy_stats(iteration)
         return out

@@ -200,3 +200,24 @@ def td3_policy_grad(cfg, policy_params, q1, q2, obs, inv_b_global=None, grad_out
            L.c_int(rows), L.ptr(_f32(obs)), L.c_float(inv_b_global if inv_b_global is not None else 1.0 / rows),
            L.ptr(stats[0:1]), L.ptr(stats[1:2]), L.ptr(grad), L.ptr(ws), L.c_size_t(ws.numel()), L.stream())
     return stats, grad
+
+
+def mpg_gradients(cfg, n_q, params, target_params, obs, act, rew, obs_tp1, y_in, select, w, grad, stats, y_out, M=1, n=None,
+                  eps=None, noise_seed=0, noise_ctr=0, inv_b_global=None):
+    """mpg_mpg_gradients: MPGLearner.compute_gradient without the clip (targets unless y_in, critic grads, mixed PG)."""
+    rows, dev = obs.shape[0], obs.device
+    if eps is not None:
+        n = eps.shape[0]
+    ns = len(select)
+    sel = (ctypes.c_int * ns)(*[int(k) for k in select])
+    wv = (ctypes.c_float * ns)(*[float(x) for x in w])
+    nb = L.lib().mpg_mpg_gradients_workspace_bytes(ctypes.byref(cfg), L.c_int(rows), L.c_int(M), L.c_int(n), L.c_int(ns),
+                                                   L.c_int(n_q))
+    if nb == 0:
+        raise L.MpgError('mpg_mpg_gradients_workspace_bytes: unsupported configuration')
+    ws = workspace(dev, nb, slot=1)
+    L.call('mpg_mpg_gradients', ctypes.byref(cfg), L.c_int(n_q), L.ptr(_f32(params)), L.ptr(target_params), L.c_int(rows),
+           L.ptr(_f32(obs)), L.ptr(_f32(act)), L.ptr(rew), L.ptr(obs_tp1), L.ptr(y_in), L.c_int(M), L.c_int(n), sel,
+           L.c_int(ns), wv, L.ptr(eps), L.c_u64(noise_seed), L.c_u64(noise_ctr),
+           L.c_float(inv_b_global if inv_b_global is not None else 1.0 / rows), L.ptr(_f32(grad)), L.ptr(_f32(stats)),
+           L.ptr(_f32(y_out)), L.ptr(ws), L.c_size_t(ws.numel()), L.stream())

@@ -171,3 +171,46 @@ def test_nstep_target_vs_golden(golden):
     np.testing.assert_allclose(rewards.cpu().numpy(), g['nstep_all_rewards'], rtol=2e-3, atol=2e-4)
     y = ops.nstep_targets(cfg, dev(targets['policy']), dev(targets['Q1']), rewards, obs).cpu().numpy()
     np.testing.assert_allclose(y, g['it100_targets'], rtol=1e-3, atol=1e-4)
+
+
+def test_weight_cache_is_bit_identical_to_the_strided_path():
+    """mpg_weight_cache_*: packed register images are an acceleration only - forward, backward and rollout results are
+    bit-identical with and without a binding, and stay so after mpg_adam_polyak rewrites the bound buffer."""
+    import ctypes
+    import mpg_amd._lib as L
+    from mpg_amd import ops
+    from tests.golden_inputs import mlp_weights_flat, reset_law_obs
+    rng = np.random.Generator(np.random.PCG64(17))
+    cfg = ops.make_cfg()
+    nq, npol = ops.q_size(cfg), ops.policy_size(cfg)
+    flat = dev(np.concatenate([mlp_weights_flat(rng, 8, 1), mlp_weights_flat(rng, 6, 4)]))
+    q1, pol = flat[:nq], flat[nq:]
+    B = 100
+    obs, act = dev(reset_law_obs(rng, B)), dev(rng.uniform(-1, 1, (B, 2)))
+    y = dev(rng.standard_normal(B))
+    eps = dev(rng.standard_normal((25, B)))
+
+    def run():
+        a = ops.policy_action(cfg, pol, obs)
+        _, g, _ = ops.q_loss_grad(cfg, q1, obs, act, y)
+        _, _, pg = ops.rollout_pg(cfg, pol, q1, obs, eps, [0, 25], [0.5, 0.5])
+        return a.clone(), g.clone(), pg.clone()
+    ref = run()
+    cache = torch.empty(L.lib().mpg_weight_cache_floats(L.c_int(2)), dtype=torch.float32, device=DEV)
+    ind, outd = (ctypes.c_int * 2)(8, 6), (ctypes.c_int * 2)(1, 4)
+    L.call('mpg_weight_cache_bind', L.ptr(flat), ind, outd, L.c_int(2), L.ptr(cache), L.stream())
+    try:
+        got = run()
+        for r, g in zip(ref, got):
+            assert torch.equal(r, g)
+        # an Adam step through the ABI refreshes the packed images by itself
+        m, v = torch.zeros_like(flat), torch.zeros_like(flat)
+        grad = dev(rng.standard_normal(nq + npol) * 0.01)
+        ops.adam_polyak(flat, m, v, None, grad, [nq, npol], [1e-2, 1e-2], [1, 1], [0, 0], 0.005)
+        got2 = run()
+    finally:
+        L.call('mpg_weight_cache_unbind', L.ptr(flat))
+    ref2 = run()                                   # unbound again: strided loads from the updated weights
+    for r, g in zip(ref2, got2):
+        assert torch.equal(r, g)
+    assert not torch.equal(ref[0], ref2[0])
