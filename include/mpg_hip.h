@@ -96,6 +96,15 @@ int mpg_env_reset(int env_kind, int n, float* state, const uint8_t* done_mask, u
 int mpg_env_step(int env_kind, int n, float* state, const float* action, float* obs, float* reward,
                  uint8_t* done, uint8_t* done_intended, mpg_stream_t stream);
 
+/* The inner body of OffPolicyWorker.sample after the policy (worker.py:108-112) in one launch: env.step, the
+ * transition (obs, action, RAW reward, obs', done) written straight into the replay ring at (next_idx + i) % capacity
+ * (ReplayBuffer.add, buffer.py:46-55), then env.reset() of the agents whose done flag is set
+ * (path_tracking_env.py:445) with the Philox stream (seed, ctr).  Same results as mpg_env_step + mpg_replay_add +
+ * mpg_env_reset.  obs_out [n][6]: the observations after the reset; done_out (nullable) [n]. */
+int mpg_env_step_store_reset(int env_kind, int n, float* state, const float* action, int capacity, int next_idx,
+                             float* ring_obs, float* ring_act, float* ring_rew, float* ring_obs2, uint8_t* ring_done,
+                             uint64_t seed, uint64_t ctr, float* obs_out, uint8_t* done_out, mpg_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Networks (K3), critic targets, losses and gradients (K5, K6)
  * ---------------------------------------------------------------------------------------------- */
@@ -219,7 +228,8 @@ int mpg_td3_policy_grad(const mpg_cfg_t* cfg, const float* policy_params, const 
  * every network whose norm is not finite, else 0 (optimizer.py:357-361 zeroes such gradient lists).  Must run
  * AFTER the cross-GPU all-reduce: the clip is not linear. */
 int mpg_clip_by_global_norm(float* grad, const int* seg_sizes, int n_seg, float clip, float* norms,
-                            int* nonfinite_flags, mpg_stream_t stream);
+                            int* nonfinite_flags, float* scratch /* nullable: n_seg*64 floats -> parallel two-launch form */,
+                            mpg_stream_t stream);
 
 /* PolicyWithQs.apply_gradients + update_*_target  - policy.py:123-171.  For every network k (HOST arrays):
  * do_adam[k]: one Keras Adam step (beta .9/.999, eps 1e-7 outside the sqrt, TF ApplyAdam form) with the
@@ -247,6 +257,13 @@ int mpg_replay_add(int capacity, int next_idx, int n, int obs_dim, int act_dim, 
 int mpg_replay_gather(int n, const int* idx, int obs_dim, int act_dim, const float* obs, const float* act,
                       const float* rew, const float* obs2, const uint8_t* done, float* o_obs, float* o_act,
                       float* o_rew, float* o_obs2, float* o_done, mpg_stream_t stream);
+
+/* ReplayBuffer.sample (buffer.py:70-78) in one launch: mpg_uniform_indices + mpg_replay_gather (same Philox stream,
+ * same results). */
+int mpg_replay_sample_uniform(int n_storage, int n, uint64_t seed, uint64_t ctr, int obs_dim, int act_dim,
+                              const float* obs, const float* act, const float* rew, const float* obs2,
+                              const uint8_t* done, int* idx, float* o_obs, float* o_act, float* o_rew, float* o_obs2,
+                              float* o_done, mpg_stream_t stream);
 
 /* ReplayBuffer.sample_idxes (buffer.py:70-71): n indices uniform in [0, n_storage), with replacement,
  * from Philox(seed, ctr). */
@@ -321,6 +338,7 @@ typedef struct {
     float *params, *targets, *adam_m, *adam_v;
     float* grad;                      /* n_grad + 16 floats: gradients then statistics (q losses, return sums) */
     float* norms;                     /* n_nets */
+    float* clip_scratch;              /* n_nets * 64 floats (nullable: single-block clip) */
     int* nonfinite;                   /* n_nets */
     /* MPG-v1 only: the learner's own env for the n-step sampler (batch agents) */
     float *l_env_state, *l_obs, *l_act, *l_rewards;

@@ -78,56 +78,58 @@ __device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& z0, fl
     z1 = rad * s;
 }
 
-__global__ void __launch_bounds__(64) k_reset(int n, float* __restrict__ st, const uint8_t* __restrict__ mask,
-                                              uint32_t k0, uint32_t k1, uint32_t c1, uint32_t c2,
-                                              float* __restrict__ obs) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    size_t N = n;
-    if (mask == nullptr || mask[i]) {
-        Philox4 a = philox4x32_10((uint32_t)i, c1, c2, 0u, k0, k1);
-        Philox4 b = philox4x32_10((uint32_t)i, c1, c2, 1u, k0, k1);
-        float x = 600.f * u01(a.v[0]);                    // :426
-        float vx = 15.f + 10.f * u01(a.v[1]);             // :434
-        float z0, z1, z2, z3;
-        box_muller(a.v[2], a.v[3], z0, z1);
-        box_muller(b.v[0], b.v[1], z2, z3);
-        float dy = z0;                                     // :428
-        float dphi = z1 * (float)(3.14159265358979323846 / 9.0);   // :431
-        float beta = z2 * 0.15f;                           // :435
-        float r = z3 * 0.3f;                               // :437
-        PathRef p = path_ref(x);
-        float y = dy + p.y;                                // compute_y :222-224
-        float phi = wrap_pi(dphi + p.phi);                 // compute_phi :230-235
-        float vy = vx * tanf(beta);                        // :436
-        st[0 * N + i] = vx;
-        st[1 * N + i] = vy;
-        st[2 * N + i] = r;
-        st[3 * N + i] = y;
-        st[4 * N + i] = phi;
-        st[5 * N + i] = x;
-        st[6 * N + i] = y - p.y;                           // :450
-        st[7 * N + i] = phi - p.phi;                       // :449
-    }
-    float* o = obs + (size_t)i * 6;                        // _get_obs :399-402
-    o[0] = st[0 * N + i] - 20.f;
-    o[1] = st[1 * N + i];
-    o[2] = st[2 * N + i];
-    o[3] = st[6 * N + i];
-    o[4] = st[7 * N + i];
-    o[5] = st[5 * N + i];
+struct Agent {   // one agent's state block in registers
+    float vx, vy, r, y, phi, x, dy, dphi;
+};
+
+__device__ __forceinline__ Agent load_agent(const float* __restrict__ st, size_t N, int i) {
+    Agent a;
+    a.vx = st[0 * N + i]; a.vy = st[1 * N + i]; a.r = st[2 * N + i]; a.y = st[3 * N + i];
+    a.phi = st[4 * N + i]; a.x = st[5 * N + i]; a.dy = st[6 * N + i]; a.dphi = st[7 * N + i];
+    return a;
+}
+__device__ __forceinline__ void store_agent(float* __restrict__ st, size_t N, int i, const Agent& a) {
+    st[0 * N + i] = a.vx; st[1 * N + i] = a.vy; st[2 * N + i] = a.r; st[3 * N + i] = a.y;
+    st[4 * N + i] = a.phi; st[5 * N + i] = a.x; st[6 * N + i] = a.dy; st[7 * N + i] = a.dphi;
+}
+__device__ __forceinline__ void write_obs(float* __restrict__ obs, int i, const Agent& a) {   // _get_obs :399-402
+    float2* o = reinterpret_cast<float2*>(obs + (size_t)i * 6);
+    o[0] = make_float2(a.vx - 20.f, a.vy);
+    o[1] = make_float2(a.r, a.dy);
+    o[2] = make_float2(a.dphi, a.x);
 }
 
-__global__ void __launch_bounds__(64) k_step(int n, float* __restrict__ st, const float* __restrict__ action,
-                                             float* __restrict__ obs, float* __restrict__ reward,
-                                             uint8_t* __restrict__ done, uint8_t* __restrict__ done_intended) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const size_t N = n;
-    float vx = st[0 * N + i], vy = st[1 * N + i], r = st[2 * N + i], y = st[3 * N + i], phi = st[4 * N + i],
-          x = st[5 * N + i], dy = st[6 * N + i], dphi = st[7 * N + i];
-    const float2 an = reinterpret_cast<const float2*>(action)[i];
+// PathTrackingEnv.reset() for one agent, path_tracking_env.py:423-454, on the Philox stream (i, ctr)
+__device__ __forceinline__ void reset_agent(Agent& ag, int i, uint32_t k0, uint32_t k1, uint32_t c1, uint32_t c2) {
+    Philox4 a = philox4x32_10((uint32_t)i, c1, c2, 0u, k0, k1);
+    Philox4 b = philox4x32_10((uint32_t)i, c1, c2, 1u, k0, k1);
+    float x = 600.f * u01(a.v[0]);                    // :426
+    float vx = 15.f + 10.f * u01(a.v[1]);             // :434
+    float z0, z1, z2, z3;
+    box_muller(a.v[2], a.v[3], z0, z1);
+    box_muller(b.v[0], b.v[1], z2, z3);
+    float dy = z0;                                     // :428
+    float dphi = z1 * (float)(3.14159265358979323846 / 9.0);   // :431
+    float beta = z2 * 0.15f;                           // :435
+    float r = z3 * 0.3f;                               // :437
+    PathRef p = path_ref(x);
+    float y = dy + p.y;                                // compute_y :222-224
+    float phi = wrap_pi(dphi + p.phi);                 // compute_phi :230-235
+    ag.vx = vx; ag.vy = vx * tanf(beta);               // :436
+    ag.r = r; ag.y = y; ag.phi = phi; ag.x = x;
+    ag.dy = y - p.y;                                   // :450
+    ag.dphi = phi - p.phi;                             // :449
+}
 
+struct StepOut {
+    float reward;
+    bool done, done_intended;
+};
+
+// PathTrackingEnv.step for one agent (:456-487): reward on the pre-step state, 20 sub-steps, done flags
+__device__ __forceinline__ StepOut step_agent(Agent& ag, const float2 an) {
+    StepOut out;
+    float vx = ag.vx, vy = ag.vy, r = ag.r, y = ag.y, phi = ag.phi, x = ag.x, dy = ag.dy, dphi = ag.dphi;
     // step(): scale and clip the action, path_tracking_env.py:457-459
     const float ACT_HI0 = (float)(1.2 * 3.14159265358979323846 / 9.0), ACT_HI1 = 3.f;
     float steer = ((an.x * 1.2f) * PI_F) / 9.f;
@@ -140,7 +142,7 @@ __global__ void __launch_bounds__(64) k_step(int n, float* __restrict__ st, cons
         float t = vx - 20.f;
         float devi_v = -(t * t), devi_y = -(dy * dy), devi_phi = -(dphi * dphi), p_yaw = -(r * r),
               p_steer = -(steer * steer), p_ax = -(a_x * a_x);
-        reward[i] = 0.01f * devi_v + 0.04f * devi_y + 0.1f * devi_phi + 0.02f * p_yaw + 5.f * p_steer + 0.05f * p_ax;
+        out.reward = 0.01f * devi_v + 0.04f * devi_y + 0.1f * devi_phi + 0.02f * p_yaw + 5.f * p_steer + 0.05f * p_ax;
     }
 
     // f_xu pieces that depend on the action only, :95-101,135-136
@@ -188,16 +190,66 @@ __global__ void __launch_bounds__(64) k_step(int n, float* __restrict__ st, cons
     const bool geo = (fabsf(dy) > 3.f) | (fabsf(dphi) > PI_F / 4.f) | (vx < 2.f);
     const bool lit = geo | (alpha_f < -afb) | (alpha_f > afb) | (alpha_r < -arb) | (alpha_r > arb) | (r < -rb) |
                      (r > rb);
-    done[i] = lit ? 1 : 0;
-    if (done_intended)
-        done_intended[i] = (geo | (fabsf(alpha_f) > fabsf(afb)) | (fabsf(alpha_r) > fabsf(arb)) | (fabsf(r) > rb)) ? 1 : 0;
+    out.done = lit;
+    out.done_intended = geo | (fabsf(alpha_f) > fabsf(afb)) | (fabsf(alpha_r) > fabsf(arb)) | (fabsf(r) > rb);
 
-    st[0 * N + i] = vx; st[1 * N + i] = vy; st[2 * N + i] = r; st[3 * N + i] = y; st[4 * N + i] = phi;
-    st[5 * N + i] = x; st[6 * N + i] = dy; st[7 * N + i] = dphi;
-    float2* o = reinterpret_cast<float2*>(obs + (size_t)i * 6);   // _get_obs :399-402
-    o[0] = make_float2(vx - 20.f, vy);
-    o[1] = make_float2(r, dy);
-    o[2] = make_float2(dphi, x);
+    ag.vx = vx; ag.vy = vy; ag.r = r; ag.y = y; ag.phi = phi; ag.x = x; ag.dy = dy; ag.dphi = dphi;
+    return out;
+}
+
+__global__ void __launch_bounds__(64) k_reset(int n, float* __restrict__ st, const uint8_t* __restrict__ mask,
+                                              uint32_t k0, uint32_t k1, uint32_t c1, uint32_t c2,
+                                              float* __restrict__ obs) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Agent ag = load_agent(st, n, i);
+    if (mask == nullptr || mask[i]) {
+        reset_agent(ag, i, k0, k1, c1, c2);
+        store_agent(st, n, i, ag);
+    }
+    write_obs(obs, i, ag);
+}
+
+__global__ void __launch_bounds__(64) k_step(int n, float* __restrict__ st, const float* __restrict__ action,
+                                             float* __restrict__ obs, float* __restrict__ reward,
+                                             uint8_t* __restrict__ done, uint8_t* __restrict__ done_intended) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Agent ag = load_agent(st, n, i);
+    const StepOut o = step_agent(ag, reinterpret_cast<const float2*>(action)[i]);
+    reward[i] = o.reward;
+    done[i] = o.done ? 1 : 0;
+    if (done_intended) done_intended[i] = o.done_intended ? 1 : 0;
+    store_agent(st, n, i, ag);
+    write_obs(obs, i, ag);
+}
+
+// OffPolicyWorker.sample's inner body after the policy (worker.py:108-112) in one launch: env.step, the transition
+// (obs, action, RAW reward, obs', done) written straight into the replay ring slot (next_idx + i) % capacity
+// (buffer.py:46-55), then env.reset() for the agents that are done (path_tracking_env.py:445).
+struct RingPtrs {
+    float *obs, *act, *rew, *obs2;
+    uint8_t* done;
+};
+__global__ void __launch_bounds__(64) k_step_store_reset(int n, float* __restrict__ st, const float* __restrict__ action,
+                                                         RingPtrs ring, int capacity, int next_idx, uint32_t k0, uint32_t k1,
+                                                         uint32_t c1, uint32_t c2, float* __restrict__ obs_out,
+                                                         uint8_t* __restrict__ done_out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Agent ag = load_agent(st, n, i);
+    const float2 an = reinterpret_cast<const float2*>(action)[i];
+    const size_t slot = (size_t)((next_idx + i) % capacity);
+    write_obs(ring.obs, (int)slot, ag);                         // obs before the step
+    reinterpret_cast<float2*>(ring.act)[slot] = an;
+    const StepOut o = step_agent(ag, an);
+    write_obs(ring.obs2, (int)slot, ag);
+    ring.rew[slot] = o.reward;
+    ring.done[slot] = o.done ? 1 : 0;
+    if (done_out) done_out[i] = o.done ? 1 : 0;
+    if (o.done) reset_agent(ag, i, k0, k1, c1, c2);
+    store_agent(st, n, i, ag);
+    write_obs(obs_out, i, ag);
 }
 
 }  // namespace
@@ -229,5 +281,22 @@ extern "C" int mpg_env_step(int env_kind, int n, float* state, const float* acti
                        done, done_intended);
     mpg_prof_end(2, mpg_stream(stream));
     MPG_CHECK_LAUNCH("mpg_env_step");
+    return MPG_OK;
+}
+
+extern "C" int mpg_env_step_store_reset(int env_kind, int n, float* state, const float* action, int capacity, int next_idx,
+                                        float* ring_obs, float* ring_act, float* ring_rew, float* ring_obs2, uint8_t* ring_done,
+                                        uint64_t seed, uint64_t ctr, float* obs_out, uint8_t* done_out, mpg_stream_t stream) {
+    MPG_REQUIRE(env_kind == MPG_ENV_PATH_TRACKING, "mpg_env_step_store_reset: only PathTracking has a real env (kind %d)", env_kind);
+    MPG_REQUIRE(n > 0 && state && action && capacity >= n && next_idx >= 0 && next_idx < capacity && ring_obs && ring_act &&
+                    ring_rew && ring_obs2 && ring_done && obs_out,
+                "mpg_env_step_store_reset: bad argument");
+    RingPtrs ring{ring_obs, ring_act, ring_rew, ring_obs2, ring_done};
+    mpg_prof_begin(2, mpg_stream(stream));
+    hipLaunchKernelGGL(k_step_store_reset, dim3((n + 63) / 64), dim3(64), 0, mpg_stream(stream), n, state, action, ring,
+                       capacity, next_idx, (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)ctr, (uint32_t)(ctr >> 32), obs_out,
+                       done_out);
+    mpg_prof_end(2, mpg_stream(stream));
+    MPG_CHECK_LAUNCH("mpg_env_step_store_reset");
     return MPG_OK;
 }

@@ -45,9 +45,60 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int sl, con
     const f32x4* H2 = reinterpret_cast<const f32x4*>(a.h2);
     const f32x4* DZ1 = reinterpret_cast<const f32x4*>(a.dz1);
     const f32x4* DZ2 = reinterpret_cast<const f32x4*>(a.dz2);
+    // ---- thin pieces (dW1, db1, db2, dW3, db3): the chunk's groups are dealt round-robin to the 8 waves.  The loads
+    //      of a wave's first thin group are issued before the MFMA loop and consumed after it, so their latency is
+    //      hidden; later groups (long chunks, e.g. NADP's 26*B rows) are prefetched one ahead. ----
+    struct Thin {
+        f32x4 d10, d11, d20, d21, h20, h21;
+        float d3[4][OU], x[4][IN];
+    };
+    auto thin_load = [&](long g, Thin& t) {
+        t.d10 = DZ1[(g * 16 + 2 * sl) * 64 + L.lane]; t.d11 = DZ1[(g * 16 + 2 * sl + 1) * 64 + L.lane];
+        t.d20 = DZ2[(g * 16 + 2 * sl) * 64 + L.lane]; t.d21 = DZ2[(g * 16 + 2 * sl + 1) * 64 + L.lane];
+        t.h20 = H2[(g * 16 + 2 * sl) * 64 + L.lane]; t.h21 = H2[(g * 16 + 2 * sl + 1) * 64 + L.lane];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const long gr = g * GROUP + L.row(j);
+            const bool live = gr < a.rows;
+#pragma unroll
+            for (int o = 0; o < OU; ++o) t.d3[j][o] = live ? a.dz3[gr * OU + o] : 0.f;
+#pragma unroll
+            for (int i = 0; i < IN; ++i) t.x[j][i] = live ? x_value<IN>(a.x, gr, i) : 0.f;
+        }
+    };
+    auto thin_accumulate = [&](const Thin& t) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            gb1[0] += t.d10[j]; gb1[1] += t.d11[j];
+            gb2[0] += t.d20[j]; gb2[1] += t.d21[j];
+#pragma unroll
+            for (int i = 0; i < IN; ++i) {
+                gW1[0][i] = fmaf(t.x[j][i], t.d10[j], gW1[0][i]);
+                gW1[1][i] = fmaf(t.x[j][i], t.d11[j], gW1[1][i]);
+            }
+#pragma unroll
+            for (int o = 0; o < OU; ++o) {
+                gW3[0][o] = fmaf(t.h20[j], t.d3[j][o], gW3[0][o]);
+                gW3[1][o] = fmaf(t.h21[j], t.d3[j][o], gW3[1][o]);
+                if (L.c == 0) gb3[o] += t.d3[j][o];
+            }
+        }
+    };
+    Thin tcur;
+    long tg = g0 + L.wave;
+    const bool has_thin = tg < g1;
+    if (has_thin) thin_load(tg, tcur);
+
+    // ---- dW2 on the matrix pipe, fragments of group g+1 in flight while group g multiplies ----
+    f32x4 nb0, nb1, na0, na1;
+    nb0 = DZ2[(g0 * 16 + 2 * sl) * 64 + L.lane]; nb1 = DZ2[(g0 * 16 + 2 * sl + 1) * 64 + L.lane];
+    na0 = H1[(g0 * 16 + 2 * L.wave) * 64 + L.lane]; na1 = H1[(g0 * 16 + 2 * L.wave + 1) * 64 + L.lane];
     for (long g = g0; g < g1; ++g) {
-        const f32x4 b0 = DZ2[(g * 16 + 2 * sl) * 64 + L.lane], b1 = DZ2[(g * 16 + 2 * sl + 1) * 64 + L.lane];
-        const f32x4 a0 = H1[(g * 16 + 2 * L.wave) * 64 + L.lane], a1 = H1[(g * 16 + 2 * L.wave + 1) * 64 + L.lane];
+        const f32x4 b0 = nb0, b1 = nb1, a0 = na0, a1 = na1;
+        if (g + 1 < g1) {
+            nb0 = DZ2[((g + 1) * 16 + 2 * sl) * 64 + L.lane]; nb1 = DZ2[((g + 1) * 16 + 2 * sl + 1) * 64 + L.lane];
+            na0 = H1[((g + 1) * 16 + 2 * L.wave) * 64 + L.lane]; na1 = H1[((g + 1) * 16 + 2 * L.wave + 1) * 64 + L.lane];
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {   // the float4's 4 entries are 4 k-steps (k = batch row)
             acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], b0[j], acc[0][0], 0, 0, 0);
@@ -55,31 +106,16 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int sl, con
             acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], b0[j], acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], b1[j], acc[1][1], 0, 0, 0);
         }
-        if ((int)((g - g0) & 7) == L.wave) {   // thin pieces: the chunk's groups are dealt round-robin to the 8 waves
-            const f32x4 d10 = DZ1[(g * 16 + 2 * sl) * 64 + L.lane], d11 = DZ1[(g * 16 + 2 * sl + 1) * 64 + L.lane];
-            const f32x4 h20 = H2[(g * 16 + 2 * sl) * 64 + L.lane], h21 = H2[(g * 16 + 2 * sl + 1) * 64 + L.lane];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const long gr = g * GROUP + L.row(j);
-                const bool live = gr < a.rows;
-                float d3[OU];
-#pragma unroll
-                for (int o = 0; o < OU; ++o) d3[o] = live ? a.dz3[gr * OU + o] : 0.f;
-                gb1[0] += d10[j]; gb1[1] += d11[j];
-                gb2[0] += b0[j];  gb2[1] += b1[j];
-#pragma unroll
-                for (int i = 0; i < IN; ++i) {
-                    const float xv = live ? x_value<IN>(a.x, gr, i) : 0.f;
-                    gW1[0][i] = fmaf(xv, d10[j], gW1[0][i]);
-                    gW1[1][i] = fmaf(xv, d11[j], gW1[1][i]);
-                }
-#pragma unroll
-                for (int o = 0; o < OU; ++o) {
-                    gW3[0][o] = fmaf(h20[j], d3[o], gW3[0][o]);
-                    gW3[1][o] = fmaf(h21[j], d3[o], gW3[1][o]);
-                    if (L.c == 0) gb3[o] += d3[o];
-                }
-            }
+    }
+    if (has_thin) {
+        for (;;) {
+            const long tnext = tg + NWAVE;
+            Thin tn;
+            if (tnext < g1) thin_load(tnext, tn);
+            thin_accumulate(tcur);
+            if (tnext >= g1) break;
+            tcur = tn;
+            tg = tnext;
         }
     }
     // ---- this workgroup's part of the chunk slab ----

@@ -7,6 +7,7 @@
 #include "mpg_common.h"
 
 int weight_cache_refresh_if_bound(const float* params, hipStream_t s);   // weight_cache.hip
+bool weight_cache_info(const float* params, float** cache, int* w2_off, int* n_nets);
 
 namespace {
 
@@ -17,7 +18,66 @@ struct Segs {
     int off[MAXSEG], n[MAXSEG];
     float lr_t[MAXSEG];
     int do_adam[MAXSEG], do_polyak[MAXSEG];
+    int w2_off[MAXSEG];              // offset of W2 inside the segment's network, -1 when no weight cache is bound
+    float *cache_w, *cache_t;        // packed register images of the bound buffers (nullable)
 };
+
+constexpr int HH = MPG_HIDDEN * MPG_HIDDEN;
+// position of W2[row][col] in the packed image where `col`-like index n owns the lane and `row`-like index k the step
+__device__ __forceinline__ int pack_index(int k, int n) {
+    const int wave = n >> 5, t = (n >> 4) & 1, c = n & 15, q = k >> 2, rg = k & 3;
+    return ((((wave * 16 + (q >> 2)) * 2 + t) * 64 + rg * 16 + c) << 2) + (q & 3);
+}
+
+// parallel two-launch form of the clip: (1) 64 partial sums of squares per network, (2) every block rebuilds its
+// network's norm from the 64 partials in a fixed order and scales its own slice.
+constexpr int CLIP_PARTS = 64;
+__global__ void __launch_bounds__(256) k_sq_partial(const Segs sg, const float* __restrict__ grad, float* __restrict__ part) {
+    __shared__ float red[256];
+    const int k = blockIdx.y, b = blockIdx.x;
+    const float* g = grad + sg.off[k];
+    const int n = sg.n[k];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int i = b * 256 + threadIdx.x;
+    const int stride = CLIP_PARTS * 256;
+    for (; i + 3 * stride < n; i += 4 * stride) {
+        const float v0 = g[i], v1 = g[i + stride], v2 = g[i + 2 * stride], v3 = g[i + 3 * stride];
+        a0 = fmaf(v0, v0, a0); a1 = fmaf(v1, v1, a1); a2 = fmaf(v2, v2, a2); a3 = fmaf(v3, v3, a3);
+    }
+    for (; i < n; i += stride) a0 = fmaf(g[i], g[i], a0);
+    red[threadIdx.x] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[k * CLIP_PARTS + b] = red[0];
+}
+
+__global__ void __launch_bounds__(256) k_clip_scale(const Segs sg, float* __restrict__ grad, const float* __restrict__ part,
+                                                    float clip, float* __restrict__ norms, int* __restrict__ nonfinite) {
+    __shared__ float s_scale;
+    const int k = blockIdx.y;
+    if (threadIdx.x == 0) {
+        float tot = 0.f;
+        for (int b = 0; b < CLIP_PARTS; ++b) tot += part[k * CLIP_PARTS + b];
+        const float nrm = sqrtf(tot);
+        s_scale = clip * fminf(1.f / nrm, 1.f / clip);
+        if (blockIdx.x == 0) {
+            norms[k] = nrm;
+            if (nonfinite) nonfinite[k] = isfinite(nrm) ? 0 : 1;
+        }
+    }
+    __syncthreads();
+    const float sc = s_scale;
+    float* g = grad + sg.off[k];
+    const int i0 = blockIdx.x * 1024 + threadIdx.x;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * 256;
+        if (i < sg.n[k]) g[i] *= sc;
+    }
+}
 
 // one block per segment: norm = sqrt(sum g^2); g *= clip * min(1/norm, 1/clip)   (tf.clip_by_global_norm)
 // 8 independent accumulators / float4 loads keep ~8 loads in flight per lane (a serial fma chain on one load per
@@ -84,7 +144,23 @@ __global__ void k_adam_polyak(const Segs sg, float* __restrict__ w, float* __res
         wj -= sg.lr_t[k] * mj / (sqrtf(vj) + eps);
         m[j] = mj; v[j] = vj; w[j] = wj;
     }
-    if (sg.do_polyak[k] && target) target[j] = tau * wj + (1.f - tau) * target[j];   // policy.py:158-171
+    // weight cache: the element's two packed copies are rewritten by the thread that owns it
+    const int e = sg.w2_off[k] >= 0 ? i - sg.w2_off[k] : -1;
+    const bool in_w2 = e >= 0 && e < HH;
+    if (in_w2 && sg.do_adam[k] && sg.cache_w) {
+        const int row = e >> 8, col = e & 255;
+        sg.cache_w[(size_t)(2 * k) * HH + pack_index(row, col)] = wj;          // forward image: k = row, n = col
+        sg.cache_w[(size_t)(2 * k + 1) * HH + pack_index(col, row)] = wj;      // backward image: k = col, n = row
+    }
+    if (sg.do_polyak[k] && target) {
+        const float tj = tau * wj + (1.f - tau) * target[j];                     // policy.py:158-171
+        target[j] = tj;
+        if (in_w2 && sg.cache_t) {
+            const int row = e >> 8, col = e & 255;
+            sg.cache_t[(size_t)(2 * k) * HH + pack_index(row, col)] = tj;
+            sg.cache_t[(size_t)(2 * k + 1) * HH + pack_index(col, row)] = tj;
+        }
+    }
 }
 
 int fill(Segs& sg, int n_seg, const int* seg_sizes) {
@@ -97,18 +173,30 @@ int fill(Segs& sg, int n_seg, const int* seg_sizes) {
         off += sg.n[k];
         sg.lr_t[k] = 0.f;
         sg.do_adam[k] = sg.do_polyak[k] = 0;
+        sg.w2_off[k] = -1;
     }
+    sg.cache_w = sg.cache_t = nullptr;
     return off;
 }
 
 }  // namespace
 
 extern "C" int mpg_clip_by_global_norm(float* grad, const int* seg_sizes, int n_seg, float clip, float* norms,
-                                       int* nonfinite_flag, mpg_stream_t stream) {
+                                       int* nonfinite_flag, float* scratch, mpg_stream_t stream) {
     Segs sg;
     MPG_REQUIRE(grad && norms && fill(sg, n_seg, seg_sizes) > 0 && clip > 0.f, "mpg_clip_by_global_norm: bad argument");
-    hipLaunchKernelGGL(k_clip, dim3(n_seg), dim3(1024), 0, mpg_stream(stream), sg, grad, clip, norms, nonfinite_flag);
-    MPG_CHECK_LAUNCH("k_clip");
+    if (!scratch) {   // single-block-per-network form
+        hipLaunchKernelGGL(k_clip, dim3(n_seg), dim3(1024), 0, mpg_stream(stream), sg, grad, clip, norms, nonfinite_flag);
+        MPG_CHECK_LAUNCH("k_clip");
+        return MPG_OK;
+    }
+    int maxn = 0;
+    for (int k = 0; k < n_seg; ++k) maxn = sg.n[k] > maxn ? sg.n[k] : maxn;
+    hipLaunchKernelGGL(k_sq_partial, dim3(CLIP_PARTS, n_seg), dim3(256), 0, mpg_stream(stream), sg, grad, scratch);
+    MPG_CHECK_LAUNCH("k_sq_partial");
+    hipLaunchKernelGGL(k_clip_scale, dim3((maxn + 1023) / 1024, n_seg), dim3(256), 0, mpg_stream(stream), sg, grad, scratch, clip,
+                       norms, nonfinite_flag);
+    MPG_CHECK_LAUNCH("k_clip_scale");
     return MPG_OK;
 }
 
@@ -125,11 +213,27 @@ extern "C" int mpg_adam_polyak(float* w, float* m, float* v, float* target, cons
         sg.do_polyak[k] = do_polyak[k];
         if (sg.n[k] > maxn) maxn = sg.n[k];
     }
+    // keep the packed register images of bound buffers in sync inside the same kernel (no extra launch)
+    {
+        int w2o[MAXSEG], nn = 0;
+        float* cw = nullptr;
+        if (weight_cache_info(w, &cw, w2o, &nn) && nn == n_seg) {
+            sg.cache_w = cw;
+            for (int k = 0; k < n_seg; ++k) sg.w2_off[k] = w2o[k] - sg.off[k];
+            float* ct = nullptr;
+            int w2t[MAXSEG], nt = 0;
+            if (target && weight_cache_info(target, &ct, w2t, &nt) && nt == n_seg) sg.cache_t = ct;
+        } else if (target) {
+            float* ct = nullptr;
+            int w2t[MAXSEG], nt = 0;
+            if (weight_cache_info(target, &ct, w2t, &nt) && nt == n_seg) {
+                sg.cache_t = ct;
+                for (int k = 0; k < n_seg; ++k) sg.w2_off[k] = w2t[k] - sg.off[k];
+            }
+        }
+    }
     hipLaunchKernelGGL(k_adam_polyak, dim3((maxn + 255) / 256, n_seg), dim3(256), 0, mpg_stream(stream), sg, w, m, v,
                        target, grad, tau, skip_flags, skip_flags ? n_skip_flags : 0);
     MPG_CHECK_LAUNCH("k_adam_polyak");
-    // keep the packed register images of bound buffers in sync with what was just written
-    int rc = weight_cache_refresh_if_bound(w, mpg_stream(stream));
-    if (rc == MPG_OK && target) rc = weight_cache_refresh_if_bound(target, mpg_stream(stream));
-    return rc;
+    return MPG_OK;
 }

@@ -50,6 +50,24 @@ __global__ void k_uniform_idx(int n_storage, int n, uint32_t k0, uint32_t k1, ui
     idx[i] = (int)(((uint64_t)p.v[i & 3] * (uint64_t)n_storage) >> 32);
 }
 
+// ReplayBuffer.sample (buffer.py:70-78): index draw + gather in one launch (same Philox stream as k_uniform_idx)
+__global__ void k_sample_gather(int n_storage, int n, uint32_t k0, uint32_t k1, uint32_t c1, uint32_t c2, int od, int ad, Ring r,
+                                int* __restrict__ idx, float* __restrict__ o_obs, float* __restrict__ o_act,
+                                float* __restrict__ o_rew, float* __restrict__ o_obs2, float* __restrict__ o_done) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Philox4 p = philox4x32_10((uint32_t)(i >> 2), c1, c2, 0x1d5u, k0, k1);
+    const long s = (long)(((uint64_t)p.v[i & 3] * (uint64_t)n_storage) >> 32);
+    idx[i] = (int)s;
+    for (int k = 0; k < od; ++k) {
+        o_obs[(long)i * od + k] = r.obs[s * od + k];
+        o_obs2[(long)i * od + k] = r.obs2[s * od + k];
+    }
+    for (int k = 0; k < ad; ++k) o_act[(long)i * ad + k] = r.act[s * ad + k];
+    o_rew[i] = r.rew[s];
+    if (o_done) o_done[i] = (float)r.done[s];
+}
+
 }  // namespace
 
 extern "C" int mpg_replay_add(int capacity, int next_idx, int n, int obs_dim, int act_dim, const float* s_obs,
@@ -83,5 +101,20 @@ extern "C" int mpg_uniform_indices(int n_storage, int n, uint64_t seed, uint64_t
     hipLaunchKernelGGL(k_uniform_idx, dim3((n + 255) / 256), dim3(256), 0, mpg_stream(stream), n_storage, n,
                        (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)ctr, (uint32_t)(ctr >> 32), idx);
     MPG_CHECK_LAUNCH("k_uniform_idx");
+    return MPG_OK;
+}
+
+extern "C" int mpg_replay_sample_uniform(int n_storage, int n, uint64_t seed, uint64_t ctr, int obs_dim, int act_dim,
+                                         const float* obs, const float* act, const float* rew, const float* obs2,
+                                         const uint8_t* done, int* idx, float* o_obs, float* o_act, float* o_rew, float* o_obs2,
+                                         float* o_done, mpg_stream_t stream) {
+    MPG_REQUIRE(n_storage > 0 && n > 0 && obs && act && rew && obs2 && done && idx && o_obs && o_act && o_rew && o_obs2,
+                "mpg_replay_sample_uniform: bad argument");
+    Ring r{const_cast<float*>(obs), const_cast<float*>(act), const_cast<float*>(rew), const_cast<float*>(obs2),
+           const_cast<uint8_t*>(done)};
+    hipLaunchKernelGGL(k_sample_gather, dim3((n + 255) / 256), dim3(256), 0, mpg_stream(stream), n_storage, n, (uint32_t)seed,
+                       (uint32_t)(seed >> 32), (uint32_t)ctr, (uint32_t)(ctr >> 32), obs_dim, act_dim, r, idx, o_obs, o_act, o_rew,
+                       o_obs2, o_done);
+    MPG_CHECK_LAUNCH("k_sample_gather");
     return MPG_OK;
 }

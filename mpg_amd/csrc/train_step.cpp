@@ -86,23 +86,22 @@ extern "C" int mpg_step_begin(mpg_train_ctx_t* c, int iteration, mpg_stream_t s)
         for (int it = 0; it < c->sample_iters; ++it) {
             TRY(mpg_policy_action(&c->cfg, policy, c->num_agent, c->w_obs, c->explore_sigma, c->worker_seed, c->noise_ctr++,
                                   c->w_act, s));
-            TRY(mpg_env_step(kind, c->num_agent, c->env_state, c->w_act, c->w_obs2, c->w_rew, c->w_done, c->w_done_intended, s));
             MPG_REQUIRE(c->num_agent <= c->ring_capacity, "mpg_step_begin: ring smaller than one sample");
-            // a batch that wraps the ring is added in two pieces by the kernel's modulo addressing
-            TRY(mpg_replay_add(c->ring_capacity, c->ring_next, c->num_agent, od, ad, c->w_obs, c->w_act, c->w_rew, c->w_obs2,
-                               c->w_done, c->ring_obs, c->ring_act, c->ring_rew, c->ring_obs2, c->ring_done, s));
+            // env.step -> ring slot (next + i) % capacity -> env.reset of the done agents, one launch
+            TRY(mpg_env_step_store_reset(kind, c->num_agent, c->env_state, c->w_act, c->ring_capacity, c->ring_next, c->ring_obs,
+                                         c->ring_act, c->ring_rew, c->ring_obs2, c->ring_done, c->env_seed, c->env_ctr++, c->w_obs,
+                                         c->w_done, s));
             c->ring_next = (c->ring_next + c->num_agent) % c->ring_capacity;
             c->ring_size = std::min(c->ring_size + c->num_agent, c->ring_capacity);
-            TRY(mpg_env_reset(kind, c->num_agent, c->env_state, c->w_done, c->env_seed, c->env_ctr++, c->w_obs, s));
         }
     }
     // ---- replay_buffer.replay (optimizer.py:340-341; buffer.py:70-91) ----
     MPG_REQUIRE(c->ring_size > 0, "mpg_step_begin: empty replay ring");
     c->replay_times++;
     if (c->learner_counter % c->num_batch_reuse == 0) {       // get_batch_data, mpg_learner.py:402-403
-        TRY(mpg_uniform_indices(c->ring_size, c->batch, c->replay_seed, c->replay_times, c->idx, s));
-        TRY(mpg_replay_gather(c->batch, c->idx, od, ad, c->ring_obs, c->ring_act, c->ring_rew, c->ring_obs2, c->ring_done,
-                              c->b_obs, c->b_act, c->b_rew, c->b_obs2, c->b_done, s));
+        TRY(mpg_replay_sample_uniform(c->ring_size, c->batch, c->replay_seed, c->replay_times, od, ad, c->ring_obs, c->ring_act,
+                                      c->ring_rew, c->ring_obs2, c->ring_done, c->idx, c->b_obs, c->b_act, c->b_rew, c->b_obs2,
+                                      c->b_done, s));
         if (c->learner_version == 2) {
             // the clipped double-Q target is computed inside mpg_mpg_gradients below
         } else {   // MPGLearner.sample + compute_n_step_target, mpg_learner.py:109-124,146-169
@@ -138,7 +137,7 @@ extern "C" int mpg_step_begin(mpg_train_ctx_t* c, int iteration, mpg_stream_t s)
 extern "C" int mpg_step_end(mpg_train_ctx_t* c, int iteration, mpg_stream_t s) {
     MPG_REQUIRE(ctx_ok(c) && c->norms && c->nonfinite && c->adam_m && c->adam_v, "mpg_step_end: incomplete context");
     const Layout l = layout(c);
-    TRY(mpg_clip_by_global_norm(c->grad, l.sizes, l.n_nets, c->clip, c->norms, c->nonfinite, s));   // mpg_learner.py:415-431
+    TRY(mpg_clip_by_global_norm(c->grad, l.sizes, l.n_nets, c->clip, c->norms, c->nonfinite, c->clip_scratch, s));   // mpg_learner.py:415-431
     // PolicyWithQs.apply_gradients, policy.py:123-156
     const bool delayed = iteration % c->delay_update == 0;
     float lr_t[3];

@@ -77,6 +77,19 @@ int weight_cache_refresh_if_bound(const float* params, hipStream_t s) {
     return found ? refresh(b, s) : MPG_OK;
 }
 
+// binding of `params` (base pointer) if any: cache pointer and the offset of every network's W2 inside params
+bool weight_cache_info(const float* params, float** cache, int* w2_off, int* n_nets) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (const Binding& b : g_bind)
+        if (b.base == params) {
+            *cache = b.cache;
+            *n_nets = b.n_nets;
+            for (int k = 0; k < b.n_nets; ++k) w2_off[k] = b.off[k] + b.in_dim[k] * mlp::H + mlp::H;
+            return true;
+        }
+    return false;
+}
+
 extern "C" size_t mpg_weight_cache_floats(int n_nets) { return n_nets > 0 ? (size_t)n_nets * 2 * mlp::H * mlp::H : 0; }
 
 extern "C" int mpg_weight_cache_bind(const float* params, const int* in_dims, const int* out_dims, int n_nets, float* cache,

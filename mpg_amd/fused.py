@@ -29,7 +29,7 @@ class TrainCtx(ctypes.Structure):
         ('env_state', _P), ('w_obs', _P), ('w_act', _P), ('w_rew', _P), ('w_obs2', _P), ('w_done', _P), ('w_done_intended', _P),
         ('ring_obs', _P), ('ring_act', _P), ('ring_rew', _P), ('ring_obs2', _P), ('ring_done', _P),
         ('idx', _P), ('b_obs', _P), ('b_act', _P), ('b_rew', _P), ('b_obs2', _P), ('b_done', _P), ('b_targets', _P),
-        ('params', _P), ('targets', _P), ('adam_m', _P), ('adam_v', _P), ('grad', _P), ('norms', _P), ('nonfinite', _P),
+        ('params', _P), ('targets', _P), ('adam_m', _P), ('adam_v', _P), ('grad', _P), ('norms', _P), ('clip_scratch', _P), ('nonfinite', _P),
         ('l_env_state', _P), ('l_obs', _P), ('l_act', _P), ('l_rewards', _P), ('l_done', _P), ('l_done_intended', _P),
         ('ws0', _P), ('ws1', _P), ('ws0_bytes', ctypes.c_size_t), ('ws1_bytes', ctypes.c_size_t)]
 
@@ -81,6 +81,7 @@ class FusedMPGStep(object):
             setattr(c, k, L.ptr(v))
         c.params, c.targets, c.adam_m, c.adam_v = L.ptr(pw.params), L.ptr(pw.targets), L.ptr(pw.m), L.ptr(pw.v)
         c.grad, c.norms, c.nonfinite = L.ptr(learner.flat), L.ptr(learner.norms), L.ptr(pw.nonfinite)
+        c.clip_scratch = L.ptr(learner.clip_scratch)
         w0, w1 = ctypes.c_size_t(0), ctypes.c_size_t(0)
         L.call('mpg_step_workspace_bytes', ctypes.byref(c), ctypes.byref(w0), ctypes.byref(w1))
         self.ws0 = torch.empty(w0.value + 256, dtype=torch.uint8, device=dev)

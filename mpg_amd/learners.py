@@ -48,6 +48,7 @@ class _LearnerBase(object):
         self.n_grad = int(pw.offsets[-1])
         self.flat = torch.zeros(self.n_grad + N_STATS, dtype=torch.float32, device=self.device)
         self.norms = torch.zeros(len(pw.names), dtype=torch.float32, device=self.device)
+        self.clip_scratch = torch.zeros(len(pw.names) * 64, dtype=torch.float32, device=self.device)
         self.seed = int(getattr(args, 'seed', 0)) + 12345
         self._noise_gen = torch.Generator(device=self.device)
         self._noise_gen.manual_seed(self.seed)
@@ -106,7 +107,8 @@ class _LearnerBase(object):
             self._views = []
             for i, n in enumerate(pw.names):
                 self._views += pw._as_list(self.flat[pw.offsets[i]:pw.offsets[i + 1]], n)
-        ops.clip_by_global_norm(self.flat_grad, pw.sizes, clip, norms_out=self.norms, nonfinite=pw.nonfinite)
+        ops.clip_by_global_norm(self.flat_grad, pw.sizes, clip, norms_out=self.norms, nonfinite=pw.nonfinite,
+                                scratch=self.clip_scratch)
         self.stats['iteration'] = iteration
         return self._views
 

@@ -158,12 +158,12 @@ def rollout_pg(cfg, policy_params, q1_params, obs0, eps, select, w, M=1, inv_b_g
     return stats[:ns], stats[ns:], grad
 
 
-def clip_by_global_norm(grad, seg_sizes, clip, norms_out=None, nonfinite=None):
+def clip_by_global_norm(grad, seg_sizes, clip, norms_out=None, nonfinite=None, scratch=None):
     ns = len(seg_sizes)
     norms = norms_out if norms_out is not None else torch.empty(ns, dtype=torch.float32, device=grad.device)
     segs = (ctypes.c_int * ns)(*[int(s) for s in seg_sizes])
     L.call('mpg_clip_by_global_norm', L.ptr(_f32(grad)), segs, L.c_int(ns), L.c_float(clip), L.ptr(norms),
-           L.ptr(nonfinite), L.stream())
+           L.ptr(nonfinite), L.ptr(scratch), L.stream())
     return norms
 
 

@@ -105,3 +105,31 @@ def test_env_25_step_rollout_stays_finite_and_matches_oracle_loosely():
     assert (full[:, 5] > 0).all() and (full[:, 5] <= 1200).all()
     assert (full[:, 4] > -np.pi - 1e-6).all() and (full[:, 4] <= np.pi + 1e-6).all()
     assert (full[:, 0] >= 1).all() and (full[:, 0] <= 35).all()
+
+
+def test_fused_step_store_reset_equals_separate_calls():
+    """mpg_env_step_store_reset == mpg_env_step + mpg_replay_add + mpg_env_reset, bit for bit, incl. a wrapping ring."""
+    import mpg_amd._lib as L
+    from mpg_amd.envs import PathTrackingEnv
+    n, cap, nxt = 300, 1000, 850                      # 850 + 300 wraps around the ring
+    rng = np.random.Generator(np.random.PCG64(3))
+    act = torch.as_tensor(rng.uniform(-1.2, 1.2, (n, 2)).astype(np.float32)).cuda()
+    env_a, env_b = PathTrackingEnv(num_agent=n, seed=9), PathTrackingEnv(num_agent=n, seed=9)
+    obs0 = env_a.reset().clone()
+    env_b.reset()
+    # separate path
+    o2, r, d, _ = env_a.step(act)
+    ring_a = [torch.zeros(cap, 6).cuda(), torch.zeros(cap, 2).cuda(), torch.zeros(cap).cuda(), torch.zeros(cap, 6).cuda(),
+              torch.zeros(cap, dtype=torch.uint8).cuda()]
+    L.call('mpg_replay_add', L.c_int(cap), L.c_int(nxt), L.c_int(n), L.c_int(6), L.c_int(2), L.ptr(obs0), L.ptr(act), L.ptr(r),
+           L.ptr(o2), L.ptr(d), *[L.ptr(t) for t in ring_a], L.stream())
+    obs_a = env_a.reset()
+    # fused path
+    ring_b = [torch.zeros_like(t) for t in ring_a]
+    obs_b = torch.empty(n, 6).cuda()
+    done_b = torch.empty(n, dtype=torch.uint8).cuda()
+    L.call('mpg_env_step_store_reset', L.c_int(0), L.c_int(n), L.ptr(env_b._state), L.ptr(act), L.c_int(cap), L.c_int(nxt),
+           *[L.ptr(t) for t in ring_b], L.c_u64(env_b.seed), L.c_u64(env_b._ctr), L.ptr(obs_b), L.ptr(done_b), L.stream())
+    for x, y in zip(ring_a, ring_b):
+        assert torch.equal(x, y)
+    assert torch.equal(obs_a, obs_b) and torch.equal(env_a._state, env_b._state) and bool(done_b.all())

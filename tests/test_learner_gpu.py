@@ -165,3 +165,25 @@ def test_native_step_driver_equals_method_by_method_path(alg):
         assert (x - y).abs().max().item() <= 1e-6 * max(1.0, y.abs().max().item())
     g1, g2 = a[6], b[6]
     assert ((g1 - g2).norm() / g2.norm()).item() < 1e-5
+
+
+def test_replay_sample_uniform_equals_indices_plus_gather():
+    import mpg_amd._lib as L
+    from mpg_amd.buffer import ReplayBuffer
+    from mpg_amd.config import default_args
+    args = default_args(max_buffer_size=5000, replay_starts=100, replay_batch_size=777)
+    rb = ReplayBuffer(args, 3)
+    g = torch.Generator().manual_seed(0)
+    n = 3000
+    rb.add_batch((torch.randn(n, 6, generator=g).cuda(), torch.randn(n, 2, generator=g).cuda(), torch.randn(n, generator=g).cuda(),
+                  torch.randn(n, 6, generator=g).cuda(), torch.ones(n, dtype=torch.uint8).cuda()))
+    ref = rb.replay()                                   # mpg_uniform_indices + mpg_replay_gather, ctr = replay_times = 1
+    B = 777
+    out = [torch.empty(B, 6).cuda(), torch.empty(B, 2).cuda(), torch.empty(B).cuda(), torch.empty(B, 6).cuda(), torch.empty(B).cuda()]
+    idx = torch.empty(B, dtype=torch.int32).cuda()
+    L.call('mpg_replay_sample_uniform', L.c_int(len(rb)), L.c_int(B), L.c_u64(rb.seed), L.c_u64(1), L.c_int(6), L.c_int(2),
+           L.ptr(rb.obs), L.ptr(rb.act), L.ptr(rb.rew), L.ptr(rb.obs2), L.ptr(rb.done), L.ptr(idx), *[L.ptr(t) for t in out],
+           L.stream())
+    assert torch.equal(idx, ref[-1])
+    for x, y in zip(out, ref[:5]):
+        assert torch.equal(x, y)
