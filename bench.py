@@ -126,6 +126,7 @@ def main():
     fwd_ms, fwd_n = slot(0)
     bwd_ms, bwd_n = slot(1)
     env_ms, env_n = slot(2)
+    wg_ms, wg_n = slot(5)
     lib.mpg_prof_enable(0)
     assert fwd_n == a.steps and bwd_n == a.steps, (fwd_n, bwd_n)
     finite = bool(torch.isfinite(worker.policy_with_value.params).all().item())
@@ -155,6 +156,7 @@ def main():
                          'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': bwd_tflops / FP32_MFMA_PEAK_TFLOPS,
                          'traffic': None, 'avg_ms': bwd_ms, 'launches': bwd_n,
                          'algorithmic_flop_per_launch': BWD_FLOP_PER_STATE * B_PER_GPU},
+        'wgrad_kernel': {'kernel': 'k_wgrad_multi', 'avg_ms': wg_ms, 'launches': wg_n},
         'env_step_kernel': {'kernel': 'k_step', 'avg_ms': env_ms, 'launches': env_n,
                             'env_steps_per_sec_kernel_only': B_PER_GPU / (env_ms * 1e-3) if env_ms else None,
                             'algorithmic_bytes_per_env_step': 85},

@@ -215,14 +215,16 @@ struct WgradMulti {
 };
 
 template <int IA, int OA, int IB, int OB>
-__global__ void __launch_bounds__(NTHREAD, 2) k_wgrad_multi(const WgradMulti m) {
+__global__ void __launch_bounds__(NTHREAD, 4) k_wgrad_multi(const WgradMulti m) {
     constexpr int NQA = wgrad_nq<IA, OA>(), NQB = wgrad_nq<IB, OB>();
     __shared__ float sRed[NWAVE * (NQA > NQB ? NQA : NQB) * 64];
+    int gchunk, sl;
+    wgrad_map(blockIdx.x, gridDim.x >> 3, gchunk, sl);
     int j = 0;
-    while (j + 1 < m.n_jobs && (int)blockIdx.y >= m.chunk_off[j + 1]) ++j;
-    const int chunk = blockIdx.y - m.chunk_off[j];
-    if (m.type[j] == 0) wgrad_body<IA, OA>(m.a[j], blockIdx.x, chunk, sRed);
-    else wgrad_body<IB, OB>(m.a[j], blockIdx.x, chunk, sRed);
+    while (j + 1 < m.n_jobs && gchunk >= m.chunk_off[j + 1]) ++j;
+    const int chunk = gchunk - m.chunk_off[j];
+    if (m.type[j] == 0) wgrad_body<IA, OA>(m.a[j], sl, chunk, sRed);
+    else wgrad_body<IB, OB>(m.a[j], sl, chunk, sRed);
 }
 
 struct ReduceMulti {
@@ -362,8 +364,8 @@ int launch_wgrad_multi(const WgradJob* jobs, int n_jobs, const SumJob* sums, int
     m.chunk_off[n_jobs] = off;
     for (int j = n_jobs; j < 3; ++j) { m.type[j] = 0; m.chunk_off[j + 1] = off; rm.slabs[j] = nullptr; rm.nslab[j] = rm.n[j] = 0; rm.out[j] = nullptr; }
     mpg_prof_begin(5, s);
-    if (!pendulum) hipLaunchKernelGGL((k_wgrad_multi<8, 1, 6, 2>), dim3(8, off), dim3(NTHREAD), 0, s, m);
-    else hipLaunchKernelGGL((k_wgrad_multi<5, 1, 4, 1>), dim3(8, off), dim3(NTHREAD), 0, s, m);
+    if (!pendulum) hipLaunchKernelGGL((k_wgrad_multi<8, 1, 6, 2>), dim3(8 * off), dim3(NTHREAD), 0, s, m);
+    else hipLaunchKernelGGL((k_wgrad_multi<5, 1, 4, 1>), dim3(8 * off), dim3(NTHREAD), 0, s, m);
     mpg_prof_end(5, s);
     MPG_CHECK_LAUNCH("k_wgrad_multi");
     rm.n_sums = n_sums;

@@ -186,9 +186,11 @@ int launch_backward(const float* params, int in_dim, int out_dim, int ou, int ro
 // by 8 workgroups; k_reduce_slabs sums the <= 32 chunk slabs in a fixed order (deterministic, no float atomics).
 // -------------------------------------------------------------------------------------------------------
 template <int IN, int OU>
-__global__ void __launch_bounds__(NTHREAD, 2) k_wgrad(const WgradArgs a) {
+__global__ void __launch_bounds__(NTHREAD, 4) k_wgrad(const WgradArgs a) {
     __shared__ float sRed[NWAVE * wgrad_nq<IN, OU>() * 64];
-    wgrad_body<IN, OU>(a, blockIdx.x, blockIdx.y, sRed);
+    int chunk, sl;
+    wgrad_map(blockIdx.x, gridDim.x >> 3, chunk, sl);
+    wgrad_body<IN, OU>(a, sl, chunk, sRed);
 }
 
 __global__ void k_reduce_slabs(const float* __restrict__ slabs, int nslab, int n, float* __restrict__ out) {
@@ -216,7 +218,7 @@ int launch_wgrad(int in_dim, int out_dim, int ou, int rows, const XSpec& x, cons
     a.groups_per_chunk = wgrad_groups_per_chunk(ngroups);
     const int nch = (int)((ngroups + a.groups_per_chunk - 1) / a.groups_per_chunk);
     mpg_prof_begin(5, s);
-#define CALL(I, O) hipLaunchKernelGGL((k_wgrad<I, O>), dim3(8, nch), dim3(NTHREAD), 0, s, a)
+#define CALL(I, O) hipLaunchKernelGGL((k_wgrad<I, O>), dim3(8 * nch), dim3(NTHREAD), 0, s, a)
     MPG_DISPATCH_NET(in_dim, ou, CALL)
 #undef CALL
     mpg_prof_end(5, s);

@@ -1,5 +1,7 @@
 // Weight-gradient workgroup body shared by the single-network and the multi-network launches.
 #pragma once
+#include <stdlib.h>
+
 #include "mlp_launch.h"
 
 namespace mlp {
@@ -50,72 +52,97 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int sl, con
     //      hidden; later groups (long chunks, e.g. NADP's 26*B rows) are prefetched one ahead. ----
     struct Thin {
         f32x4 d10, d11, d20, d21, h20, h21;
-        float d3[4][OU], x[4][IN];
     };
     auto thin_load = [&](long g, Thin& t) {
         t.d10 = DZ1[(g * 16 + 2 * sl) * 64 + L.lane]; t.d11 = DZ1[(g * 16 + 2 * sl + 1) * 64 + L.lane];
         t.d20 = DZ2[(g * 16 + 2 * sl) * 64 + L.lane]; t.d21 = DZ2[(g * 16 + 2 * sl + 1) * 64 + L.lane];
         t.h20 = H2[(g * 16 + 2 * sl) * 64 + L.lane]; t.h21 = H2[(g * 16 + 2 * sl + 1) * 64 + L.lane];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const long gr = g * GROUP + L.row(j);
-            const bool live = gr < a.rows;
-#pragma unroll
-            for (int o = 0; o < OU; ++o) t.d3[j][o] = live ? a.dz3[gr * OU + o] : 0.f;
-#pragma unroll
-            for (int i = 0; i < IN; ++i) t.x[j][i] = live ? x_value<IN>(a.x, gr, i) : 0.f;
-        }
     };
-    auto thin_accumulate = [&](const Thin& t) {
+    // the per-row inputs (x, dz3) of the group are staged through a wave-private corner of the LDS scratch (64-bit
+    // global addressing for 4 rows x (IN + OU) scalars per lane would cost ~100 registers and one workgroup of residency)
+    float* stage = sRed + L.wave * (GROUP * 12);
+    auto thin_accumulate = [&](long g, const Thin& t) {
+#pragma unroll
+        for (int e = L.lane; e < GROUP * 12; e += 64) {
+            const int row = e / 12, i = e % 12;
+            const long gr = g * GROUP + row;
+            float v = 0.f;
+            if (gr < a.rows) {
+                if (i < IN) v = x_value<IN>(a.x, gr, i);
+                else if (i >= 8 && i - 8 < OU) v = a.dz3[gr * OU + (i - 8)];
+            }
+            stage[e] = v;
+        }
+        __builtin_amdgcn_wave_barrier();      // same wave writes and reads: LDS is in order within a wave
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
+            const float* rowp = stage + L.row(j) * 12;
+            float d3[OU], x[IN];
+#pragma unroll
+            for (int i = 0; i < IN; ++i) x[i] = rowp[i];
+#pragma unroll
+            for (int o = 0; o < OU; ++o) d3[o] = rowp[8 + o];
             gb1[0] += t.d10[j]; gb1[1] += t.d11[j];
             gb2[0] += t.d20[j]; gb2[1] += t.d21[j];
 #pragma unroll
             for (int i = 0; i < IN; ++i) {
-                gW1[0][i] = fmaf(t.x[j][i], t.d10[j], gW1[0][i]);
-                gW1[1][i] = fmaf(t.x[j][i], t.d11[j], gW1[1][i]);
+                gW1[0][i] = fmaf(x[i], t.d10[j], gW1[0][i]);
+                gW1[1][i] = fmaf(x[i], t.d11[j], gW1[1][i]);
             }
 #pragma unroll
             for (int o = 0; o < OU; ++o) {
-                gW3[0][o] = fmaf(t.h20[j], t.d3[j][o], gW3[0][o]);
-                gW3[1][o] = fmaf(t.h21[j], t.d3[j][o], gW3[1][o]);
-                if (L.c == 0) gb3[o] += t.d3[j][o];
+                gW3[0][o] = fmaf(t.h20[j], d3[o], gW3[0][o]);
+                gW3[1][o] = fmaf(t.h21[j], d3[o], gW3[1][o]);
+                if (L.c == 0) gb3[o] += d3[o];
             }
         }
+        __builtin_amdgcn_wave_barrier();
     };
-    Thin tcur;
     long tg = g0 + L.wave;
+#ifdef MPG_AB_WG_NOTHIN
+    const bool has_thin = false;
+#else
     const bool has_thin = tg < g1;
-    if (has_thin) thin_load(tg, tcur);
+#endif
 
-    // ---- dW2 on the matrix pipe, fragments of group g+1 in flight while group g multiplies ----
-    f32x4 nb0, nb1, na0, na1;
-    nb0 = DZ2[(g0 * 16 + 2 * sl) * 64 + L.lane]; nb1 = DZ2[(g0 * 16 + 2 * sl + 1) * 64 + L.lane];
-    na0 = H1[(g0 * 16 + 2 * L.wave) * 64 + L.lane]; na1 = H1[(g0 * 16 + 2 * L.wave + 1) * 64 + L.lane];
-    for (long g = g0; g < g1; ++g) {
-        const f32x4 b0 = nb0, b1 = nb1, a0 = na0, a1 = na1;
-        if (g + 1 < g1) {
-            nb0 = DZ2[((g + 1) * 16 + 2 * sl) * 64 + L.lane]; nb1 = DZ2[((g + 1) * 16 + 2 * sl + 1) * 64 + L.lane];
-            na0 = H1[((g + 1) * 16 + 2 * L.wave) * 64 + L.lane]; na1 = H1[((g + 1) * 16 + 2 * L.wave + 1) * 64 + L.lane];
-        }
+    // ---- dW2 on the matrix pipe.  The stashes come from HBM / Infinity Cache (~1.5 us away) while a group's 16 MFMAs
+    //      take 0.4 us: a ring of 2 groups of fragments per wave x 4 resident waves per SIMD keeps 8 groups in flight. ----
+    constexpr int DEPTH = 2;
+    f32x4 fb0[DEPTH], fb1[DEPTH], fa0[DEPTH], fa1[DEPTH];
+    auto frag_load = [&](long g, int slot) {
+        fb0[slot] = DZ2[(g * 16 + 2 * sl) * 64 + L.lane]; fb1[slot] = DZ2[(g * 16 + 2 * sl + 1) * 64 + L.lane];
+        fa0[slot] = H1[(g * 16 + 2 * L.wave) * 64 + L.lane]; fa1[slot] = H1[(g * 16 + 2 * L.wave + 1) * 64 + L.lane];
+    };
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {   // the float4's 4 entries are 4 k-steps (k = batch row)
-            acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], b0[j], acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], b1[j], acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], b0[j], acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], b1[j], acc[1][1], 0, 0, 0);
+    for (int d = 0; d < DEPTH; ++d)
+        if (g0 + d < g1) frag_load(g0 + d, d);
+#ifdef MPG_AB_WG_NOMFMA
+    for (long g = g0; g < g0; g += DEPTH) {
+#else
+    for (long g = g0; g < g1; g += DEPTH) {
+#endif
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            if (g + d < g1) {
+                const f32x4 b0 = fb0[d], b1 = fb1[d], a0 = fa0[d], a1 = fa1[d];
+                if (g + d + DEPTH < g1) frag_load(g + d + DEPTH, d);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {   // the float4's 4 entries are 4 k-steps (k = batch row)
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], b0[j], acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], b1[j], acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], b0[j], acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], b1[j], acc[1][1], 0, 0, 0);
+                }
+            }
         }
     }
+    // thin pieces after the matrix loop (their registers are then free): the chunk's groups are dealt round-robin to
+    // the 8 waves; the load latency is covered by the other resident waves
     if (has_thin) {
-        for (;;) {
-            const long tnext = tg + NWAVE;
-            Thin tn;
-            if (tnext < g1) thin_load(tnext, tn);
-            thin_accumulate(tcur);
-            if (tnext >= g1) break;
-            tcur = tn;
-            tg = tnext;
+        for (; tg < g1; tg += NWAVE) {
+            Thin tcur;
+            thin_load(tg, tcur);
+            thin_accumulate(tg, tcur);
         }
     }
     // ---- this workgroup's part of the chunk slab ----
@@ -134,6 +161,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int sl, con
             for (int j = 0; j < 4; ++j)
                 sW2[(16 * (2 * L.wave + u) + 4 * L.rg + j) * H + 32 * sl + 16 * t + L.c] = acc[u][t][j];
     // thin pieces: sum over the 8 waves and the 4 row quads through LDS in a fixed order
+    __syncthreads();   // the staging corners used above alias this scratch
     {
         float* dst = sRed + (L.wave * NQ) * 64 + L.lane;
         int q = 0;
@@ -180,8 +208,28 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int sl, con
 
 
 
+// 1-D grid of 8*nch workgroups -> (chunk, column slice).  Workgroups are dealt round-robin to the 8 XCDs, each with
+// its own L2; all 8 column slices of a chunk re-read the same H1 tiles, so they are mapped to the SAME XCD and to
+// consecutive dispatch slots there: the re-reads then hit that XCD's L2 instead of going to HBM 8 times.
+// (speed only - any mapping is correct.)
+__device__ __forceinline__ void wgrad_map(int b, int nch, int& chunk, int& sl) {
+    if ((nch & 7) == 0) {
+        const int xcd = b & 7, k = b >> 3;
+        chunk = xcd + 8 * (k >> 3);
+        sl = k & 7;
+    } else {
+        chunk = b >> 3;
+        sl = b & 7;
+    }
+}
+
 inline int wgrad_groups_per_chunk(long ngroups) {
-    long gp = (ngroups + 31) / 32;   // <= 32 chunk slabs
+    static const int max_chunks = [] {   // tuning knob for experiments (default 32 chunk slabs)
+        const char* e = getenv("MPG_WGRAD_CHUNKS");
+        const int v = e ? atoi(e) : 32;
+        return v >= 1 && v <= 64 ? v : 32;
+    }();
+    long gp = (ngroups + max_chunks - 1) / max_chunks;
     return (int)(gp < 1 ? 1 : gp);
 }
 
