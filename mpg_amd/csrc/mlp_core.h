@@ -286,11 +286,10 @@ __device__ __forceinline__ void stash_load(const float* __restrict__ base, long 
 // sD3 [16][MAXOUT] holds dL/dz3 (pre-activation of the used outputs).  h1/h2: this lane's stashed activations.
 // Produces dz2 and dz1 (C layout).  If WANT_DX, leaves per-wave partial sums of dz1*W1^T in sPartX
 // [NWAVE][16][XS] and ends on a barrier; the caller reduces them.
-template <int IN, int OU, bool WANT_DX>
-__device__ __forceinline__ void backward_group(const float* sD3, float* sA, float* sPartX, const Lane& L,
-                                               const float (&w2t)[128], const SmallRegs<IN, OU>& r,
-                                               const float (&h1)[2][4], const float (&h2)[2][4],
-                                               float (&dz1)[2][4], float (&dz2)[2][4]) {
+// first half: dz2 = (dz3 W3^T) * ELU'(h2) into the LDS A image (ends on the barrier that publishes it)
+template <int IN, int OU>
+__device__ __forceinline__ void backward_dz2(const float* sD3, float* sA, const Lane& L, const SmallRegs<IN, OU>& r,
+                                             const float (&h2)[2][4], float (&dz2)[2][4]) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         float d3[OU];
@@ -305,9 +304,20 @@ __device__ __forceinline__ void backward_group(const float* sD3, float* sA, floa
         }
     }
     store_c_to_a(sA, L, dz2);
+    MPG_STAMP_AT(1);
     lds_barrier();
+    MPG_STAMP_AT(2);
+}
+
+// second half: dh1 = dz2 W2^T on the matrix pipe, dz1 = dh1 * ELU'(h1), optional dx partials.  Global loads whose
+// results are needed after the MFMA block (h1) or in a later step should be issued between the two halves: any
+// s_waitcnt vmcnt(0) the compiler places earlier would otherwise also wait for them (the counter retires in order).
+template <int IN, int OU, bool WANT_DX>
+__device__ __forceinline__ void backward_rest(float* sA, float* sPartX, const Lane& L, const float (&w2t)[128],
+                                              const SmallRegs<IN, OU>& r, const float (&h1)[2][4], float (&dz1)[2][4]) {
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     mfma_16x256x32(sA, L, w2t, acc0, acc1);
+    MPG_STAMP_AT(3);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         dz1[0][j] = acc0[j] * elu_grad_from_out(h1[0][j]);
@@ -332,7 +342,38 @@ __device__ __forceinline__ void backward_group(const float* sD3, float* sA, floa
             for (int j = 0; j < 4; ++j) sPartX[(L.wave * GROUP + L.row(j)) * XS + L.c] = dx[j];
         }
     }
+    MPG_STAMP_AT(4);
     lds_barrier();
+    MPG_STAMP_AT(5);
+}
+
+
+template <int IN, int OU, bool WANT_DX>
+__device__ __forceinline__ void backward_group(const float* sD3, float* sA, float* sPartX, const Lane& L,
+                                               const float (&w2t)[128], const SmallRegs<IN, OU>& r,
+                                               const float (&h1)[2][4], const float (&h2)[2][4],
+                                               float (&dz1)[2][4], float (&dz2)[2][4]) {
+    backward_dz2<IN, OU>(sD3, sA, L, r, h2, dz2);
+    backward_rest<IN, OU, WANT_DX>(sA, sPartX, L, w2t, r, h1, dz1);
+}
+
+// all XS partial sums of one row at once: 2 x ds_read_b128 per wave, every read in flight before the first add
+__device__ __forceinline__ void dx_reduce_row(const float* sPartX, int row, float (&out)[XS]) {
+    f32x4 lo[NWAVE], hi[NWAVE];
+#pragma unroll
+    for (int w = 0; w < NWAVE; ++w) {
+        const f32x4* p = reinterpret_cast<const f32x4*>(sPartX + (w * GROUP + row) * XS);
+        lo[w] = p[0];
+        hi[w] = p[1];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int w = 0; w < NWAVE; ++w) { a += lo[w][i]; b += hi[w][i]; }
+        out[i] = a;
+        out[4 + i] = b;
+    }
 }
 
 __device__ __forceinline__ float dx_reduce(const float* sPartX, int row, int i) {

@@ -371,6 +371,7 @@ struct RollBwdArgs {
     int stash_all;                      // 0: parameter gradient through step 0 only (MPG); 1: every step (NADP)
     float *DZ1, *DZ2, *DZ3;             // stashes for the weight gradient: T = stash_all ? n+1 : 1 steps
     const float* pack;                  // nullable: packed backward image of the policy's W2
+    float* dbg;                         // diagnostic builds only
 };
 
 template <class ENV>
@@ -380,6 +381,9 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_bwd(const RollBwdArgs a)
     float* sA = smem;
     float* sD3 = sA + GROUP * LDA;
     float* sPartX = sD3 + GROUP * MAXOUT;
+    // carry state of the 16 trajectory lanes between steps (adjoint of the next obs, record of the next step): kept in
+    // LDS because registers are allocated for all 512 lanes while only 16 use them (the kernel sits at the 256 VGPR limit)
+    __shared__ __attribute__((aligned(16))) float sCarry[GROUP * 16];
     const Lane L;
     const int tid = threadIdx.x;
     const Net net = make_net(a.policy, OBS, 2 * ACT);
@@ -389,14 +393,23 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_bwd(const RollBwdArgs a)
     load_small<OBS, ACT>(net, L, r);
     const long R = (long)a.rows * a.M;
     const long ngroups = (R + GROUP - 1) / GROUP;
+#ifdef MPG_STAMP
+    if ((tid & 63) == 0) {
+        for (int k = 0; k < 10; ++k) g_st_acc[tid >> 6][k] = 0;
+        g_st_prev[tid >> 6] = __builtin_amdgcn_s_memtime();
+    }
+#endif
     for (long g = blockIdx.x; g < ngroups; g += gridDim.x) {
         const long tr = g * GROUP + tid;
         const bool own = tid < GROUP, live = own && tr < R;
-        float lam_next[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // dL/d(obs_{t+1})
+        if (tid < GROUP) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sCarry[tid * 16 + i] = 0.f;   // [0..8): dL/d(obs_{t+1}), [8..16): record t+1
+        }
         float lam[8];
         // Software pipeline over the steps: the (obs | action) record and the h2 stash of step t-1 are requested while
         // step t computes, so that no HBM / L2 latency sits on the serial chain.
-        float rec_cur[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, rec_next[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        float rec_cur[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         float rec_pre[8];
         float h2_cur[2][4], h2_pre[2][4];
         if (live) {
@@ -407,17 +420,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_bwd(const RollBwdArgs a)
         }
         stash_load(a.H2, (long)a.n * ngroups + g, L, h2_cur);
         for (int t = a.n; t >= 0; --t) {
-            if (t > 0) {   // prefetch step t-1
-                if (live) {
-                    const f32x4* rp = reinterpret_cast<const f32x4*>(a.SA + ((long)(t - 1) * R + tr) * SAW);
-                    const f32x4 r0 = rp[0], r1 = rp[1];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) { rec_pre[i] = r0[i]; rec_pre[4 + i] = r1[i]; }
-                }
-                stash_load(a.H2, (long)(t - 1) * ngroups + g, L, h2_pre);
-            }
             float h1[2][4];
-            stash_load(a.H1, (long)t * ngroups + g, L, h1);          // consumed after the MFMA block
             if (own) {
                 float ga[2] = {0.f, 0.f};
 #pragma unroll
@@ -431,7 +434,10 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_bwd(const RollBwdArgs a)
                     if (t < a.n) {
                         float on[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                        for (int i = 0; i < OBS; ++i) on[i] = rec_next[i];
+                        for (int i = 0; i < OBS; ++i) on[i] = sCarry[tid * 16 + 8 + i];
+                        float lam_next[8];
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) lam_next[i] = sCarry[tid * 16 + i];
                         ENV::vjp(o, act, on, lam_next, a.rho[t], lam, ga);
                     }
                     for (int ks = 0; ks < a.n_sel; ++ks)
@@ -457,10 +463,24 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_bwd(const RollBwdArgs a)
             }
             float dz1[2][4], dz2[2][4];
             lds_barrier();
+            MPG_STAMP_AT(0);
+            backward_dz2<OBS, ACT>(sD3, sA, L, r, h2_cur, dz2);
+            // all global loads of the step are issued HERE, behind the dz2 phase: h1 is consumed after the MFMA block,
+            // the record and h2 stash of step t-1 in the next iteration (software pipeline)
+            stash_load(a.H1, (long)t * ngroups + g, L, h1);
+            if (t > 0) {
+                if (live) {
+                    const f32x4* rp = reinterpret_cast<const f32x4*>(a.SA + ((long)(t - 1) * R + tr) * SAW);
+                    const f32x4 r0 = rp[0], r1 = rp[1];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { rec_pre[i] = r0[i]; rec_pre[4 + i] = r1[i]; }
+                }
+                stash_load(a.H2, (long)(t - 1) * ngroups + g, L, h2_pre);
+            }
             if (t > 0)
-                backward_group<OBS, ACT, true>(sD3, sA, sPartX, L, w2t, r, h1, h2_cur, dz1, dz2);
+                backward_rest<OBS, ACT, true>(sA, sPartX, L, w2t, r, h1, dz1);
             else
-                backward_group<OBS, ACT, false>(sD3, sA, sPartX, L, w2t, r, h1, h2_cur, dz1, dz2);
+                backward_rest<OBS, ACT, false>(sA, sPartX, L, w2t, r, h1, dz1);
             if (a.DZ1 && (a.stash_all || t == 0)) {
                 const long sg = (long)(a.stash_all ? t : 0) * ngroups + g;
                 stash_store(a.DZ1, sg, L, dz1);
@@ -468,13 +488,15 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_bwd(const RollBwdArgs a)
             }
             if (own) {
                 if (t > 0) {
+                    float dxr[XS];
+                    dx_reduce_row(sPartX, tid, dxr);
 #pragma unroll
-                    for (int i = 0; i < OBS; ++i) lam[i] += dx_reduce(sPartX, tid, i) * a.obs_scale[i];
+                    for (int i = 0; i < OBS; ++i) lam[i] += dxr[i] * a.obs_scale[i];
                 }
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    lam_next[i] = lam[i];
-                    rec_next[i] = rec_cur[i];
+                    sCarry[tid * 16 + i] = lam[i];
+                    sCarry[tid * 16 + 8 + i] = rec_cur[i];
                     rec_cur[i] = rec_pre[i];
                 }
             }
@@ -482,9 +504,14 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_bwd(const RollBwdArgs a)
             for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) h2_cur[tt][j] = h2_pre[tt][j];
+            MPG_STAMP_AT(7);
             // next iteration: sD3 is rewritten by wave 0 only after it has passed backward_group's final barrier,
             // and read by the others only after the __syncthreads above -> no extra barrier needed.
         }
+#ifdef MPG_STAMP
+        if ((tid & 63) == 0 && a.dbg)
+            for (int k = 0; k < 8; ++k) a.dbg[((long)blockIdx.x * NWAVE + (tid >> 6)) * 8 + k] = (float)g_st_acc[tid >> 6][k];
+#endif
     }
 }
 
@@ -631,6 +658,13 @@ int run_rollout_bwd(const mpg_cfg_t* cfg, const float* policy_params, int rows, 
     ba.stash_all = all_steps_param_grad ? 1 : 0;
     ba.DZ1 = DZ1; ba.DZ2 = DZ2; ba.DZ3 = DZ3;
     ba.pack = weight_cache_lookup(make_net(policy_params, od, 2 * ad).W2, 1);
+    ba.dbg = nullptr;
+#ifdef MPG_STAMP
+    static float* s_dbg_b = nullptr;
+    static int s_calls_b = 0;
+    if (!s_dbg_b) (void)hipMalloc(&s_dbg_b, 256 * 8 * 8 * sizeof(float));
+    ba.dbg = s_dbg_b;
+#endif
     mpg_prof_begin(1, s);
     if (cfg->env_kind == MPG_ENV_PATH_TRACKING)
         hipLaunchKernelGGL((k_rollout_bwd<PathTracking>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, ba);
@@ -638,6 +672,22 @@ int run_rollout_bwd(const mpg_cfg_t* cfg, const float* policy_params, int rows, 
         hipLaunchKernelGGL((k_rollout_bwd<Pendulum>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, ba);
     mpg_prof_end(1, s);
     MPG_CHECK_LAUNCH("k_rollout_bwd");
+#ifdef MPG_STAMP
+    if (++s_calls_b % 50 == 0) {
+        static float h[256 * 8 * 8];
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(h, s_dbg_b, sizeof(h), hipMemcpyDeviceToHost);
+        const int nwg = grid_for(ngroups);
+        for (int w = 0; w < 8; w += 7) {
+            double acc[8] = {0};
+            for (int b = 0; b < nwg; ++b) for (int k = 0; k < 8; ++k) acc[k] += h[(b * 8 + w) * 8 + k];
+            fprintf(stderr, "[stamp bwd] wave %d cycles/step:", w);
+            double tot = 0;
+            for (int k = 0; k < 8; ++k) { fprintf(stderr, " p%d=%.0f", k, acc[k] / nwg / (n + 1)); tot += acc[k] / nwg / (n + 1); }
+            fprintf(stderr, " total=%.0f\n", tot);
+        }
+    }
+#endif
     return MPG_OK;
 }
 
