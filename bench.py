@@ -52,6 +52,7 @@ def build_stack(dev, seed):
     learner = MPGLearner(PolicyWithQs, args, device=dev)
     rb = ReplayBuffer(args, seed, device=dev)
     opt = SingleProcessOffPolicyOptimizer(worker, learner, rb, None, args, sampling_interval=1)
+    worker.policy_with_value.sync_from_rank0()      # replicas start (and, with identical updates, stay) identical
     return args, worker, learner, rb, opt
 
 
@@ -134,8 +135,22 @@ def main():
 
     if rank != 0:
         return
-    fwd_tflops = FWD_FLOP_PER_STATE * B_PER_GPU / (fwd_ms * 1e-3) / 1e12
-    bwd_tflops = BWD_FLOP_PER_STATE * B_PER_GPU / (bwd_ms * 1e-3) / 1e12
+    # HBM bytes per launch from the PMC counters (FETCH_SIZE/WRITE_SIZE, separate rocprofv3 --pmc passes, gfx950
+    # correction FETCH x2 for wide coalesced reads) - collected by tools/pmc.sh and committed under profiles/
+    traffic = {}
+    tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    if os.path.exists(tpath):
+        with open(tpath) as fh:
+            traffic = json.load(fh).get('bytes_per_launch', {})
+
+    def roof(kernel, flop, ms, n):
+        tf = flop * B_PER_GPU / (ms * 1e-3) / 1e12
+        return {'kernel': kernel, 'bound': 'mfma', 'achieved': tf, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': tf / FP32_MFMA_PEAK_TFLOPS, 'traffic': traffic.get(kernel.split('<')[0]), 'avg_ms': ms, 'launches': n,
+                'algorithmic_flop_per_launch': flop * B_PER_GPU}
+    r_fwd = roof('k_rollout_fwd<PathTracking>', FWD_FLOP_PER_STATE, fwd_ms, fwd_n)
+    r_bwd = roof('k_rollout_bwd<PathTracking>', BWD_FLOP_PER_STATE, bwd_ms, bwd_n)
+    dominant, other = (r_bwd, r_fwd) if bwd_ms >= fwd_ms else (r_fwd, r_bwd)   # the dominant kernel of the step
     out = {
         'metric': 'env-steps/sec + grad-steps/sec, PathTrackingEnv MPG n=25 batch=4096',
         'value': world * B_PER_GPU * a.steps / dt, 'unit': 'env-steps/s',
@@ -147,17 +162,11 @@ def main():
                                'GPU; step = worker.sample(4096 env-steps) + add_batch + replay + compute_gradient + '
                                '(all-reduce) + apply_gradients',
                    'global_batch': world * B_PER_GPU, 'parallelism': 'dp%d' % world,
-                   'grad_allreduce_floats': int(learner.flat.numel())},
-        'roofline': {'kernel': 'k_rollout_fwd<PathTracking>', 'bound': 'mfma', 'achieved': fwd_tflops,
-                     'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': fwd_tflops / FP32_MFMA_PEAK_TFLOPS,
-                     'traffic': None, 'avg_ms': fwd_ms, 'launches': fwd_n,
-                     'algorithmic_flop_per_launch': FWD_FLOP_PER_STATE * B_PER_GPU},
-        'roofline_bwd': {'kernel': 'k_rollout_bwd<PathTracking>', 'bound': 'mfma', 'achieved': bwd_tflops,
-                         'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': bwd_tflops / FP32_MFMA_PEAK_TFLOPS,
-                         'traffic': None, 'avg_ms': bwd_ms, 'launches': bwd_n,
-                         'algorithmic_flop_per_launch': BWD_FLOP_PER_STATE * B_PER_GPU},
+                   'grad_allreduce_floats': int(learner.flat.numel()), 'native_step_driver': opt._fused is not None},
+        'roofline': dominant,
+        'roofline_other_rollout_kernel': other,
         'wgrad_kernel': {'kernel': 'k_wgrad_multi', 'avg_ms': wg_ms, 'launches': wg_n},
-        'env_step_kernel': {'kernel': 'k_step', 'avg_ms': env_ms, 'launches': env_n,
+        'env_step_kernel': {'kernel': 'k_step_store_reset', 'avg_ms': env_ms, 'launches': env_n,
                             'env_steps_per_sec_kernel_only': B_PER_GPU / (env_ms * 1e-3) if env_ms else None,
                             'algorithmic_bytes_per_env_step': 85},
     }

@@ -27,6 +27,6 @@ def default_args(alg='MPG-v2', env_id=None, **overrides):
         obs_ptype='scale', obs_scale=[0.001, 1 / 3, 0.1, 0.5] if pend else [1., 1., 2., 1., 2.4, 1 / 1200],
         rew_ptype='scale', rew_scale=1. if pend else 0.01, rew_shift=0.,
         policy_smoothing_sigma=0.2, policy_smoothing_clip=0.5,
-        max_iter=100000, seed=0)
+        max_iter=100000, seed=0, init_seed=0)
     d.update(overrides)
     return argparse.Namespace(**d)

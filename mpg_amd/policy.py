@@ -48,7 +48,7 @@ class PolicyWithQs(object):
                  double_Q=True, target=True, tau=0.005, delay_update=2, deterministic_policy=True, action_range=None,
                  policy_out_activation='tanh', env_id='PathTracking-v0', obs_scale=None, rew_scale=None, rew_shift=0.,
                  gamma=0.98, value_num_hidden_units=256, policy_num_hidden_units=256, policy_only=False,
-                 device='cuda', seed=0, **kwargs):
+                 device='cuda', seed=0, init_seed=0, **kwargs):
         assert value_num_hidden_units == 256 and policy_num_hidden_units == 256, 'kernels are built for 2x256 nets'
         assert deterministic_policy and not policy_only and target, 'hot-path scope: deterministic actor-critic with targets'
         self.device = torch.device(device)
@@ -60,7 +60,9 @@ class PolicyWithQs(object):
         self.dims = {'Q1': (obs_dim + act_dim, 1), 'Q2': (obs_dim + act_dim, 1), 'policy': (obs_dim, 2 * act_dim)}
         self.sizes = [ops.net_size(*self.dims[n]) for n in self.names]
         self.offsets = np.cumsum([0] + self.sizes)
-        gen = torch.Generator().manual_seed(seed)
+        # `init_seed` (not the per-process `seed` that drives exploration / replay / model noise) seeds the initial
+        # weights, so that data-parallel replicas start identical
+        gen = torch.Generator().manual_seed(init_seed)
         flat = torch.cat([init_mlp_flat(gen, *self.dims[n]) for n in self.names])
         self.params = flat.to(self.device)
         self.targets = self.params.clone()                                             # policy.py:60,68
@@ -93,6 +95,14 @@ class PolicyWithQs(object):
                 L.lib().mpg_weight_cache_unbind(ctypes.c_void_p(p))
         except Exception:
             pass
+
+    def sync_from_rank0(self):
+        """Data-parallel start-up: every replica takes rank 0's parameters / targets / optimizer state."""
+        import torch.distributed as dist
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            for t in (self.params, self.targets, self.m, self.v):
+                dist.broadcast(t, src=0)
+            self.refresh_weight_cache()
 
     # ---- views ----
     def net(self, name, target=False):
