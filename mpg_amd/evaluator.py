@@ -1,0 +1,61 @@
+"""Evaluator - device mirror of evaluator.py:25-236: deterministic fixed-length parallel episodes on the
+HIP env and the reference's per-episode metrics (evaluator.py:160-211), averaged over the agents.  Not on the throughput
+path; it is the learning-curve check that the fast path still learns (the reference's plots use a base score of -30,
+ploter.py:85)."""
+import torch
+
+from . import ops
+from .envs import PathTrackingEnv
+
+
+class Evaluator(object):
+    def __init__(self, policy_cls, env_id, args, device='cuda'):
+        assert env_id == 'PathTracking-v0'
+        self.args = args
+        self.device = torch.device(device)
+        self.num_eval_agent = int(getattr(args, 'num_eval_agent', 5))
+        self.fixed_steps = int(getattr(args, 'fixed_steps', 200))
+        self.env = PathTrackingEnv(num_agent=self.num_eval_agent, num_future_data=args.num_future_data, device=device,
+                                   seed=int(getattr(args, 'seed', 0)) + 424242)
+        self.policy_with_value = policy_cls(**vars(args), device=device)
+        self.iteration = 0
+        self.stats = {}
+
+    def set_weights(self, weights):
+        if weights is self.policy_with_value:
+            return
+        self.policy_with_value.set_weights(weights)
+
+    def share_policy(self, policy):
+        self.policy_with_value = policy
+
+    def set_ppc_params(self, params):
+        pass
+
+    def run_n_episodes_parallel(self, n=None):
+        """evaluator.py:118-156: reset, `fixed_steps` deterministic steps (done is ignored), metrics per episode."""
+        pw = self.policy_with_value
+        self.env._initialised = False                      # fresh draw of every agent
+        obses = self.env.reset()
+        obs_l, act_l, rew_l = [], [], []
+        for _ in range(self.fixed_steps):
+            actions = ops.policy_action(pw.cfg, pw.net('policy'), obses)      # compute_mode, policy.py:173-177
+            obs_l.append(obses)
+            act_l.append(actions)
+            obses, rewards, _, _ = self.env.step(actions)
+            rew_l.append(rewards)
+        obs, act, rew = torch.stack(obs_l), torch.stack(act_l), torch.stack(rew_l)      # [T, N, .]
+        rms = lambda x: torch.sqrt(torch.mean(torch.square(x), 0))
+        per_episode = dict(                                # metrics_for_an_episode, evaluator.py:160-184
+            episode_return=rew.sum(0), episode_len=torch.full_like(rew[0], float(self.fixed_steps)),
+            delta_y_mse=rms(obs[:, :, 3]), delta_phi_mse=rms(obs[:, :, 4]), delta_v_mse=rms(obs[:, :, 0]),
+            stationary_rew_mean=rew[20:].mean(0), steer_mse=rms(act[:, :, 0] * (1.2 * 3.141592653589793 / 9)),
+            acc_mse=rms(act[:, :, 1] * 3.))
+        mean = {k: float(v.mean().item()) for k, v in per_episode.items()}
+        return per_episode, mean
+
+    def run_evaluation(self, iteration):
+        self.iteration = iteration
+        _, mean = self.run_n_episodes_parallel()
+        self.stats = dict(iteration=iteration, **mean)
+        return mean

@@ -119,7 +119,7 @@ class MPGLearner(_LearnerBase):
         self.sample_num_in_learner = args.sample_num_in_learner
         self.M = args.M
         self.num_rollout_list_for_policy_update = list(args.num_rollout_list_for_policy_update)
-        assert not getattr(args, 'deriv_interval_policy', False), 'deriv_interval_policy=True is a "next" row (SURVEY §8 f4)'
+        self.deriv_interval_policy = bool(getattr(args, 'deriv_interval_policy', False))   # mpg_learner.py:247-248
         self.env = None
         if args.learner_version == 'MPG-v1':
             self.env = PathTrackingEnv(num_agent=self.batch_size, num_future_data=args.num_future_data, device=device)
@@ -183,6 +183,18 @@ class MPGLearner(_LearnerBase):
         inv_b = 1.0 / (rows * world)
         select = self.num_rollout_list_for_policy_update
         ws = rule_based_weights(iteration, self.args.rule_based_bias_total_ite, self.args.eta, select)
+        if self.deriv_interval_policy:
+            # every rollout step goes through pi_theta (full BPTT, mpg_learner.py:247-248): the fine-grained entry points
+            stats = self.flat[self.n_grad:]
+            for i, nm in enumerate(n for n in pw.names if n != 'policy'):
+                ops.q_loss_grad(self.cfg, pw.net(nm), b['batch_obs'], b['batch_actions'], b['batch_targets'],
+                                inv_b_global=inv_b, grad_out=self.grad(nm), loss_out=stats[i:i + 1])
+            ops.rollout_pg(self.cfg, pw.net('policy'), pw.net('Q1'), b['batch_obs'], eps, select, ws, M=self.M,
+                           inv_b_global=inv_b, all_steps_param_grad=True, grad_out=self.grad('policy'),
+                           stats_out=stats[2:2 + 2 * len(select)], n=max(select), noise_seed=self.seed, noise_ctr=self.counter)
+            out = self._finish(iteration, float(self.args.gradient_clip_norm))
+            self._lazy_stats = self._mpg_lazy_stats(iteration)
+            return out
         # one native call: critic losses/gradients + model rollout + mixed policy gradient (7 launches); the targets
         # were computed by get_batch_data (the reference caches them per batch, mpg_learner.py:402-403)
         ops.mpg_gradients(self.cfg, len(pw.names) - 1, pw.params, pw.targets, b['batch_obs'], b['batch_actions'],

@@ -27,7 +27,7 @@ class SingleProcessOffPolicyOptimizer(object):
             from .buffer import PrioritizedReplayBuffer
             from .learners import MPGLearner
             if type(learner) is MPGLearner and not isinstance(replay_buffer, PrioritizedReplayBuffer) and \
-                    getattr(args, 'buffer_type', 'normal') == 'normal':
+                    getattr(args, 'buffer_type', 'normal') == 'normal' and not learner.deriv_interval_policy:
                 from .fused import FusedMPGStep
                 self._fused = FusedMPGStep(worker, learner, replay_buffer, sampling_interval)
 

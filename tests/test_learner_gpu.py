@@ -187,3 +187,56 @@ def test_replay_sample_uniform_equals_indices_plus_gather():
     assert torch.equal(idx, ref[-1])
     for x, y in zip(out, ref[:5]):
         assert torch.equal(x, y)
+
+
+def test_fast_path_still_learns_path_tracking():
+    """Learning-curve check: MPG-v2 with the reference's default learning rates, 2000 iterations of
+    the native step driver (< 2 s), evaluated like evaluator.py:118-184 (200-step deterministic episodes).  A randomly
+    initialised policy scores about -4000 per episode; the reference's plots draw their base line at -30 (ploter.py:85)."""
+    from mpg_amd.buffer import ReplayBuffer
+    from mpg_amd.config import default_args
+    from mpg_amd.evaluator import Evaluator
+    from mpg_amd.learners import MPGLearner
+    from mpg_amd.optimizer import SingleProcessOffPolicyOptimizer
+    from mpg_amd.policy import PolicyWithQs
+    from mpg_amd.worker import OffPolicyWorker
+    args = default_args('MPG-v2', num_agent=256, batch_size=256, replay_batch_size=256, replay_starts=3000, num_eval_agent=256,
+                        rule_based_bias_total_ite=6000)
+    worker = OffPolicyWorker(PolicyWithQs, args.env_id, args, 0)
+    learner = MPGLearner(PolicyWithQs, args)
+    rb = ReplayBuffer(args, 0)
+    opt = SingleProcessOffPolicyOptimizer(worker, learner, rb, None, args, sampling_interval=1)
+    ev = Evaluator(PolicyWithQs, args.env_id, args)
+    ev.share_policy(worker.policy_with_value)
+    before = ev.run_evaluation(0)
+    for _ in range(2000):
+        opt.step()
+    after = ev.run_evaluation(2000)
+    assert before['episode_return'] < -1000
+    assert after['episode_return'] > -300 and after['delta_y_mse'] < 5.0 and after['delta_phi_mse'] < 0.2, (before, after)
+    assert int(worker.policy_with_value.nonfinite.sum().item()) == 0
+
+
+def test_deriv_interval_policy_learner_path(golden):
+    """deriv_interval_policy=True (mpg_learner.py:247-248): the learner routes through the fine-grained entry points;
+    critic gradients are the default path's, the policy gradient is the clipped full-BPTT gradient of the same loss."""
+    g = golden('mpg_v2_H256_B64.npz')
+    base = _learner(g, 'v2')
+    batch = [dev(g[k]) for k in ('batch_obs', 'batch_actions', 'batch_rewards', 'batch_obs_tp1', 'batch_dones')]
+    ref = torch.cat([x.reshape(-1) for x in base.compute_gradient(batch, None, None, 100, eps=dev(g['eps']))]).cpu().numpy()
+    full = _learner(g, 'v2')
+    full.deriv_interval_policy = True
+    got = torch.cat([x.reshape(-1) for x in full.compute_gradient(batch, None, None, 100, eps=dev(g['eps']))]).cpu().numpy()
+    pw = full.policy_with_value
+    nq = pw.offsets[2]
+    assert rel_l2(got[:nq], ref[:nq]) < 2e-6
+    ocfg = O.Cfg()
+    nets = O.Nets(ocfg, {n: g['w_' + n] for n in pw.names}, dtype=torch.float64)
+    reduced, _, _ = O.model_rollout_for_policy_update(ocfg, nets, torch.as_tensor(g['batch_obs']).double(),
+                                                      torch.as_tensor(g['eps']).double(), rollout_policy='policy')
+    ws = O.rule_based_weights(100, ocfg.total_ite, ocfg.eta, ocfg.select, torch.float64)
+    loss = torch.sum(ws * torch.stack([-reduced[k] for k in ocfg.select]))
+    pg, _ = O.clip_by_global_norm(list(torch.autograd.grad(loss, nets.w['policy'])), ocfg.clip)
+    want = np.concatenate([x.numpy().ravel() for x in pg])
+    assert rel_l2(got[nq:], want) < 1e-4
+    np.testing.assert_allclose(full.get_stats()['all_losses'], base.get_stats()['all_losses'], rtol=1e-5)
