@@ -99,6 +99,7 @@ class FusedMPGStep(object):
         """python objects -> context counters"""
         c, w, rb, ln, pw = self.c, self.worker, self.rb, self.learner, self.pw
         c.noise_ctr, c.env_ctr, c.replay_times, c.learner_counter = w._noise_ctr, w.env._ctr, rb.replay_times, ln.counter
+        c.worker_seed, c.env_seed, c.replay_seed, c.learner_seed = w.seed, w.env.seed, rb.seed, ln.seed
         c.ring_next, c.ring_size = rb._next_idx, rb._size
         for i, n in enumerate(pw.names):
             c.opt_steps[i] = pw.opt_steps[n]
@@ -113,6 +114,16 @@ class FusedMPGStep(object):
         w.obs = w.env.obs = self.t['w_obs']
         w.env.done = self.t['w_done']
         w.env._initialised = True
+
+    def reload(self):
+        """after the python objects were restored from a checkpoint: refresh the driver's own buffers and counters"""
+        w = self.worker
+        if w.obs is not self.t['w_obs']:
+            self.t['w_obs'].copy_(w.obs)
+        if w.env.done is not self.t['w_done']:
+            self.t['w_done'].copy_(w.env.done)
+        self.pull()
+        self.push()
 
     def step(self, iteration):
         s = L.stream()
