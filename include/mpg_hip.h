@@ -193,13 +193,16 @@ int mpg_rollout_pg(const mpg_cfg_t* cfg, const float* policy_params, const float
  * stats (16 floats): [0..n_q) critic losses, [2..2+n_select) return sums, [2+n_select..2+2 n_select) sums of squares.
  * Everything is this GPU's UN-clipped partial, scaled by inv_b_global = 1/B_global: all-reduce, then
  * mpg_clip_by_global_norm.  Same results as mpg_q_targets + mpg_q_loss_grad + mpg_rollout_pg (up to the association
- * of the slab sums) in 7 launches instead of 22 when rows % 16 == 0 and M == 1; otherwise it calls those. */
+ * of the slab sums) in 7 launches instead of 22 when rows % 16 == 0 and M == 1; otherwise it calls those.
+ * sq_part (nullable, (n_q+1)*MPG_CLIP_PARTS floats): on a single GPU the last launch also leaves the clip's partial sums
+ * of squares of `grad` there (what mpg_sq_partials would compute), ready for mpg_clip_adam_polyak. */
 size_t mpg_mpg_gradients_workspace_bytes(const mpg_cfg_t* cfg, int rows, int M, int n, int n_select, int n_q);
 int mpg_mpg_gradients(const mpg_cfg_t* cfg, int n_q, const float* params, const float* target_params, int rows,
                       const float* obs, const float* act, const float* rew, const float* obs_tp1, const float* y_in,
                       int M, int n, const int* select, int n_select, const float* w, const float* eps,
                       uint64_t noise_seed, uint64_t noise_ctr, float inv_b_global, float* grad, float* stats,
-                      float* y_out, void* ws, size_t ws_bytes, mpg_stream_t stream);
+                      float* y_out, float* sq_part /* nullable: see mpg_sq_partials */, void* ws, size_t ws_bytes,
+                      mpg_stream_t stream);
 
 /* NADPLearner.model_rollout_for_q_estimation  - learners/nadp.py:87-126: from (s, a_replay) roll n model steps,
  * later actions from pi_theta, y = G_n + gamma^n * Q1_target(s~_n, pi_theta(s~_n)) (no gradient).
@@ -227,9 +230,23 @@ int mpg_td3_policy_grad(const mpg_cfg_t* cfg, const float* policy_params, const 
  * g_k *= clip * min(1/norm, 1/clip) in place.  nonfinite_flags (device int[n_seg], nullable) receives 1 for
  * every network whose norm is not finite, else 0 (optimizer.py:357-361 zeroes such gradient lists).  Must run
  * AFTER the cross-GPU all-reduce: the clip is not linear. */
+#define MPG_CLIP_PARTS 272 /* partial sums of squares per network: one per 256 elements up to 69 632, strided beyond */
 int mpg_clip_by_global_norm(float* grad, const int* seg_sizes, int n_seg, float clip, float* norms,
-                            int* nonfinite_flags, float* scratch /* nullable: n_seg*64 floats -> parallel two-launch form */,
+                            int* nonfinite_flags,
+                            float* scratch /* nullable: n_seg*MPG_CLIP_PARTS floats -> parallel two-launch form */,
                             mpg_stream_t stream);
+
+/* The first half of the parallel clip on its own: sq_part[k*MPG_CLIP_PARTS + b] = sum of squares of block b
+ * (elements 256 b ... 256 b + 255, + multiples of 256*MPG_CLIP_PARTS) of network k, fixed summation order. */
+int mpg_sq_partials(const float* grad, const int* seg_sizes, int n_seg, float* sq_part, mpg_stream_t stream);
+
+/* mpg_clip_by_global_norm's second half + mpg_adam_polyak in ONE launch: norms from sq_part (mpg_sq_partials or
+ * mpg_mpg_gradients' by-product), grad scaled in place (it is the list compute_gradient returns), NaN guard
+ * (optimizer.py:357-361: any non-finite norm -> every Adam step sees zeros), Adam, Polyak.  Bit-identical to
+ * mpg_clip_by_global_norm(scratch) followed by mpg_adam_polyak(skip_flags = nonfinite_flags). */
+int mpg_clip_adam_polyak(float* w, float* m, float* v, float* target, float* grad, const float* sq_part,
+                         const int* seg_sizes, int n_seg, float clip, const float* lr_t, const int* do_adam,
+                         const int* do_polyak, float tau, float* norms, int* nonfinite_flags, mpg_stream_t stream);
 
 /* PolicyWithQs.apply_gradients + update_*_target  - policy.py:123-171.  For every network k (HOST arrays):
  * do_adam[k]: one Keras Adam step (beta .9/.999, eps 1e-7 outside the sqrt, TF ApplyAdam form) with the
@@ -338,7 +355,7 @@ typedef struct {
     float *params, *targets, *adam_m, *adam_v;
     float* grad;                      /* n_grad + 16 floats: gradients then statistics (q losses, return sums) */
     float* norms;                     /* n_nets */
-    float* clip_scratch;              /* n_nets * 64 floats (nullable: single-block clip) */
+    float* clip_scratch;              /* n_nets * MPG_CLIP_PARTS floats */
     int* nonfinite;                   /* n_nets */
     /* MPG-v1 only: the learner's own env for the n-step sampler (batch agents) */
     float *l_env_state, *l_obs, *l_act, *l_rewards;

@@ -234,38 +234,41 @@ struct ReduceMulti {
     float* out[3];
     int n_sums;
     SumJob sums[8];
+    float* sq_part;        // nullable: [n_jobs][MPG_CLIP_PARTS]
 };
 
 // blockIdx.y < n_jobs: out = sum of the chunk slabs (fixed order); blockIdx.y == n_jobs: the scalar sums, one per block
 __global__ void __launch_bounds__(256) k_reduce_multi(const ReduceMulti m) {
+    __shared__ float red[256];
     const int j = blockIdx.y;
     if (j < m.n_jobs) {
         const int i = blockIdx.x * blockDim.x + threadIdx.x;
-        if (i >= m.n[j]) return;
         const float* sl = m.slabs[j];
         const int n = m.n[j], ns = m.nslab[j];
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        int k = 0;
-        for (; k + 3 < ns; k += 4) {      // 4 loads in flight; the association ((s0+s4+..)+(s1+s5+..))+... is fixed
-            acc[0] += sl[(size_t)k * n + i];
-            acc[1] += sl[(size_t)(k + 1) * n + i];
-            acc[2] += sl[(size_t)(k + 2) * n + i];
-            acc[3] += sl[(size_t)(k + 3) * n + i];
+        float tot = 0.f;
+        if (i < n) {
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            int k = 0;
+            for (; k + 3 < ns; k += 4) {      // 4 loads in flight; the association ((s0+s4+..)+(s1+s5+..))+... is fixed
+                acc[0] += sl[(size_t)k * n + i];
+                acc[1] += sl[(size_t)(k + 1) * n + i];
+                acc[2] += sl[(size_t)(k + 2) * n + i];
+                acc[3] += sl[(size_t)(k + 3) * n + i];
+            }
+            for (; k < ns; ++k) acc[0] += sl[(size_t)k * n + i];
+            tot = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+            m.out[j][i] = tot;
         }
-        for (; k < ns; ++k) acc[0] += sl[(size_t)k * n + i];
-        m.out[j][i] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        if (m.sq_part) {   // the clip's per-block partial sums of squares (k_sq_blocks computes the same numbers)
+            const float sq = mpg_block_sum256(fmaf(tot, tot, 0.f), red);
+            if (threadIdx.x == 0 && (int)blockIdx.x < MPG_CLIP_PARTS) m.sq_part[j * MPG_CLIP_PARTS + blockIdx.x] = sq;
+        }
     } else if ((int)blockIdx.x < m.n_sums) {
-        __shared__ float red[256];
         const SumJob sj = m.sums[blockIdx.x];
         float s = 0.f;
         for (int i = threadIdx.x; i < sj.n; i += 256) s += sj.src[(size_t)i * sj.stride];
-        red[threadIdx.x] = s;
-        __syncthreads();
-        for (int w = 128; w > 0; w >>= 1) {
-            if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) sj.dst[0] = red[0];
+        const float t = mpg_block_sum256(s, red);
+        if (threadIdx.x == 0) sj.dst[0] = t;
     }
 }
 
@@ -336,7 +339,7 @@ int launch_qslice_fused(const float* q_params, int qin, int R, int n_sel, const 
     return MPG_OK;
 }
 
-int launch_wgrad_multi(const WgradJob* jobs, int n_jobs, const SumJob* sums, int n_sums, hipStream_t s) {
+int launch_wgrad_multi(const WgradJob* jobs, int n_jobs, const SumJob* sums, int n_sums, float* sq_part, hipStream_t s) {
     MPG_REQUIRE(jobs && n_jobs >= 1 && n_jobs <= 3 && n_sums >= 0 && n_sums <= 8, "launch_wgrad_multi: bad argument");
     WgradMulti m;
     ReduceMulti rm;
@@ -375,6 +378,13 @@ int launch_wgrad_multi(const WgradJob* jobs, int n_jobs, const SumJob* sums, int
     }
     int gx = (maxn + 255) / 256;
     if (gx < n_sums) gx = n_sums;
+    // the partials cover the grid only if every network fits MPG_CLIP_PARTS blocks and unused slots are written (as 0)
+    rm.sq_part = nullptr;
+    if (sq_part) {
+        MPG_REQUIRE(gx <= MPG_CLIP_PARTS, "launch_wgrad_multi: network larger than MPG_CLIP_PARTS * 256");
+        rm.sq_part = sq_part;
+        gx = MPG_CLIP_PARTS;
+    }
     hipLaunchKernelGGL(k_reduce_multi, dim3(gx, n_jobs + (n_sums ? 1 : 0)), dim3(256), 0, s, rm);
     MPG_CHECK_LAUNCH("k_reduce_multi");
     return MPG_OK;

@@ -105,7 +105,7 @@ struct SumJob {
     int n, stride;         // sums src[0], src[stride], ... (n terms)
     float* dst;
 };
-int launch_wgrad_multi(const WgradJob* jobs, int n_jobs, const SumJob* sums, int n_sums, hipStream_t s);
+int launch_wgrad_multi(const WgradJob* jobs, int n_jobs, const SumJob* sums, int n_sums, float* sq_part, hipStream_t s);
 
 inline size_t stash_floats(int rows) { return (size_t)((rows + GROUP - 1) / GROUP) * GROUP * H; }
 

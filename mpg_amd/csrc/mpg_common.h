@@ -59,3 +59,18 @@ __host__ __device__ static inline Philox4 philox4x32_10(uint32_t c0, uint32_t c1
 
 // u32 -> float in the open interval (0,1): 24 random mantissa bits, centred.
 __host__ __device__ static inline float u01(uint32_t u) { return ((float)(u >> 8) + 0.5f) * 5.9604644775390625e-08f; }
+
+// sum over the 256 threads of a block of one value each, fixed tree order; `red` = 256 floats of LDS.  Shared by every
+// kernel that produces the clip's per-block partial sums of squares, so that they are bit-identical.
+#ifdef __HIPCC__
+__device__ __forceinline__ float mpg_block_sum256(float a, float* red) {
+    red[threadIdx.x] = a;
+    __syncthreads();
+#pragma unroll
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    return red[0];
+}
+#endif

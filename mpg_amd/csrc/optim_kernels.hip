@@ -29,43 +29,48 @@ __device__ __forceinline__ int pack_index(int k, int n) {
     return ((((wave * 16 + (q >> 2)) * 2 + t) * 64 + rg * 16 + c) << 2) + (q & 3);
 }
 
-// parallel two-launch form of the clip: (1) 64 partial sums of squares per network, (2) every block rebuilds its
-// network's norm from the 64 partials in a fixed order and scales its own slice.
-constexpr int CLIP_PARTS = 64;
-__global__ void __launch_bounds__(256) k_sq_partial(const Segs sg, const float* __restrict__ grad, float* __restrict__ part) {
+// Parallel form of the clip.  (1) per-network partial sums of squares, one per 256-element block, MPG_CLIP_PARTS slots
+// per network (`k_sq_blocks`; the fused gradient kernel's final slab reduction writes the SAME partials for free, see
+// mpg_block_sum256 in mpg_common.h); (2) every consumer rebuilds its network's norm from the partials in one fixed order
+// (seg_sumsq) - so the norm is bit-identical whichever kernel produced the partials.
+constexpr int CLIP_PARTS = MPG_CLIP_PARTS;
+__global__ void __launch_bounds__(256) k_sq_blocks(const Segs sg, const float* __restrict__ grad, float* __restrict__ part) {
     __shared__ float red[256];
     const int k = blockIdx.y, b = blockIdx.x;
     const float* g = grad + sg.off[k];
     const int n = sg.n[k];
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    int i = b * 256 + threadIdx.x;
-    const int stride = CLIP_PARTS * 256;
-    for (; i + 3 * stride < n; i += 4 * stride) {
-        const float v0 = g[i], v1 = g[i + stride], v2 = g[i + 2 * stride], v3 = g[i + 3 * stride];
-        a0 = fmaf(v0, v0, a0); a1 = fmaf(v1, v1, a1); a2 = fmaf(v2, v2, a2); a3 = fmaf(v3, v3, a3);
+    float a = 0.f;
+    for (int i = b * 256 + threadIdx.x; i < n; i += CLIP_PARTS * 256) a = fmaf(g[i], g[i], a);   // one term when n <= 69 632
+    const float tot = mpg_block_sum256(a, red);
+    if (threadIdx.x == 0) part[k * CLIP_PARTS + b] = tot;
+}
+
+// sum of a network's CLIP_PARTS partials, executed by ONE wave (all 64 lanes return the total); fixed association
+__device__ __forceinline__ float seg_sumsq(const float* __restrict__ part, int k) {
+    const int lane = threadIdx.x & 63;
+    float a = 0.f;
+#pragma unroll
+    for (int j = 0; j < (CLIP_PARTS + 63) / 64; ++j) {
+        const int i = lane + 64 * j;
+        a += i < CLIP_PARTS ? part[k * CLIP_PARTS + i] : 0.f;
     }
-    for (; i < n; i += stride) a0 = fmaf(g[i], g[i], a0);
-    red[threadIdx.x] = (a0 + a1) + (a2 + a3);
-    __syncthreads();
-    for (int w = 128; w > 0; w >>= 1) {
-        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) part[k * CLIP_PARTS + b] = red[0];
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) a += __shfl_xor(a, m, 64);
+    return a;
 }
 
 __global__ void __launch_bounds__(256) k_clip_scale(const Segs sg, float* __restrict__ grad, const float* __restrict__ part,
                                                     float clip, float* __restrict__ norms, int* __restrict__ nonfinite) {
     __shared__ float s_scale;
     const int k = blockIdx.y;
-    if (threadIdx.x == 0) {
-        float tot = 0.f;
-        for (int b = 0; b < CLIP_PARTS; ++b) tot += part[k * CLIP_PARTS + b];
-        const float nrm = sqrtf(tot);
-        s_scale = clip * fminf(1.f / nrm, 1.f / clip);
-        if (blockIdx.x == 0) {
-            norms[k] = nrm;
-            if (nonfinite) nonfinite[k] = isfinite(nrm) ? 0 : 1;
+    if (threadIdx.x < 64) {
+        const float nrm = sqrtf(seg_sumsq(part, k));
+        if (threadIdx.x == 0) {
+            s_scale = clip * fminf(1.f / nrm, 1.f / clip);
+            if (blockIdx.x == 0) {
+                norms[k] = nrm;
+                if (nonfinite) nonfinite[k] = isfinite(nrm) ? 0 : 1;
+            }
         }
     }
     __syncthreads();
@@ -163,6 +168,60 @@ __global__ void k_adam_polyak(const Segs sg, float* __restrict__ w, float* __res
     }
 }
 
+// clip (from the partials) + Adam + Polyak in one launch: mpg_clip_adam_polyak.  Same arithmetic as
+// k_clip_scale followed by k_adam_polyak (the clipped gradient is also written back: it is the list the learner returns).
+__global__ void __launch_bounds__(256) k_clip_adam_polyak(const Segs sg, float* __restrict__ w, float* __restrict__ m,
+                                                          float* __restrict__ v, float* __restrict__ target,
+                                                          float* __restrict__ grad, const float* __restrict__ part, float clip,
+                                                          float tau, float* __restrict__ norms, int* __restrict__ nonfinite) {
+    __shared__ float s_norm[MAXSEG];
+    const int k = blockIdx.y;
+    const int wave = threadIdx.x >> 6;
+    for (int q = wave; q < sg.n_seg; q += 4) {
+        const float nrm = sqrtf(seg_sumsq(part, q));
+        if ((threadIdx.x & 63) == 0) s_norm[q] = nrm;
+    }
+    __syncthreads();
+    bool bad = false;                                         // optimizer.py:357-361
+    for (int q = 0; q < sg.n_seg; ++q) bad |= !isfinite(s_norm[q]);
+    const float nrm = s_norm[k];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        norms[k] = nrm;
+        if (nonfinite) nonfinite[k] = isfinite(nrm) ? 0 : 1;
+    }
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= sg.n[k]) return;
+    const int j = sg.off[k] + i;
+    const float gc = grad[j] * (clip * fminf(1.f / nrm, 1.f / clip));
+    grad[j] = gc;
+    const float b1 = 0.9f, b2 = 0.999f, eps = 1e-7f;
+    float wj = w[j];
+    if (sg.do_adam[k]) {
+        const float g = bad ? 0.f : gc;
+        float mj = m[j], vj = v[j];
+        mj += (g - mj) * (1.f - b1);
+        vj += (g * g - vj) * (1.f - b2);
+        wj -= sg.lr_t[k] * mj / (sqrtf(vj) + eps);
+        m[j] = mj; v[j] = vj; w[j] = wj;
+    }
+    const int e = sg.w2_off[k] >= 0 ? i - sg.w2_off[k] : -1;
+    const bool in_w2 = e >= 0 && e < HH;
+    if (in_w2 && sg.do_adam[k] && sg.cache_w) {
+        const int row = e >> 8, col = e & 255;
+        sg.cache_w[(size_t)(2 * k) * HH + pack_index(row, col)] = wj;
+        sg.cache_w[(size_t)(2 * k + 1) * HH + pack_index(col, row)] = wj;
+    }
+    if (sg.do_polyak[k] && target) {
+        const float tj = tau * wj + (1.f - tau) * target[j];
+        target[j] = tj;
+        if (in_w2 && sg.cache_t) {
+            const int row = e >> 8, col = e & 255;
+            sg.cache_t[(size_t)(2 * k) * HH + pack_index(row, col)] = tj;
+            sg.cache_t[(size_t)(2 * k + 1) * HH + pack_index(col, row)] = tj;
+        }
+    }
+}
+
 int fill(Segs& sg, int n_seg, const int* seg_sizes) {
     if (n_seg <= 0 || n_seg > MAXSEG || !seg_sizes) return -1;
     sg.n_seg = n_seg;
@@ -192,20 +251,19 @@ extern "C" int mpg_clip_by_global_norm(float* grad, const int* seg_sizes, int n_
     }
     int maxn = 0;
     for (int k = 0; k < n_seg; ++k) maxn = sg.n[k] > maxn ? sg.n[k] : maxn;
-    hipLaunchKernelGGL(k_sq_partial, dim3(CLIP_PARTS, n_seg), dim3(256), 0, mpg_stream(stream), sg, grad, scratch);
-    MPG_CHECK_LAUNCH("k_sq_partial");
+    hipLaunchKernelGGL(k_sq_blocks, dim3(CLIP_PARTS, n_seg), dim3(256), 0, mpg_stream(stream), sg, grad, scratch);
+    MPG_CHECK_LAUNCH("k_sq_blocks");
     hipLaunchKernelGGL(k_clip_scale, dim3((maxn + 1023) / 1024, n_seg), dim3(256), 0, mpg_stream(stream), sg, grad, scratch, clip,
                        norms, nonfinite_flag);
     MPG_CHECK_LAUNCH("k_clip_scale");
     return MPG_OK;
 }
 
-extern "C" int mpg_adam_polyak(float* w, float* m, float* v, float* target, const float* grad, const int* seg_sizes,
-                               int n_seg, const float* lr_t, const int* do_adam, const int* do_polyak, float tau,
-                               const int* skip_flags, int n_skip_flags, mpg_stream_t stream) {
-    Segs sg;
-    MPG_REQUIRE(w && m && v && grad && lr_t && do_adam && do_polyak && fill(sg, n_seg, seg_sizes) > 0,
-                "mpg_adam_polyak: bad argument");
+namespace {
+// per-network Adam/Polyak switches + the packed register images of bound buffers (kept in sync inside the same kernel)
+int fill_adam(Segs& sg, int n_seg, const int* seg_sizes, const float* w, const float* target, const float* lr_t,
+              const int* do_adam, const int* do_polyak, int* maxn_out) {
+    if (fill(sg, n_seg, seg_sizes) <= 0) return -1;
     int maxn = 0;
     for (int k = 0; k < n_seg; ++k) {
         sg.lr_t[k] = lr_t[k];
@@ -213,27 +271,59 @@ extern "C" int mpg_adam_polyak(float* w, float* m, float* v, float* target, cons
         sg.do_polyak[k] = do_polyak[k];
         if (sg.n[k] > maxn) maxn = sg.n[k];
     }
-    // keep the packed register images of bound buffers in sync inside the same kernel (no extra launch)
-    {
-        int w2o[MAXSEG], nn = 0;
-        float* cw = nullptr;
-        if (weight_cache_info(w, &cw, w2o, &nn) && nn == n_seg) {
-            sg.cache_w = cw;
-            for (int k = 0; k < n_seg; ++k) sg.w2_off[k] = w2o[k] - sg.off[k];
-            float* ct = nullptr;
-            int w2t[MAXSEG], nt = 0;
-            if (target && weight_cache_info(target, &ct, w2t, &nt) && nt == n_seg) sg.cache_t = ct;
-        } else if (target) {
-            float* ct = nullptr;
-            int w2t[MAXSEG], nt = 0;
-            if (weight_cache_info(target, &ct, w2t, &nt) && nt == n_seg) {
-                sg.cache_t = ct;
-                for (int k = 0; k < n_seg; ++k) sg.w2_off[k] = w2t[k] - sg.off[k];
-            }
+    *maxn_out = maxn;
+    int w2o[MAXSEG], nn = 0;
+    float* cw = nullptr;
+    if (weight_cache_info(w, &cw, w2o, &nn) && nn == n_seg) {
+        sg.cache_w = cw;
+        for (int k = 0; k < n_seg; ++k) sg.w2_off[k] = w2o[k] - sg.off[k];
+        float* ct = nullptr;
+        int w2t[MAXSEG], nt = 0;
+        if (target && weight_cache_info(target, &ct, w2t, &nt) && nt == n_seg) sg.cache_t = ct;
+    } else if (target) {
+        float* ct = nullptr;
+        int w2t[MAXSEG], nt = 0;
+        if (weight_cache_info(target, &ct, w2t, &nt) && nt == n_seg) {
+            sg.cache_t = ct;
+            for (int k = 0; k < n_seg; ++k) sg.w2_off[k] = w2t[k] - sg.off[k];
         }
     }
+    return 0;
+}
+}  // namespace
+
+extern "C" int mpg_adam_polyak(float* w, float* m, float* v, float* target, const float* grad, const int* seg_sizes,
+                               int n_seg, const float* lr_t, const int* do_adam, const int* do_polyak, float tau,
+                               const int* skip_flags, int n_skip_flags, mpg_stream_t stream) {
+    Segs sg;
+    int maxn = 0;
+    MPG_REQUIRE(w && m && v && grad && lr_t && do_adam && do_polyak &&
+                    fill_adam(sg, n_seg, seg_sizes, w, target, lr_t, do_adam, do_polyak, &maxn) == 0,
+                "mpg_adam_polyak: bad argument");
     hipLaunchKernelGGL(k_adam_polyak, dim3((maxn + 255) / 256, n_seg), dim3(256), 0, mpg_stream(stream), sg, w, m, v,
                        target, grad, tau, skip_flags, skip_flags ? n_skip_flags : 0);
     MPG_CHECK_LAUNCH("k_adam_polyak");
+    return MPG_OK;
+}
+
+extern "C" int mpg_sq_partials(const float* grad, const int* seg_sizes, int n_seg, float* sq_part, mpg_stream_t stream) {
+    Segs sg;
+    MPG_REQUIRE(grad && sq_part && fill(sg, n_seg, seg_sizes) > 0, "mpg_sq_partials: bad argument");
+    hipLaunchKernelGGL(k_sq_blocks, dim3(CLIP_PARTS, n_seg), dim3(256), 0, mpg_stream(stream), sg, grad, sq_part);
+    MPG_CHECK_LAUNCH("k_sq_blocks");
+    return MPG_OK;
+}
+
+extern "C" int mpg_clip_adam_polyak(float* w, float* m, float* v, float* target, float* grad, const float* sq_part,
+                                    const int* seg_sizes, int n_seg, float clip, const float* lr_t, const int* do_adam,
+                                    const int* do_polyak, float tau, float* norms, int* nonfinite_flags, mpg_stream_t stream) {
+    Segs sg;
+    int maxn = 0;
+    MPG_REQUIRE(w && m && v && grad && sq_part && norms && lr_t && do_adam && do_polyak && clip > 0.f &&
+                    fill_adam(sg, n_seg, seg_sizes, w, target, lr_t, do_adam, do_polyak, &maxn) == 0,
+                "mpg_clip_adam_polyak: bad argument");
+    hipLaunchKernelGGL(k_clip_adam_polyak, dim3((maxn + 255) / 256, n_seg), dim3(256), 0, mpg_stream(stream), sg, w, m, v,
+                       target, grad, sq_part, clip, tau, norms, nonfinite_flags);
+    MPG_CHECK_LAUNCH("k_clip_adam_polyak");
     return MPG_OK;
 }

@@ -845,7 +845,7 @@ extern "C" int mpg_mpg_gradients(const mpg_cfg_t* cfg, int n_q, const float* par
                                  const float* obs, const float* act, const float* rew, const float* obs_tp1,
                                  const float* y_in, int M, int n, const int* select, int n_select, const float* w,
                                  const float* eps, uint64_t noise_seed, uint64_t noise_ctr, float inv_b_global, float* grad,
-                                 float* stats, float* y_out, void* ws, size_t ws_bytes, mpg_stream_t stream) {
+                                 float* stats, float* y_out, float* sq_part, void* ws, size_t ws_bytes, mpg_stream_t stream) {
     MPG_REQUIRE(cfg_ok(cfg) && (n_q == 1 || n_q == 2), "mpg_mpg_gradients: unsupported cfg / n_q");
     MPG_REQUIRE(params && obs && act && select && w && grad && stats && y_out && ws, "mpg_mpg_gradients: null pointer");
     MPG_REQUIRE(y_in || (target_params && rew && obs_tp1), "mpg_mpg_gradients: either y_in or the target inputs are required");
@@ -879,8 +879,11 @@ extern "C" int mpg_mpg_gradients(const mpg_cfg_t* cfg, int n_q, const float* par
             int rc = mpg_q_loss_grad(cfg, qp[k], rows, obs, act, y, inv_b_global, stats + k, gq[k], nullptr, w0, l.fallback0, stream);
             if (rc) return rc;
         }
-        return mpg_rollout_pg(cfg, policy, qp[0], rows, M, n, select, n_select, w, obs, eps, noise_seed, noise_ctr, inv_b_global, 0,
-                              stats + 2, stats + 2 + n_select, gp, w1, l.fallback1, stream);
+        int rc = mpg_rollout_pg(cfg, policy, qp[0], rows, M, n, select, n_select, w, obs, eps, noise_seed, noise_ctr, inv_b_global, 0,
+                                stats + 2, stats + 2 + n_select, gp, w1, l.fallback1, stream);
+        if (rc || !sq_part) return rc;
+        const int sizes[3] = {q_size, n_q == 2 ? q_size : net_size(od, 2 * ad), net_size(od, 2 * ad)};
+        return mpg_sq_partials(grad, sizes, n_q + 1, sq_part, stream);
     }
 
     Carver cv(ws, ws_bytes);
@@ -939,5 +942,5 @@ extern "C" int mpg_mpg_gradients(const mpg_cfg_t* cfg, int n_q, const float* par
         sums[ns].src = ret_part + (size_t)k * ngroups * 2 + 1; sums[ns].n = ngroups; sums[ns].stride = 2; sums[ns].dst = stats + 2 + n_select + k; ++ns;
     }
     MPG_REQUIRE(n_q + 2 * n_select <= 8, "mpg_mpg_gradients: too many statistics (n_select <= 3 with two critics)");
-    return launch_wgrad_multi(jobs, n_q + 1, sums, ns, s);
+    return launch_wgrad_multi(jobs, n_q + 1, sums, ns, sq_part, s);
 }

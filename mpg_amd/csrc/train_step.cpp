@@ -130,14 +130,17 @@ extern "C" int mpg_step_begin(mpg_train_ctx_t* c, int iteration, mpg_stream_t s)
     const float* y_in = (c->learner_version == 2 && fresh) ? nullptr : c->b_targets;
     TRY(mpg_mpg_gradients(&c->cfg, l.n_nets - 1, c->params, c->targets, c->batch, c->b_obs, c->b_act, c->b_rew, c->b_obs2, y_in,
                           c->M, c->n, c->select, c->n_select, w, nullptr, c->learner_seed, c->learner_counter, inv_b, c->grad,
-                          c->grad + l.n_grad, c->b_targets, c->ws1, c->ws1_bytes, s));
+                          c->grad + l.n_grad, c->b_targets, c->world_size == 1 ? c->clip_scratch : nullptr, c->ws1, c->ws1_bytes,
+                          s));
     return MPG_OK;
 }
 
 extern "C" int mpg_step_end(mpg_train_ctx_t* c, int iteration, mpg_stream_t s) {
-    MPG_REQUIRE(ctx_ok(c) && c->norms && c->nonfinite && c->adam_m && c->adam_v, "mpg_step_end: incomplete context");
+    MPG_REQUIRE(ctx_ok(c) && c->norms && c->nonfinite && c->adam_m && c->adam_v && c->clip_scratch, "mpg_step_end: incomplete context");
     const Layout l = layout(c);
-    TRY(mpg_clip_by_global_norm(c->grad, l.sizes, l.n_nets, c->clip, c->norms, c->nonfinite, c->clip_scratch, s));   // mpg_learner.py:415-431
+    // per-network clip_by_global_norm (mpg_learner.py:415-431): on one GPU the partial sums of squares were left in
+    // clip_scratch by mpg_mpg_gradients; after an all-reduce they are recomputed from the reduced gradient
+    if (c->world_size > 1) TRY(mpg_sq_partials(c->grad, l.sizes, l.n_nets, c->clip_scratch, s));
     // PolicyWithQs.apply_gradients, policy.py:123-156
     const bool delayed = iteration % c->delay_update == 0;
     float lr_t[3];
@@ -152,6 +155,6 @@ extern "C" int mpg_step_end(mpg_train_ctx_t* c, int iteration, mpg_stream_t s) {
         do_polyak[k] = delayed ? 1 : 0;
         if (upd) c->opt_steps[k] = t;
     }
-    return mpg_adam_polyak(c->params, c->adam_m, c->adam_v, c->targets, c->grad, l.sizes, l.n_nets, lr_t, do_adam, do_polyak,
-                           c->tau, c->nonfinite, l.n_nets, s);
+    return mpg_clip_adam_polyak(c->params, c->adam_m, c->adam_v, c->targets, c->grad, c->clip_scratch, l.sizes, l.n_nets, c->clip,
+                                lr_t, do_adam, do_polyak, c->tau, c->norms, c->nonfinite, s);
 }

@@ -48,7 +48,7 @@ class _LearnerBase(object):
         self.n_grad = int(pw.offsets[-1])
         self.flat = torch.zeros(self.n_grad + N_STATS, dtype=torch.float32, device=self.device)
         self.norms = torch.zeros(len(pw.names), dtype=torch.float32, device=self.device)
-        self.clip_scratch = torch.zeros(len(pw.names) * 64, dtype=torch.float32, device=self.device)
+        self.clip_scratch = torch.zeros(len(pw.names) * ops.CLIP_PARTS, dtype=torch.float32, device=self.device)
         self.seed = int(getattr(args, 'seed', 0)) + 12345
         self._noise_gen = torch.Generator(device=self.device)
         self._noise_gen.manual_seed(self.seed)

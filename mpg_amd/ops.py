@@ -158,6 +158,29 @@ def rollout_pg(cfg, policy_params, q1_params, obs0, eps, select, w, M=1, inv_b_g
     return stats[:ns], stats[ns:], grad
 
 
+CLIP_PARTS = 272          # MPG_CLIP_PARTS (include/mpg_hip.h)
+
+
+def sq_partials(grad, seg_sizes, sq_part=None):
+    ns = len(seg_sizes)
+    part = sq_part if sq_part is not None else torch.empty(ns * CLIP_PARTS, dtype=torch.float32, device=grad.device)
+    segs = (ctypes.c_int * ns)(*[int(s) for s in seg_sizes])
+    L.call('mpg_sq_partials', L.ptr(_f32(grad)), segs, L.c_int(ns), L.ptr(part), L.stream())
+    return part
+
+
+def clip_adam_polyak(w, m, v, target, grad, sq_part, seg_sizes, clip, lr_t, do_adam, do_polyak, tau, norms, nonfinite=None):
+    """mpg_clip_adam_polyak: second half of the clip + Adam + Polyak in one launch"""
+    ns = len(seg_sizes)
+    segs = (ctypes.c_int * ns)(*[int(s) for s in seg_sizes])
+    lr = (ctypes.c_float * ns)(*[float(x) for x in lr_t])
+    da = (ctypes.c_int * ns)(*[int(x) for x in do_adam])
+    dp = (ctypes.c_int * ns)(*[int(x) for x in do_polyak])
+    L.call('mpg_clip_adam_polyak', L.ptr(_f32(w)), L.ptr(_f32(m)), L.ptr(_f32(v)), L.ptr(target), L.ptr(_f32(grad)),
+           L.ptr(_f32(sq_part)), segs, L.c_int(ns), L.c_float(clip), lr, da, dp, L.c_float(tau), L.ptr(norms), L.ptr(nonfinite),
+           L.stream())
+
+
 def clip_by_global_norm(grad, seg_sizes, clip, norms_out=None, nonfinite=None, scratch=None):
     ns = len(seg_sizes)
     norms = norms_out if norms_out is not None else torch.empty(ns, dtype=torch.float32, device=grad.device)
@@ -203,7 +226,7 @@ def td3_policy_grad(cfg, policy_params, q1, q2, obs, inv_b_global=None, grad_out
 
 
 def mpg_gradients(cfg, n_q, params, target_params, obs, act, rew, obs_tp1, y_in, select, w, grad, stats, y_out, M=1, n=None,
-                  eps=None, noise_seed=0, noise_ctr=0, inv_b_global=None):
+                  eps=None, noise_seed=0, noise_ctr=0, inv_b_global=None, sq_part=None):
     """mpg_mpg_gradients: MPGLearner.compute_gradient without the clip (targets unless y_in, critic grads, mixed PG)."""
     rows, dev = obs.shape[0], obs.device
     if eps is not None:
@@ -220,4 +243,4 @@ def mpg_gradients(cfg, n_q, params, target_params, obs, act, rew, obs_tp1, y_in,
            L.ptr(_f32(obs)), L.ptr(_f32(act)), L.ptr(rew), L.ptr(obs_tp1), L.ptr(y_in), L.c_int(M), L.c_int(n), sel,
            L.c_int(ns), wv, L.ptr(eps), L.c_u64(noise_seed), L.c_u64(noise_ctr),
            L.c_float(inv_b_global if inv_b_global is not None else 1.0 / rows), L.ptr(_f32(grad)), L.ptr(_f32(stats)),
-           L.ptr(_f32(y_out)), L.ptr(ws), L.c_size_t(ws.numel()), L.stream())
+           L.ptr(_f32(y_out)), L.ptr(sq_part), L.ptr(ws), L.c_size_t(ws.numel()), L.stream())
