@@ -15,12 +15,13 @@ __device__ __forceinline__ void load_w2(const float* pack, const float* W2, bool
     else load_w2_fwd(W2, L, w);
 }
 
-constexpr int SMEM_FLOATS = GROUP * LDA + GROUP * XS + NWAVE * GROUP * MAXOUT + GROUP * MAXOUT + NWAVE * GROUP * XS + 4 * GROUP;
+constexpr int SMEM_FLOATS = 2 * GROUP * LDA + GROUP * XS + NWAVE * GROUP * MAXOUT + GROUP * MAXOUT + NWAVE * GROUP * XS + 4 * GROUP;
 struct Smem {
-    float *sA, *sX, *sPart, *sD3, *sPartX, *sQ;
+    float *sA, *sA1, *sX, *sPart, *sD3, *sPartX, *sQ;
     __device__ explicit Smem(float* base) {
         sA = base;
-        sX = sA + GROUP * LDA;
+        sA1 = sA + GROUP * LDA;
+        sX = sA1 + GROUP * LDA;
         sPart = sX + GROUP * XS;
         sD3 = sPart + NWAVE * GROUP * MAXOUT;
         sPartX = sD3 + GROUP * MAXOUT;
@@ -142,7 +143,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_qloss_fused(const QlossArgs a) {
         for (int i = 0; i < GROUP; ++i) s2 += m.sQ[i];
         a.loss_part[qi * ngroups + g] = 0.5f * a.inv_b * s2;
     }
-    backward_group<QIN, 1, false>(m.sD3, m.sA, m.sPartX, L, w2, r, h1, h2, dz1, dz2);
+    backward_group<QIN, 1, false>(m.sD3, m.sA, m.sA1, m.sPartX, L, w2, r, h1, h2, dz1, dz2);
     stash_store(st.dz1, g, L, dz1);
     stash_store(st.dz2, g, L, dz2);
 }
@@ -198,7 +199,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_qslice_fused(const QsliceArgs a)
         a.ret_part[g * 2] = s1;
         a.ret_part[g * 2 + 1] = s2;
     }
-    backward_group<QIN, 1, true>(m.sD3, m.sA, m.sPartX, L, w2, r, h1, h2, dz1, dz2);
+    backward_group<QIN, 1, true>(m.sD3, m.sA, m.sA1, m.sPartX, L, w2, r, h1, h2, dz1, dz2);
     if (tid < GROUP * QIN) {
         const int row = tid / QIN, i = tid % QIN;
         const long gr = g * GROUP + row;

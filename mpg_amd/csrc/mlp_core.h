@@ -312,8 +312,10 @@ __device__ __forceinline__ void backward_dz2(const float* sD3, float* sA, const 
 // second half: dh1 = dz2 W2^T on the matrix pipe, dz1 = dh1 * ELU'(h1), optional dx partials.  Global loads whose
 // results are needed after the MFMA block (h1) or in a later step should be issued between the two halves: any
 // s_waitcnt vmcnt(0) the compiler places earlier would otherwise also wait for them (the counter retires in order).
+// sA1: a second LDS image (GROUP*LDA floats) for dz1 - every wave reads back only the columns it wrote itself, so no
+// barrier is needed around it (re-using sA would need one: other waves may still be reading dz2 from it).
 template <int IN, int OU, bool WANT_DX>
-__device__ __forceinline__ void backward_rest(float* sA, float* sPartX, const Lane& L, const float (&w2t)[128],
+__device__ __forceinline__ void backward_rest(float* sA, float* sA1, float* sPartX, const Lane& L, const float (&w2t)[128],
                                               const SmallRegs<IN, OU>& r, const float (&h1)[2][4], float (&dz1)[2][4]) {
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     mfma_16x256x32(sA, L, w2t, acc0, acc1);
@@ -325,12 +327,11 @@ __device__ __forceinline__ void backward_rest(float* sA, float* sPartX, const La
     }
     if (WANT_DX) {
         // dx partial of this wave's 32 hidden columns on the matrix pipe: A = dz1 (this wave's own columns of the
-        // LDS A image), B = W1^T.  The barrier orders the image rewrite behind every wave's reads of dz2.
-        lds_barrier();
-        store_c_to_a(sA, L, dz1);
+        // second LDS image), B = W1^T.
+        store_c_to_a(sA1, L, dz1);
         __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): this wave reads back only what it wrote itself
         __builtin_amdgcn_wave_barrier();
-        const float* base = sA + L.c * LDA + L.rg * KS + 8 * L.wave;
+        const float* base = sA1 + L.c * LDA + L.rg * KS + 8 * L.wave;
         const f32x4 a0 = *reinterpret_cast<const f32x4*>(base), a1 = *reinterpret_cast<const f32x4*>(base + 4);
         f32x4 dx = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -349,12 +350,12 @@ __device__ __forceinline__ void backward_rest(float* sA, float* sPartX, const La
 
 
 template <int IN, int OU, bool WANT_DX>
-__device__ __forceinline__ void backward_group(const float* sD3, float* sA, float* sPartX, const Lane& L,
+__device__ __forceinline__ void backward_group(const float* sD3, float* sA, float* sA1, float* sPartX, const Lane& L,
                                                const float (&w2t)[128], const SmallRegs<IN, OU>& r,
                                                const float (&h1)[2][4], const float (&h2)[2][4],
                                                float (&dz1)[2][4], float (&dz2)[2][4]) {
     backward_dz2<IN, OU>(sD3, sA, L, r, h2, dz2);
-    backward_rest<IN, OU, WANT_DX>(sA, sPartX, L, w2t, r, h1, dz1);
+    backward_rest<IN, OU, WANT_DX>(sA, sA1, sPartX, L, w2t, r, h1, dz1);
 }
 
 // all XS partial sums of one row at once: 2 x ds_read_b128 per wave, every read in flight before the first add

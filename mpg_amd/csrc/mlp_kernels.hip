@@ -109,9 +109,10 @@ struct BwdArgs {
 
 template <int IN, int OU, bool WANT_DX>
 __global__ void __launch_bounds__(NTHREAD, 2) k_backward(const BwdArgs a) {
-    __shared__ __attribute__((aligned(16))) float smem[GROUP * LDA + GROUP * MAXOUT + NWAVE * GROUP * XS];
+    __shared__ __attribute__((aligned(16))) float smem[2 * GROUP * LDA + GROUP * MAXOUT + NWAVE * GROUP * XS];
     float* sA = smem;
-    float* sD3 = sA + GROUP * LDA;
+    float* sA1 = sA + GROUP * LDA;
+    float* sD3 = sA1 + GROUP * LDA;
     float* sPartX = sD3 + GROUP * MAXOUT;
     const Lane L;
     const Net net = make_net(a.params, a.in_dim, a.out_dim);
@@ -140,7 +141,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_backward(const BwdArgs a) {
         stash_load(a.h1, g, L, h1);
         stash_load(a.h2, g, L, h2);
         lds_barrier();
-        backward_group<IN, OU, WANT_DX>(sD3, sA, sPartX, L, w2t, r, h1, h2, dz1, dz2);
+        backward_group<IN, OU, WANT_DX>(sD3, sA, sA1, sPartX, L, w2t, r, h1, h2, dz1, dz2);
         if (a.dz1) stash_store(a.dz1, g, L, dz1);
         if (a.dz2) stash_store(a.dz2, g, L, dz2);
         if (WANT_DX) {

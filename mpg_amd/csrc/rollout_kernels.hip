@@ -377,9 +377,10 @@ struct RollBwdArgs {
 template <class ENV>
 __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_bwd(const RollBwdArgs a) {
     constexpr int OBS = ENV::OBS, ACT = ENV::ACT, QIN = OBS + ACT;
-    __shared__ __attribute__((aligned(16))) float smem[GROUP * LDA + GROUP * MAXOUT + NWAVE * GROUP * XS];
+    __shared__ __attribute__((aligned(16))) float smem[2 * GROUP * LDA + GROUP * MAXOUT + NWAVE * GROUP * XS];
     float* sA = smem;
-    float* sD3 = sA + GROUP * LDA;
+    float* sA1 = sA + GROUP * LDA;
+    float* sD3 = sA1 + GROUP * LDA;
     float* sPartX = sD3 + GROUP * MAXOUT;
     // carry state of the 16 trajectory lanes between steps (adjoint of the next obs, record of the next step): kept in
     // LDS because registers are allocated for all 512 lanes while only 16 use them (the kernel sits at the 256 VGPR limit)
@@ -478,9 +479,9 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_bwd(const RollBwdArgs a)
                 stash_load(a.H2, (long)(t - 1) * ngroups + g, L, h2_pre);
             }
             if (t > 0)
-                backward_rest<OBS, ACT, true>(sA, sPartX, L, w2t, r, h1, dz1);
+                backward_rest<OBS, ACT, true>(sA, sA1, sPartX, L, w2t, r, h1, dz1);
             else
-                backward_rest<OBS, ACT, false>(sA, sPartX, L, w2t, r, h1, dz1);
+                backward_rest<OBS, ACT, false>(sA, sA1, sPartX, L, w2t, r, h1, dz1);
             if (a.DZ1 && (a.stash_all || t == 0)) {
                 const long sg = (long)(a.stash_all ? t : 0) * ngroups + g;
                 stash_store(a.DZ1, sg, L, dz1);
