@@ -204,7 +204,7 @@ __device__ __forceinline__ void load_small(const Net& n, const Lane& L, SmallReg
 // sX  [16][XS]  inputs (already scaled), sA the LDS A image, sPart [NWAVE][16][MAXOUT] output partials.
 // On return h1/h2 hold this lane's C-layout activations and sPart the per-wave partial sums of h2*W3 (no bias);
 // the caller must have synchronised sX before the call and may read sPart right after (ends on a barrier).
-template <int IN, int OU>
+template <int IN, int OU, bool FINAL_BARRIER = true>
 __device__ __forceinline__ void forward_group(const float* sX, float* sA, float* sPart, const Lane& L,
                                               const float (&w2)[128], const SmallRegs<IN, OU>& r,
                                               float (&h1)[2][4], float (&h2)[2][4]) {
@@ -254,8 +254,10 @@ __device__ __forceinline__ void forward_group(const float* sX, float* sA, float*
         }
     }
     MPG_STAMP_AT(4);
-    lds_barrier();
-    MPG_STAMP_AT(5);
+    if (FINAL_BARRIER) {      // callers that have work to hide behind the slower waves issue the barrier themselves
+        lds_barrier();
+        MPG_STAMP_AT(5);
+    }
 }
 
 // sum of the 8 per-wave partials + bias for (row, o)
@@ -264,6 +266,13 @@ __device__ __forceinline__ float out_preact(const float* sPart, float bias, int 
 #pragma unroll
     for (int w = 0; w < NWAVE; ++w) z += sPart[(w * GROUP + row) * MAXOUT + o];
     return z;
+}
+// same sum as a depth-3 tree (the rollout's serial chain: 3 dependent adds instead of 8)
+__device__ __forceinline__ float out_preact_tree(const float* sPart, float bias, int row, int o) {
+    float p[NWAVE];
+#pragma unroll
+    for (int w = 0; w < NWAVE; ++w) p[w] = sPart[(w * GROUP + row) * MAXOUT + o];
+    return (((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]))) + bias;
 }
 
 // ---- G16 stash ------------------------------------------------------------------------------------------
@@ -314,7 +323,7 @@ __device__ __forceinline__ void backward_dz2(const float* sD3, float* sA, const 
 // s_waitcnt vmcnt(0) the compiler places earlier would otherwise also wait for them (the counter retires in order).
 // sA1: a second LDS image (GROUP*LDA floats) for dz1 - every wave reads back only the columns it wrote itself, so no
 // barrier is needed around it (re-using sA would need one: other waves may still be reading dz2 from it).
-template <int IN, int OU, bool WANT_DX>
+template <int IN, int OU, bool WANT_DX, bool FINAL_BARRIER = true>
 __device__ __forceinline__ void backward_rest(float* sA, float* sA1, float* sPartX, const Lane& L, const float (&w2t)[128],
                                               const SmallRegs<IN, OU>& r, const float (&h1)[2][4], float (&dz1)[2][4]) {
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -344,8 +353,10 @@ __device__ __forceinline__ void backward_rest(float* sA, float* sA1, float* sPar
         }
     }
     MPG_STAMP_AT(4);
-    lds_barrier();
-    MPG_STAMP_AT(5);
+    if (FINAL_BARRIER) {
+        lds_barrier();
+        MPG_STAMP_AT(5);
+    }
 }
 
 
@@ -358,22 +369,25 @@ __device__ __forceinline__ void backward_group(const float* sD3, float* sA, floa
     backward_rest<IN, OU, WANT_DX>(sA, sA1, sPartX, L, w2t, r, h1, dz1);
 }
 
-// all XS partial sums of one row at once: 2 x ds_read_b128 per wave, every read in flight before the first add
+// all XS partial sums of one row: ds_read_b128 pairs in two batches of four waves (32 VGPRs in flight; all sixteen
+// reads at once cost 64 VGPRs at a point where the reverse sweep has none to spare)
 __device__ __forceinline__ void dx_reduce_row(const float* sPartX, int row, float (&out)[XS]) {
-    f32x4 lo[NWAVE], hi[NWAVE];
 #pragma unroll
-    for (int w = 0; w < NWAVE; ++w) {
-        const f32x4* p = reinterpret_cast<const f32x4*>(sPartX + (w * GROUP + row) * XS);
-        lo[w] = p[0];
-        hi[w] = p[1];
-    }
+    for (int i = 0; i < XS; ++i) out[i] = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        float a = 0.f, b = 0.f;
+    for (int b = 0; b < NWAVE; b += 4) {
+        f32x4 lo[4], hi[4];
 #pragma unroll
-        for (int w = 0; w < NWAVE; ++w) { a += lo[w][i]; b += hi[w][i]; }
-        out[i] = a;
-        out[4 + i] = b;
+        for (int w = 0; w < 4; ++w) {
+            const f32x4* p = reinterpret_cast<const f32x4*>(sPartX + ((b + w) * GROUP + row) * XS);
+            lo[w] = p[0];
+            hi[w] = p[1];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            out[i] += (lo[0][i] + lo[1][i]) + (lo[2][i] + lo[3][i]);
+            out[4 + i] += (hi[0][i] + hi[1][i]) + (hi[2][i] + hi[3][i]);
+        }
     }
 }
 

@@ -38,8 +38,16 @@ __device__ __forceinline__ float fast_tanh(float z) {                       // 1
     return 1.f - 2.f * frcp(__expf(2.f * z) + 1.f);
 }
 
+// The forward step is split so that the part that needs the LATE-arriving action is a handful of fmas:
+//   pre(obs, eps) -> everything that does not depend on the action (the new state is affine in the action);
+//   finish(pre, action) -> new obs, raw reward.
+// pre runs before the barrier that publishes the output-layer partials, so the serial chain between two policy
+// evaluations only contains tanh + finish.  (The same split of the adjoint - Jacobian entries ahead of time, a
+// matrix-vector product on the chain - was tried for the reverse sweep: it needs ~30 more live registers at a point
+// where the kernel has none, the compiler spilled part of the stationary weights, 158 -> 218 us.)
 struct PathTracking {
     static constexpr int OBS = 6, ACT = 2;
+    static constexpr int NPRE = 9;
     // vehicle parameters, path_tracking_env.py:60-68; tau = 1/10 (:248)
     static constexpr float C_f = -128915.5f, C_r = -85943.6f, A = 1.06f, B = 1.85f, MASS = 1412.f, I_z = 1536.7f;
     static constexpr float TAU = 0.1f;
@@ -49,24 +57,42 @@ struct PathTracking {
     static constexpr float PI_F = 3.14159265358979323846f;
 
     // obs -> veh state is a shift of entry 0 by 20 (:268-277); we carry obs and add the shift on use.
-    // One model step: obs/act in, new obs + RAW reward out.  eps: standard normal (noise = 0.5 + 0.01 eps, :119).
-    __device__ static void step(const float (&o)[8], const float (&a)[2], float eps, float (&on)[8], float& rew) {
+    // One model step (f_xu :78-138 with tau = 0.1, rewards :181-199 on the PRE-step state and scaled action).
+    // eps: standard normal (noise = 0.5 + 0.01 eps, :119).
+    // p: [0] nvx without the action term, [1],[2] nvy = p1 + p2*de, [3],[4] nr = p3 + p4*de, [5] ndy, [6] ndphi,
+    //    [7] nx, [8] state part of -reward
+    __device__ static void pre(const float (&o)[8], float eps, float (&p)[NPRE]) {
         const float vx = o[0] + 20.f, vy = o[1], r = o[2], dy = o[3], dphi = o[4], x = o[5];
-        const float de = a[0] * S0, ax = a[1] * S1;
-        const float dv = vx - 20.f;
-        rew = -(0.01f * dv * dv + 0.04f * dy * dy + 0.1f * dphi * dphi + 0.02f * r * r + 5.f * de * de + 0.05f * ax * ax);
-        float nvx = vx + TAU * (ax + vy * r);
-        const float nvy = (MASS * vy * vx + K1 * r - K2 * de * vx - K3 * vx * vx * r) * frcp(MASS * vx - K4);
-        const float nr = (-I_z * r * vx - K1 * vy + K5 * de * vx) * frcp(K6 - I_z * vx);
+        const float iD1 = frcp(MASS * vx - K4), iD2 = frcp(K6 - I_z * vx);
+        p[0] = vx + TAU * (vy * r);
+        p[1] = (MASS * vy * vx + K1 * r - K3 * vx * vx * r) * iD1;
+        p[2] = -K2 * vx * iD1;
+        p[3] = (-I_z * r * vx - K1 * vy) * iD2;
+        p[4] = K5 * vx * iD2;
         float sp, cp;
         fast_sincos(dphi, &sp, &cp);
-        const float ndy = dy + TAU * (vx * sp + vy * cp) + (0.5f + 0.01f * eps);
+        p[5] = dy + TAU * (vx * sp + vy * cp) + (0.5f + 0.01f * eps);
         float ndphi = dphi + TAU * r;
-        const float nx = x + TAU * (vx * cp - vy * sp);
-        nvx = fminf(fmaxf(nvx, 1.f), 35.f);                      // :289
         if (ndphi > PI_F) ndphi -= 2.f * PI_F;                   // :290
         if (ndphi <= -PI_F) ndphi += 2.f * PI_F;                 // :291
-        on[0] = nvx - 20.f; on[1] = nvy; on[2] = nr; on[3] = ndy; on[4] = ndphi; on[5] = nx;
+        p[6] = ndphi;
+        p[7] = x + TAU * (vx * cp - vy * sp);
+        const float dv = vx - 20.f;
+        p[8] = 0.01f * dv * dv + 0.04f * dy * dy + 0.1f * dphi * dphi + 0.02f * r * r;
+    }
+    __device__ static void finish(const float (&p)[NPRE], const float (&a)[2], float (&on)[8], float& rew) {
+        const float de = a[0] * S0, ax = a[1] * S1;
+        const float nvx = fminf(fmaxf(fmaf(TAU, ax, p[0]), 1.f), 35.f);      // :289
+        on[0] = nvx - 20.f;
+        on[1] = fmaf(p[2], de, p[1]);
+        on[2] = fmaf(p[4], de, p[3]);
+        on[3] = p[5]; on[4] = p[6]; on[5] = p[7]; on[6] = 0.f; on[7] = 0.f;
+        rew = -(p[8] + 5.f * de * de + 0.05f * ax * ax);
+    }
+    __device__ static void step(const float (&o)[8], const float (&a)[2], float eps, float (&on)[8], float& rew) {
+        float p[NPRE];
+        pre(o, eps, p);
+        finish(p, a, on, rew);
     }
 
     // adjoint of step(): lam = dL/d(new obs), rho = dL/d(raw reward).  Returns dL/d(obs) and dL/d(action).
@@ -106,24 +132,37 @@ struct PathTracking {
 
 struct Pendulum {
     static constexpr int OBS = 4, ACT = 1;
+    static constexpr int NPRE = 6;
     // inverted_pendulum_model.py:18-26,38-44: m = 9.42, m1 = 4.89, m2 = 0, l1 = 0.6
     static constexpr float D1c = 9.42f + 4.89f, D2c = 0.5f * 4.89f * 0.6f, D4c = (1.f / 3.f) * 4.89f * 0.6f * 0.6f;
     static constexpr float F1c = 0.5f * 4.89f * 0.6f * 9.81f, TAU = 0.04f;
 
-    __device__ static void step(const float (&o)[8], const float (&a)[2], float eps, float (&on)[8], float& rew) {
-        const float p = o[0], th = o[1], pd = o[2], thd = o[3];
-        const float u = 100.f * a[0];                                       // action_trans :96-97
+    // p: [0] new p, [1] new theta, [2],[3] new pdot = p2 + p3*a, [4],[5] new thetadot = p4 + p5*a
+    __device__ static void pre(const float (&o)[8], float eps, float (&p)[NPRE]) {
+        const float pos = o[0], th = o[1], pd = o[2], thd = o[3];
         float sn, c;
         sincosf(th, &sn, &c);                                               // theta is not range-limited: keep the library routine
         const float idet = frcp(D1c * D4c - D2c * D2c * c * c);             // closed-form 2x2 inverse (:53)
-        const float F1 = D2c * sn * thd * thd + u, F2 = F1c * sn;
-        const float pdd = (D4c * F1 - D2c * c * F2) * idet;
-        const float thdd = (-D2c * c * F1 + D1c * F2) * idet;
-        on[0] = p + TAU * pd + (0.1f + 0.5f * eps);                         // :57,:61
-        on[1] = th + TAU * thd;
-        on[2] = pd + TAU * pdd;
-        on[3] = thd + TAU * thdd;
+        const float F1s = D2c * sn * thd * thd, F2 = F1c * sn;              // F1 = F1s + u, u = 100 a (action_trans :96-97)
+        p[0] = pos + TAU * pd + (0.1f + 0.5f * eps);                        // :57,:61
+        p[1] = th + TAU * thd;
+        p[2] = pd + TAU * ((D4c * F1s - D2c * c * F2) * idet);
+        p[3] = TAU * 100.f * D4c * idet;
+        p[4] = thd + TAU * ((-D2c * c * F1s + D1c * F2) * idet);
+        p[5] = -TAU * 100.f * D2c * c * idet;
+    }
+    __device__ static void finish(const float (&p)[NPRE], const float (&a)[2], float (&on)[8], float& rew) {
+        on[0] = p[0];
+        on[1] = p[1];
+        on[2] = fmaf(p[3], a[0], p[2]);
+        on[3] = fmaf(p[5], a[0], p[4]);
+        on[4] = on[5] = on[6] = on[7] = 0.f;
         rew = -(0.01f * on[0] * on[0] + on[1] * on[1]) - (1e-3f * on[2] * on[2] + 1e-3f * on[3] * on[3]);   // :66-73,:93
+    }
+    __device__ static void step(const float (&o)[8], const float (&a)[2], float eps, float (&on)[8], float& rew) {
+        float p[NPRE];
+        pre(o, eps, p);
+        finish(p, a, on, rew);
     }
 
     __device__ static void vjp(const float (&o)[8], const float (&a)[2], const float (&onext)[8], const float (&lam_in)[8],
@@ -236,66 +275,86 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_fwd(const RollArgs a) {
             }
             sEps[idx] = z;
         }
-        for (int t = 0; t <= a.n; ++t) {
-            if (own) {
+        // Per step: B0 (input published) -> layer 1 -> barrier -> layer-2 MFMA block -> output partials -> B2 -> the
+        // trajectory lanes' serial chain (tanh, action-dependent part of the model step, publish the next input).
+        // Everything the chain does not strictly need sits in the trajectory wave's idle time before B2: it is the
+        // older wave of its SIMD and leaves the MFMA block ~4000 cycles before the younger ones.
+        float act[2] = {0.f, 0.f}, rew = 0.f;
+        // record the action of step tb, its critic-input part and the discounted reward (late by one step: off the chain)
+        auto book = [&](int tb) {
+            if (live) {
+                if (a.SA) {
+                    float* rec = a.SA + ((long)tb * R + tr) * SAW + OBS;
 #pragma unroll
-                for (int i = 0; i < XS; ++i) sX[tid * XS + i] = i < OBS ? o[i] * a.obs_scale[i] : 0.f;
+                    for (int k = 0; k < ACT; ++k) rec[k] = act[k];
+                }
+                for (int ks = 0; ks < a.n_sel; ++ks)
+                    if (a.sel[ks] == tb) {
+                        float* xq = a.XQ + ((long)ks * R + tr) * QIN + OBS;
+#pragma unroll
+                        for (int k = 0; k < ACT; ++k) xq[k] = act[k];
+                    }
             }
+            if (tb < a.n) G += sGp[tb] * ((rew + a.rew_shift) * a.rew_scale);                 // mpg_learner.py:245
+        };
+        if (own) {
+#pragma unroll
+            for (int i = 0; i < XS; ++i) sX[tid * XS + i] = i < OBS ? o[i] * a.obs_scale[i] : 0.f;
+        }
+        for (int t = 0; t <= a.n; ++t) {
             lds_barrier();
             MPG_STAMP_AT(0);
             float h1[2][4], h2[2][4];
-            forward_group<OBS, ACT>(sX, sA, sPart, L, w2, r, h1, h2);
+            forward_group<OBS, ACT, false>(sX, sA, sPart, L, w2, r, h1, h2);
             if (a.H1) {
                 stash_store(a.H1, (long)t * ngroups + g, L, h1);
                 stash_store(a.H2, (long)t * ngroups + g, L, h2);
             }
-            MPG_STAMP_AT(6);
+            float pre[ENV::NPRE];
             if (own) {
-                float act[2] = {0.f, 0.f};
-#pragma unroll
-                for (int k = 0; k < ACT; ++k) {
-                    const float z = out_preact(sPart, b3r[k], tid, k);
-                    act[k] = a.out_tanh ? a.out_scale * fast_tanh(z) : z;
-                }
-                if (t == 0 && a.act0) {
-#pragma unroll
-                    for (int k = 0; k < ACT; ++k) act[k] = act_first[k];
-                }
+                if (t > 0) book(t - 1);
                 if (live) {
                     if (a.SA) {
                         float* rec = a.SA + ((long)t * R + tr) * SAW;
 #pragma unroll
                         for (int i = 0; i < OBS; ++i) rec[i] = o[i];
-#pragma unroll
-                        for (int k = 0; k < ACT; ++k) rec[OBS + k] = act[k];
                     }
                     for (int ks = 0; ks < a.n_sel; ++ks)
                         if (a.sel[ks] == t) {
                             float* xq = a.XQ + ((long)ks * R + tr) * QIN;
 #pragma unroll
                             for (int i = 0; i < OBS; ++i) xq[i] = o[i] * a.obs_scale[i];
-#pragma unroll
-                            for (int k = 0; k < ACT; ++k) xq[OBS + k] = act[k];
                             a.GK[(long)ks * R + tr] = G;
                         }
                 }
+                if (t < a.n) ENV::pre(o, sEps[t * GROUP + tid], pre);
+            }
+            MPG_STAMP_AT(6);
+            lds_barrier();
+            MPG_STAMP_AT(5);
+            if (own) {
+#pragma unroll
+                for (int k = 0; k < ACT; ++k) {
+                    const float z = out_preact_tree(sPart, b3r[k], tid, k);
+                    act[k] = a.out_tanh ? a.out_scale * fast_tanh(z) : z;
+                }
+                if (t == 0 && a.act0) {
+#pragma unroll
+                    for (int k = 0; k < ACT; ++k) act[k] = act_first[k];
+                }
                 if (t < a.n) {
-                    const float e = sEps[t * GROUP + tid];
-                    float on[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                    float rew;
-#ifdef MPG_AB_NODYN   // ablation build: skip the model step (timing only, results meaningless)
-                    rew = e; for (int i = 0; i < 8; ++i) on[i] = o[i] + act[0];
-#else
-                    ENV::step(o, act, e, on, rew);
-#endif
-                    G += sGp[t] * ((rew + a.rew_shift) * a.rew_scale);                     // mpg_learner.py:245
+                    float on[8];
+                    ENV::finish(pre, act, on, rew);
+#pragma unroll
+                    for (int i = 0; i < XS; ++i) sX[tid * XS + i] = i < OBS ? on[i] * a.obs_scale[i] : 0.f;
 #pragma unroll
                     for (int i = 0; i < 8; ++i) o[i] = on[i];
                 }
             }
-            // the next iteration's sX write is ordered behind this iteration's reads by forward_group's barriers
+            // sX of the next step is ordered behind this step's reads by the two barriers above
             MPG_STAMP_AT(7);
         }
+        if (own) book(a.n);
 #ifdef MPG_STAMP
         if ((tid & 63) == 0 && a.dbg)
             for (int k = 0; k < 8; ++k) a.dbg[((long)blockIdx.x * NWAVE + (tid >> 6)) * 8 + k] = (float)g_st_acc[tid >> 6][k];
