@@ -200,6 +200,22 @@ __device__ __forceinline__ void load_small(const Net& n, const Lane& L, SmallReg
     }
 }
 
+// ---- G16 stash ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void stash_store(float* __restrict__ base, long group, const Lane& L, const float (&v)[2][4]) {
+    f32x4* p = reinterpret_cast<f32x4*>(base) + (group * 16 + 2 * L.wave) * 64 + L.lane;
+    p[0] = f32x4{v[0][0], v[0][1], v[0][2], v[0][3]};
+    p[64] = f32x4{v[1][0], v[1][1], v[1][2], v[1][3]};
+}
+__device__ __forceinline__ void stash_load(const float* __restrict__ base, long group, const Lane& L, float (&v)[2][4]) {
+    const f32x4* p = reinterpret_cast<const f32x4*>(base) + (group * 16 + 2 * L.wave) * 64 + L.lane;
+    const f32x4 a = p[0], b = p[64];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        v[0][j] = a[j];
+        v[1][j] = b[j];
+    }
+}
+
 // ---- forward through the two hidden layers + partial output layer for one row group ---------------------
 // sX  [16][XS]  inputs (already scaled), sA the LDS A image, sPart [NWAVE][16][MAXOUT] output partials.
 // On return h1/h2 hold this lane's C-layout activations and sPart the per-wave partial sums of h2*W3 (no bias);
@@ -207,7 +223,8 @@ __device__ __forceinline__ void load_small(const Net& n, const Lane& L, SmallReg
 template <int IN, int OU, bool FINAL_BARRIER = true>
 __device__ __forceinline__ void forward_group(const float* sX, float* sA, float* sPart, const Lane& L,
                                               const float (&w2)[128], const SmallRegs<IN, OU>& r,
-                                              float (&h1)[2][4], float (&h2)[2][4]) {
+                                              float (&h1)[2][4], float (&h2)[2][4], float* h1_stash = nullptr,
+                                              long stash_group = 0) {
     {   // layer 1 on the matrix pipe too: K = IN <= 8 zero-padded = 2 k-steps (sX rows are zero beyond IN)
         f32x4 z0 = {r.b1[0], r.b1[0], r.b1[0], r.b1[0]}, z1 = {r.b1[1], r.b1[1], r.b1[1], r.b1[1]};
 #pragma unroll
@@ -223,6 +240,9 @@ __device__ __forceinline__ void forward_group(const float* sX, float* sA, float*
         }
     }
     store_c_to_a(sA, L, h1);
+    // h1 is final here: its stash goes out now and drains under the MFMA block instead of queueing behind the h2
+    // stash of all eight waves at the end of the step (the CU's store path moves 64 B/clk)
+    if (h1_stash) stash_store(h1_stash, stash_group, L, h1);
     MPG_STAMP_AT(1);
     lds_barrier();
     MPG_STAMP_AT(2);
@@ -273,22 +293,6 @@ __device__ __forceinline__ float out_preact_tree(const float* sPart, float bias,
 #pragma unroll
     for (int w = 0; w < NWAVE; ++w) p[w] = sPart[(w * GROUP + row) * MAXOUT + o];
     return (((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]))) + bias;
-}
-
-// ---- G16 stash ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void stash_store(float* __restrict__ base, long group, const Lane& L, const float (&v)[2][4]) {
-    f32x4* p = reinterpret_cast<f32x4*>(base) + (group * 16 + 2 * L.wave) * 64 + L.lane;
-    p[0] = f32x4{v[0][0], v[0][1], v[0][2], v[0][3]};
-    p[64] = f32x4{v[1][0], v[1][1], v[1][2], v[1][3]};
-}
-__device__ __forceinline__ void stash_load(const float* __restrict__ base, long group, const Lane& L, float (&v)[2][4]) {
-    const f32x4* p = reinterpret_cast<const f32x4*>(base) + (group * 16 + 2 * L.wave) * 64 + L.lane;
-    const f32x4 a = p[0], b = p[64];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        v[0][j] = a[j];
-        v[1][j] = b[j];
-    }
 }
 
 // ---- backward through the hidden layers for one row group ---------------------------------------------

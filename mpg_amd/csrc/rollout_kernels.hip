@@ -305,11 +305,8 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_fwd(const RollArgs a) {
             lds_barrier();
             MPG_STAMP_AT(0);
             float h1[2][4], h2[2][4];
-            forward_group<OBS, ACT, false>(sX, sA, sPart, L, w2, r, h1, h2);
-            if (a.H1) {
-                stash_store(a.H1, (long)t * ngroups + g, L, h1);
-                stash_store(a.H2, (long)t * ngroups + g, L, h2);
-            }
+            forward_group<OBS, ACT, false>(sX, sA, sPart, L, w2, r, h1, h2, a.H1, (long)t * ngroups + g);
+            if (a.H1) stash_store(a.H2, (long)t * ngroups + g, L, h2);
             float pre[ENV::NPRE];
             if (own) {
                 if (t > 0) book(t - 1);
