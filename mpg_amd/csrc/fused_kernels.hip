@@ -207,6 +207,58 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_qslice_fused(const QsliceArgs a)
     }
 }
 
+// Two slices per workgroup (the default {0, n} selection): workgroup gb handles row group gb of BOTH slices, so each of
+// the two register images of W2 is loaded once per 32 rows instead of once per 16 (the prologue, not the MFMA work,
+// dominates these kernels at one row group per CU).
+template <int QIN>
+__global__ void __launch_bounds__(NTHREAD, 2) k_qslice_fused2(const QsliceArgs a) {
+    __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
+    __shared__ __attribute__((aligned(16))) float sX2[2 * GROUP * XS];
+    __shared__ float sD32[2 * GROUP * MAXOUT], sQ2[2 * GROUP];
+    const Smem m(smem);
+    const Lane L;
+    const int tid = threadIdx.x;
+    const long gpers = a.R / GROUP;                    // groups per slice (R % 16 == 0)
+    const long gb = blockIdx.x;
+    const Net net = make_net(a.q, QIN, 1);
+    if (tid < 2 * GROUP * XS) {
+        const int sl = tid / (GROUP * XS), row = (tid / XS) % GROUP, i = tid % XS;
+        const long gr = (sl * gpers + gb) * GROUP + row;
+        sX2[tid] = i < QIN ? a.xq[gr * QIN + i] : 0.f;
+    }
+    lds_barrier();
+    float w2[128], h1[2][2][4], h2[2][2][4], dz1[2][4], dz2[2][4];
+    SmallRegs<QIN, 1> r;
+    load_w2(a.pkf, net.W2, false, L, w2);
+    load_small<QIN, 1>(net, L, r);
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {
+        forward_group<QIN, 1>(sX2 + sl * GROUP * XS, m.sA, m.sPart, L, w2, r, h1[sl], h2[sl]);
+        if (tid < GROUP) {
+            const long gr = (sl * gpers + gb) * GROUP + tid;
+            sQ2[sl * GROUP + tid] = a.gk[gr] + a.gpow[sl] * out_preact(m.sPart, net.b3[0], tid, 0);   // mpg_learner.py:266
+            sD32[(sl * GROUP + tid) * MAXOUT] = a.coef[sl];
+        }
+    }
+    load_w2(a.pkb, net.W2, true, L, w2);
+    lds_barrier();
+    if (tid < 2) {
+        float s1 = 0.f, s2 = 0.f;
+        for (int i = 0; i < GROUP; ++i) { const float q = sQ2[tid * GROUP + i]; s1 += q; s2 += q * q; }
+        a.ret_part[(tid * gpers + gb) * 2] = s1;
+        a.ret_part[(tid * gpers + gb) * 2 + 1] = s2;
+    }
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {
+        backward_group<QIN, 1, true>(sD32 + sl * GROUP * MAXOUT, m.sA, m.sA1, m.sPartX, L, w2, r, h1[sl], h2[sl], dz1, dz2);
+        if (tid < GROUP * QIN) {
+            const int row = tid / QIN, i = tid % QIN;
+            const long gr = (sl * gpers + gb) * GROUP + row;
+            a.gxq[gr * QIN + i] = dx_reduce(m.sPartX, row, i);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 struct WgradMulti {
     int n_jobs;
@@ -333,7 +385,11 @@ int launch_qslice_fused(const float* q_params, int qin, int R, int n_sel, const 
     a.R = R; a.n_sel = n_sel; a.xq = xq; a.gk = gk; a.ret_part = ret_part; a.gxq = gxq;
     for (int k = 0; k < 4; ++k) { a.gpow[k] = k < n_sel ? gpow[k] : 0.f; a.coef[k] = k < n_sel ? coef[k] : 0.f; }
     const int ngroups = n_sel * (R / GROUP);
-    if (qin == 8) hipLaunchKernelGGL((k_qslice_fused<8>), dim3(ngroups), dim3(NTHREAD), 0, s, a);
+    if (n_sel == 2) {
+        if (qin == 8) hipLaunchKernelGGL((k_qslice_fused2<8>), dim3(R / GROUP), dim3(NTHREAD), 0, s, a);
+        else if (qin == 5) hipLaunchKernelGGL((k_qslice_fused2<5>), dim3(R / GROUP), dim3(NTHREAD), 0, s, a);
+        else { mpg_set_error("launch_qslice_fused: unsupported dims"); return MPG_EINVAL; }
+    } else if (qin == 8) hipLaunchKernelGGL((k_qslice_fused<8>), dim3(ngroups), dim3(NTHREAD), 0, s, a);
     else if (qin == 5) hipLaunchKernelGGL((k_qslice_fused<5>), dim3(ngroups), dim3(NTHREAD), 0, s, a);
     else { mpg_set_error("launch_qslice_fused: unsupported dims"); return MPG_EINVAL; }
     MPG_CHECK_LAUNCH("k_qslice_fused");

@@ -681,7 +681,7 @@ int run_rollout_fwd(const mpg_cfg_t* cfg, const float* policy_params, int rows, 
         (void)hipStreamSynchronize(s);
         (void)hipMemcpy(h, s_dbg, sizeof(h), hipMemcpyDeviceToHost);
         const int nwg = grid_for(ngroups);
-        for (int w = 0; w < 8; w += 7) {
+        for (int w = 0; w < 8; ++w) {
             double acc[8] = {0};
             for (int b = 0; b < nwg; ++b) for (int k = 0; k < 8; ++k) acc[k] += h[(b * 8 + w) * 8 + k];
             fprintf(stderr, "[stamp fwd] wave %d cycles/step:", w);
@@ -735,7 +735,7 @@ int run_rollout_bwd(const mpg_cfg_t* cfg, const float* policy_params, int rows, 
         (void)hipStreamSynchronize(s);
         (void)hipMemcpy(h, s_dbg_b, sizeof(h), hipMemcpyDeviceToHost);
         const int nwg = grid_for(ngroups);
-        for (int w = 0; w < 8; w += 7) {
+        for (int w = 0; w < 8; ++w) {
             double acc[8] = {0};
             for (int b = 0; b < nwg; ++b) for (int k = 0; k < 8; ++k) acc[k] += h[(b * 8 + w) * 8 + k];
             fprintf(stderr, "[stamp bwd] wave %d cycles/step:", w);

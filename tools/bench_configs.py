@@ -121,5 +121,6 @@ def c4():
 
 if __name__ == '__main__':
     torch.zeros(1, device=DEV)
-    for f in (env_rates, c1, c3, c4):
-        f()
+    which = sys.argv[1:] or ['env_rates', 'c1', 'c3', 'c4']
+    for name in which:
+        globals()[name]()
