@@ -102,6 +102,10 @@ def main():
     rank, world, local = D.init_from_env()
     assert world == a.gpus, 'launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)' % (a.gpus, world)
     assert torch.cuda.is_available(), 'bench.py needs a GPU: the product path has no CPU fallback'
+    ndev = torch.cuda.device_count()
+    if local >= ndev:        # only in MPG_DIST_BACKEND=gloo dry runs with more ranks than GPUs
+        assert os.environ.get('MPG_DIST_BACKEND') == 'gloo', 'LOCAL_RANK %d but %d GPUs' % (local, ndev)
+        local = local % ndev
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
     args, worker, learner, rb, opt = build_stack(dev, seed=rank)
