@@ -196,13 +196,26 @@ int mpg_rollout_pg(const mpg_cfg_t* cfg, const float* policy_params, const float
  * of the slab sums) in 7 launches instead of 22 when rows % 16 == 0 and M == 1; otherwise it calls those.
  * sq_part (nullable, (n_q+1)*MPG_CLIP_PARTS floats): on a single GPU the last launch also leaves the clip's partial sums
  * of squares of `grad` there (what mpg_sq_partials would compute), ready for mpg_clip_adam_polyak. */
+/* Optional fused minibatch draw: ReplayBuffer.sample (buffer.py:70-78) from the device ring, the same draw as
+ * mpg_replay_sample_uniform(n_storage, rows, seed, ctr, ...).  With `draw` != NULL the obs / act / rew / obs_tp1
+ * arguments of mpg_mpg_gradients are OUTPUTS: the minibatch is gathered inside the first launch (one launch less per
+ * iteration) and left there, the indices in idx_out and the dones (as float) in done_out (both nullable). */
+typedef struct {
+    int n_storage;                    /* transitions currently stored */
+    uint64_t seed, ctr;               /* Philox key / counter of this draw (ctr = ReplayBuffer.replay_times) */
+    const float *ring_obs, *ring_act, *ring_rew, *ring_obs2;
+    const uint8_t* ring_done;
+    int* idx_out;
+    float* done_out;
+} mpg_replay_draw_t;
+
 size_t mpg_mpg_gradients_workspace_bytes(const mpg_cfg_t* cfg, int rows, int M, int n, int n_select, int n_q);
 int mpg_mpg_gradients(const mpg_cfg_t* cfg, int n_q, const float* params, const float* target_params, int rows,
-                      const float* obs, const float* act, const float* rew, const float* obs_tp1, const float* y_in,
+                      float* obs, float* act, float* rew, float* obs_tp1, const float* y_in,
                       int M, int n, const int* select, int n_select, const float* w, const float* eps,
                       uint64_t noise_seed, uint64_t noise_ctr, float inv_b_global, float* grad, float* stats,
-                      float* y_out, float* sq_part /* nullable: see mpg_sq_partials */, void* ws, size_t ws_bytes,
-                      mpg_stream_t stream);
+                      float* y_out, float* sq_part /* nullable: see mpg_sq_partials */,
+                      const mpg_replay_draw_t* draw /* nullable */, void* ws, size_t ws_bytes, mpg_stream_t stream);
 
 /* NADPLearner.model_rollout_for_q_estimation  - learners/nadp.py:87-126: from (s, a_replay) roll n model steps,
  * later actions from pi_theta, y = G_n + gamma^n * Q1_target(s~_n, pi_theta(s~_n)) (no gradient).

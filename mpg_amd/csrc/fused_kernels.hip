@@ -39,6 +39,14 @@ struct TargetArgs {
     int out_tanh;
     float out_scale, sigma, clipc, rshift, rscale, gamma;
     float* y;
+    // optional fused minibatch draw (ReplayBuffer.sample, buffer.py:70-78; same Philox stream as k_sample_gather): the
+    // kernel's 16 rows are drawn and gathered by its own first 16 lanes and written out for the later kernels
+    int draw, n_storage;
+    uint32_t dk0, dk1, dc1, dc2;
+    const float *r_obs, *r_act, *r_rew, *r_obs2;
+    const uint8_t* r_done;
+    int* o_idx;
+    float *o_obs, *o_act, *o_rew, *o_obs2, *o_done;
 };
 
 template <int OBS, int ACT>
@@ -49,10 +57,41 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_target_fused(const TargetArgs a)
     const Lane L;
     const int tid = threadIdx.x;
     const long g = blockIdx.x;
-    if (tid < GROUP * XS) {
+    __shared__ float sRew[GROUP];
+    if (a.draw) {
+        if (tid < GROUP) {
+            const long gr = g * GROUP + tid;
+            float o2[OBS];
+#pragma unroll
+            for (int i = 0; i < OBS; ++i) o2[i] = 0.f;
+            float rw = 0.f;
+            if (gr < a.rows) {
+                const Philox4 p = philox4x32_10((uint32_t)(gr >> 2), a.dc1, a.dc2, 0x1d5u, a.dk0, a.dk1);
+                const long sr = (long)(((uint64_t)p.v[gr & 3] * (uint64_t)a.n_storage) >> 32);
+                float o1[OBS], ac[ACT];
+#pragma unroll
+                for (int i = 0; i < OBS; ++i) { o1[i] = a.r_obs[sr * OBS + i]; o2[i] = a.r_obs2[sr * OBS + i]; }
+#pragma unroll
+                for (int k = 0; k < ACT; ++k) ac[k] = a.r_act[sr * ACT + k];
+                rw = a.r_rew[sr];
+                const uint8_t dn = a.r_done[sr];
+                if (a.o_idx) a.o_idx[gr] = (int)sr;
+#pragma unroll
+                for (int i = 0; i < OBS; ++i) { a.o_obs[gr * OBS + i] = o1[i]; a.o_obs2[gr * OBS + i] = o2[i]; }
+#pragma unroll
+                for (int k = 0; k < ACT; ++k) a.o_act[gr * ACT + k] = ac[k];
+                a.o_rew[gr] = rw;
+                if (a.o_done) a.o_done[gr] = (float)dn;
+            }
+            sRew[tid] = rw;
+#pragma unroll
+            for (int i = 0; i < XS; ++i) m.sX[tid * XS + i] = i < OBS ? o2[i < OBS ? i : 0] * a.scale[i] : 0.f;
+        }
+    } else if (tid < GROUP * XS) {
         const int row = tid / XS, i = tid % XS;
         const long gr = g * GROUP + row;
         m.sX[tid] = (gr < a.rows && i < OBS) ? a.obs2[gr * OBS + i] * a.scale[i] : 0.f;
+        if (i == 0) sRew[row] = gr < a.rows ? a.rew[gr] : 0.f;
     }
     lds_barrier();
     float w2[128], h1[2][4], h2[2][4];
@@ -87,7 +126,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_target_fused(const TargetArgs a)
         const long gr = g * GROUP + tid;
         if (gr < a.rows) {
             const float q = a.q2 ? fminf(m.sQ[tid], m.sQ[GROUP + tid]) : m.sQ[tid];
-            a.y[gr] = (a.rew[gr] + a.rshift) * a.rscale + a.gamma * q;      // mpg_learner.py:132-133
+            a.y[gr] = (sRew[tid] + a.rshift) * a.rscale + a.gamma * q;      // mpg_learner.py:132-133
         }
     }
 }
@@ -333,9 +372,23 @@ inline void fill_scale(float (&dst)[8], const mpg_cfg_t* cfg) {
 
 int launch_target_fused(const mpg_cfg_t* cfg, const float* policy_t, const float* q1t, const float* q2t, int rows,
                         const float* rew, const float* obs_tp1, const float* smooth_eps, float sigma, float clipc, float* y,
-                        hipStream_t s) {
+                        hipStream_t s, const mpg_replay_draw_t* draw, const DrawOut* draw_out) {
     const int od = cfg->obs_dim, ad = cfg->act_dim;
     TargetArgs a;
+    a.draw = 0; a.n_storage = 0; a.dk0 = a.dk1 = a.dc1 = a.dc2 = 0;
+    a.r_obs = a.r_act = a.r_rew = a.r_obs2 = nullptr; a.r_done = nullptr; a.o_idx = nullptr;
+    a.o_obs = a.o_act = a.o_rew = a.o_obs2 = a.o_done = nullptr;
+    if (draw) {
+        MPG_REQUIRE(draw_out && draw->n_storage > 0 && draw->ring_obs && draw->ring_act && draw->ring_rew && draw->ring_obs2 &&
+                        draw->ring_done && draw_out->obs && draw_out->act && draw_out->rew && draw_out->obs2,
+                    "launch_target_fused: incomplete replay draw");
+        a.draw = 1; a.n_storage = draw->n_storage;
+        a.dk0 = (uint32_t)draw->seed; a.dk1 = (uint32_t)(draw->seed >> 32);
+        a.dc1 = (uint32_t)draw->ctr; a.dc2 = (uint32_t)(draw->ctr >> 32);
+        a.r_obs = draw->ring_obs; a.r_act = draw->ring_act; a.r_rew = draw->ring_rew; a.r_obs2 = draw->ring_obs2;
+        a.r_done = draw->ring_done; a.o_idx = draw->idx_out; a.o_done = draw->done_out;
+        a.o_obs = draw_out->obs; a.o_act = draw_out->act; a.o_rew = draw_out->rew; a.o_obs2 = draw_out->obs2;
+    }
     a.pol = policy_t; a.q1 = q1t; a.q2 = q2t;
     a.pk_pol = weight_cache_lookup(make_net(policy_t, od, 2 * ad).W2, 0);
     a.pk_q1 = weight_cache_lookup(make_net(q1t, od + ad, 1).W2, 0);

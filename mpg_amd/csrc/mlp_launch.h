@@ -73,9 +73,13 @@ struct NetRef {            // one network: Keras-ordered parameters (+ optional 
 };
 
 // y = (rew + shift) * scale + gamma * min_i Qt_i(s~', a'),  a' = pi_t(s~') (+ clipped smoothing noise): ONE launch.
+// draw (nullable): the minibatch is drawn from the replay ring inside the same launch and written to draw_out
+struct DrawOut {
+    float *obs, *act, *rew, *obs2;
+};
 int launch_target_fused(const mpg_cfg_t* cfg, const float* policy_t, const float* q1t, const float* q2t, int rows,
                         const float* rew, const float* obs_tp1, const float* smooth_eps, float sigma, float clipc, float* y,
-                        hipStream_t s);
+                        hipStream_t s, const mpg_replay_draw_t* draw = nullptr, const DrawOut* draw_out = nullptr);
 
 struct CriticStash {       // G16 stashes + dz3 of one critic, kept for the weight-gradient launch
     float *h1, *h2, *dz1, *dz2, *dz3;

@@ -899,10 +899,11 @@ extern "C" size_t mpg_mpg_gradients_workspace_bytes(const mpg_cfg_t* cfg, int ro
 }
 
 extern "C" int mpg_mpg_gradients(const mpg_cfg_t* cfg, int n_q, const float* params, const float* target_params, int rows,
-                                 const float* obs, const float* act, const float* rew, const float* obs_tp1,
+                                 float* obs, float* act, float* rew, float* obs_tp1,
                                  const float* y_in, int M, int n, const int* select, int n_select, const float* w,
                                  const float* eps, uint64_t noise_seed, uint64_t noise_ctr, float inv_b_global, float* grad,
-                                 float* stats, float* y_out, float* sq_part, void* ws, size_t ws_bytes, mpg_stream_t stream) {
+                                 float* stats, float* y_out, float* sq_part, const mpg_replay_draw_t* draw, void* ws,
+                                 size_t ws_bytes, mpg_stream_t stream) {
     MPG_REQUIRE(cfg_ok(cfg) && (n_q == 1 || n_q == 2), "mpg_mpg_gradients: unsupported cfg / n_q");
     MPG_REQUIRE(params && obs && act && select && w && grad && stats && y_out && ws, "mpg_mpg_gradients: null pointer");
     MPG_REQUIRE(y_in || (target_params && rew && obs_tp1), "mpg_mpg_gradients: either y_in or the target inputs are required");
@@ -922,8 +923,17 @@ extern "C" int mpg_mpg_gradients(const mpg_cfg_t* cfg, int n_q, const float* par
     float* gq[2] = {grad, grad + q_size};
     float* gp = grad + (size_t)n_q * q_size;
     const MgLayout l = mg_layout(cfg, rows, M, n, n_select, n_q);
+    const bool fused = rows % GROUP == 0 && M == 1;
+    if (draw && (!fused || y_in)) {      // the draw cannot ride in the target launch: do it as its own launch
+        MPG_REQUIRE(rew && obs_tp1, "mpg_mpg_gradients: a replay draw needs the rew / obs_tp1 output buffers");
+        int rc = mpg_replay_sample_uniform(draw->n_storage, rows, draw->seed, draw->ctr, cfg->obs_dim, cfg->act_dim, draw->ring_obs,
+                                           draw->ring_act, draw->ring_rew, draw->ring_obs2, draw->ring_done, draw->idx_out, obs, act,
+                                           rew, obs_tp1, draw->done_out, stream);
+        if (rc) return rc;
+        draw = nullptr;
+    }
 
-    if (rows % GROUP != 0 || M != 1) {   // ---- fallback: the fine-grained entry points ----
+    if (!fused) {   // ---- fallback: the fine-grained entry points ----
         char* w0 = align256((char*)ws);
         char* w1 = align256(w0 + l.fallback0);
         const float* y = y_in;
@@ -960,7 +970,8 @@ extern "C" int mpg_mpg_gradients(const mpg_cfg_t* cfg, int n_q, const float* par
 
     const float* y = y_in;
     if (!y) {   // 1. clipped double-Q (or single-Q) target, mpg_learner.py:126-134
-        int rc = launch_target_fused(cfg, policy_t, qt[0], qt[1], rows, rew, obs_tp1, nullptr, 0.f, 0.f, y_out, s);
+        const DrawOut dout{obs, act, rew, obs_tp1};
+        int rc = launch_target_fused(cfg, policy_t, qt[0], qt[1], rows, rew, obs_tp1, nullptr, 0.f, 0.f, y_out, s, draw, &dout);
         if (rc) return rc;
         y = y_out;
     }

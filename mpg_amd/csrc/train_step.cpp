@@ -98,13 +98,19 @@ extern "C" int mpg_step_begin(mpg_train_ctx_t* c, int iteration, mpg_stream_t s)
     // ---- replay_buffer.replay (optimizer.py:340-341; buffer.py:70-91) ----
     MPG_REQUIRE(c->ring_size > 0, "mpg_step_begin: empty replay ring");
     c->replay_times++;
+    mpg_replay_draw_t draw;
+    bool draw_in_gradients = false;
     if (c->learner_counter % c->num_batch_reuse == 0) {       // get_batch_data, mpg_learner.py:402-403
-        TRY(mpg_replay_sample_uniform(c->ring_size, c->batch, c->replay_seed, c->replay_times, od, ad, c->ring_obs, c->ring_act,
-                                      c->ring_rew, c->ring_obs2, c->ring_done, c->idx, c->b_obs, c->b_act, c->b_rew, c->b_obs2,
-                                      c->b_done, s));
         if (c->learner_version == 2) {
-            // the clipped double-Q target is computed inside mpg_mpg_gradients below
+            // the minibatch draw and the clipped double-Q target both ride in the first launch of mpg_mpg_gradients
+            draw.n_storage = c->ring_size; draw.seed = c->replay_seed; draw.ctr = c->replay_times;
+            draw.ring_obs = c->ring_obs; draw.ring_act = c->ring_act; draw.ring_rew = c->ring_rew; draw.ring_obs2 = c->ring_obs2;
+            draw.ring_done = c->ring_done; draw.idx_out = c->idx; draw.done_out = c->b_done;
+            draw_in_gradients = true;
         } else {   // MPGLearner.sample + compute_n_step_target, mpg_learner.py:109-124,146-169
+            TRY(mpg_replay_sample_uniform(c->ring_size, c->batch, c->replay_seed, c->replay_times, od, ad, c->ring_obs, c->ring_act,
+                                          c->ring_rew, c->ring_obs2, c->ring_done, c->idx, c->b_obs, c->b_act, c->b_rew, c->b_obs2,
+                                          c->b_done, s));
             MPG_REQUIRE(c->l_env_state && c->l_obs && c->l_act && c->l_rewards && c->l_done, "mpg_step_begin: MPG-v1 needs the learner env buffers");
             TRY(mpg_env_reset_from_obs(kind, c->batch, c->l_env_state, c->b_obs, s));
             for (int t = 0; t < c->n; ++t) {
@@ -130,8 +136,8 @@ extern "C" int mpg_step_begin(mpg_train_ctx_t* c, int iteration, mpg_stream_t s)
     const float* y_in = (c->learner_version == 2 && fresh) ? nullptr : c->b_targets;
     TRY(mpg_mpg_gradients(&c->cfg, l.n_nets - 1, c->params, c->targets, c->batch, c->b_obs, c->b_act, c->b_rew, c->b_obs2, y_in,
                           c->M, c->n, c->select, c->n_select, w, nullptr, c->learner_seed, c->learner_counter, inv_b, c->grad,
-                          c->grad + l.n_grad, c->b_targets, c->world_size == 1 ? c->clip_scratch : nullptr, c->ws1, c->ws1_bytes,
-                          s));
+                          c->grad + l.n_grad, c->b_targets, c->world_size == 1 ? c->clip_scratch : nullptr,
+                          draw_in_gradients ? &draw : nullptr, c->ws1, c->ws1_bytes, s));
     return MPG_OK;
 }
 

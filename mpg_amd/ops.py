@@ -243,4 +243,4 @@ def mpg_gradients(cfg, n_q, params, target_params, obs, act, rew, obs_tp1, y_in,
            L.ptr(_f32(obs)), L.ptr(_f32(act)), L.ptr(rew), L.ptr(obs_tp1), L.ptr(y_in), L.c_int(M), L.c_int(n), sel,
            L.c_int(ns), wv, L.ptr(eps), L.c_u64(noise_seed), L.c_u64(noise_ctr),
            L.c_float(inv_b_global if inv_b_global is not None else 1.0 / rows), L.ptr(_f32(grad)), L.ptr(_f32(stats)),
-           L.ptr(_f32(y_out)), L.ptr(sq_part), L.ptr(ws), L.c_size_t(ws.numel()), L.stream())
+           L.ptr(_f32(y_out)), L.ptr(sq_part), None, L.ptr(ws), L.c_size_t(ws.numel()), L.stream())
