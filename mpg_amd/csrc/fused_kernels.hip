@@ -58,23 +58,37 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_target_fused(const TargetArgs a)
     const int tid = threadIdx.x;
     const long g = blockIdx.x;
     __shared__ float sRew[GROUP];
+    // Minibatch draw: the 16 trajectory lanes issue their (random-access) ring reads FIRST, then every wave requests the
+    // policy's weights, and only then are the gathered values consumed - the vector-memory counter retires in order, so
+    // this is the order in which the two latencies overlap instead of adding up.
+    float o1[OBS], o2[OBS], ac[ACT], rw = 0.f;
+    uint8_t dn = 0;
+    long sr = 0;
+#pragma unroll
+    for (int i = 0; i < OBS; ++i) o1[i] = o2[i] = 0.f;
+#pragma unroll
+    for (int k = 0; k < ACT; ++k) ac[k] = 0.f;
+    const bool drawn = a.draw && tid < GROUP && g * GROUP + tid < a.rows;
+    if (drawn) {
+        const long gr = g * GROUP + tid;
+        const Philox4 p = philox4x32_10((uint32_t)(gr >> 2), a.dc1, a.dc2, 0x1d5u, a.dk0, a.dk1);
+        sr = (long)(((uint64_t)p.v[gr & 3] * (uint64_t)a.n_storage) >> 32);
+#pragma unroll
+        for (int i = 0; i < OBS; ++i) { o1[i] = a.r_obs[sr * OBS + i]; o2[i] = a.r_obs2[sr * OBS + i]; }
+#pragma unroll
+        for (int k = 0; k < ACT; ++k) ac[k] = a.r_act[sr * ACT + k];
+        rw = a.r_rew[sr];
+        dn = a.r_done[sr];
+    }
+    float w2[128], h1[2][4], h2[2][4];
+    const Net pnet = make_net(a.pol, OBS, 2 * ACT);
+    SmallRegs<OBS, ACT> pr;
+    load_w2(a.pk_pol, pnet.W2, false, L, w2);
+    load_small<OBS, ACT>(pnet, L, pr);
     if (a.draw) {
         if (tid < GROUP) {
-            const long gr = g * GROUP + tid;
-            float o2[OBS];
-#pragma unroll
-            for (int i = 0; i < OBS; ++i) o2[i] = 0.f;
-            float rw = 0.f;
-            if (gr < a.rows) {
-                const Philox4 p = philox4x32_10((uint32_t)(gr >> 2), a.dc1, a.dc2, 0x1d5u, a.dk0, a.dk1);
-                const long sr = (long)(((uint64_t)p.v[gr & 3] * (uint64_t)a.n_storage) >> 32);
-                float o1[OBS], ac[ACT];
-#pragma unroll
-                for (int i = 0; i < OBS; ++i) { o1[i] = a.r_obs[sr * OBS + i]; o2[i] = a.r_obs2[sr * OBS + i]; }
-#pragma unroll
-                for (int k = 0; k < ACT; ++k) ac[k] = a.r_act[sr * ACT + k];
-                rw = a.r_rew[sr];
-                const uint8_t dn = a.r_done[sr];
+            if (drawn) {
+                const long gr = g * GROUP + tid;
                 if (a.o_idx) a.o_idx[gr] = (int)sr;
 #pragma unroll
                 for (int i = 0; i < OBS; ++i) { a.o_obs[gr * OBS + i] = o1[i]; a.o_obs2[gr * OBS + i] = o2[i]; }
@@ -94,13 +108,9 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_target_fused(const TargetArgs a)
         if (i == 0) sRew[row] = gr < a.rows ? a.rew[gr] : 0.f;
     }
     lds_barrier();
-    float w2[128], h1[2][4], h2[2][4];
     {   // a' = pi_target(s~')  (+ clip(sigma*eps, +-c), td3.py:74-76)
-        const Net net = make_net(a.pol, OBS, 2 * ACT);
-        SmallRegs<OBS, ACT> r;
-        load_w2(a.pk_pol, net.W2, false, L, w2);
-        load_small<OBS, ACT>(net, L, r);
-        forward_group<OBS, ACT>(m.sX, m.sA, m.sPart, L, w2, r, h1, h2);
+        const Net& net = pnet;
+        forward_group<OBS, ACT>(m.sX, m.sA, m.sPart, L, w2, pr, h1, h2);
         if (tid < GROUP * ACT) {
             const int row = tid / ACT, k = tid % ACT;
             const long gr = g * GROUP + row;
