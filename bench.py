@@ -37,6 +37,10 @@ FWD_FLOP_PER_STATE = 26 * 2 * (6 * 256 + 256 * 256 + 256 * 2) + 25 * 100
 # reverse sweep = 26 input-side backward passes through the same policy (W3^T, W2^T, W1^T) + 25 model adjoints
 BWD_FLOP_PER_STATE = 26 * 2 * (2 * 256 + 256 * 256 + 256 * 6) + 25 * 200
 FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+# The kernel durations behind `roofline` are measured live, with HIP events on the launch stream, on every PROF_EVERY-th
+# launch of the timed region: an event record is a stream packet of its own (~4-5 us between two otherwise back-to-back
+# kernels; 8 of them per step with every launch timed = 6 % of a 0.5 ms step - profiles/README.md has the trace).
+PROF_EVERY = 16
 
 
 def build_stack(dev, seed):
@@ -115,7 +119,7 @@ def main():
     lib = L.lib()
     D.barrier()
     torch.cuda.synchronize()
-    lib.mpg_prof_enable(1)
+    lib.mpg_prof_enable(PROF_EVERY)      # HIP events around every PROF_EVERY-th launch of the timed region (see PROF_EVERY)
     t0 = time.perf_counter()
     for _ in range(a.steps):
         opt.step()
@@ -133,7 +137,8 @@ def main():
     env_ms, env_n = slot(2)
     wg_ms, wg_n = slot(5)
     lib.mpg_prof_enable(0)
-    assert fwd_n == a.steps and bwd_n == a.steps, (fwd_n, bwd_n)
+    n_sampled = (a.steps + PROF_EVERY - 1) // PROF_EVERY
+    assert fwd_n == n_sampled and bwd_n == n_sampled, (fwd_n, bwd_n, n_sampled)
     finite = bool(torch.isfinite(worker.policy_with_value.params).all().item())
     assert finite and int(worker.policy_with_value.nonfinite.sum().item()) == 0, 'non-finite parameters after the timed region'
 
@@ -151,6 +156,7 @@ def main():
         tf = flop * B_PER_GPU / (ms * 1e-3) / 1e12
         return {'kernel': kernel, 'bound': 'mfma', 'achieved': tf, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': tf / FP32_MFMA_PEAK_TFLOPS, 'traffic': traffic.get(kernel.split('<')[0]), 'avg_ms': ms, 'launches': n,
+                'timed_with': 'HIP events on the launch stream around every %d-th launch of the timed region' % PROF_EVERY,
                 'algorithmic_flop_per_launch': flop * B_PER_GPU}
     r_fwd = roof('k_rollout_fwd<PathTracking>', FWD_FLOP_PER_STATE, fwd_ms, fwd_n)
     r_bwd = roof('k_rollout_bwd<PathTracking>', BWD_FLOP_PER_STATE, bwd_ms, bwd_n)

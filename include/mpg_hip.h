@@ -52,11 +52,13 @@ int mpg_abi_version(void);
 const char* mpg_last_error(void);
 
 /* Optional per-kernel timing with HIP events recorded on the launch stream (the one piece of process-wide state;
- * off by default).  mpg_prof_enable(1) resets and starts recording, mpg_prof_read waits for the recorded events of a
- * slot and returns their summed duration and count; slot names via mpg_prof_slot_name (0 k_rollout_fwd,
- * 1 k_rollout_bwd, 2 env k_step, 3 k_forward, 4 k_backward, 5 k_wgrad).  No reference counterpart
- * (the reference times with utils/misc.py:39-90 TimerStat on the host). */
-int mpg_prof_enable(int on);
+ * off by default).  mpg_prof_enable(every) resets and starts recording every `every`-th launch of each slot (0: off;
+ * an event record is a stream packet of its own and costs ~4-5 us between two otherwise back-to-back kernels, so timing
+ * EVERY launch slows a 0.5 ms step by 6 %); mpg_prof_read waits for the recorded events of a slot and returns their
+ * summed duration and count; slot names via mpg_prof_slot_name (0 k_rollout_fwd, 1 k_rollout_bwd, 2 env k_step,
+ * 3 k_forward, 4 k_backward, 5 k_wgrad).  No reference counterpart (the reference times with utils/misc.py:39-90
+ * TimerStat on the host). */
+int mpg_prof_enable(int every);
 int mpg_prof_read(int slot, double* total_ms, int* count);
 const char* mpg_prof_slot_name(int slot);
 
