@@ -6,7 +6,7 @@
 
 #include "../../include/mpg_hip.h"
 
-#define MPG_ABI_VERSION 1
+#define MPG_ABI_VERSION 2   // 2: mpg_mpg_gradients(sq_part, draw), MPG_CLIP_PARTS scratch, mpg_clip_adam_polyak, mpg_prof_enable(every)
 
 void mpg_set_error(const char* fmt, ...);
 
