@@ -261,11 +261,25 @@ __device__ __forceinline__ void forward_group(const float* sX, float* sA, float*
         for (int o = 0; o < OU; ++o)
 #pragma unroll
             for (int j = 0; j < 4; ++j) p[o][j] = fmaf(h2[1][j], r.w3[1][o], h2[0][j] * r.w3[0][o]);
+#ifndef MPG_AB_NO_DPPASM
+        // one v_add_f32_dpp per value and stage (the compiler's own lowering is v_mov_b32_dpp + a packed add: 1.5
+        // instructions per value).  volatile keeps the stage-major order, which also keeps every DPP read >= 8
+        // instructions behind the write of its operand (the 2-wait-state VALU->DPP hazard is not checked inside asm).
+#define MPG_DPP_STAGE(PRE, MODS)                                \
+        _Pragma("unroll") for (int o = 0; o < OU; ++o)           \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)            \
+            asm volatile(PRE "v_add_f32_dpp %0, %1, %1 " MODS " row_mask:0xf bank_mask:0xf" : "=v"(p[o][j]) : "v"(p[o][j]));
+        // first stage: its operands come from ordinary fmas the scheduler may place right in front of the asm -> own wait
+        MPG_DPP_STAGE("s_nop 1\n\t", "quad_perm:[1,0,3,2]") MPG_DPP_STAGE("", "quad_perm:[2,3,0,1]")
+        MPG_DPP_STAGE("", "row_half_mirror") MPG_DPP_STAGE("", "row_mirror")
+#undef MPG_DPP_STAGE
+#else
 #define MPG_DPP_STAGE(CTRL)                                     \
         _Pragma("unroll") for (int o = 0; o < OU; ++o)           \
         _Pragma("unroll") for (int j = 0; j < 4; ++j) p[o][j] += dpp_mov<CTRL>(p[o][j]);
         MPG_DPP_STAGE(0xB1) MPG_DPP_STAGE(0x4E) MPG_DPP_STAGE(0x141) MPG_DPP_STAGE(0x140)
 #undef MPG_DPP_STAGE
+#endif
         if (L.c == 0) {
 #pragma unroll
             for (int o = 0; o < OU; ++o)
