@@ -89,8 +89,9 @@ __device__ __forceinline__ void mpg_stamp(int k) {
 // ELU(z) = z for z > 0, exp(z) - 1 otherwise.  exp(z) - 1 >= z everywhere, so the selection is the MEDIAN of
 // (z, exp(z) - 1, 0): one v_med3_f32 instead of compare + select (same values bit for bit).
 __device__ __forceinline__ float elu(float z) { return __builtin_amdgcn_fmed3f(z, __expf(z) - 1.f, 0.f); }
-// ELU'(z) expressed through the stored output h = ELU(z): 1 for z > 0, exp(z) = h + 1 otherwise = min(h, 0) + 1.
-__device__ __forceinline__ float elu_grad_from_out(float h) { return fminf(h, 0.f) + 1.f; }
+// ELU'(z) expressed through the stored output h = ELU(z): 1 for z > 0, exp(z) = h + 1 in (0, 1] otherwise, i.e. the
+// median of (h + 1, 1, 0).  (fminf(h, 0) + 1 costs an extra v_max canonicalisation of its operand.)
+__device__ __forceinline__ float elu_grad_from_out(float h) { return __builtin_amdgcn_fmed3f(h + 1.f, 1.f, 0.f); }
 
 // ---- cross-lane sum over the 16 lanes of a DPP row (lanes sharing l>>4) -------------------------------
 template <int CTRL>
