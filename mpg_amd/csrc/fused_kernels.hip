@@ -182,7 +182,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_qloss_fused(const QlossArgs a) {
             st.dz3[gr] = e * a.inv_b;
             if (a.td && qi == 0) a.td[gr] = e;
         }
-        m.sD3[tid * MAXOUT] = e * a.inv_b;
+        m.sD3[d3_index(tid, 0)] = e * a.inv_b;
         m.sQ[tid] = e * e;
     }
     load_w2(a.pkb[qi], net.W2, true, L, w2);     // same registers, backward image
@@ -236,7 +236,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_qslice_fused(const QsliceArgs a)
             ret = a.gk[gr] + a.gpow[k] * out_preact(m.sPart, net.b3[0], tid, 0);   // mpg_learner.py:266
             d = a.coef[k];
         }
-        m.sD3[tid * MAXOUT] = d;
+        m.sD3[d3_index(tid, 0)] = d;
         m.sQ[tid] = ret;
         m.sQ[GROUP + tid] = (gr < total) ? (float)(gr / a.R) : -1.f;
     }
@@ -263,7 +263,8 @@ template <int QIN>
 __global__ void __launch_bounds__(NTHREAD, 2) k_qslice_fused2(const QsliceArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
     __shared__ __attribute__((aligned(16))) float sX2[2 * GROUP * XS];
-    __shared__ float sD32[2 * GROUP * MAXOUT], sQ2[2 * GROUP];
+    __shared__ __attribute__((aligned(16))) float sD32[2 * GROUP * MAXOUT];
+    __shared__ float sQ2[2 * GROUP];
     const Smem m(smem);
     const Lane L;
     const int tid = threadIdx.x;
@@ -286,7 +287,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_qslice_fused2(const QsliceArgs a
         if (tid < GROUP) {
             const long gr = (sl * gpers + gb) * GROUP + tid;
             sQ2[sl * GROUP + tid] = a.gk[gr] + a.gpow[sl] * out_preact(m.sPart, net.b3[0], tid, 0);   // mpg_learner.py:266
-            sD32[(sl * GROUP + tid) * MAXOUT] = a.coef[sl];
+            sD32[sl * GROUP * MAXOUT + d3_index(tid, 0)] = a.coef[sl];
         }
     }
     load_w2(a.pkb, net.W2, true, L, w2);

@@ -312,6 +312,10 @@ __device__ __forceinline__ float out_preact_tree(const float* sPart, float bias,
     return (((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]))) + bias;
 }
 
+// sD3 [MAXOUT][16]: dL/dz3 of the used outputs, OUTPUT-major so that the four rows a lane needs (4 rg .. 4 rg + 3) are
+// one aligned 16-byte read per output and pair up for packed fmas without register shuffles
+__device__ __forceinline__ int d3_index(int row, int o) { return o * GROUP + row; }
+
 // ---- backward through the hidden layers for one row group ---------------------------------------------
 // sD3 [16][MAXOUT] holds dL/dz3 (pre-activation of the used outputs).  h1/h2: this lane's stashed activations.
 // Produces dz2 and dz1 (C layout).  If WANT_DX, leaves per-wave partial sums of dz1*W1^T in sPartX
@@ -320,16 +324,16 @@ __device__ __forceinline__ float out_preact_tree(const float* sPart, float bias,
 template <int IN, int OU>
 __device__ __forceinline__ void backward_dz2(const float* sD3, float* sA, const Lane& L, const SmallRegs<IN, OU>& r,
                                              const float (&h2)[2][4], float (&dz2)[2][4]) {
+    f32x4 d3v[OU];
+#pragma unroll
+    for (int o = 0; o < OU; ++o) d3v[o] = *reinterpret_cast<const f32x4*>(sD3 + d3_index(4 * L.rg, o));
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        float d3[OU];
-#pragma unroll
-        for (int o = 0; o < OU; ++o) d3[o] = sD3[L.row(j) * MAXOUT + o];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             float dh = 0.f;
 #pragma unroll
-            for (int o = 0; o < OU; ++o) dh = fmaf(d3[o], r.w3[t][o], dh);
+            for (int o = 0; o < OU; ++o) dh = fmaf(d3v[o][j], r.w3[t][o], dh);
             dz2[t][j] = dh * elu_grad_from_out(h2[t][j]);
         }
     }

@@ -135,7 +135,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_backward(const BwdArgs a) {
                 }
                 if (a.dz3) a.dz3[gr * OU + o] = d;
             }
-            sD3[row * MAXOUT + o] = d;
+            sD3[d3_index(row, o)] = d;
         }
         float h1[2][4], h2[2][4], dz1[2][4], dz2[2][4];
         stash_load(a.h1, g, L, h1);

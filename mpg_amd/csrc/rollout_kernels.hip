@@ -513,7 +513,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_bwd(const RollBwdArgs a)
                         const float th = act[k] / a.out_scale;
                         d *= a.out_scale * (1.f - th * th);
                     }
-                    sD3[tid * MAXOUT + k] = d;
+                    sD3[d3_index(tid, k)] = d;
                     if (live && a.DZ3 && (a.stash_all || t == 0))
                         a.DZ3[((long)(a.stash_all ? t : 0) * R + tr) * ACT + k] = d;
                 }
