@@ -268,13 +268,19 @@ __device__ __forceinline__ void forward_group(const float* sX, float* sA, float*
         // one v_add_f32_dpp per value and stage (the compiler's own lowering is v_mov_b32_dpp + a packed add: 1.5
         // instructions per value).  volatile keeps the stage-major order, which also keeps every DPP read >= 8
         // instructions behind the write of its operand (the 2-wait-state VALU->DPP hazard is not checked inside asm).
-#define MPG_DPP_STAGE(PRE, MODS)                                \
+#define MPG_DPP_STAGE(MODS)                                     \
         _Pragma("unroll") for (int o = 0; o < OU; ++o)           \
         _Pragma("unroll") for (int j = 0; j < 4; ++j)            \
-            asm volatile(PRE "v_add_f32_dpp %0, %1, %1 " MODS " row_mask:0xf bank_mask:0xf" : "=v"(p[o][j]) : "v"(p[o][j]));
-        // first stage: its operands come from ordinary fmas the scheduler may place right in front of the asm -> own wait
-        MPG_DPP_STAGE("s_nop 1\n\t", "quad_perm:[1,0,3,2]") MPG_DPP_STAGE("", "quad_perm:[2,3,0,1]")
-        MPG_DPP_STAGE("", "row_half_mirror") MPG_DPP_STAGE("", "row_mirror")
+            asm volatile("v_add_f32_dpp %0, %1, %1 " MODS " row_mask:0xf bank_mask:0xf" : "=v"(p[o][j]) : "v"(p[o][j]));
+        // the first stage's operands come from ordinary fmas the scheduler could place right in front of a DPP read:
+        // one wait that depends on ALL of them (so every producer is ahead of it) covers the whole stage
+        if constexpr (OU == 2)
+            asm volatile("s_nop 1" : "+v"(p[0][0]), "+v"(p[0][1]), "+v"(p[0][2]), "+v"(p[0][3]), "+v"(p[OU - 1][0]),
+                         "+v"(p[OU - 1][1]), "+v"(p[OU - 1][2]), "+v"(p[OU - 1][3]));
+        else
+            asm volatile("s_nop 1" : "+v"(p[0][0]), "+v"(p[0][1]), "+v"(p[0][2]), "+v"(p[0][3]));
+        MPG_DPP_STAGE("quad_perm:[1,0,3,2]") MPG_DPP_STAGE("quad_perm:[2,3,0,1]")
+        MPG_DPP_STAGE("row_half_mirror") MPG_DPP_STAGE("row_mirror")
 #undef MPG_DPP_STAGE
 #else
 #define MPG_DPP_STAGE(CTRL)                                     \
