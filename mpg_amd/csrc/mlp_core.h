@@ -89,6 +89,32 @@ __device__ __forceinline__ void mpg_stamp(int k) {
 // ELU(z) = z for z > 0, exp(z) - 1 otherwise.  exp(z) - 1 >= z everywhere, so the selection is the MEDIAN of
 // (z, exp(z) - 1, 0): one v_med3_f32 instead of compare + select (same values bit for bit).
 __device__ __forceinline__ float elu(float z) { return __builtin_amdgcn_fmed3f(z, __expf(z) - 1.f, 0.f); }
+// ELU of the 8 values of a lane, stage by stage (all multiplies, all exps, all adds, all selects): eight independent
+// chains keep the quarter-rate exp pipe busy; element by element through one temporary - what the scheduler picks at
+// this register pressure - every v_exp_f32 is followed by a hazard wait
+__device__ __forceinline__ void elu8(const f32x4& z0, const f32x4& z1, float (&h)[2][4]) {
+#ifdef MPG_AB_NO_ELU8
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { h[0][j] = elu(z0[j]); h[1][j] = elu(z1[j]); }
+#else
+    float e[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { e[j] = z0[j] * 1.4426950408889634f; e[4 + j] = z1[j] * 1.4426950408889634f; }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) e[i] = __builtin_amdgcn_exp2f(e[i]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) e[i] -= 1.f;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        h[0][j] = __builtin_amdgcn_fmed3f(z0[j], e[j], 0.f);
+        h[1][j] = __builtin_amdgcn_fmed3f(z1[j], e[4 + j], 0.f);
+    }
+#endif
+}
+
 // ELU'(z) expressed through the stored output h = ELU(z): 1 for z > 0, exp(z) = h + 1 in (0, 1] otherwise, i.e. the
 // median of (h + 1, 1, 0).  (fminf(h, 0) + 1 costs an extra v_max canonicalisation of its operand.)
 __device__ __forceinline__ float elu_grad_from_out(float h) { return __builtin_amdgcn_fmed3f(h + 1.f, 1.f, 0.f); }
@@ -236,11 +262,7 @@ __device__ __forceinline__ void forward_group(const float* sX, float* sA, float*
             z0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, r.w1p[q][0], z0, 0, 0, 0);
             z1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, r.w1p[q][1], z1, 0, 0, 0);
         }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            h1[0][j] = elu(z0[j]);
-            h1[1][j] = elu(z1[j]);
-        }
+        elu8(z0, z1, h1);
     }
     store_c_to_a(sA, L, h1);
     // h1 is final here: its stash goes out now and drains under the MFMA block instead of queueing behind the h2
@@ -253,11 +275,7 @@ __device__ __forceinline__ void forward_group(const float* sX, float* sA, float*
     f32x4 acc1 = {r.b2[1], r.b2[1], r.b2[1], r.b2[1]};
     mfma_16x256x32(sA, L, w2, acc0, acc1);
     MPG_STAMP_AT(3);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        h2[0][j] = elu(acc0[j]);
-        h2[1][j] = elu(acc1[j]);
-    }
+    elu8(acc0, acc1, h2);
     {   // output-layer partials: all 4*OU row sums advance stage by stage so that the DPP latencies interleave
         float p[OU][4];
 #pragma unroll
