@@ -320,7 +320,7 @@ struct WgradMulti {
 template <int IA, int OA, int IB, int OB>
 __global__ void __launch_bounds__(NTHREAD, 4) k_wgrad_multi(const WgradMulti m) {
     constexpr int NQA = wgrad_nq<IA, OA>(), NQB = wgrad_nq<IB, OB>();
-    __shared__ float sRed[NWAVE * (NQA > NQB ? NQA : NQB) * 64];
+    __shared__ __attribute__((aligned(16))) float sRed[NWAVE * (NQA > NQB ? NQA : NQB) * 64];
     int gchunk, sl;
     wgrad_map(blockIdx.x, gridDim.x >> 3, gchunk, sl);
     int j = 0;

@@ -188,7 +188,7 @@ int launch_backward(const float* params, int in_dim, int out_dim, int ou, int ro
 // -------------------------------------------------------------------------------------------------------
 template <int IN, int OU>
 __global__ void __launch_bounds__(NTHREAD, 4) k_wgrad(const WgradArgs a) {
-    __shared__ float sRed[NWAVE * wgrad_nq<IN, OU>() * 64];
+    __shared__ __attribute__((aligned(16))) float sRed[NWAVE * wgrad_nq<IN, OU>() * 64];
     int chunk, sl;
     wgrad_map(blockIdx.x, gridDim.x >> 3, chunk, sl);
     wgrad_body<IN, OU>(a, sl, chunk, sRed);

@@ -105,37 +105,54 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int sl, con
     const bool has_thin = tg < g1;
 #endif
 
-    // ---- dW2 on the matrix pipe.  The stashes come from HBM / Infinity Cache (~1.5 us away) while a group's 16 MFMAs
-    //      take 0.4 us: a ring of 2 groups of fragments per wave x 4 resident waves per SIMD keeps 8 groups in flight. ----
+    // ---- dW2 on the matrix pipe.  A operand: this wave's 32 rows of dW2 = 2 fragments of H1 per row group, straight
+    //      from the stash (HBM / Infinity Cache, ~1.5 us away: a ring of 2 groups per wave x 4 resident waves per SIMD
+    //      keeps 8 groups in flight).  B operand: the workgroup's 32-column slice of DZ2 - the SAME two fragments for
+    //      all eight waves, so they go through LDS: each wave fetches them for one group of an 8-group tile and every
+    //      wave reads the tile back (the kernel is bound by L2 -> CU traffic: this removes 7/16 of it). ----
     constexpr int DEPTH = 2;
-    f32x4 fb0[DEPTH], fb1[DEPTH], fa0[DEPTH], fa1[DEPTH];
-    auto frag_load = [&](long g, int slot) {
-        fb0[slot] = DZ2[(g * 16 + 2 * sl) * 64 + L.lane]; fb1[slot] = DZ2[(g * 16 + 2 * sl + 1) * 64 + L.lane];
+    f32x4 fa0[DEPTH], fa1[DEPTH];
+    auto a_load = [&](long g, int slot) {
         fa0[slot] = H1[(g * 16 + 2 * L.wave) * 64 + L.lane]; fa1[slot] = H1[(g * 16 + 2 * L.wave + 1) * 64 + L.lane];
     };
+    f32x4* sB = reinterpret_cast<f32x4*>(sRed);          // [NWAVE groups][2 fragments][64 lanes], aliases the thin scratch
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d)
-        if (g0 + d < g1) frag_load(g0 + d, d);
+        if (g0 + d < g1) a_load(g0 + d, d);
 #ifdef MPG_AB_WG_NOMFMA
-    for (long g = g0; g < g0; g += DEPTH) {
+    for (long tile = g0; tile < g0; tile += NWAVE) {
 #else
-    for (long g = g0; g < g1; g += DEPTH) {
+    for (long tile = g0; tile < g1; tile += NWAVE) {
 #endif
+        const long gb = tile + L.wave;
+        f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
+        if (gb < g1) {
+            b0 = DZ2[(gb * 16 + 2 * sl) * 64 + L.lane];
+            b1 = DZ2[(gb * 16 + 2 * sl + 1) * 64 + L.lane];
+        }
+        __syncthreads();                                  // the previous tile has been read by every wave
+        sB[(L.wave * 2) * 64 + L.lane] = b0;
+        sB[(L.wave * 2 + 1) * 64 + L.lane] = b1;
+        __syncthreads();
 #pragma unroll
-        for (int d = 0; d < DEPTH; ++d) {
-            if (g + d < g1) {
-                const f32x4 b0 = fb0[d], b1 = fb1[d], a0 = fa0[d], a1 = fa1[d];
-                if (g + d + DEPTH < g1) frag_load(g + d + DEPTH, d);
+        for (int d = 0; d < NWAVE; ++d) {
+            const long g = tile + d;
+            if (g < g1) {
+                const int slot = d & (DEPTH - 1);             // tiles start at multiples of NWAVE from g0: (g - g0) & 1 == d & 1
+                const f32x4 fb0 = sB[(d * 2) * 64 + L.lane], fb1 = sB[(d * 2 + 1) * 64 + L.lane];
+                const f32x4 a0 = fa0[slot], a1 = fa1[slot];
+                if (g + DEPTH < g1) a_load(g + DEPTH, slot);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {   // the float4's 4 entries are 4 k-steps (k = batch row)
-                    acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], b0[j], acc[0][0], 0, 0, 0);
-                    acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], b1[j], acc[0][1], 0, 0, 0);
-                    acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], b0[j], acc[1][0], 0, 0, 0);
-                    acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], b1[j], acc[1][1], 0, 0, 0);
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], fb0[j], acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], fb1[j], acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], fb0[j], acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], fb1[j], acc[1][1], 0, 0, 0);
                 }
             }
         }
     }
+    __syncthreads();                                      // the staging corners of the thin part alias the B tile
     // thin pieces after the matrix loop (their registers are then free): the chunk's groups are dealt round-robin to
     // the 8 waves; the load latency is covered by the other resident waves
     if (has_thin) {
