@@ -310,6 +310,102 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_qslice_fused2(const QsliceArgs a
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Critic losses AND the critic at the two selected rollout slices in one launch (the default {0, n} selection):
+// workgroup (g, 0) runs Q1 on row group g of the replay batch and of both slices - three forward passes behind ONE load of
+// the forward register image, three reverse passes behind one load of the transposed image - workgroup (g, 1) runs Q2 on
+// the batch group.  Same arithmetic as k_qloss_fused + k_qslice_fused2, two weight-image loads per CU and one launch less.
+struct CriticArgs {
+    QlossArgs ql;
+    QsliceArgs qs;
+};
+
+template <int QIN>
+__global__ void __launch_bounds__(NTHREAD, 2) k_critic_fused(const CriticArgs ca) {
+    __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
+    __shared__ __attribute__((aligned(16))) float sX2[2 * GROUP * XS];
+    __shared__ __attribute__((aligned(16))) float sD32[2 * GROUP * MAXOUT];
+    __shared__ float sQ2[2 * GROUP];
+    const QlossArgs& a = ca.ql;
+    const QsliceArgs& q = ca.qs;
+    const Smem m(smem);
+    const Lane L;
+    const int tid = threadIdx.x;
+    const long g = blockIdx.x;
+    const int qi = blockIdx.y;
+    const long ngroups = gridDim.x;                    // == q.R / GROUP == a.rows / GROUP
+    const bool slices = qi == 0;
+    const Net net = make_net(a.q[qi], QIN, 1);
+    const CriticStash st = a.st[qi];
+    load_x_group<QIN>(a.x, a.rows, g, m.sX);
+    if (slices && tid < 2 * GROUP * XS) {
+        const int sl = tid / (GROUP * XS), row = (tid / XS) % GROUP, i = tid % XS;
+        const long gr = (sl * ngroups + g) * GROUP + row;
+        sX2[tid] = i < QIN ? q.xq[gr * QIN + i] : 0.f;
+    }
+    lds_barrier();
+    float w2[128], h1[3][2][4], h2[3][2][4], dz1[2][4], dz2[2][4];
+    SmallRegs<QIN, 1> r;
+    load_w2(a.pkf[qi], net.W2, false, L, w2);
+    load_small<QIN, 1>(net, L, r);
+    // ---- forward: replay batch group ----
+    forward_group<QIN, 1>(m.sX, m.sA, m.sPart, L, w2, r, h1[0], h2[0]);
+    stash_store(st.h1, g, L, h1[0]);
+    stash_store(st.h2, g, L, h2[0]);
+    if (tid < GROUP) {   // err = Q(s~,a) - y; dL/dq = err / B_global   (mpg_learner.py:331-336)
+        const long gr = g * GROUP + tid;
+        float e = 0.f;
+        if (gr < a.rows) {
+            e = out_preact(m.sPart, net.b3[0], tid, 0) - a.y[gr];
+            st.dz3[gr] = e * a.inv_b;
+            if (a.td && qi == 0) a.td[gr] = e;
+        }
+        m.sD3[d3_index(tid, 0)] = e * a.inv_b;
+        m.sQ[tid] = e * e;
+    }
+    // ---- forward: the two slices (Q1 workgroups only; wave-uniform branch) ----
+    if (slices) {
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+            forward_group<QIN, 1>(sX2 + sl * GROUP * XS, m.sA, m.sPart, L, w2, r, h1[1 + sl], h2[1 + sl]);
+            if (tid < GROUP) {
+                const long gr = (sl * ngroups + g) * GROUP + tid;
+                sQ2[sl * GROUP + tid] = q.gk[gr] + q.gpow[sl] * out_preact(m.sPart, net.b3[0], tid, 0);   // mpg_learner.py:266
+                sD32[sl * GROUP * MAXOUT + d3_index(tid, 0)] = q.coef[sl];
+            }
+        }
+    }
+    load_w2(a.pkb[qi], net.W2, true, L, w2);     // same registers, backward image
+    lds_barrier();
+    if (tid == 0) {
+        float s2 = 0.f;
+        for (int i = 0; i < GROUP; ++i) s2 += m.sQ[i];
+        a.loss_part[qi * ngroups + g] = 0.5f * a.inv_b * s2;
+    }
+    if (slices && tid >= 64 && tid < 66) {
+        const int sl = tid - 64;
+        float s1 = 0.f, s2 = 0.f;
+        for (int i = 0; i < GROUP; ++i) { const float v = sQ2[sl * GROUP + i]; s1 += v; s2 += v * v; }
+        q.ret_part[(sl * ngroups + g) * 2] = s1;
+        q.ret_part[(sl * ngroups + g) * 2 + 1] = s2;
+    }
+    // ---- reverse: replay batch group (weight-gradient stashes), then the slices (input gradients) ----
+    backward_group<QIN, 1, false>(m.sD3, m.sA, m.sA1, m.sPartX, L, w2, r, h1[0], h2[0], dz1, dz2);
+    stash_store(st.dz1, g, L, dz1);
+    stash_store(st.dz2, g, L, dz2);
+    if (slices) {
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+            backward_group<QIN, 1, true>(sD32 + sl * GROUP * MAXOUT, m.sA, m.sA1, m.sPartX, L, w2, r, h1[1 + sl], h2[1 + sl], dz1, dz2);
+            if (tid < GROUP * QIN) {
+                const int row = tid / QIN, i = tid % QIN;
+                const long gr = (sl * ngroups + g) * GROUP + row;
+                q.gxq[gr * QIN + i] = dx_reduce(m.sPartX, row, i);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 struct WgradMulti {
     int n_jobs;
     WgradArgs a[3];
@@ -457,6 +553,32 @@ int launch_qslice_fused(const float* q_params, int qin, int R, int n_sel, const 
     else if (qin == 5) hipLaunchKernelGGL((k_qslice_fused<5>), dim3(ngroups), dim3(NTHREAD), 0, s, a);
     else { mpg_set_error("launch_qslice_fused: unsupported dims"); return MPG_EINVAL; }
     MPG_CHECK_LAUNCH("k_qslice_fused");
+    return MPG_OK;
+}
+
+int launch_critic_fused(const mpg_cfg_t* cfg, const float* const* q_params, int n_q, int rows, const float* obs,
+                        const float* act, const float* y, float inv_b, const CriticStash* st, float* loss_part, const float* xq,
+                        const float* gk, const float* gpow, const float* coef, float* ret_part, float* gxq, hipStream_t s) {
+    MPG_REQUIRE((n_q == 1 || n_q == 2) && rows % GROUP == 0, "launch_critic_fused: n_q / rows");
+    const int od = cfg->obs_dim, ad = cfg->act_dim, qin = od + ad;
+    CriticArgs c;
+    QlossArgs& a = c.ql;
+    for (int k = 0; k < 2; ++k) {
+        a.q[k] = k < n_q ? q_params[k] : nullptr;
+        a.pkf[k] = k < n_q ? weight_cache_lookup(make_net(q_params[k], qin, 1).W2, 0) : nullptr;
+        a.pkb[k] = k < n_q ? weight_cache_lookup(make_net(q_params[k], qin, 1).W2, 1) : nullptr;
+        if (k < n_q) a.st[k] = st[k];
+    }
+    a.rows = rows; a.x = xspec(obs, od, act, ad, cfg->obs_scale, od); a.y = y; a.inv_b = inv_b; a.loss_part = loss_part; a.td = nullptr;
+    QsliceArgs& q = c.qs;
+    q.q = q_params[0]; q.pkf = a.pkf[0]; q.pkb = a.pkb[0];
+    q.R = rows; q.n_sel = 2; q.xq = xq; q.gk = gk; q.ret_part = ret_part; q.gxq = gxq;
+    for (int k = 0; k < 4; ++k) { q.gpow[k] = k < 2 ? gpow[k] : 0.f; q.coef[k] = k < 2 ? coef[k] : 0.f; }
+    const int ngroups = rows / GROUP;
+    if (qin == 8) hipLaunchKernelGGL((k_critic_fused<8>), dim3(ngroups, n_q), dim3(NTHREAD), 0, s, c);
+    else if (qin == 5) hipLaunchKernelGGL((k_critic_fused<5>), dim3(ngroups, n_q), dim3(NTHREAD), 0, s, c);
+    else { mpg_set_error("launch_critic_fused: unsupported dims"); return MPG_EINVAL; }
+    MPG_CHECK_LAUNCH("k_critic_fused");
     return MPG_OK;
 }
 

@@ -110,6 +110,10 @@ struct SumJob {
     float* dst;
 };
 int launch_wgrad_multi(const WgradJob* jobs, int n_jobs, const SumJob* sums, int n_sums, float* sq_part, hipStream_t s);
+// critic losses + critic at the two selected slices in one launch (launch_qloss_fused + launch_qslice_fused with n_sel == 2)
+int launch_critic_fused(const mpg_cfg_t* cfg, const float* const* q_params, int n_q, int rows, const float* obs,
+                        const float* act, const float* y, float inv_b, const CriticStash* st, float* loss_part, const float* xq,
+                        const float* gk, const float* gpow, const float* coef, float* ret_part, float* gxq, hipStream_t s);
 
 inline size_t stash_floats(int rows) { return (size_t)((rows + GROUP - 1) / GROUP) * GROUP * H; }
 

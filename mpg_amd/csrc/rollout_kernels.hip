@@ -975,16 +975,28 @@ extern "C" int mpg_mpg_gradients(const mpg_cfg_t* cfg, int n_q, const float* par
         if (rc) return rc;
         y = y_out;
     }
-    // 2. critics: forward, error, input-side backward (mpg_learner.py:326-354)
-    int rc = launch_qloss_fused(cfg, qp, n_q, rows, obs, act, y, inv_b_global, st, loss_part, nullptr, s);
-    if (rc) return rc;
-    // 3. rollout forward sweep
-    rc = run_rollout_fwd(cfg, policy, rows, 1, n, select, n_select, obs, eps, noise_seed, noise_ctr, H1, H2, SA, XQ, GK, s);
-    if (rc) return rc;
-    // 4. critic at the selected slices: returns and input gradients
+    int rc;
     const Coefs cf = make_coefs(cfg, select, n_select, w, inv_b_global, 1);
-    rc = launch_qslice_fused(qp[0], qin, rows, n_select, XQ, GK, cf.gpow, cf.coef, ret_part, GXQ, s);
-    if (rc) return rc;
+    if (n_select == 2) {
+        // 2. rollout forward sweep
+        rc = run_rollout_fwd(cfg, policy, rows, 1, n, select, n_select, obs, eps, noise_seed, noise_ctr, H1, H2, SA, XQ, GK, s);
+        if (rc) return rc;
+        // 3.+4. critics (forward, error, input-side backward, mpg_learner.py:326-354) and the critic at the two selected
+        //       slices (returns and input gradients) in one launch
+        rc = launch_critic_fused(cfg, qp, n_q, rows, obs, act, y, inv_b_global, st, loss_part, XQ, GK, cf.gpow, cf.coef, ret_part,
+                                 GXQ, s);
+        if (rc) return rc;
+    } else {
+        // 2. critics: forward, error, input-side backward (mpg_learner.py:326-354)
+        rc = launch_qloss_fused(cfg, qp, n_q, rows, obs, act, y, inv_b_global, st, loss_part, nullptr, s);
+        if (rc) return rc;
+        // 3. rollout forward sweep
+        rc = run_rollout_fwd(cfg, policy, rows, 1, n, select, n_select, obs, eps, noise_seed, noise_ctr, H1, H2, SA, XQ, GK, s);
+        if (rc) return rc;
+        // 4. critic at the selected slices: returns and input gradients
+        rc = launch_qslice_fused(qp[0], qin, rows, n_select, XQ, GK, cf.gpow, cf.coef, ret_part, GXQ, s);
+        if (rc) return rc;
+    }
     // 5. reverse sweep
     rc = run_rollout_bwd(cfg, policy, rows, 1, n, select, n_select, cf.rho, H1, H2, SA, GXQ, 0, DZ1, DZ2, DZ3, s);
     if (rc) return rc;
