@@ -12,6 +12,7 @@
 // NADPLearner (learners/nadp.py:87-194).  The reverse sweep replaces tf.GradientTape; its closed-form model adjoints
 // are pinned against autograd in tests/test_model_vjp.py.
 #include <algorithm>
+#include <stdlib.h>
 
 #include "mlp_launch.h"
 
@@ -977,7 +978,8 @@ extern "C" int mpg_mpg_gradients(const mpg_cfg_t* cfg, int n_q, const float* par
     }
     int rc;
     const Coefs cf = make_coefs(cfg, select, n_select, w, inv_b_global, 1);
-    if (n_select == 2) {
+    static const bool merged_critic = getenv("MPG_NO_CRITIC_FUSED") == nullptr;    // A/B switch (tools only)
+    if (n_select == 2 && merged_critic) {
         // 2. rollout forward sweep
         rc = run_rollout_fwd(cfg, policy, rows, 1, n, select, n_select, obs, eps, noise_seed, noise_ctr, H1, H2, SA, XQ, GK, s);
         if (rc) return rc;
