@@ -195,7 +195,7 @@ int mpg_rollout_pg(const mpg_cfg_t* cfg, const float* policy_params, const float
  * stats (16 floats): [0..n_q) critic losses, [2..2+n_select) return sums, [2+n_select..2+2 n_select) sums of squares.
  * Everything is this GPU's UN-clipped partial, scaled by inv_b_global = 1/B_global: all-reduce, then
  * mpg_clip_by_global_norm.  Same results as mpg_q_targets + mpg_q_loss_grad + mpg_rollout_pg (up to the association
- * of the slab sums) in 7 launches instead of 22 when rows % 16 == 0 and M == 1; otherwise it calls those.
+ * of the slab sums) in 6 launches instead of 22 when rows % 16 == 0 and M == 1; otherwise it calls those.
  * sq_part (nullable, (n_q+1)*MPG_CLIP_PARTS floats): on a single GPU the last launch also leaves the clip's partial sums
  * of squares of `grad` there (what mpg_sq_partials would compute), ready for mpg_clip_adam_polyak. */
 /* Optional fused minibatch draw: ReplayBuffer.sample (buffer.py:70-78) from the device ring, the same draw as
