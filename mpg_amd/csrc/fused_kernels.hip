@@ -507,9 +507,11 @@ int launch_target_fused(const mpg_cfg_t* cfg, const float* policy_t, const float
     a.out_scale = ranged ? cfg->action_range : 1.f;
     a.sigma = sigma; a.clipc = clipc; a.rshift = cfg->rew_shift; a.rscale = cfg->rew_scale; a.gamma = cfg->gamma; a.y = y;
     const int ngroups = (rows + GROUP - 1) / GROUP;
+    mpg_prof_begin(6, s);
     if (od == 6 && ad == 2) hipLaunchKernelGGL((k_target_fused<6, 2>), dim3(ngroups), dim3(NTHREAD), 0, s, a);
     else if (od == 4 && ad == 1) hipLaunchKernelGGL((k_target_fused<4, 1>), dim3(ngroups), dim3(NTHREAD), 0, s, a);
     else { mpg_set_error("launch_target_fused: unsupported dims"); return MPG_EINVAL; }
+    mpg_prof_end(6, s);
     MPG_CHECK_LAUNCH("k_target_fused");
     return MPG_OK;
 }

@@ -31,7 +31,7 @@ struct ProfSlot {
 ProfSlot g_slot[NSLOT];
 int g_prof_on = 0;
 const char* g_slot_name[NSLOT] = {"k_rollout_fwd", "k_rollout_bwd", "k_step (env)", "k_forward", "k_backward",
-                                  "k_wgrad", "", ""};
+                                  "k_wgrad", "k_target_fused", ""};
 }  // namespace
 
 void mpg_prof_begin(int slot, hipStream_t s) {
