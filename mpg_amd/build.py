@@ -18,7 +18,12 @@ ARCH = os.environ.get('MPG_ARCH', 'gfx950')      # MPG_ARCH=gfx950:xnack- for ex
 COMMON = os.environ.get('MPG_EXTRA_CFLAGS', '').split() + ['-O3', '-fPIC', '-std=c++17', '--offload-arch=' + ARCH, '-Wall', '-Wno-unused-function', '-Wno-bitwise-instead-of-logical',
           '-I' + os.path.join(HERE, '..', 'include')]
 # per-file extras: the real-env kernel mirrors the reference op-by-op, so no fused multiply-adds there
-EXTRA = {'env_path_tracking.hip': ['-ffp-contract=off']}
+EXTRA = {'env_path_tracking.hip': ['-ffp-contract=off'],
+         # the two rollout sweeps are separate translation units so that each gets the scheduling options that suit it
+         # (MPG_FWD_CFLAGS / MPG_BWD_CFLAGS override them in experiments, tools/ab_sweeps.sh)
+         'rollout_fwd.hip': os.environ.get('MPG_FWD_CFLAGS', '').split(),
+         # reverse sweep: the max-memory-clause scheduler strategy measures 1.7 us faster than the default (tools/ab_sweeps.sh)
+         'rollout_bwd.hip': os.environ.get('MPG_BWD_CFLAGS', '-mllvm -amdgpu-sched-strategy=max-memory-clause').split()}
 
 
 def hipcc():

@@ -1,0 +1,187 @@
+// Reverse sweep of the fused n-step model rollout (see rollout_kernels.hip for the overview and the references).
+#include "rollout_common.h"
+
+namespace rollout {
+namespace {
+
+template <class ENV>
+__global__ void __launch_bounds__(NTHREAD, 2) k_rollout_bwd(const RollBwdArgs a) {
+    constexpr int OBS = ENV::OBS, ACT = ENV::ACT, QIN = OBS + ACT;
+    __shared__ __attribute__((aligned(16))) float smem[2 * GROUP * LDA + GROUP * MAXOUT + NWAVE * GROUP * XS];
+    float* sA = smem;
+    float* sA1 = sA + GROUP * LDA;
+    float* sD3 = sA1 + GROUP * LDA;
+    float* sPartX = sD3 + GROUP * MAXOUT;
+    // carry state of the 16 trajectory lanes between steps (adjoint of the next obs, record of the next step): kept in
+    // LDS because registers are allocated for all 512 lanes while only 16 use them (the kernel sits at the 256 VGPR limit)
+    __shared__ __attribute__((aligned(16))) float sCarry[GROUP * 16];
+    const Lane L;
+    const int tid = threadIdx.x;
+    const Net net = make_net(a.policy, OBS, 2 * ACT);
+    float w2t[128];
+    SmallRegs<OBS, ACT> r;
+    if (a.pack) load_w2_packed(a.pack, L, w2t); else load_w2_bwd(net.W2, L, w2t);
+    load_small<OBS, ACT>(net, L, r);
+    const long R = (long)a.rows * a.M;
+    const long ngroups = (R + GROUP - 1) / GROUP;
+#ifdef MPG_STAMP
+    if ((tid & 63) == 0) {
+        for (int k = 0; k < 10; ++k) g_st_acc[tid >> 6][k] = 0;
+        g_st_prev[tid >> 6] = __builtin_amdgcn_s_memtime();
+    }
+#endif
+    for (long g = blockIdx.x; g < ngroups; g += gridDim.x) {
+        const long tr = g * GROUP + tid;
+        const bool own = tid < GROUP, live = own && tr < R;
+        if (tid < GROUP) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sCarry[tid * 16 + i] = 0.f;   // [0..8): dL/d(obs_{t+1}), [8..16): record t+1
+        }
+        float lam[8];
+        // Software pipeline over the steps: the (obs | action) record and the h2 stash of step t-1 are requested while
+        // step t computes, so that no HBM / L2 latency sits on the serial chain.
+        float rec_cur[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        float rec_pre[8];
+        float h2_cur[2][4], h2_pre[2][4];
+        if (live) {
+            const f32x4* rp = reinterpret_cast<const f32x4*>(a.SA + ((long)a.n * R + tr) * SAW);
+            const f32x4 r0 = rp[0], r1 = rp[1];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { rec_cur[i] = r0[i]; rec_cur[4 + i] = r1[i]; }
+        }
+        stash_load(a.H2, (long)a.n * ngroups + g, L, h2_cur);
+        for (int t = a.n; t >= 0; --t) {
+            float h1[2][4];
+            if (own) {
+                float ga[2] = {0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < 8; ++i) lam[i] = 0.f;
+                float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, act[2] = {0.f, 0.f};
+                if (live) {
+#pragma unroll
+                    for (int i = 0; i < OBS; ++i) o[i] = rec_cur[i];
+#pragma unroll
+                    for (int k = 0; k < ACT; ++k) act[k] = rec_cur[OBS + k];
+                    if (t < a.n) {
+                        float on[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int i = 0; i < OBS; ++i) on[i] = sCarry[tid * 16 + 8 + i];
+                        float lam_next[8];
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) lam_next[i] = sCarry[tid * 16 + i];
+                        ENV::vjp(o, act, on, lam_next, a.rho[t], lam, ga);
+                    }
+                    for (int ks = 0; ks < a.n_sel; ++ks)
+                        if (a.sel[ks] == t) {
+                            const float* gx = a.GXQ + ((long)ks * R + tr) * QIN;
+#pragma unroll
+                            for (int i = 0; i < OBS; ++i) lam[i] += gx[i] * a.obs_scale[i];
+#pragma unroll
+                            for (int k = 0; k < ACT; ++k) ga[k] += gx[OBS + k];
+                        }
+                }
+#pragma unroll
+                for (int k = 0; k < ACT; ++k) {
+                    float d = ga[k];
+                    if (a.out_tanh) {
+                        const float th = act[k] / a.out_scale;
+                        d *= a.out_scale * (1.f - th * th);
+                    }
+                    sD3[d3_index(tid, k)] = d;
+                    if (live && a.DZ3 && (a.stash_all || t == 0))
+                        a.DZ3[((long)(a.stash_all ? t : 0) * R + tr) * ACT + k] = d;
+                }
+            }
+            float dz1[2][4], dz2[2][4];
+            lds_barrier();
+            MPG_STAMP_AT(0);
+            backward_dz2<OBS, ACT>(sD3, sA, L, r, h2_cur, dz2);
+            // all global loads of the step are issued HERE, behind the dz2 phase: h1 is consumed after the MFMA block,
+            // the record and h2 stash of step t-1 in the next iteration (software pipeline)
+            stash_load(a.H1, (long)t * ngroups + g, L, h1);
+            if (t > 0) {
+                if (live) {
+                    const f32x4* rp = reinterpret_cast<const f32x4*>(a.SA + ((long)(t - 1) * R + tr) * SAW);
+                    const f32x4 r0 = rp[0], r1 = rp[1];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { rec_pre[i] = r0[i]; rec_pre[4 + i] = r1[i]; }
+                }
+                stash_load(a.H2, (long)(t - 1) * ngroups + g, L, h2_pre);
+            }
+            if (t > 0)
+                backward_rest<OBS, ACT, true>(sA, sA1, sPartX, L, w2t, r, h1, dz1);
+            else
+                backward_rest<OBS, ACT, false>(sA, sA1, sPartX, L, w2t, r, h1, dz1);
+            if (a.DZ1 && (a.stash_all || t == 0)) {
+                const long sg = (long)(a.stash_all ? t : 0) * ngroups + g;
+                stash_store(a.DZ1, sg, L, dz1);
+                stash_store(a.DZ2, sg, L, dz2);
+            }
+            if (own) {
+                if (t > 0) {
+                    float dxr[XS];
+                    dx_reduce_row(sPartX, tid, dxr);
+#pragma unroll
+                    for (int i = 0; i < OBS; ++i) lam[i] += dxr[i] * a.obs_scale[i];
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    sCarry[tid * 16 + i] = lam[i];
+                    sCarry[tid * 16 + 8 + i] = rec_cur[i];
+                    rec_cur[i] = rec_pre[i];
+                }
+            }
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) h2_cur[tt][j] = h2_pre[tt][j];
+            MPG_STAMP_AT(7);
+            // next iteration: sD3 is rewritten by wave 0 only after it has passed backward_group's final barrier,
+            // and read by the others only after the __syncthreads above -> no extra barrier needed.
+        }
+#ifdef MPG_STAMP
+        if ((tid & 63) == 0 && a.dbg)
+            for (int k = 0; k < 8; ++k) a.dbg[((long)blockIdx.x * NWAVE + (tid >> 6)) * 8 + k] = (float)g_st_acc[tid >> 6][k];
+#endif
+    }
+}
+
+}  // namespace
+
+int launch_rollout_bwd(const RollBwdArgs& ba_in, int env_kind, long ngroups, int n, hipStream_t s) {
+    RollBwdArgs ba = ba_in;
+    ba.dbg = nullptr;
+#ifdef MPG_STAMP
+    static float* s_dbg_b = nullptr;
+    static int s_calls_b = 0;
+    if (!s_dbg_b) (void)hipMalloc(&s_dbg_b, 256 * 8 * 8 * sizeof(float));
+    ba.dbg = s_dbg_b;
+#endif
+    mpg_prof_begin(1, s);
+    if (env_kind == MPG_ENV_PATH_TRACKING)
+        hipLaunchKernelGGL((k_rollout_bwd<PathTracking>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, ba);
+    else
+        hipLaunchKernelGGL((k_rollout_bwd<Pendulum>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, ba);
+    mpg_prof_end(1, s);
+    MPG_CHECK_LAUNCH("k_rollout_bwd");
+#ifdef MPG_STAMP
+    if (++s_calls_b % 50 == 0) {
+        static float h[256 * 8 * 8];
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(h, s_dbg_b, sizeof(h), hipMemcpyDeviceToHost);
+        const int nwg = grid_for(ngroups);
+        for (int w = 0; w < 8; ++w) {
+            double acc[8] = {0};
+            for (int b = 0; b < nwg; ++b) for (int k = 0; k < 8; ++k) acc[k] += h[(b * 8 + w) * 8 + k];
+            fprintf(stderr, "[stamp bwd] wave %d cycles/step:", w);
+            double tot = 0;
+            for (int k = 0; k < 8; ++k) { fprintf(stderr, " p%d=%.0f", k, acc[k] / nwg / (n + 1)); tot += acc[k] / nwg / (n + 1); }
+            fprintf(stderr, " total=%.0f\n", tot);
+        }
+    }
+#endif
+    (void)n;
+    return MPG_OK;
+}
+
+}  // namespace rollout

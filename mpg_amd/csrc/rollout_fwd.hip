@@ -1,0 +1,186 @@
+// Forward sweep of the fused n-step model rollout (see rollout_kernels.hip for the overview and the references).
+#include "rollout_common.h"
+
+namespace rollout {
+namespace {
+
+template <class ENV>
+__global__ void __launch_bounds__(NTHREAD, 2) k_rollout_fwd(const RollArgs a) {
+    constexpr int OBS = ENV::OBS, ACT = ENV::ACT, QIN = OBS + ACT;
+    __shared__ __attribute__((aligned(16))) float smem[GROUP * LDA + GROUP * XS + NWAVE * GROUP * MAXOUT + MAXN * GROUP];
+    float* sA = smem;
+    float* sX = sA + GROUP * LDA;
+    float* sPart = sX + GROUP * XS;
+    float* sEps = sPart + NWAVE * GROUP * MAXOUT;
+    __shared__ float sGp[MAXN];
+    const Lane L;
+    const int tid = threadIdx.x;
+    if (tid <= a.n) sGp[tid] = powf(a.gamma, (float)tid);     // tf.pow(gamma, ri) in float32, mpg_learner.py:245
+    const Net net = make_net(a.policy, OBS, 2 * ACT);
+    float w2[128];
+    SmallRegs<OBS, ACT> r;
+    if (a.pack) load_w2_packed(a.pack, L, w2); else load_w2_fwd(net.W2, L, w2);
+    load_small<OBS, ACT>(net, L, r);
+    float b3r[2] = {0.f, 0.f};                         // output bias in registers: no global load on the serial chain
+#pragma unroll
+    for (int k = 0; k < ACT; ++k) b3r[k] = net.b3[k];
+    const long R = (long)a.rows * a.M;
+    const long ngroups = (R + GROUP - 1) / GROUP;
+#ifdef MPG_STAMP
+    if ((tid & 63) == 0) {
+        for (int k = 0; k < 10; ++k) g_st_acc[tid >> 6][k] = 0;
+        g_st_prev[tid >> 6] = __builtin_amdgcn_s_memtime();
+    }
+#endif
+    for (long g = blockIdx.x; g < ngroups; g += gridDim.x) {
+        const long tr = g * GROUP + tid;               // this lane's trajectory (tid < 16 only)
+        const bool own = tid < GROUP, live = own && tr < R;
+        float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        float G = 0.f;
+        float act_first[2] = {0.f, 0.f};
+        if (live) {
+            const float* src = a.obs0 + (tr % a.rows) * OBS;
+#pragma unroll
+            for (int i = 0; i < OBS; ++i) o[i] = src[i];
+            if (a.act0) {
+#pragma unroll
+                for (int k = 0; k < ACT; ++k) act_first[k] = a.act0[(tr % a.rows) * ACT + k];
+            }
+        }
+        // the whole group's model noise goes to LDS up front (one value per thread), off the serial chain: either the
+        // caller's eps or Philox draws.  Visible to the dynamics lanes after the first barrier of the step loop.
+        for (int idx = tid; idx < a.n * GROUP; idx += NTHREAD) {
+            const int t = idx / GROUP;
+            const long trj = g * GROUP + (idx % GROUP);
+            float z = 0.f;
+            if (a.eps) {
+                if (trj < R) z = a.eps[(long)t * R + trj];
+            } else {
+                const Philox4 p = philox4x32_10((uint32_t)trj, (uint32_t)t, a.nc0, a.nc1 ^ 0x6e6f6973u, a.nk0, a.nk1);
+                z = sqrtf(-2.f * logf(u01(p.v[0]))) * cosf(6.283185307179586f * u01(p.v[1]));
+            }
+            sEps[idx] = z;
+        }
+        // Per step: B0 (input published) -> layer 1 -> barrier -> layer-2 MFMA block -> output partials -> B2 -> the
+        // trajectory lanes' serial chain (tanh, action-dependent part of the model step, publish the next input).
+        // Everything the chain does not strictly need sits in the trajectory wave's idle time before B2: it is the
+        // older wave of its SIMD and leaves the MFMA block ~4000 cycles before the younger ones.
+        float act[2] = {0.f, 0.f}, rew = 0.f;
+        // record the action of step tb, its critic-input part and the discounted reward (late by one step: off the chain)
+        auto book = [&](int tb) {
+            if (live) {
+                if (a.SA) {
+                    float* rec = a.SA + ((long)tb * R + tr) * SAW + OBS;
+#pragma unroll
+                    for (int k = 0; k < ACT; ++k) rec[k] = act[k];
+                }
+                for (int ks = 0; ks < a.n_sel; ++ks)
+                    if (a.sel[ks] == tb) {
+                        float* xq = a.XQ + ((long)ks * R + tr) * QIN + OBS;
+#pragma unroll
+                        for (int k = 0; k < ACT; ++k) xq[k] = act[k];
+                    }
+            }
+            if (tb < a.n) G += sGp[tb] * ((rew + a.rew_shift) * a.rew_scale);                 // mpg_learner.py:245
+        };
+        if (own) {
+#pragma unroll
+            for (int i = 0; i < XS; ++i) sX[tid * XS + i] = i < OBS ? o[i] * a.obs_scale[i] : 0.f;
+        }
+        for (int t = 0; t <= a.n; ++t) {
+            lds_barrier();
+            MPG_STAMP_AT(0);
+            float h1[2][4], h2[2][4];
+            forward_group<OBS, ACT, false>(sX, sA, sPart, L, w2, r, h1, h2, a.H1, (long)t * ngroups + g);
+            if (a.H1) stash_store(a.H2, (long)t * ngroups + g, L, h2);
+            float pre[ENV::NPRE];
+            if (own) {
+                if (t > 0) book(t - 1);
+                if (live) {
+                    if (a.SA) {
+                        float* rec = a.SA + ((long)t * R + tr) * SAW;
+#pragma unroll
+                        for (int i = 0; i < OBS; ++i) rec[i] = o[i];
+                    }
+                    for (int ks = 0; ks < a.n_sel; ++ks)
+                        if (a.sel[ks] == t) {
+                            float* xq = a.XQ + ((long)ks * R + tr) * QIN;
+#pragma unroll
+                            for (int i = 0; i < OBS; ++i) xq[i] = o[i] * a.obs_scale[i];
+                            a.GK[(long)ks * R + tr] = G;
+                        }
+                }
+                if (t < a.n) ENV::pre(o, sEps[t * GROUP + tid], pre);
+            }
+            MPG_STAMP_AT(6);
+            lds_barrier();
+            MPG_STAMP_AT(5);
+            if (own) {
+#pragma unroll
+                for (int k = 0; k < ACT; ++k) {
+                    const float z = out_preact_tree(sPart, b3r[k], tid, k);
+                    act[k] = a.out_tanh ? a.out_scale * fast_tanh(z) : z;
+                }
+                if (t == 0 && a.act0) {
+#pragma unroll
+                    for (int k = 0; k < ACT; ++k) act[k] = act_first[k];
+                }
+                if (t < a.n) {
+                    float on[8];
+                    ENV::finish(pre, act, on, rew);
+#pragma unroll
+                    for (int i = 0; i < XS; ++i) sX[tid * XS + i] = i < OBS ? on[i] * a.obs_scale[i] : 0.f;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) o[i] = on[i];
+                }
+            }
+            // sX of the next step is ordered behind this step's reads by the two barriers above
+            MPG_STAMP_AT(7);
+        }
+        if (own) book(a.n);
+#ifdef MPG_STAMP
+        if ((tid & 63) == 0 && a.dbg)
+            for (int k = 0; k < 8; ++k) a.dbg[((long)blockIdx.x * NWAVE + (tid >> 6)) * 8 + k] = (float)g_st_acc[tid >> 6][k];
+#endif
+    }
+}
+
+}  // namespace
+
+int launch_rollout_fwd(const RollArgs& fa_in, int env_kind, long ngroups, int n, hipStream_t s, bool timed) {
+    RollArgs fa = fa_in;
+    fa.dbg = nullptr;
+#ifdef MPG_STAMP
+    static float* s_dbg = nullptr;
+    static int s_calls = 0;
+    if (!s_dbg) (void)hipMalloc(&s_dbg, 256 * 8 * 8 * sizeof(float));
+    fa.dbg = s_dbg;
+#endif
+    if (timed) mpg_prof_begin(0, s);
+    if (env_kind == MPG_ENV_PATH_TRACKING)
+        hipLaunchKernelGGL((k_rollout_fwd<PathTracking>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, fa);
+    else
+        hipLaunchKernelGGL((k_rollout_fwd<Pendulum>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, fa);
+    if (timed) mpg_prof_end(0, s);
+    MPG_CHECK_LAUNCH("k_rollout_fwd");
+#ifdef MPG_STAMP
+    if (++s_calls % 50 == 0) {
+        static float h[256 * 8 * 8];
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(h, s_dbg, sizeof(h), hipMemcpyDeviceToHost);
+        const int nwg = grid_for(ngroups);
+        for (int w = 0; w < 8; ++w) {
+            double acc[8] = {0};
+            for (int b = 0; b < nwg; ++b) for (int k = 0; k < 8; ++k) acc[k] += h[(b * 8 + w) * 8 + k];
+            fprintf(stderr, "[stamp fwd] wave %d cycles/step:", w);
+            double tot = 0;
+            for (int k = 0; k < 8; ++k) { fprintf(stderr, " p%d=%.0f", k, acc[k] / nwg / (n + 1)); tot += acc[k] / nwg / (n + 1); }
+            fprintf(stderr, " total=%.0f\n", tot);
+        }
+    }
+#endif
+    (void)n;
+    return MPG_OK;
+}
+
+}  // namespace rollout

@@ -11,354 +11,14 @@
 // 279-297, f_xu :78-138, rewards :181-199), InvertedPendulumModel (envs_and_models/inverted_pendulum_model.py:16-97),
 // NADPLearner (learners/nadp.py:87-194).  The reverse sweep replaces tf.GradientTape; its closed-form model adjoints
 // are pinned against autograd in tests/test_model_vjp.py.
-#include <algorithm>
-#include <stdlib.h>
-
-#include "mlp_launch.h"
+//
+// This translation unit holds the entry points and the small kernels; the two sweeps are rollout_fwd.hip / rollout_bwd.hip.
+#include "rollout_common.h"
 
 using namespace mlp;
+using namespace rollout;
 
 namespace {
-
-constexpr int MAXN = 32;      // horizon limit (reference default n = 25)
-constexpr int MAXSEL = 4;     // slices entering the loss (reference default {0, 25})
-constexpr int SAW = 8;        // floats per (step, trajectory) record: obs | action
-
-// ---------------------------------------------------------------------------------------------------------------
-// differentiable models: one lane = one trajectory
-// ---------------------------------------------------------------------------------------------------------------
-// The model step sits on the serial chain of the rollout (16 lanes work, 496 wait), so it uses the hardware
-// reciprocal / exp / sin / cos (<= 1-2 ulp, far inside the stated 1e-4 gradient tolerance) instead of the
-// correctly-rounded library routines.
-__device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
-__device__ __forceinline__ void fast_sincos(float x, float* s, float* c) {   // |x| <= pi here
-    *s = __sinf(x);
-    *c = __cosf(x);
-}
-__device__ __forceinline__ float fast_tanh(float z) {                       // 1 - 2/(e^{2z} + 1); exact limits +-1
-    return 1.f - 2.f * frcp(__expf(2.f * z) + 1.f);
-}
-
-// The forward step is split so that the part that needs the LATE-arriving action is a handful of fmas:
-//   pre(obs, eps) -> everything that does not depend on the action (the new state is affine in the action);
-//   finish(pre, action) -> new obs, raw reward.
-// pre runs before the barrier that publishes the output-layer partials, so the serial chain between two policy
-// evaluations only contains tanh + finish.  (The same split of the adjoint - Jacobian entries ahead of time, a
-// matrix-vector product on the chain - was tried for the reverse sweep: it needs ~30 more live registers at a point
-// where the kernel has none, the compiler spilled part of the stationary weights, 158 -> 218 us.)
-struct PathTracking {
-    static constexpr int OBS = 6, ACT = 2;
-    static constexpr int NPRE = 9;
-    // vehicle parameters, path_tracking_env.py:60-68; tau = 1/10 (:248)
-    static constexpr float C_f = -128915.5f, C_r = -85943.6f, A = 1.06f, B = 1.85f, MASS = 1412.f, I_z = 1536.7f;
-    static constexpr float TAU = 0.1f;
-    static constexpr float K1 = TAU * (A * C_f - B * C_r), K2 = TAU * C_f, K3 = TAU * MASS, K4 = TAU * (C_f + C_r);
-    static constexpr float K5 = TAU * A * C_f, K6 = TAU * (A * A * C_f + B * B * C_r);
-    static constexpr float S0 = (float)(1.2 * 3.14159265358979323846 / 9.0), S1 = 3.f;   // action scaling :282
-    static constexpr float PI_F = 3.14159265358979323846f;
-
-    // obs -> veh state is a shift of entry 0 by 20 (:268-277); we carry obs and add the shift on use.
-    // One model step (f_xu :78-138 with tau = 0.1, rewards :181-199 on the PRE-step state and scaled action).
-    // eps: standard normal (noise = 0.5 + 0.01 eps, :119).
-    // p: [0] nvx without the action term, [1],[2] nvy = p1 + p2*de, [3],[4] nr = p3 + p4*de, [5] ndy, [6] ndphi,
-    //    [7] nx, [8] state part of -reward
-    __device__ static void pre(const float (&o)[8], float eps, float (&p)[NPRE]) {
-        const float vx = o[0] + 20.f, vy = o[1], r = o[2], dy = o[3], dphi = o[4], x = o[5];
-        const float iD1 = frcp(MASS * vx - K4), iD2 = frcp(K6 - I_z * vx);
-        p[0] = vx + TAU * (vy * r);
-        p[1] = (MASS * vy * vx + K1 * r - K3 * vx * vx * r) * iD1;
-        p[2] = -K2 * vx * iD1;
-        p[3] = (-I_z * r * vx - K1 * vy) * iD2;
-        p[4] = K5 * vx * iD2;
-        float sp, cp;
-        fast_sincos(dphi, &sp, &cp);
-        p[5] = dy + TAU * (vx * sp + vy * cp) + (0.5f + 0.01f * eps);
-        float ndphi = dphi + TAU * r;
-        if (ndphi > PI_F) ndphi -= 2.f * PI_F;                   // :290
-        if (ndphi <= -PI_F) ndphi += 2.f * PI_F;                 // :291
-        p[6] = ndphi;
-        p[7] = x + TAU * (vx * cp - vy * sp);
-        const float dv = vx - 20.f;
-        p[8] = 0.01f * dv * dv + 0.04f * dy * dy + 0.1f * dphi * dphi + 0.02f * r * r;
-    }
-    __device__ static void finish(const float (&p)[NPRE], const float (&a)[2], float (&on)[8], float& rew) {
-        const float de = a[0] * S0, ax = a[1] * S1;
-        const float nvx = fminf(fmaxf(fmaf(TAU, ax, p[0]), 1.f), 35.f);      // :289
-        on[0] = nvx - 20.f;
-        on[1] = fmaf(p[2], de, p[1]);
-        on[2] = fmaf(p[4], de, p[3]);
-        on[3] = p[5]; on[4] = p[6]; on[5] = p[7]; on[6] = 0.f; on[7] = 0.f;
-        rew = -(p[8] + 5.f * de * de + 0.05f * ax * ax);
-    }
-    __device__ static void step(const float (&o)[8], const float (&a)[2], float eps, float (&on)[8], float& rew) {
-        float p[NPRE];
-        pre(o, eps, p);
-        finish(p, a, on, rew);
-    }
-
-    // adjoint of step(): lam = dL/d(new obs), rho = dL/d(raw reward).  Returns dL/d(obs) and dL/d(action).
-    // (oracle/mpg_oracle.py:pt_model_step_vjp is the float64 statement of the same formulas)
-    __device__ static void vjp(const float (&o)[8], const float (&a)[2], const float (&onext)[8], const float (&lam)[8],
-                               float rho, float (&g)[8], float (&ga)[2]) {
-        const float vx = o[0] + 20.f, vy = o[1], r = o[2], dy = o[3], dphi = o[4];
-        const float de = a[0] * S0, ax = a[1] * S1;
-        const float nvx_raw = vx + TAU * (ax + vy * r);
-        const float l_vx = (nvx_raw >= 1.f && nvx_raw <= 35.f) ? lam[0] : 0.f;
-        const float l_vy = lam[1], l_r = lam[2], l_dy = lam[3], l_dphi = lam[4], l_x = lam[5];
-        const float D1 = MASS * vx - K4, D2 = K6 - I_z * vx;
-        const float iD1 = frcp(D1), iD2 = frcp(D2);
-        const float nvy = (MASS * vy * vx + K1 * r - K2 * de * vx - K3 * vx * vx * r) * iD1;
-        const float nr = (-I_z * r * vx - K1 * vy + K5 * de * vx) * iD2;
-        float sp, cp;
-        fast_sincos(dphi, &sp, &cp);
-        const float dvy_vx = (MASS * vy - K2 * de - 2.f * K3 * vx * r - nvy * MASS) * iD1;
-        const float dvy_vy = MASS * vx * iD1;
-        const float dvy_r = (K1 - K3 * vx * vx) * iD1;
-        const float dvy_de = -K2 * vx * iD1;
-        const float dr_vx = (-I_z * r + K5 * de + nr * I_z) * iD2;
-        const float dr_vy = -K1 * iD2;
-        const float dr_r = -I_z * vx * iD2;
-        const float dr_de = K5 * vx * iD2;
-        g[0] = l_vx + l_vy * dvy_vx + l_r * dr_vx + l_dy * TAU * sp + l_x * TAU * cp + rho * (-0.02f * (vx - 20.f));
-        g[1] = l_vx * TAU * r + l_vy * dvy_vy + l_r * dr_vy + l_dy * TAU * cp - l_x * TAU * sp;
-        g[2] = l_vx * TAU * vy + l_vy * dvy_r + l_r * dr_r + l_dphi * TAU + rho * (-0.04f * r);
-        g[3] = l_dy + rho * (-0.08f * dy);
-        g[4] = l_dphi + l_dy * TAU * (vx * cp - vy * sp) - l_x * TAU * (vx * sp + vy * cp) + rho * (-0.2f * dphi);
-        g[5] = l_x;
-        ga[0] = (l_vy * dvy_de + l_r * dr_de + rho * (-10.f * de)) * S0;
-        ga[1] = (l_vx * TAU + rho * (-0.1f * ax)) * S1;
-        (void)onext;
-    }
-};
-
-struct Pendulum {
-    static constexpr int OBS = 4, ACT = 1;
-    static constexpr int NPRE = 6;
-    // inverted_pendulum_model.py:18-26,38-44: m = 9.42, m1 = 4.89, m2 = 0, l1 = 0.6
-    static constexpr float D1c = 9.42f + 4.89f, D2c = 0.5f * 4.89f * 0.6f, D4c = (1.f / 3.f) * 4.89f * 0.6f * 0.6f;
-    static constexpr float F1c = 0.5f * 4.89f * 0.6f * 9.81f, TAU = 0.04f;
-
-    // p: [0] new p, [1] new theta, [2],[3] new pdot = p2 + p3*a, [4],[5] new thetadot = p4 + p5*a
-    __device__ static void pre(const float (&o)[8], float eps, float (&p)[NPRE]) {
-        const float pos = o[0], th = o[1], pd = o[2], thd = o[3];
-        float sn, c;
-        sincosf(th, &sn, &c);                                               // theta is not range-limited: keep the library routine
-        const float idet = frcp(D1c * D4c - D2c * D2c * c * c);             // closed-form 2x2 inverse (:53)
-        const float F1s = D2c * sn * thd * thd, F2 = F1c * sn;              // F1 = F1s + u, u = 100 a (action_trans :96-97)
-        p[0] = pos + TAU * pd + (0.1f + 0.5f * eps);                        // :57,:61
-        p[1] = th + TAU * thd;
-        p[2] = pd + TAU * ((D4c * F1s - D2c * c * F2) * idet);
-        p[3] = TAU * 100.f * D4c * idet;
-        p[4] = thd + TAU * ((-D2c * c * F1s + D1c * F2) * idet);
-        p[5] = -TAU * 100.f * D2c * c * idet;
-    }
-    __device__ static void finish(const float (&p)[NPRE], const float (&a)[2], float (&on)[8], float& rew) {
-        on[0] = p[0];
-        on[1] = p[1];
-        on[2] = fmaf(p[3], a[0], p[2]);
-        on[3] = fmaf(p[5], a[0], p[4]);
-        on[4] = on[5] = on[6] = on[7] = 0.f;
-        rew = -(0.01f * on[0] * on[0] + on[1] * on[1]) - (1e-3f * on[2] * on[2] + 1e-3f * on[3] * on[3]);   // :66-73,:93
-    }
-    __device__ static void step(const float (&o)[8], const float (&a)[2], float eps, float (&on)[8], float& rew) {
-        float p[NPRE];
-        pre(o, eps, p);
-        finish(p, a, on, rew);
-    }
-
-    __device__ static void vjp(const float (&o)[8], const float (&a)[2], const float (&onext)[8], const float (&lam_in)[8],
-                               float rho, float (&g)[8], float (&ga)[2]) {
-        // the reward is taken on the NEW (noisy) state: fold it into the adjoint of the new state first
-        const float l_p = lam_in[0] + rho * (-0.02f * onext[0]);
-        const float l_th = lam_in[1] + rho * (-2.f * onext[1]);
-        const float l_pd = lam_in[2] + rho * (-2e-3f * onext[2]);
-        const float l_thd = lam_in[3] + rho * (-2e-3f * onext[3]);
-        const float th = o[1], thd = o[3];
-        const float u = 100.f * a[0];
-        float sn, c;
-        sincosf(th, &sn, &c);
-        const float det = D1c * D4c - D2c * D2c * c * c, idet = frcp(det);
-        const float F1 = D2c * sn * thd * thd + u, F2 = F1c * sn;
-        const float pdd = (D4c * F1 - D2c * c * F2) * idet;
-        const float thdd = (-D2c * c * F1 + D1c * F2) * idet;
-        const float ddet_th = 2.f * D2c * D2c * c * sn;
-        const float dF1_th = D2c * c * thd * thd, dF1_thd = 2.f * D2c * sn * thd, dF2_th = F1c * c;
-        const float dpdd_th = (D4c * dF1_th + D2c * sn * F2 - D2c * c * dF2_th - pdd * ddet_th) * idet;
-        const float dthdd_th = (D2c * sn * F1 - D2c * c * dF1_th + D1c * dF2_th - thdd * ddet_th) * idet;
-        const float dpdd_thd = D4c * dF1_thd * idet, dthdd_thd = -D2c * c * dF1_thd * idet;
-        const float dpdd_u = D4c * idet, dthdd_u = -D2c * c * idet;
-        g[0] = l_p;
-        g[1] = l_th + TAU * (l_pd * dpdd_th + l_thd * dthdd_th);
-        g[2] = l_p * TAU + l_pd;
-        g[3] = l_th * TAU + l_thd + TAU * (l_pd * dpdd_thd + l_thd * dthdd_thd);
-        ga[0] = 100.f * TAU * (l_pd * dpdd_u + l_thd * dthdd_u);
-        ga[1] = 0.f;
-    }
-};
-
-// ---------------------------------------------------------------------------------------------------------------
-// forward sweep
-// ---------------------------------------------------------------------------------------------------------------
-struct RollArgs {
-    const float* policy;
-    int rows, M, n;                     // R = rows * M trajectories, horizon n
-    float obs_scale[8];
-    float rew_scale, rew_shift, gamma;
-    int out_tanh;
-    float out_scale;
-    const float* obs0;                  // [rows][OBS]
-    const float* act0;                  // nullable [rows][ACT]: first action given (NADP Q-target rollout)
-    const float* eps;                   // [n][R] standard normal, or nullptr: Philox4x32-10(noise_seed, noise_ctr, t, trajectory)
-    uint32_t nk0, nk1, nc0, nc1;
-    float *H1, *H2;                     // nullable G16 stashes, group index t*ngroups + g
-    float* SA;                          // nullable [(n+1)][R][SAW]: obs | action of every step
-    int sel[MAXSEL], n_sel;
-    float* XQ;                          // [n_sel][R][OBS+ACT] critic inputs (scaled obs | action) at the selected slices
-    float* GK;                          // [n_sel][R] discounted reward sums G_k
-    const float* pack;                  // nullable: packed forward image of the policy's W2
-    float* dbg;                         // diagnostic builds only
-};
-
-template <class ENV>
-__global__ void __launch_bounds__(NTHREAD, 2) k_rollout_fwd(const RollArgs a) {
-    constexpr int OBS = ENV::OBS, ACT = ENV::ACT, QIN = OBS + ACT;
-    __shared__ __attribute__((aligned(16))) float smem[GROUP * LDA + GROUP * XS + NWAVE * GROUP * MAXOUT + MAXN * GROUP];
-    float* sA = smem;
-    float* sX = sA + GROUP * LDA;
-    float* sPart = sX + GROUP * XS;
-    float* sEps = sPart + NWAVE * GROUP * MAXOUT;
-    __shared__ float sGp[MAXN];
-    const Lane L;
-    const int tid = threadIdx.x;
-    if (tid <= a.n) sGp[tid] = powf(a.gamma, (float)tid);     // tf.pow(gamma, ri) in float32, mpg_learner.py:245
-    const Net net = make_net(a.policy, OBS, 2 * ACT);
-    float w2[128];
-    SmallRegs<OBS, ACT> r;
-    if (a.pack) load_w2_packed(a.pack, L, w2); else load_w2_fwd(net.W2, L, w2);
-    load_small<OBS, ACT>(net, L, r);
-    float b3r[2] = {0.f, 0.f};                         // output bias in registers: no global load on the serial chain
-#pragma unroll
-    for (int k = 0; k < ACT; ++k) b3r[k] = net.b3[k];
-    const long R = (long)a.rows * a.M;
-    const long ngroups = (R + GROUP - 1) / GROUP;
-#ifdef MPG_STAMP
-    if ((tid & 63) == 0) {
-        for (int k = 0; k < 10; ++k) g_st_acc[tid >> 6][k] = 0;
-        g_st_prev[tid >> 6] = __builtin_amdgcn_s_memtime();
-    }
-#endif
-    for (long g = blockIdx.x; g < ngroups; g += gridDim.x) {
-        const long tr = g * GROUP + tid;               // this lane's trajectory (tid < 16 only)
-        const bool own = tid < GROUP, live = own && tr < R;
-        float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        float G = 0.f;
-        float act_first[2] = {0.f, 0.f};
-        if (live) {
-            const float* src = a.obs0 + (tr % a.rows) * OBS;
-#pragma unroll
-            for (int i = 0; i < OBS; ++i) o[i] = src[i];
-            if (a.act0) {
-#pragma unroll
-                for (int k = 0; k < ACT; ++k) act_first[k] = a.act0[(tr % a.rows) * ACT + k];
-            }
-        }
-        // the whole group's model noise goes to LDS up front (one value per thread), off the serial chain: either the
-        // caller's eps or Philox draws.  Visible to the dynamics lanes after the first barrier of the step loop.
-        for (int idx = tid; idx < a.n * GROUP; idx += NTHREAD) {
-            const int t = idx / GROUP;
-            const long trj = g * GROUP + (idx % GROUP);
-            float z = 0.f;
-            if (a.eps) {
-                if (trj < R) z = a.eps[(long)t * R + trj];
-            } else {
-                const Philox4 p = philox4x32_10((uint32_t)trj, (uint32_t)t, a.nc0, a.nc1 ^ 0x6e6f6973u, a.nk0, a.nk1);
-                z = sqrtf(-2.f * logf(u01(p.v[0]))) * cosf(6.283185307179586f * u01(p.v[1]));
-            }
-            sEps[idx] = z;
-        }
-        // Per step: B0 (input published) -> layer 1 -> barrier -> layer-2 MFMA block -> output partials -> B2 -> the
-        // trajectory lanes' serial chain (tanh, action-dependent part of the model step, publish the next input).
-        // Everything the chain does not strictly need sits in the trajectory wave's idle time before B2: it is the
-        // older wave of its SIMD and leaves the MFMA block ~4000 cycles before the younger ones.
-        float act[2] = {0.f, 0.f}, rew = 0.f;
-        // record the action of step tb, its critic-input part and the discounted reward (late by one step: off the chain)
-        auto book = [&](int tb) {
-            if (live) {
-                if (a.SA) {
-                    float* rec = a.SA + ((long)tb * R + tr) * SAW + OBS;
-#pragma unroll
-                    for (int k = 0; k < ACT; ++k) rec[k] = act[k];
-                }
-                for (int ks = 0; ks < a.n_sel; ++ks)
-                    if (a.sel[ks] == tb) {
-                        float* xq = a.XQ + ((long)ks * R + tr) * QIN + OBS;
-#pragma unroll
-                        for (int k = 0; k < ACT; ++k) xq[k] = act[k];
-                    }
-            }
-            if (tb < a.n) G += sGp[tb] * ((rew + a.rew_shift) * a.rew_scale);                 // mpg_learner.py:245
-        };
-        if (own) {
-#pragma unroll
-            for (int i = 0; i < XS; ++i) sX[tid * XS + i] = i < OBS ? o[i] * a.obs_scale[i] : 0.f;
-        }
-        for (int t = 0; t <= a.n; ++t) {
-            lds_barrier();
-            MPG_STAMP_AT(0);
-            float h1[2][4], h2[2][4];
-            forward_group<OBS, ACT, false>(sX, sA, sPart, L, w2, r, h1, h2, a.H1, (long)t * ngroups + g);
-            if (a.H1) stash_store(a.H2, (long)t * ngroups + g, L, h2);
-            float pre[ENV::NPRE];
-            if (own) {
-                if (t > 0) book(t - 1);
-                if (live) {
-                    if (a.SA) {
-                        float* rec = a.SA + ((long)t * R + tr) * SAW;
-#pragma unroll
-                        for (int i = 0; i < OBS; ++i) rec[i] = o[i];
-                    }
-                    for (int ks = 0; ks < a.n_sel; ++ks)
-                        if (a.sel[ks] == t) {
-                            float* xq = a.XQ + ((long)ks * R + tr) * QIN;
-#pragma unroll
-                            for (int i = 0; i < OBS; ++i) xq[i] = o[i] * a.obs_scale[i];
-                            a.GK[(long)ks * R + tr] = G;
-                        }
-                }
-                if (t < a.n) ENV::pre(o, sEps[t * GROUP + tid], pre);
-            }
-            MPG_STAMP_AT(6);
-            lds_barrier();
-            MPG_STAMP_AT(5);
-            if (own) {
-#pragma unroll
-                for (int k = 0; k < ACT; ++k) {
-                    const float z = out_preact_tree(sPart, b3r[k], tid, k);
-                    act[k] = a.out_tanh ? a.out_scale * fast_tanh(z) : z;
-                }
-                if (t == 0 && a.act0) {
-#pragma unroll
-                    for (int k = 0; k < ACT; ++k) act[k] = act_first[k];
-                }
-                if (t < a.n) {
-                    float on[8];
-                    ENV::finish(pre, act, on, rew);
-#pragma unroll
-                    for (int i = 0; i < XS; ++i) sX[tid * XS + i] = i < OBS ? on[i] * a.obs_scale[i] : 0.f;
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) o[i] = on[i];
-                }
-            }
-            // sX of the next step is ordered behind this step's reads by the two barriers above
-            MPG_STAMP_AT(7);
-        }
-        if (own) book(a.n);
-#ifdef MPG_STAMP
-        if ((tid & 63) == 0 && a.dbg)
-            for (int k = 0; k < 8; ++k) a.dbg[((long)blockIdx.x * NWAVE + (tid >> 6)) * 8 + k] = (float)g_st_acc[tid >> 6][k];
-#endif
-    }
-}
 
 // ---------------------------------------------------------------------------------------------------------------
 // returns, statistics and the critic-side seeds of the reverse sweep
@@ -413,167 +73,6 @@ __global__ void k_gq(int n, const float* __restrict__ G, const float* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// reverse sweep
-// ---------------------------------------------------------------------------------------------------------------
-struct RollBwdArgs {
-    const float* policy;
-    int rows, M, n;
-    float obs_scale[8];
-    int out_tanh;
-    float out_scale;
-    const float *H1, *H2, *SA;
-    int sel[MAXSEL], n_sel;
-    const float* GXQ;                   // [n_sel][R][OBS+ACT] dL/d(critic input) at the selected slices
-    float rho[MAXN];                    // dL/d(raw reward of step t)
-    int stash_all;                      // 0: parameter gradient through step 0 only (MPG); 1: every step (NADP)
-    float *DZ1, *DZ2, *DZ3;             // stashes for the weight gradient: T = stash_all ? n+1 : 1 steps
-    const float* pack;                  // nullable: packed backward image of the policy's W2
-    float* dbg;                         // diagnostic builds only
-};
-
-template <class ENV>
-__global__ void __launch_bounds__(NTHREAD, 2) k_rollout_bwd(const RollBwdArgs a) {
-    constexpr int OBS = ENV::OBS, ACT = ENV::ACT, QIN = OBS + ACT;
-    __shared__ __attribute__((aligned(16))) float smem[2 * GROUP * LDA + GROUP * MAXOUT + NWAVE * GROUP * XS];
-    float* sA = smem;
-    float* sA1 = sA + GROUP * LDA;
-    float* sD3 = sA1 + GROUP * LDA;
-    float* sPartX = sD3 + GROUP * MAXOUT;
-    // carry state of the 16 trajectory lanes between steps (adjoint of the next obs, record of the next step): kept in
-    // LDS because registers are allocated for all 512 lanes while only 16 use them (the kernel sits at the 256 VGPR limit)
-    __shared__ __attribute__((aligned(16))) float sCarry[GROUP * 16];
-    const Lane L;
-    const int tid = threadIdx.x;
-    const Net net = make_net(a.policy, OBS, 2 * ACT);
-    float w2t[128];
-    SmallRegs<OBS, ACT> r;
-    if (a.pack) load_w2_packed(a.pack, L, w2t); else load_w2_bwd(net.W2, L, w2t);
-    load_small<OBS, ACT>(net, L, r);
-    const long R = (long)a.rows * a.M;
-    const long ngroups = (R + GROUP - 1) / GROUP;
-#ifdef MPG_STAMP
-    if ((tid & 63) == 0) {
-        for (int k = 0; k < 10; ++k) g_st_acc[tid >> 6][k] = 0;
-        g_st_prev[tid >> 6] = __builtin_amdgcn_s_memtime();
-    }
-#endif
-    for (long g = blockIdx.x; g < ngroups; g += gridDim.x) {
-        const long tr = g * GROUP + tid;
-        const bool own = tid < GROUP, live = own && tr < R;
-        if (tid < GROUP) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) sCarry[tid * 16 + i] = 0.f;   // [0..8): dL/d(obs_{t+1}), [8..16): record t+1
-        }
-        float lam[8];
-        // Software pipeline over the steps: the (obs | action) record and the h2 stash of step t-1 are requested while
-        // step t computes, so that no HBM / L2 latency sits on the serial chain.
-        float rec_cur[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        float rec_pre[8];
-        float h2_cur[2][4], h2_pre[2][4];
-        if (live) {
-            const f32x4* rp = reinterpret_cast<const f32x4*>(a.SA + ((long)a.n * R + tr) * SAW);
-            const f32x4 r0 = rp[0], r1 = rp[1];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { rec_cur[i] = r0[i]; rec_cur[4 + i] = r1[i]; }
-        }
-        stash_load(a.H2, (long)a.n * ngroups + g, L, h2_cur);
-        for (int t = a.n; t >= 0; --t) {
-            float h1[2][4];
-            if (own) {
-                float ga[2] = {0.f, 0.f};
-#pragma unroll
-                for (int i = 0; i < 8; ++i) lam[i] = 0.f;
-                float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, act[2] = {0.f, 0.f};
-                if (live) {
-#pragma unroll
-                    for (int i = 0; i < OBS; ++i) o[i] = rec_cur[i];
-#pragma unroll
-                    for (int k = 0; k < ACT; ++k) act[k] = rec_cur[OBS + k];
-                    if (t < a.n) {
-                        float on[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                        for (int i = 0; i < OBS; ++i) on[i] = sCarry[tid * 16 + 8 + i];
-                        float lam_next[8];
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) lam_next[i] = sCarry[tid * 16 + i];
-                        ENV::vjp(o, act, on, lam_next, a.rho[t], lam, ga);
-                    }
-                    for (int ks = 0; ks < a.n_sel; ++ks)
-                        if (a.sel[ks] == t) {
-                            const float* gx = a.GXQ + ((long)ks * R + tr) * QIN;
-#pragma unroll
-                            for (int i = 0; i < OBS; ++i) lam[i] += gx[i] * a.obs_scale[i];
-#pragma unroll
-                            for (int k = 0; k < ACT; ++k) ga[k] += gx[OBS + k];
-                        }
-                }
-#pragma unroll
-                for (int k = 0; k < ACT; ++k) {
-                    float d = ga[k];
-                    if (a.out_tanh) {
-                        const float th = act[k] / a.out_scale;
-                        d *= a.out_scale * (1.f - th * th);
-                    }
-                    sD3[d3_index(tid, k)] = d;
-                    if (live && a.DZ3 && (a.stash_all || t == 0))
-                        a.DZ3[((long)(a.stash_all ? t : 0) * R + tr) * ACT + k] = d;
-                }
-            }
-            float dz1[2][4], dz2[2][4];
-            lds_barrier();
-            MPG_STAMP_AT(0);
-            backward_dz2<OBS, ACT>(sD3, sA, L, r, h2_cur, dz2);
-            // all global loads of the step are issued HERE, behind the dz2 phase: h1 is consumed after the MFMA block,
-            // the record and h2 stash of step t-1 in the next iteration (software pipeline)
-            stash_load(a.H1, (long)t * ngroups + g, L, h1);
-            if (t > 0) {
-                if (live) {
-                    const f32x4* rp = reinterpret_cast<const f32x4*>(a.SA + ((long)(t - 1) * R + tr) * SAW);
-                    const f32x4 r0 = rp[0], r1 = rp[1];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) { rec_pre[i] = r0[i]; rec_pre[4 + i] = r1[i]; }
-                }
-                stash_load(a.H2, (long)(t - 1) * ngroups + g, L, h2_pre);
-            }
-            if (t > 0)
-                backward_rest<OBS, ACT, true>(sA, sA1, sPartX, L, w2t, r, h1, dz1);
-            else
-                backward_rest<OBS, ACT, false>(sA, sA1, sPartX, L, w2t, r, h1, dz1);
-            if (a.DZ1 && (a.stash_all || t == 0)) {
-                const long sg = (long)(a.stash_all ? t : 0) * ngroups + g;
-                stash_store(a.DZ1, sg, L, dz1);
-                stash_store(a.DZ2, sg, L, dz2);
-            }
-            if (own) {
-                if (t > 0) {
-                    float dxr[XS];
-                    dx_reduce_row(sPartX, tid, dxr);
-#pragma unroll
-                    for (int i = 0; i < OBS; ++i) lam[i] += dxr[i] * a.obs_scale[i];
-                }
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    sCarry[tid * 16 + i] = lam[i];
-                    sCarry[tid * 16 + 8 + i] = rec_cur[i];
-                    rec_cur[i] = rec_pre[i];
-                }
-            }
-#pragma unroll
-            for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) h2_cur[tt][j] = h2_pre[tt][j];
-            MPG_STAMP_AT(7);
-            // next iteration: sD3 is rewritten by wave 0 only after it has passed backward_group's final barrier,
-            // and read by the others only after the __syncthreads above -> no extra barrier needed.
-        }
-#ifdef MPG_STAMP
-        if ((tid & 63) == 0 && a.dbg)
-            for (int k = 0; k < 8; ++k) a.dbg[((long)blockIdx.x * NWAVE + (tid >> 6)) * 8 + k] = (float)g_st_acc[tid >> 6][k];
-#endif
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------
 inline char* align256(char* p) { return reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(p) + 255) & ~uintptr_t(255)); }
@@ -593,17 +92,6 @@ inline bool cfg_ok(const mpg_cfg_t* c) {
                  (c->obs_dim == 4 && c->act_dim == 1 && c->env_kind == MPG_ENV_INVERTED_PENDULUM));
 }
 
-void fill_roll(RollArgs& a, const mpg_cfg_t* cfg, const float* policy, int rows, int M, int n) {
-    a.policy = policy; a.rows = rows; a.M = M; a.n = n;
-    for (int i = 0; i < 8; ++i) a.obs_scale[i] = i < cfg->obs_dim ? cfg->obs_scale[i] : 1.f;
-    a.rew_scale = cfg->rew_scale; a.rew_shift = cfg->rew_shift; a.gamma = cfg->gamma;
-    const bool ranged = cfg->action_range > 0.f;
-    a.out_tanh = (cfg->policy_out_act == MPG_ACT_TANH || ranged) ? 1 : 0;
-    a.out_scale = ranged ? cfg->action_range : 1.f;
-    a.pack = weight_cache_lookup(make_net(policy, cfg->obs_dim, 2 * cfg->act_dim).W2, 0);
-}
-
-int grid_for(long ngroups) { return (int)(ngroups < 256 ? ngroups : 256); }
 
 struct PgLayout {
     size_t h, sa, xq, gk, q, dyq, hq, gxq, dz, dz3, slabs, small, total;
@@ -662,37 +150,7 @@ int run_rollout_fwd(const mpg_cfg_t* cfg, const float* policy_params, int rows, 
     for (int k = 0; k < MAXSEL; ++k) fa.sel[k] = k < n_select ? select[k] : -1;
     fa.XQ = XQ; fa.GK = GK;
     const long ngroups = (R + GROUP - 1) / GROUP;
-    fa.dbg = nullptr;
-#ifdef MPG_STAMP
-    static float* s_dbg = nullptr;
-    static int s_calls = 0;
-    if (!s_dbg) (void)hipMalloc(&s_dbg, 256 * 8 * 8 * sizeof(float));
-    fa.dbg = s_dbg;
-#endif
-    mpg_prof_begin(0, s);
-    if (cfg->env_kind == MPG_ENV_PATH_TRACKING)
-        hipLaunchKernelGGL((k_rollout_fwd<PathTracking>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, fa);
-    else
-        hipLaunchKernelGGL((k_rollout_fwd<Pendulum>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, fa);
-    mpg_prof_end(0, s);
-    MPG_CHECK_LAUNCH("k_rollout_fwd");
-#ifdef MPG_STAMP
-    if (++s_calls % 50 == 0) {
-        static float h[256 * 8 * 8];
-        (void)hipStreamSynchronize(s);
-        (void)hipMemcpy(h, s_dbg, sizeof(h), hipMemcpyDeviceToHost);
-        const int nwg = grid_for(ngroups);
-        for (int w = 0; w < 8; ++w) {
-            double acc[8] = {0};
-            for (int b = 0; b < nwg; ++b) for (int k = 0; k < 8; ++k) acc[k] += h[(b * 8 + w) * 8 + k];
-            fprintf(stderr, "[stamp fwd] wave %d cycles/step:", w);
-            double tot = 0;
-            for (int k = 0; k < 8; ++k) { fprintf(stderr, " p%d=%.0f", k, acc[k] / nwg / (n + 1)); tot += acc[k] / nwg / (n + 1); }
-            fprintf(stderr, " total=%.0f\n", tot);
-        }
-    }
-#endif
-    return MPG_OK;
+    return launch_rollout_fwd(fa, cfg->env_kind, ngroups, n, s, true);
 }
 
 int run_rollout_bwd(const mpg_cfg_t* cfg, const float* policy_params, int rows, int M, int n, const int* select, int n_select,
@@ -716,37 +174,7 @@ int run_rollout_bwd(const mpg_cfg_t* cfg, const float* policy_params, int rows, 
     ba.stash_all = all_steps_param_grad ? 1 : 0;
     ba.DZ1 = DZ1; ba.DZ2 = DZ2; ba.DZ3 = DZ3;
     ba.pack = weight_cache_lookup(make_net(policy_params, od, 2 * ad).W2, 1);
-    ba.dbg = nullptr;
-#ifdef MPG_STAMP
-    static float* s_dbg_b = nullptr;
-    static int s_calls_b = 0;
-    if (!s_dbg_b) (void)hipMalloc(&s_dbg_b, 256 * 8 * 8 * sizeof(float));
-    ba.dbg = s_dbg_b;
-#endif
-    mpg_prof_begin(1, s);
-    if (cfg->env_kind == MPG_ENV_PATH_TRACKING)
-        hipLaunchKernelGGL((k_rollout_bwd<PathTracking>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, ba);
-    else
-        hipLaunchKernelGGL((k_rollout_bwd<Pendulum>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, ba);
-    mpg_prof_end(1, s);
-    MPG_CHECK_LAUNCH("k_rollout_bwd");
-#ifdef MPG_STAMP
-    if (++s_calls_b % 50 == 0) {
-        static float h[256 * 8 * 8];
-        (void)hipStreamSynchronize(s);
-        (void)hipMemcpy(h, s_dbg_b, sizeof(h), hipMemcpyDeviceToHost);
-        const int nwg = grid_for(ngroups);
-        for (int w = 0; w < 8; ++w) {
-            double acc[8] = {0};
-            for (int b = 0; b < nwg; ++b) for (int k = 0; k < 8; ++k) acc[k] += h[(b * 8 + w) * 8 + k];
-            fprintf(stderr, "[stamp bwd] wave %d cycles/step:", w);
-            double tot = 0;
-            for (int k = 0; k < 8; ++k) { fprintf(stderr, " p%d=%.0f", k, acc[k] / nwg / (n + 1)); tot += acc[k] / nwg / (n + 1); }
-            fprintf(stderr, " total=%.0f\n", tot);
-        }
-    }
-#endif
-    return MPG_OK;
+    return launch_rollout_bwd(ba, cfg->env_kind, ngroups, n, s);
 }
 
 }  // namespace
@@ -841,11 +269,10 @@ extern "C" int mpg_rollout_q_target(const mpg_cfg_t* cfg, const float* policy_pa
     for (int k = 0; k < MAXSEL; ++k) fa.sel[k] = k == 0 ? n : -1;
     fa.XQ = XQ; fa.GK = GK;
     const long ngroups = (rows + GROUP - 1) / GROUP;
-    if (cfg->env_kind == MPG_ENV_PATH_TRACKING)
-        hipLaunchKernelGGL((k_rollout_fwd<PathTracking>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, fa);
-    else
-        hipLaunchKernelGGL((k_rollout_fwd<Pendulum>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, fa);
-    MPG_CHECK_LAUNCH("k_rollout_fwd (q target)");
+    {
+        int rcq = launch_rollout_fwd(fa, cfg->env_kind, ngroups, n, s, false);
+        if (rcq) return rcq;
+    }
     OutSpec lin; lin.out_tanh = 0; lin.out_scale = 1.f; lin.sigma = 0.f; lin.seed = lin.ctr = 0;
     int rc = launch_forward(q1t, qin, 1, 1, rows, xspec(XQ, qin, nullptr, 0, nullptr, 0), lin, Q, 1, nullptr, nullptr, s);
     if (rc) return rc;
