@@ -9,34 +9,46 @@ One "step" = one pass of the hot path over one batch, in SingleProcessOffPolicyO
 Q1/Q2 loss+grad, 25-step model rollout + mixed policy gradient) -> all-reduce (N > 1) -> clip_by_global_norm ->
 worker.apply_gradients (Adam + Polyak).  So every step is 4096 env-steps and 1 gradient step per GPU.
 
-    python bench.py --gpus 1 --steps 200 --warmup 20
+    python bench.py --gpus 1 --steps 20 --warmup 5          (the driver's form; defaults: --steps 200 --warmup 20)
+    python bench.py --gpus N ...                            (N > 1: this process only spawns the N ranks below)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
 Rank 0 prints ONE JSON line.  value = whole-job env-steps/s (all GPUs); grad_steps_per_sec beside it; scaling is
 weak (per-GPU batch fixed, global batch = N * 4096, gradient all-reduced over RCCL).
+
+What happens around the timed region (all of it disclosed in the JSON line):
+  * `burn_in_steps` (fixed, 200 ~ 0.1 s) untimed steps BEFORE the W warm-up steps: the GPU's clocks and caches take
+    ~40-100 steps to settle (kernels are 8-10 % slower until then), which a 5-step warm-up does not cover;
+  * Python's cyclic garbage collector is collected + frozen before the burn-in and disabled inside the timed region
+    (`gc`): a generation-2 collection of the ~10^6 objects that `import torch` leaves behind takes 40-100 ms, and
+    round 1's driver run caught one inside its 20 timed steps (4.62 ms/step against 0.47; tools/stall_scan.py shows it
+    at the same step index run after run).  A training loop that cares does the same (`mpg_amd.optimizer.quiesce_gc`);
+  * the kernel timer's HIP events all exist before the burn-in (`ops.Profiler`), nothing is created in the loop;
+  * after the timed region, a second pass of the same K steps with one HIP event per step gives the per-step
+    distribution (`step_ms_median/min/max`); it is NOT part of `value`.
 """
 import argparse
-import ctypes
+import gc
 import json
 import os
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 B_PER_GPU = 4096
 N_STEP = 25
+BURN_IN_STEPS = 200
 # algorithmic work of the dominant kernel (DESIGN.md §kernels): forward rollout = 26 policy evaluations per start
 # state, each 2*(6*256 + 256*256 + 256*2) flop (mean half of the output layer only), + 25 model steps of ~100 flop
 FWD_FLOP_PER_STATE = 26 * 2 * (6 * 256 + 256 * 256 + 256 * 2) + 25 * 100
 # reverse sweep = 26 input-side backward passes through the same policy (W3^T, W2^T, W1^T) + 25 model adjoints
 BWD_FLOP_PER_STATE = 26 * 2 * (2 * 256 + 256 * 256 + 256 * 6) + 25 * 200
 FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 # The kernel durations behind `roofline` are measured live, with HIP events on the launch stream, on every PROF_EVERY-th
 # launch of the timed region: an event record is a stream packet of its own (~4-5 us between two otherwise back-to-back
 # kernels; 8 of them per step with every launch timed = 6 % of a 0.5 ms step - profiles/README.md has the trace).
@@ -60,37 +72,110 @@ def build_stack(dev, seed):
     return args, worker, learner, rb, opt
 
 
-def cpu_baseline(budget_s=15.0):
-    """The oracle ("port": torch-CPU/numpy restatement of the reference, op by op) timed on the host cores on a bounded
-    sample of the SAME workload: steps of [4096-agent worker sample + MPG-v2 compute_gradient at B = 4096 + Adam]."""
+# ---- CPU baseline: the oracle, the way the reference scales (1 thread per process x P processes) -------------------
+def _cpu_worker(budget_s, seed, q):
+    """One reference-style actor: torch pinned to ONE thread (the reference pins TF the same way, mpg_learner.py:27-28),
+    steps of [4096-agent worker.sample + MPG-v2 compute_gradient at B = 4096] of the torch-CPU/numpy oracle."""
+    import numpy as np
+    import torch
+    torch.set_num_threads(1)
     from oracle import mpg_oracle as O
     from tests.golden_inputs import mlp_weights_flat
-    # torch's intra-op pool: more threads than ~16 only adds overhead on these small tensors (measured: 256 threads
-    # on the MI355X host is >100x slower than 8)
-    cores = min(os.cpu_count() or 1, 16)
-    torch.set_num_threads(cores)
-    rng = np.random.Generator(np.random.PCG64(0))
+    rng = np.random.Generator(np.random.PCG64(seed))
     cfg = O.Cfg()
-    names = ['Q1', 'Q2', 'policy']
     flat = {'policy': mlp_weights_flat(rng, 6, 4), 'Q1': mlp_weights_flat(rng, 8, 1), 'Q2': mlp_weights_flat(rng, 8, 1)}
     env = O.PathTrackingEnvOracle(B_PER_GPU)
     env.reset(rng=rng)
-    env.obs = env.obs
     n_done, t0 = 0, time.perf_counter()
     while True:
         nets = O.Nets(cfg, flat, target_scale=1.0)
         tr = O.worker_sample(cfg, nets, env, rng, 1)[0]
         batch = [tr[0], tr[1], tr[2], tr[3], tr[4].astype(np.float32)]
         eps = rng.standard_normal((N_STEP, B_PER_GPU)).astype(np.float32)
-        grads, _ = O.mpg_compute_gradient(cfg, nets, batch, eps, 100 + n_done, 'MPG-v2')
+        O.mpg_compute_gradient(cfg, nets, batch, eps, 100 + n_done, 'MPG-v2')
         n_done += 1
         el = time.perf_counter() - t0
         if el > budget_s or n_done >= 200:
             break
-    return {'value': n_done * B_PER_GPU / el, 'unit': 'env-steps/s', 'cores': cores, 'kind': 'port',
-            'grad_steps_per_sec': n_done / el,
-            'sample': '%d steps of [4096-agent worker.sample + MPG-v2 compute_gradient B=4096] in %.1f s, '
-                      'torch-CPU oracle, %d threads' % (n_done, el, cores)}
+    q.put((n_done, el))
+
+
+def _cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def cpu_baseline(budget_s=12.0, max_procs=256):
+    """`kind: port` - the oracle timed on the host cores on a bounded sample of the SAME workload, shaped like the
+    reference's own scaling: P single-threaded processes side by side.  P = min(host cores, max_procs,
+    what the free memory allows at ~1.5 GB per process: `import torch` alone is 0.6 GB of private pages)."""
+    import multiprocessing as mp
+    try:
+        host = len(os.sched_getaffinity(0))
+    except AttributeError:
+        host = os.cpu_count() or 1
+    try:
+        import psutil
+        mem_cap = max(1, int(psutil.virtual_memory().available * 0.5 / 1.5e9))
+    except Exception:
+        mem_cap = 8
+    procs = max(1, min(host, max_procs, mem_cap))
+    # one thread per process means ONE: without these every child would start an OpenMP/MKL pool as wide as the host
+    # (256 threads each on the MI355X box) before torch.set_num_threads(1) is reached
+    for k in ('OMP_NUM_THREADS', 'MKL_NUM_THREADS', 'OPENBLAS_NUM_THREADS', 'NUMEXPR_NUM_THREADS'):
+        os.environ[k] = '1'
+    os.environ['HIP_VISIBLE_DEVICES'] = ''      # the CPU actors never touch the GPU
+    ctx = mp.get_context('spawn')          # fresh interpreters: nothing of this process' GPU state is inherited
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_cpu_worker, args=(budget_s, 1000 + i, q)) for i in range(procs)]
+    t0 = time.perf_counter()
+    for p in ps:
+        p.start()
+    res = []
+    for _ in ps:
+        try:
+            res.append(q.get(timeout=budget_s * 6 + 120))
+        except Exception:
+            break
+    for p in ps:
+        p.join(timeout=10)
+        if p.is_alive():
+            p.kill()
+    wall = time.perf_counter() - t0
+    steps_per_s = sum(n / el for n, el in res)
+    return {'value': steps_per_s * B_PER_GPU, 'unit': 'env-steps/s', 'cores': len(res), 'kind': 'port',
+            'grad_steps_per_sec': steps_per_s, 'host_cores': host, 'cpu_model': _cpu_model(),
+            'per_process_grad_steps_per_sec': steps_per_s / max(1, len(res)),
+            'sample': '%d single-threaded processes side by side, each %.0f s of steps of [4096-agent worker.sample + MPG-v2 '
+                      'compute_gradient B=4096] of the torch-CPU oracle (%d steps in total, %.0f s wall incl. start-up); process '
+                      'count = min(host cores %d, %d, free-memory cap %d)'
+                      % (len(res), budget_s, sum(n for n, _ in res), wall, host, max_procs, mem_cap)}
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(a):
+    """`python bench.py --gpus N` from a plain shell: this process touches no GPU and starts the N ranks as children
+    (torch.distributed.run, one process per GPU), then leaves with their exit code."""
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(a.gpus), '--master-addr',
+           '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__), '--gpus', str(a.gpus), '--steps',
+           str(a.steps), '--warmup', str(a.warmup)] + (['--no-cpu-baseline'] if a.no_cpu_baseline else [])
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '1')
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -100,11 +185,15 @@ def main():
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     a = ap.parse_args()
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(launch_ranks(a))
 
+    import torch
     from mpg_amd import dist as D
-    import mpg_amd._lib as L
+    from mpg_amd import ops
+    from mpg_amd.optimizer import quiesce_gc
     rank, world, local = D.init_from_env()
-    assert world == a.gpus, 'launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)' % (a.gpus, world)
+    assert world == a.gpus, '--gpus %d but WORLD_SIZE=%d' % (a.gpus, world)
     assert torch.cuda.is_available(), 'bench.py needs a GPU: the product path has no CPU fallback'
     ndev = torch.cuda.device_count()
     if local >= ndev:        # only in MPG_DIST_BACKEND=gloo dry runs with more ranks than GPUs
@@ -113,32 +202,48 @@ def main():
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
     args, worker, learner, rb, opt = build_stack(dev, seed=rank)
-
+    n_samples = (max(a.steps, 1) + PROF_EVERY - 1) // PROF_EVERY + 1
+    prof = ops.Profiler(max_samples=n_samples)      # every HIP event exists from here on
+    opt.set_profiler(prof)
+    quiesce_gc()                                     # gc.collect() + gc.freeze(): see the module docstring
+    prof.start(PROF_EVERY)
+    for _ in range(BURN_IN_STEPS):
+        opt.step()
     for _ in range(a.warmup):
         opt.step()
-    lib = L.lib()
     D.barrier()
     torch.cuda.synchronize()
-    lib.mpg_prof_enable(PROF_EVERY)      # HIP events around every PROF_EVERY-th launch of the timed region (see PROF_EVERY)
+    prof.start(PROF_EVERY)                           # clears the samples; no event is created
+    gc.disable()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         opt.step()
     D.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    gc.enable()
     dt = D.max_over_ranks(dt)
 
-    def slot(i):
-        ms, cnt = ctypes.c_double(0), ctypes.c_int(0)
-        L.check(lib.mpg_prof_read(i, ctypes.byref(ms), ctypes.byref(cnt)), 'mpg_prof_read')
-        return (ms.value / cnt.value if cnt.value else None), cnt.value
-    fwd_ms, fwd_n = slot(0)
-    bwd_ms, bwd_n = slot(1)
-    env_ms, env_n = slot(2)
-    wg_ms, wg_n = slot(5)
-    lib.mpg_prof_enable(0)
+    fwd_ms, fwd_n = prof.read(0)
+    bwd_ms, bwd_n = prof.read(1)
+    env_ms, env_n = prof.read(2)
+    pol_ms, pol_n = prof.read(3)
+    wg_ms, wg_n = prof.read(5)
+    tgt_ms, tgt_n = prof.read(6)
+    crit_ms, crit_n = prof.read(7)
+    prof.stop()
     n_sampled = (a.steps + PROF_EVERY - 1) // PROF_EVERY
     assert fwd_n == n_sampled and bwd_n == n_sampled, (fwd_n, bwd_n, n_sampled)
+    # per-step distribution: a second pass of the same K steps, one HIP event per step (not part of `value`)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
+    gc.disable()
+    ev[0].record()
+    for i in range(a.steps):
+        opt.step()
+        ev[i + 1].record()
+    torch.cuda.synchronize()
+    gc.enable()
+    per_step = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(a.steps))
     finite = bool(torch.isfinite(worker.policy_with_value.params).all().item())
     assert finite and int(worker.policy_with_value.nonfinite.sum().item()) == 0, 'non-finite parameters after the timed region'
 
@@ -154,10 +259,14 @@ def main():
 
     def roof(kernel, flop, ms, n):
         tf = flop * B_PER_GPU / (ms * 1e-3) / 1e12
+        tr = traffic.get(kernel.split('<')[0])
         return {'kernel': kernel, 'bound': 'mfma', 'achieved': tf, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': tf / FP32_MFMA_PEAK_TFLOPS, 'traffic': traffic.get(kernel.split('<')[0]), 'avg_ms': ms, 'launches': n,
+                'frac': tf / FP32_MFMA_PEAK_TFLOPS, 'traffic': tr, 'avg_ms': ms, 'launches': n,
                 'timed_with': 'HIP events on the launch stream around every %d-th launch of the timed region' % PROF_EVERY,
-                'algorithmic_flop_per_launch': flop * B_PER_GPU}
+                'algorithmic_flop_per_launch': flop * B_PER_GPU,
+                # the north star asks for the HBM side of the rollout kernel too: PMC bytes per launch / kernel time
+                'hbm_gbs': (tr / (ms * 1e-3) / 1e9) if tr else None,
+                'hbm_frac_of_peak': (tr / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if tr else None}
     r_fwd = roof('k_rollout_fwd<PathTracking>', FWD_FLOP_PER_STATE, fwd_ms, fwd_n)
     r_bwd = roof('k_rollout_bwd<PathTracking>', BWD_FLOP_PER_STATE, bwd_ms, bwd_n)
     dominant, other = (r_bwd, r_fwd) if bwd_ms >= fwd_ms else (r_fwd, r_bwd)   # the dominant kernel of the step
@@ -167,22 +276,28 @@ def main():
         'grad_steps_per_sec': a.steps / dt,
         'model_steps_per_sec': world * B_PER_GPU * N_STEP * a.steps / dt,
         'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': 1e3 * dt / a.steps,
+        'burn_in_steps': BURN_IN_STEPS,
+        'gc': 'gc.collect()+gc.freeze() before the burn-in, gc.disable() inside the timed region',
+        'step_ms_median': per_step[len(per_step) // 2], 'step_ms_min': per_step[0], 'step_ms_max': per_step[-1],
+        'step_ms_from': 'second pass of the same %d steps, one HIP event per step (not part of value)' % a.steps,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': 'PathTrackingEnv, MPG-v2 learner, n=25, M=1, 4096 vectorised envs + replay batch 4096 per '
                                'GPU; step = worker.sample(4096 env-steps) + add_batch + replay + compute_gradient + '
                                '(all-reduce) + apply_gradients',
                    'global_batch': world * B_PER_GPU, 'parallelism': 'dp%d' % world,
-                   'grad_allreduce_floats': int(learner.flat.numel()), 'native_step_driver': opt._fused is not None},
+                   'grad_allreduce_floats': int(learner.flat.numel()), 'native_step_driver': opt._fused is not None,
+                   'dist_backend': D.backend()},
         'roofline': dominant,
         'roofline_other_rollout_kernel': other,
-        'wgrad_kernel': {'kernel': 'k_wgrad_multi', 'avg_ms': wg_ms, 'launches': wg_n},
+        'other_kernels_avg_ms': {'k_target_fused': tgt_ms, 'k_critic_fused': crit_ms, 'k_wgrad_multi': wg_ms,
+                                 'k_forward (worker policy)': pol_ms, 'k_step_store_reset (env)': env_ms},
         'env_step_kernel': {'kernel': 'k_step_store_reset', 'avg_ms': env_ms, 'launches': env_n,
                             'env_steps_per_sec_kernel_only': B_PER_GPU / (env_ms * 1e-3) if env_ms else None,
                             'algorithmic_bytes_per_env_step': 85},
     }
     if world == 1 and not a.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline()
-    print(json.dumps(out))
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == '__main__':

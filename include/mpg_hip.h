@@ -15,7 +15,8 @@
  *     the call returns immediately (no host synchronisation);
  *   - return value: 0 on success, a negative MPG_E* code or -(hipError_t) otherwise; no exceptions cross
  *     the boundary;
- *   - re-entrant per (device, stream): no global mutable state;
+ *   - re-entrant per (device, stream): no global mutable state (caches and timers are caller-owned handles, see
+ *     mpg_wcache_t / mpg_prof_t; hyper-parameters arrive in mpg_cfg_t, never through the environment);
  *   - networks are 2-hidden-layer ELU MLPs with 256 hidden units (model.py:20-43), parameters stored as
  *     ONE flat float32 vector in Keras order  W1[in][256] b1[256] W2[256][256] b2[256] W3[256][out] b3[out]
  *     (kernels row-major (in,out), exactly `Model.get_weights()` flattened);
@@ -51,29 +52,48 @@ int mpg_abi_version(void);
 /* Human-readable description of the last error on this thread ("" if none). */
 const char* mpg_last_error(void);
 
-/* Optional per-kernel timing with HIP events recorded on the launch stream (the one piece of process-wide state;
- * off by default).  mpg_prof_enable(every) resets and starts recording every `every`-th launch of each slot (0: off;
- * an event record is a stream packet of its own and costs ~4-5 us between two otherwise back-to-back kernels, so timing
- * EVERY launch slows a 0.5 ms step by 6 %); mpg_prof_read waits for the recorded events of a slot and returns their
- * summed duration and count; slot names via mpg_prof_slot_name (0 k_rollout_fwd, 1 k_rollout_bwd, 2 env k_step,
- * 3 k_forward, 4 k_backward, 5 k_wgrad).  No reference counterpart (the reference times with utils/misc.py:39-90
- * TimerStat on the host). */
-int mpg_prof_enable(int every);
-int mpg_prof_read(int slot, double* total_ms, int* count);
-const char* mpg_prof_slot_name(int slot);
+/* ------------------------------------------------------------------------------------------------
+ * Caller-owned handles (no reference counterpart).  The library keeps NO process-wide mutable state: the packed
+ * weight images and the optional kernel timer below are objects the caller creates, owns and passes in (through
+ * mpg_cfg_t or an explicit argument).  The one thing kept on the library side is the thread-local text behind
+ * mpg_last_error().
+ * ---------------------------------------------------------------------------------------------- */
 
-/* Weight cache (acceleration only, no reference counterpart): pre-packed register images of the 256x256 hidden
- * kernels of the networks stored in `params` = [net0 | net1 | ...] (Keras order each, in_dims/out_dims HOST arrays,
- * n_nets <= 8).  Once bound, every entry point that receives a pointer into `params` loads its stationary weights
- * with coalesced 1 KiB reads instead of strided ones; results are bit-identical with and without the cache.
- * The binding is process-wide state keyed by the pointer: unbind before freeing `params`; after writing `params`
- * by any means other than mpg_adam_polyak (which refreshes bound buffers itself) call mpg_weight_cache_refresh.
- * cache: caller-owned device array of mpg_weight_cache_floats(n_nets) floats. */
+/* Packed register images of the 256x256 hidden kernels ("weight cache", acceleration only).  Describes ONE flat
+ * parameter vector `params` = [net0 | net1 | ...] (Keras order each) and a caller-owned device array `packed` of
+ * mpg_weight_cache_floats(n_nets) floats holding, per network, the forward and the transposed image of W2 in the
+ * order the lanes of the MLP engine consume them (1 KiB coalesced loads instead of strided ones).  Entry points that
+ * are told about a descriptor (mpg_cfg_t.wcache, or their explicit `wcache` argument) and receive a pointer into
+ * `params` use the images; results are bit-identical with and without them.  The descriptor itself is HOST memory,
+ * read at call time.  Whoever writes `params` keeps `packed` current: mpg_adam_polyak / mpg_clip_adam_polyak do so
+ * themselves for the descriptors they are given, anything else calls mpg_weight_cache_pack afterwards. */
+typedef struct {
+    const float* params;  /* device: base of the flat vector the images mirror */
+    float* packed;        /* device: mpg_weight_cache_floats(n_nets) floats */
+    int n_nets;           /* <= 8 */
+    int in_dim[8], out_dim[8];
+} mpg_wcache_t;
 size_t mpg_weight_cache_floats(int n_nets);
-int mpg_weight_cache_bind(const float* params, const int* in_dims, const int* out_dims, int n_nets, float* cache,
-                          mpg_stream_t stream);
-int mpg_weight_cache_refresh(const float* params, mpg_stream_t stream);
-int mpg_weight_cache_unbind(const float* params);
+/* (re)builds both images of every network of `wc` from wc->params: one launch on `stream`. */
+int mpg_weight_cache_pack(const mpg_wcache_t* wc, mpg_stream_t stream);
+
+/* Optional per-kernel timing with HIP events recorded on the launch stream.  mpg_prof_create allocates every event
+ * up front (2 * MPG_PROF_SLOTS * max_samples of them), so that nothing is created inside a timed region;
+ * mpg_prof_start(p, every) clears the samples and records around every `every`-th launch of each slot from then on
+ * (0: stop; an event record is a stream packet of its own and costs ~4-5 us between two otherwise back-to-back
+ * kernels, so timing EVERY launch slows a 0.5 ms step by 6 %); mpg_prof_read waits for the recorded events of a slot
+ * and returns their summed duration and count.  A timer takes effect on the calls made with a mpg_cfg_t whose `prof`
+ * field points to it (and on the native step driver's env launch).  Slots: 0 k_rollout_fwd, 1 k_rollout_bwd,
+ * 2 env step, 3 k_forward, 4 k_backward, 5 k_wgrad, 6 k_target_fused, 7 k_critic_fused.  No reference counterpart
+ * (the reference times with utils/misc.py:39-90 TimerStat on the host).  Not thread-safe: one timer per launching
+ * thread. */
+enum { MPG_PROF_SLOTS = 8 };
+typedef struct mpg_prof mpg_prof_t;
+int mpg_prof_create(int max_samples, mpg_prof_t** out);
+int mpg_prof_destroy(mpg_prof_t* p);
+int mpg_prof_start(mpg_prof_t* p, int every);
+int mpg_prof_read(mpg_prof_t* p, int slot, double* total_ms, int* count);
+const char* mpg_prof_slot_name(int slot);
 
 /* ------------------------------------------------------------------------------------------------
  * Vectorised real environment (K1)
@@ -120,13 +140,18 @@ typedef struct {
     float rew_scale, rew_shift; /* preprocessor.py:155-157 */
     float gamma;                /* 0.98 */
     int env_kind;               /* differentiable model used by the rollout: MPG_ENV_* */
+    /* optional caller-owned handles (NULL: none) */
+    const mpg_wcache_t* wcache[2]; /* packed images of up to two parameter vectors (e.g. networks, targets) that calls
+                                      made with this cfg may receive pointers into */
+    mpg_prof_t* prof;           /* kernel timer that the calls made with this cfg report to */
 } mpg_cfg_t;
 
 /* MLPNet.call  - model.py:39-43:  y[rows][out_used] = act(ELU(ELU(x W1 + b1) W2 + b2) W3 + b3)[:, :out_used].
  * x [rows][in_dim] (supported (in_dim, out_used): (6,2) (8,1) (4,1) (5,1) (6,1)); the first n_scaled input
  * columns are multiplied by in_scale[] (host array, may be NULL). */
 int mpg_mlp_forward(const float* params, int in_dim, int out_dim, int out_used, int out_act, int rows,
-                    const float* x, const float* in_scale, int n_scaled, float* y, mpg_stream_t stream);
+                    const float* x, const float* in_scale, int n_scaled, float* y,
+                    const mpg_wcache_t* wcache /* nullable */, mpg_stream_t stream);
 
 /* PolicyWithQs.compute_action / compute_target_action, deterministic branch  - policy.py:193-217:
  * act[rows][act_dim] = mean half of the policy output on obs*obs_scale (x action_range*tanh if set).
@@ -261,7 +286,9 @@ int mpg_sq_partials(const float* grad, const int* seg_sizes, int n_seg, float* s
  * mpg_clip_by_global_norm(scratch) followed by mpg_adam_polyak(skip_flags = nonfinite_flags). */
 int mpg_clip_adam_polyak(float* w, float* m, float* v, float* target, float* grad, const float* sq_part,
                          const int* seg_sizes, int n_seg, float clip, const float* lr_t, const int* do_adam,
-                         const int* do_polyak, float tau, float* norms, int* nonfinite_flags, mpg_stream_t stream);
+                         const int* do_polyak, float tau, float* norms, int* nonfinite_flags,
+                         const mpg_wcache_t* wc_w /* nullable: packed images of w, kept current */,
+                         const mpg_wcache_t* wc_target /* nullable: same for target */, mpg_stream_t stream);
 
 /* PolicyWithQs.apply_gradients + update_*_target  - policy.py:123-171.  For every network k (HOST arrays):
  * do_adam[k]: one Keras Adam step (beta .9/.999, eps 1e-7 outside the sqrt, TF ApplyAdam form) with the
@@ -271,7 +298,9 @@ int mpg_clip_adam_polyak(float* w, float* m, float* v, float* target, float* gra
  * zeros (NaN guard, optimizer.py:357-361). */
 int mpg_adam_polyak(float* w, float* m, float* v, float* target, const float* grad, const int* seg_sizes,
                     int n_seg, const float* lr_t, const int* do_adam, const int* do_polyak, float tau,
-                    const int* skip_flags, int n_skip_flags, mpg_stream_t stream);
+                    const int* skip_flags, int n_skip_flags,
+                    const mpg_wcache_t* wc_w /* nullable: packed images of w, kept current */,
+                    const mpg_wcache_t* wc_target /* nullable: same for target */, mpg_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * On-device replay ring (K9, uniform part)  - buffer.py:21-91
@@ -352,6 +381,10 @@ typedef struct {
     int total_ite;
     float clip, tau;
     int delay_update, num_batch_reuse, world_size;
+    int grads_exchanged;              /* != 0: the caller sums grad[] across processes between mpg_step_begin and mpg_step_end
+                                         (every run with world_size > 1): the clip's partial sums of squares are then taken
+                                         from the exchanged gradient in mpg_step_end instead of being a by-product of
+                                         mpg_step_begin's last launch.  Same partials, same order, either way. */
     float explore_sigma;
     float value_lr[3], policy_lr[3];  /* PolynomialDecay(lr0, steps, lr_end), policy.py:54-70 */
     /* counters */

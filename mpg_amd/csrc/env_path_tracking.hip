@@ -276,10 +276,8 @@ extern "C" int mpg_env_step(int env_kind, int n, float* state, const float* acti
                             uint8_t* done, uint8_t* done_intended, mpg_stream_t stream) {
     MPG_REQUIRE(env_kind == MPG_ENV_PATH_TRACKING, "mpg_env_step: only PathTracking has a real env (kind %d)", env_kind);
     MPG_REQUIRE(n > 0 && state && action && obs && reward && done, "mpg_env_step: bad argument");
-    mpg_prof_begin(2, mpg_stream(stream));
     hipLaunchKernelGGL(k_step, dim3((n + 63) / 64), dim3(64), 0, mpg_stream(stream), n, state, action, obs, reward,
                        done, done_intended);
-    mpg_prof_end(2, mpg_stream(stream));
     MPG_CHECK_LAUNCH("mpg_env_step");
     return MPG_OK;
 }
@@ -292,11 +290,9 @@ extern "C" int mpg_env_step_store_reset(int env_kind, int n, float* state, const
                     ring_rew && ring_obs2 && ring_done && obs_out,
                 "mpg_env_step_store_reset: bad argument");
     RingPtrs ring{ring_obs, ring_act, ring_rew, ring_obs2, ring_done};
-    mpg_prof_begin(2, mpg_stream(stream));
     hipLaunchKernelGGL(k_step_store_reset, dim3((n + 63) / 64), dim3(64), 0, mpg_stream(stream), n, state, action, ring,
                        capacity, next_idx, (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)ctr, (uint32_t)(ctr >> 32), obs_out,
                        done_out);
-    mpg_prof_end(2, mpg_stream(stream));
     MPG_CHECK_LAUNCH("mpg_env_step_store_reset");
     return MPG_OK;
 }

@@ -497,9 +497,9 @@ int launch_target_fused(const mpg_cfg_t* cfg, const float* policy_t, const float
         a.o_obs = draw_out->obs; a.o_act = draw_out->act; a.o_rew = draw_out->rew; a.o_obs2 = draw_out->obs2;
     }
     a.pol = policy_t; a.q1 = q1t; a.q2 = q2t;
-    a.pk_pol = weight_cache_lookup(make_net(policy_t, od, 2 * ad).W2, 0);
-    a.pk_q1 = weight_cache_lookup(make_net(q1t, od + ad, 1).W2, 0);
-    a.pk_q2 = q2t ? weight_cache_lookup(make_net(q2t, od + ad, 1).W2, 0) : nullptr;
+    a.pk_pol = weight_cache_lookup(cfg, make_net(policy_t, od, 2 * ad).W2, 0);
+    a.pk_q1 = weight_cache_lookup(cfg, make_net(q1t, od + ad, 1).W2, 0);
+    a.pk_q2 = q2t ? weight_cache_lookup(cfg, make_net(q2t, od + ad, 1).W2, 0) : nullptr;
     a.rows = rows; a.obs2 = obs_tp1; a.rew = rew; a.smooth_eps = smooth_eps;
     fill_scale(a.scale, cfg);
     const bool ranged = cfg->action_range > 0.f;
@@ -507,11 +507,11 @@ int launch_target_fused(const mpg_cfg_t* cfg, const float* policy_t, const float
     a.out_scale = ranged ? cfg->action_range : 1.f;
     a.sigma = sigma; a.clipc = clipc; a.rshift = cfg->rew_shift; a.rscale = cfg->rew_scale; a.gamma = cfg->gamma; a.y = y;
     const int ngroups = (rows + GROUP - 1) / GROUP;
-    mpg_prof_begin(6, s);
+    mpg_prof_begin(mpg_prof_of(cfg), 6, s);
     if (od == 6 && ad == 2) hipLaunchKernelGGL((k_target_fused<6, 2>), dim3(ngroups), dim3(NTHREAD), 0, s, a);
     else if (od == 4 && ad == 1) hipLaunchKernelGGL((k_target_fused<4, 1>), dim3(ngroups), dim3(NTHREAD), 0, s, a);
     else { mpg_set_error("launch_target_fused: unsupported dims"); return MPG_EINVAL; }
-    mpg_prof_end(6, s);
+    mpg_prof_end(mpg_prof_of(cfg), 6, s);
     MPG_CHECK_LAUNCH("k_target_fused");
     return MPG_OK;
 }
@@ -524,8 +524,8 @@ int launch_qloss_fused(const mpg_cfg_t* cfg, const float* const* q_params, int n
     QlossArgs a;
     for (int k = 0; k < 2; ++k) {
         a.q[k] = k < n_q ? q_params[k] : nullptr;
-        a.pkf[k] = k < n_q ? weight_cache_lookup(make_net(q_params[k], qin, 1).W2, 0) : nullptr;
-        a.pkb[k] = k < n_q ? weight_cache_lookup(make_net(q_params[k], qin, 1).W2, 1) : nullptr;
+        a.pkf[k] = k < n_q ? weight_cache_lookup(cfg, make_net(q_params[k], qin, 1).W2, 0) : nullptr;
+        a.pkb[k] = k < n_q ? weight_cache_lookup(cfg, make_net(q_params[k], qin, 1).W2, 1) : nullptr;
         if (k < n_q) a.st[k] = st[k];
     }
     a.rows = rows; a.x = xspec(obs, od, act, ad, cfg->obs_scale, od); a.y = y; a.inv_b = inv_b; a.loss_part = loss_part; a.td = td;
@@ -537,13 +537,13 @@ int launch_qloss_fused(const mpg_cfg_t* cfg, const float* const* q_params, int n
     return MPG_OK;
 }
 
-int launch_qslice_fused(const float* q_params, int qin, int R, int n_sel, const float* xq, const float* gk, const float* gpow,
+int launch_qslice_fused(const mpg_cfg_t* cfg, const float* q_params, int qin, int R, int n_sel, const float* xq, const float* gk, const float* gpow,
                         const float* coef, float* ret_part, float* gxq, hipStream_t s) {
     MPG_REQUIRE(R % GROUP == 0 && n_sel >= 1 && n_sel <= 4, "launch_qslice_fused: needs rows %% 16 == 0");
     QsliceArgs a;
     a.q = q_params;
-    a.pkf = weight_cache_lookup(make_net(q_params, qin, 1).W2, 0);
-    a.pkb = weight_cache_lookup(make_net(q_params, qin, 1).W2, 1);
+    a.pkf = weight_cache_lookup(cfg, make_net(q_params, qin, 1).W2, 0);
+    a.pkb = weight_cache_lookup(cfg, make_net(q_params, qin, 1).W2, 1);
     a.R = R; a.n_sel = n_sel; a.xq = xq; a.gk = gk; a.ret_part = ret_part; a.gxq = gxq;
     for (int k = 0; k < 4; ++k) { a.gpow[k] = k < n_sel ? gpow[k] : 0.f; a.coef[k] = k < n_sel ? coef[k] : 0.f; }
     const int ngroups = n_sel * (R / GROUP);
@@ -567,8 +567,8 @@ int launch_critic_fused(const mpg_cfg_t* cfg, const float* const* q_params, int 
     QlossArgs& a = c.ql;
     for (int k = 0; k < 2; ++k) {
         a.q[k] = k < n_q ? q_params[k] : nullptr;
-        a.pkf[k] = k < n_q ? weight_cache_lookup(make_net(q_params[k], qin, 1).W2, 0) : nullptr;
-        a.pkb[k] = k < n_q ? weight_cache_lookup(make_net(q_params[k], qin, 1).W2, 1) : nullptr;
+        a.pkf[k] = k < n_q ? weight_cache_lookup(cfg, make_net(q_params[k], qin, 1).W2, 0) : nullptr;
+        a.pkb[k] = k < n_q ? weight_cache_lookup(cfg, make_net(q_params[k], qin, 1).W2, 1) : nullptr;
         if (k < n_q) a.st[k] = st[k];
     }
     a.rows = rows; a.x = xspec(obs, od, act, ad, cfg->obs_scale, od); a.y = y; a.inv_b = inv_b; a.loss_part = loss_part; a.td = nullptr;
@@ -577,14 +577,16 @@ int launch_critic_fused(const mpg_cfg_t* cfg, const float* const* q_params, int 
     q.R = rows; q.n_sel = 2; q.xq = xq; q.gk = gk; q.ret_part = ret_part; q.gxq = gxq;
     for (int k = 0; k < 4; ++k) { q.gpow[k] = k < 2 ? gpow[k] : 0.f; q.coef[k] = k < 2 ? coef[k] : 0.f; }
     const int ngroups = rows / GROUP;
+    mpg_prof_begin(mpg_prof_of(cfg), 7, s);
     if (qin == 8) hipLaunchKernelGGL((k_critic_fused<8>), dim3(ngroups, n_q), dim3(NTHREAD), 0, s, c);
     else if (qin == 5) hipLaunchKernelGGL((k_critic_fused<5>), dim3(ngroups, n_q), dim3(NTHREAD), 0, s, c);
     else { mpg_set_error("launch_critic_fused: unsupported dims"); return MPG_EINVAL; }
+    mpg_prof_end(mpg_prof_of(cfg), 7, s);
     MPG_CHECK_LAUNCH("k_critic_fused");
     return MPG_OK;
 }
 
-int launch_wgrad_multi(const WgradJob* jobs, int n_jobs, const SumJob* sums, int n_sums, float* sq_part, hipStream_t s) {
+int launch_wgrad_multi(const mpg_cfg_t* cfg, const WgradJob* jobs, int n_jobs, const SumJob* sums, int n_sums, float* sq_part, hipStream_t s) {
     MPG_REQUIRE(jobs && n_jobs >= 1 && n_jobs <= 3 && n_sums >= 0 && n_sums <= 8, "launch_wgrad_multi: bad argument");
     WgradMulti m;
     ReduceMulti rm;
@@ -611,10 +613,10 @@ int launch_wgrad_multi(const WgradJob* jobs, int n_jobs, const SumJob* sums, int
     }
     m.chunk_off[n_jobs] = off;
     for (int j = n_jobs; j < 3; ++j) { m.type[j] = 0; m.chunk_off[j + 1] = off; rm.slabs[j] = nullptr; rm.nslab[j] = rm.n[j] = 0; rm.out[j] = nullptr; }
-    mpg_prof_begin(5, s);
+    mpg_prof_begin(mpg_prof_of(cfg), 5, s);
     if (!pendulum) hipLaunchKernelGGL((k_wgrad_multi<8, 1, 6, 2>), dim3(8 * off), dim3(NTHREAD), 0, s, m);
     else hipLaunchKernelGGL((k_wgrad_multi<5, 1, 4, 1>), dim3(8 * off), dim3(NTHREAD), 0, s, m);
-    mpg_prof_end(5, s);
+    mpg_prof_end(mpg_prof_of(cfg), 5, s);
     MPG_CHECK_LAUNCH("k_wgrad_multi");
     rm.n_sums = n_sums;
     for (int k = 0; k < 8; ++k) {

@@ -123,17 +123,24 @@ inline OutSpec linear_out() {
 }
 
 inline bool cfg_ok(const mpg_cfg_t* c) {
-    return c && ((c->obs_dim == 6 && c->act_dim == 2) || (c->obs_dim == 4 && c->act_dim == 1));
+    // policy_out_activation='tanh' WITH an action_range would be range*tanh(tanh(z)) in the reference (policy.py:176-177,
+    // 197-199); the kernels implement range*tanh(z) / tanh(z) / z only, so that combination is refused, not approximated
+    return c && ((c->obs_dim == 6 && c->act_dim == 2) || (c->obs_dim == 4 && c->act_dim == 1)) &&
+           !(c->policy_out_act == MPG_ACT_TANH && c->action_range > 0.f);
 }
 
 }  // namespace
 
 extern "C" int mpg_mlp_forward(const float* params, int in_dim, int out_dim, int out_used, int out_act, int rows,
-                               const float* x, const float* in_scale, int n_scaled, float* y, mpg_stream_t stream) {
+                               const float* x, const float* in_scale, int n_scaled, float* y, const mpg_wcache_t* wcache,
+                               mpg_stream_t stream) {
     MPG_REQUIRE(params && x && y && rows > 0, "mpg_mlp_forward: null pointer / rows");
     OutSpec o = linear_out();
     o.out_tanh = out_act == MPG_ACT_TANH;
-    return launch_forward(params, in_dim, out_dim, out_used, rows, xspec(x, in_dim, nullptr, 0, in_scale, n_scaled), o, y,
+    mpg_cfg_t handles = {};                    // only the handle fields are read by the launcher
+    handles.wcache[0] = wcache;
+    const mpg_cfg_t* cfg = &handles;
+    return launch_forward(cfg, params, in_dim, out_dim, out_used, rows, xspec(x, in_dim, nullptr, 0, in_scale, n_scaled), o, y,
                           out_used, nullptr, nullptr, mpg_stream(stream));
 }
 
@@ -142,7 +149,7 @@ extern "C" int mpg_policy_action(const mpg_cfg_t* cfg, const float* policy_param
     MPG_REQUIRE(cfg_ok(cfg) && policy_params && obs && act && rows > 0, "mpg_policy_action: bad argument");
     OutSpec o = policy_out(cfg);
     o.sigma = explore_sigma; o.seed = seed; o.ctr = ctr;
-    return launch_forward(policy_params, cfg->obs_dim, 2 * cfg->act_dim, cfg->act_dim, rows,
+    return launch_forward(cfg, policy_params, cfg->obs_dim, 2 * cfg->act_dim, cfg->act_dim, rows,
                           xspec(obs, cfg->obs_dim, nullptr, 0, cfg->obs_scale, cfg->obs_dim), o, act, cfg->act_dim,
                           nullptr, nullptr, mpg_stream(stream));
 }
@@ -166,7 +173,7 @@ extern "C" int mpg_q_targets(const mpg_cfg_t* cfg, const float* policy_t, const 
     float* q1 = cv.take(rows);
     float* q2 = cv.take(rows);
     const int od = cfg->obs_dim, ad = cfg->act_dim;
-    int rc = launch_forward(policy_t, od, 2 * ad, ad, rows, xspec(obs_tp1, od, nullptr, 0, cfg->obs_scale, od),
+    int rc = launch_forward(cfg, policy_t, od, 2 * ad, ad, rows, xspec(obs_tp1, od, nullptr, 0, cfg->obs_scale, od),
                             policy_out(cfg), a, ad, nullptr, nullptr, s);
     if (rc) return rc;
     if (smooth_eps) {
@@ -175,10 +182,10 @@ extern "C" int mpg_q_targets(const mpg_cfg_t* cfg, const float* policy_t, const 
         MPG_CHECK_LAUNCH("k_smooth");
     }
     const XSpec xq = xspec(obs_tp1, od, a, ad, cfg->obs_scale, od);
-    rc = launch_forward(q1t, od + ad, 1, 1, rows, xq, linear_out(), q1, 1, nullptr, nullptr, s);
+    rc = launch_forward(cfg, q1t, od + ad, 1, 1, rows, xq, linear_out(), q1, 1, nullptr, nullptr, s);
     if (rc) return rc;
     if (q2t) {
-        rc = launch_forward(q2t, od + ad, 1, 1, rows, xq, linear_out(), q2, 1, nullptr, nullptr, s);
+        rc = launch_forward(cfg, q2t, od + ad, 1, 1, rows, xq, linear_out(), q2, 1, nullptr, nullptr, s);
         if (rc) return rc;
     }
     hipLaunchKernelGGL(k_combine_target, dim3((rows + 255) / 256), dim3(256), 0, s, rows, rew, q1, q2t ? q2 : nullptr,
@@ -201,10 +208,10 @@ extern "C" int mpg_nstep_targets(const mpg_cfg_t* cfg, const float* policy_t, co
     float* a = cv.take((size_t)rows * cfg->act_dim);
     float* q1 = cv.take(rows);
     const int od = cfg->obs_dim, ad = cfg->act_dim;
-    int rc = launch_forward(policy_t, od, 2 * ad, ad, rows, xspec(last_obs, od, nullptr, 0, cfg->obs_scale, od),
+    int rc = launch_forward(cfg, policy_t, od, 2 * ad, ad, rows, xspec(last_obs, od, nullptr, 0, cfg->obs_scale, od),
                             policy_out(cfg), a, ad, nullptr, nullptr, s);
     if (rc) return rc;
-    rc = launch_forward(q1t, od + ad, 1, 1, rows, xspec(last_obs, od, a, ad, cfg->obs_scale, od), linear_out(), q1, 1,
+    rc = launch_forward(cfg, q1t, od + ad, 1, 1, rows, xspec(last_obs, od, a, ad, cfg->obs_scale, od), linear_out(), q1, 1,
                         nullptr, nullptr, s);
     if (rc) return rc;
     hipLaunchKernelGGL(k_nstep, dim3((rows + 255) / 256), dim3(256), 0, s, rows, n, rewards, q1, cfg->rew_shift,
@@ -239,13 +246,13 @@ extern "C" int mpg_q_loss_grad(const mpg_cfg_t* cfg, const float* q_params, int 
     float* dz3 = cv.take(rows);
     float* slabs = cv.take(wgrad_workspace_floats(rows, in, 1));
     const XSpec xq = xspec(obs, od, act, ad, cfg->obs_scale, od);
-    int rc = launch_forward(q_params, in, 1, 1, rows, xq, linear_out(), q, 1, h1, h2, s);
+    int rc = launch_forward(cfg, q_params, in, 1, 1, rows, xq, linear_out(), q, 1, h1, h2, s);
     if (rc) return rc;
     hipLaunchKernelGGL(k_q_err, dim3(1), dim3(1024), 0, s, rows, q, y, inv_b_global, dz3, td, loss_sum);
     MPG_CHECK_LAUNCH("k_q_err");
-    rc = launch_backward(q_params, in, 1, 1, rows, dz3, 1, nullptr, 0, 0, 1.f, h1, h2, dz1, dz2, nullptr, nullptr, 0, s);
+    rc = launch_backward(cfg, q_params, in, 1, 1, rows, dz3, 1, nullptr, 0, 0, 1.f, h1, h2, dz1, dz2, nullptr, nullptr, 0, s);
     if (rc) return rc;
-    return launch_wgrad(in, 1, 1, rows, xq, h1, h2, dz1, dz2, dz3, grad, slabs, s);
+    return launch_wgrad(cfg, in, 1, 1, rows, xq, h1, h2, dz1, dz2, dz3, grad, slabs, s);
 }
 
 extern "C" size_t mpg_td3_policy_grad_workspace_bytes(const mpg_cfg_t* cfg, int rows) {
@@ -278,23 +285,23 @@ extern "C" int mpg_td3_policy_grad(const mpg_cfg_t* cfg, const float* policy_par
     float* slabs = cv.take(wgrad_workspace_floats(rows, od, 2 * ad));
     const OutSpec po = policy_out(cfg);
     const XSpec xp = xspec(obs, od, nullptr, 0, cfg->obs_scale, od);
-    int rc = launch_forward(policy_params, od, 2 * ad, ad, rows, xp, po, a, ad, hp1, hp2, s);        // td3.py:123
+    int rc = launch_forward(cfg, policy_params, od, 2 * ad, ad, rows, xp, po, a, ad, hp1, hp2, s);        // td3.py:123
     if (rc) return rc;
     const XSpec xq = xspec(obs, od, a, ad, cfg->obs_scale, od);
-    rc = launch_forward(q1, qin, 1, 1, rows, xq, linear_out(), qv1, 1, h11, h12, s);                  // :124
+    rc = launch_forward(cfg, q1, qin, 1, 1, rows, xq, linear_out(), qv1, 1, h11, h12, s);                  // :124
     if (rc) return rc;
-    rc = launch_forward(q2, qin, 1, 1, rows, xq, linear_out(), qv2, 1, h21, h22, s);                  // :125
+    rc = launch_forward(cfg, q2, qin, 1, 1, rows, xq, linear_out(), qv2, 1, h21, h22, s);                  // :125
     if (rc) return rc;
     hipLaunchKernelGGL(k_td3_dy, dim3(1), dim3(1024), 0, s, rows, qv1, qv2, inv_b_global, dy1, dy2, qmin_sum, qmin_sqsum);
     MPG_CHECK_LAUNCH("k_td3_dy");
-    rc = launch_backward(q1, qin, 1, 1, rows, dy1, 1, nullptr, 0, 0, 1.f, h11, h12, nullptr, nullptr, nullptr, dx1, qin, s);
+    rc = launch_backward(cfg, q1, qin, 1, 1, rows, dy1, 1, nullptr, 0, 0, 1.f, h11, h12, nullptr, nullptr, nullptr, dx1, qin, s);
     if (rc) return rc;
-    rc = launch_backward(q2, qin, 1, 1, rows, dy2, 1, nullptr, 0, 0, 1.f, h21, h22, nullptr, nullptr, nullptr, dx2, qin, s);
+    rc = launch_backward(cfg, q2, qin, 1, 1, rows, dy2, 1, nullptr, 0, 0, 1.f, h21, h22, nullptr, nullptr, nullptr, dx2, qin, s);
     if (rc) return rc;
     hipLaunchKernelGGL(k_sum_action_grad, dim3((rows * ad + 255) / 256), dim3(256), 0, s, rows, od, ad, dx1, dx2, ga);
     MPG_CHECK_LAUNCH("k_sum_action_grad");
-    rc = launch_backward(policy_params, od, 2 * ad, ad, rows, ga, ad, a, ad, po.out_tanh, po.out_scale, hp1, hp2, dz1, dz2, dz3,
+    rc = launch_backward(cfg, policy_params, od, 2 * ad, ad, rows, ga, ad, a, ad, po.out_tanh, po.out_scale, hp1, hp2, dz1, dz2, dz3,
                          nullptr, 0, s);
     if (rc) return rc;
-    return launch_wgrad(od, 2 * ad, ad, rows, xp, hp1, hp2, dz1, dz2, dz3, grad, slabs, s);
+    return launch_wgrad(cfg, od, 2 * ad, ad, rows, xp, hp1, hp2, dz1, dz2, dz3, grad, slabs, s);
 }

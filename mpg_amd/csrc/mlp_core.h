@@ -174,9 +174,12 @@ __device__ __forceinline__ void load_w2_packed(const float* __restrict__ pack, c
         }
 }
 
-// host side: packed copy of W2 for direction dir (0 forward, 1 backward) if `W2` belongs to a bound parameter
-// buffer (mpg_weight_cache_bind), else nullptr.
-const float* weight_cache_lookup(const float* W2, int dir);
+// host side: packed copy of W2 for direction dir (0 forward, 1 backward) if `W2` is the hidden kernel of a network
+// covered by one of the caller's weight-cache descriptors (cfg->wcache[], include/mpg_hip.h), else nullptr.  Pure
+// functions of their arguments: the library keeps no binding table.
+const float* weight_cache_lookup(const mpg_cfg_t* cfg, const float* W2, int dir);
+const float* wcache_lookup(const mpg_wcache_t* wc, const float* W2, int dir);
+int wcache_w2_offset(const mpg_wcache_t* wc, int k);
 
 // 16 x 256 (LDS A image) times the wave's stationary 256 x 32 slice; 128 MFMAs, two independent accumulators.
 __device__ __forceinline__ void mfma_16x256x32(const float* sA, const Lane& L, const float (&w)[128], f32x4& acc0,

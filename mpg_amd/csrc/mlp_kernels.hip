@@ -71,21 +71,21 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_forward(const FwdArgs a) {
 
 static int grid_for(long ngroups) { return (int)(ngroups < 256 ? ngroups : 256); }
 
-int launch_forward(const float* params, int in_dim, int out_dim, int ou, int rows, const XSpec& x, const OutSpec& o,
-                   float* y, int ldy, float* h1, float* h2, hipStream_t s) {
+int launch_forward(const mpg_cfg_t* cfg, const float* params, int in_dim, int out_dim, int ou, int rows, const XSpec& x,
+                   const OutSpec& o, float* y, int ldy, float* h1, float* h2, hipStream_t s) {
     MPG_REQUIRE(params && rows > 0 && y && x.d0 + x.d1 == in_dim && ou <= out_dim, "launch_forward: bad argument");
     FwdArgs a;
     a.params = params; a.in_dim = in_dim; a.out_dim = out_dim; a.rows = rows; a.x = x;
     a.out_tanh = o.out_tanh; a.out_scale = o.out_scale; a.sigma = o.sigma;
     a.k0 = (uint32_t)o.seed; a.k1 = (uint32_t)(o.seed >> 32); a.c1 = (uint32_t)o.ctr; a.c2 = (uint32_t)(o.ctr >> 32);
     a.y = y; a.ldy = ldy; a.h1 = h1; a.h2 = h2;
-    a.pack = weight_cache_lookup(make_net(params, in_dim, out_dim).W2, 0);
+    a.pack = weight_cache_lookup(cfg, make_net(params, in_dim, out_dim).W2, 0);
     const long ngroups = (rows + GROUP - 1) / GROUP;
-    mpg_prof_begin(3, s);
+    mpg_prof_begin(mpg_prof_of(cfg), 3, s);
 #define CALL(I, O) hipLaunchKernelGGL((k_forward<I, O>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, a)
     MPG_DISPATCH_NET(in_dim, ou, CALL)
 #undef CALL
-    mpg_prof_end(3, s);
+    mpg_prof_end(mpg_prof_of(cfg), 3, s);
     MPG_CHECK_LAUNCH("k_forward");
     return MPG_OK;
 }
@@ -155,7 +155,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_backward(const BwdArgs a) {
     }
 }
 
-int launch_backward(const float* params, int in_dim, int out_dim, int ou, int rows, const float* dy, int lddy,
+int launch_backward(const mpg_cfg_t* cfg, const float* params, int in_dim, int out_dim, int ou, int rows, const float* dy, int lddy,
                     const float* yout, int ldyo, int out_tanh, float out_scale, const float* h1, const float* h2,
                     float* dz1, float* dz2, float* dz3, float* dx, int lddx, hipStream_t s) {
     MPG_REQUIRE(params && rows > 0 && dy && h1 && h2 && (!out_tanh || yout), "launch_backward: bad argument");
@@ -163,9 +163,9 @@ int launch_backward(const float* params, int in_dim, int out_dim, int ou, int ro
     a.params = params; a.in_dim = in_dim; a.out_dim = out_dim; a.rows = rows; a.dy = dy; a.lddy = lddy;
     a.yout = yout; a.ldyo = ldyo; a.out_tanh = out_tanh; a.out_scale = out_scale; a.h1 = h1; a.h2 = h2;
     a.dz1 = dz1; a.dz2 = dz2; a.dz3 = dz3; a.dx = dx; a.lddx = lddx;
-    a.pack = weight_cache_lookup(make_net(params, in_dim, out_dim).W2, 1);
+    a.pack = weight_cache_lookup(cfg, make_net(params, in_dim, out_dim).W2, 1);
     const long ngroups = (rows + GROUP - 1) / GROUP;
-    mpg_prof_begin(4, s);
+    mpg_prof_begin(mpg_prof_of(cfg), 4, s);
     if (dx) {
 #define CALL(I, O) hipLaunchKernelGGL((k_backward<I, O, true>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, a)
         MPG_DISPATCH_NET(in_dim, ou, CALL)
@@ -175,7 +175,7 @@ int launch_backward(const float* params, int in_dim, int out_dim, int ou, int ro
         MPG_DISPATCH_NET(in_dim, ou, CALL)
 #undef CALL
     }
-    mpg_prof_end(4, s);
+    mpg_prof_end(mpg_prof_of(cfg), 4, s);
     MPG_CHECK_LAUNCH("k_backward");
     return MPG_OK;
 }
@@ -209,7 +209,7 @@ size_t wgrad_workspace_floats(int rows, int in_dim, int out_dim) {
     return (size_t)nch * net_size(in_dim, out_dim);
 }
 
-int launch_wgrad(int in_dim, int out_dim, int ou, int rows, const XSpec& x, const float* h1, const float* h2,
+int launch_wgrad(const mpg_cfg_t* cfg, int in_dim, int out_dim, int ou, int rows, const XSpec& x, const float* h1, const float* h2,
                  const float* dz1, const float* dz2, const float* dz3, float* grad, float* ws, hipStream_t s) {
     MPG_REQUIRE(rows > 0 && h1 && h2 && dz1 && dz2 && dz3 && grad && ws, "launch_wgrad: bad argument");
     WgradArgs a;
@@ -218,11 +218,11 @@ int launch_wgrad(int in_dim, int out_dim, int ou, int rows, const XSpec& x, cons
     const long ngroups = (rows + GROUP - 1) / GROUP;
     a.groups_per_chunk = wgrad_groups_per_chunk(ngroups);
     const int nch = (int)((ngroups + a.groups_per_chunk - 1) / a.groups_per_chunk);
-    mpg_prof_begin(5, s);
+    mpg_prof_begin(mpg_prof_of(cfg), 5, s);
 #define CALL(I, O) hipLaunchKernelGGL((k_wgrad<I, O>), dim3(8 * nch), dim3(NTHREAD), 0, s, a)
     MPG_DISPATCH_NET(in_dim, ou, CALL)
 #undef CALL
-    mpg_prof_end(5, s);
+    mpg_prof_end(mpg_prof_of(cfg), 5, s);
     MPG_CHECK_LAUNCH("k_wgrad");
     const int n = net_size(in_dim, out_dim);
     hipLaunchKernelGGL(k_reduce_slabs, dim3((n + 255) / 256), dim3(256), 0, s, ws, nch, n, grad);

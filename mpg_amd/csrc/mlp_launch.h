@@ -49,20 +49,21 @@ struct OutSpec {            // y = out_scale * tanh(z) (out_tanh) or z; optional
 };
 
 // y[rows][ldy] (first `ou` columns) = net(x); optional G16 stashes of both hidden activations.
-int launch_forward(const float* params, int in_dim, int out_dim, int ou, int rows, const XSpec& x, const OutSpec& o,
-                   float* y, int ldy, float* h1, float* h2, hipStream_t s);
+// cfg (nullable): source of the caller's weight-cache descriptors and kernel timer, nothing else is read from it here
+int launch_forward(const mpg_cfg_t* cfg, const float* params, int in_dim, int out_dim, int ou, int rows, const XSpec& x,
+                   const OutSpec& o, float* y, int ldy, float* h1, float* h2, hipStream_t s);
 
 // Input-side backward: dy [rows][lddy] is dL/d(output after activation); yout [rows][ldyo] the forward outputs.
 // Writes (each nullable) dz1, dz2 (G16), dz3 [rows][ou] and dx [rows][lddx] (in_dim columns, w.r.t. the network
 // input as seen by the first layer, i.e. after scaling).
-int launch_backward(const float* params, int in_dim, int out_dim, int ou, int rows, const float* dy, int lddy,
+int launch_backward(const mpg_cfg_t* cfg, const float* params, int in_dim, int out_dim, int ou, int rows, const float* dy, int lddy,
                     const float* yout, int ldyo, int out_tanh, float out_scale, const float* h1, const float* h2,
                     float* dz1, float* dz2, float* dz3, float* dx, int lddx, hipStream_t s);
 
 // Weight gradient of one network over `rows` rows from stashes; result (net_size floats, fully reduced over rows,
 // accumulate == 0: overwritten) in grad.  ws must hold wgrad_workspace_floats(rows, in_dim, out_dim) floats.
 size_t wgrad_workspace_floats(int rows, int in_dim, int out_dim);
-int launch_wgrad(int in_dim, int out_dim, int ou, int rows, const XSpec& x, const float* h1, const float* h2,
+int launch_wgrad(const mpg_cfg_t* cfg, int in_dim, int out_dim, int ou, int rows, const XSpec& x, const float* h1, const float* h2,
                  const float* dz1, const float* dz2, const float* dz3, float* grad, float* ws, hipStream_t s);
 
 // ---- fused critic-side kernels (one 16-row group per workgroup; callers fall back to the unfused launchers when a
@@ -92,7 +93,7 @@ int launch_qloss_fused(const mpg_cfg_t* cfg, const float* const* q_params, int n
 
 // critic value + input gradient at the selected rollout slices in ONE launch: q = Q(xq), per-group partial sums of
 // the returns G + gpow*q and of their squares (ret_part [n_sel][ngroups][2]), dx = coef_k * dQ/dxq.  xq [n_sel*R][qin].
-int launch_qslice_fused(const float* q_params, int qin, int R, int n_sel, const float* xq, const float* gk, const float* gpow,
+int launch_qslice_fused(const mpg_cfg_t* cfg, const float* q_params, int qin, int R, int n_sel, const float* xq, const float* gk, const float* gpow,
                         const float* coef, float* ret_part, float* gxq, hipStream_t s);
 
 // weight gradients of up to 3 networks in one launch + one reduce launch.  Also folds the fixed-order sums of the
@@ -109,7 +110,7 @@ struct SumJob {
     int n, stride;         // sums src[0], src[stride], ... (n terms)
     float* dst;
 };
-int launch_wgrad_multi(const WgradJob* jobs, int n_jobs, const SumJob* sums, int n_sums, float* sq_part, hipStream_t s);
+int launch_wgrad_multi(const mpg_cfg_t* cfg, const WgradJob* jobs, int n_jobs, const SumJob* sums, int n_sums, float* sq_part, hipStream_t s);
 // critic losses + critic at the two selected slices in one launch (launch_qloss_fused + launch_qslice_fused with n_sel == 2)
 int launch_critic_fused(const mpg_cfg_t* cfg, const float* const* q_params, int n_q, int rows, const float* obs,
                         const float* act, const float* y, float inv_b, const CriticStash* st, float* loss_part, const float* xq,

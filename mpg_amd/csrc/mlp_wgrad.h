@@ -240,13 +240,9 @@ __device__ __forceinline__ void wgrad_map(int b, int nch, int& chunk, int& sl) {
     }
 }
 
+constexpr int WGRAD_MAX_CHUNKS = 32;      // chunk slabs per network (16 and 64 measure the same, tools/ab_wgrad.sh history)
 inline int wgrad_groups_per_chunk(long ngroups) {
-    static const int max_chunks = [] {   // tuning knob for experiments (default 32 chunk slabs)
-        const char* e = getenv("MPG_WGRAD_CHUNKS");
-        const int v = e ? atoi(e) : 32;
-        return v >= 1 && v <= 64 ? v : 32;
-    }();
-    long gp = (ngroups + max_chunks - 1) / max_chunks;
+    long gp = (ngroups + WGRAD_MAX_CHUNKS - 1) / WGRAD_MAX_CHUNKS;
     return (int)(gp < 1 ? 1 : gp);
 }
 

@@ -6,7 +6,7 @@
 
 #include "../../include/mpg_hip.h"
 
-#define MPG_ABI_VERSION 2   // 2: mpg_mpg_gradients(sq_part, draw), MPG_CLIP_PARTS scratch, mpg_clip_adam_polyak, mpg_prof_enable(every)
+#define MPG_ABI_VERSION 3   // 3: caller-owned handles (mpg_wcache_t, mpg_prof_t) instead of process-wide state
 
 void mpg_set_error(const char* fmt, ...);
 
@@ -28,9 +28,10 @@ void mpg_set_error(const char* fmt, ...);
         }                                                                   \
     } while (0)
 
-// optional HIP-event timing of a launch (no-ops unless mpg_prof_enable(1)); slots: see mpg_api.cpp
-void mpg_prof_begin(int slot, hipStream_t s);
-void mpg_prof_end(int slot, hipStream_t s);
+// optional HIP-event timing of a launch (no-ops for a null timer); slots: see include/mpg_hip.h
+void mpg_prof_begin(mpg_prof_t* p, int slot, hipStream_t s);
+void mpg_prof_end(mpg_prof_t* p, int slot, hipStream_t s);
+inline mpg_prof_t* mpg_prof_of(const mpg_cfg_t* cfg) { return cfg ? cfg->prof : nullptr; }
 
 static inline hipStream_t mpg_stream(mpg_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 

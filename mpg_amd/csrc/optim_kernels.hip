@@ -4,10 +4,8 @@
 // Reference: learners/mpg_learner.py:415-431 (clip), policy.py:123-171 (apply_gradients, update_*_target),
 // optimizer.py:357-361 (NaN guard).  Adam follows TensorFlow's ApplyAdam functor:
 //   m += (g - m)(1 - b1);  v += (g^2 - v)(1 - b2);  w -= lr_t * m / (sqrt(v) + eps),  lr_t = lr sqrt(1-b2^t)/(1-b1^t).
-#include "mpg_common.h"
+#include "mlp_core.h"   // net_size, wcache_w2_offset
 
-int weight_cache_refresh_if_bound(const float* params, hipStream_t s);   // weight_cache.hip
-bool weight_cache_info(const float* params, float** cache, int* w2_off, int* n_nets);
 
 namespace {
 
@@ -262,7 +260,7 @@ extern "C" int mpg_clip_by_global_norm(float* grad, const int* seg_sizes, int n_
 namespace {
 // per-network Adam/Polyak switches + the packed register images of bound buffers (kept in sync inside the same kernel)
 int fill_adam(Segs& sg, int n_seg, const int* seg_sizes, const float* w, const float* target, const float* lr_t,
-              const int* do_adam, const int* do_polyak, int* maxn_out) {
+              const int* do_adam, const int* do_polyak, const mpg_wcache_t* wc_w, const mpg_wcache_t* wc_t, int* maxn_out) {
     if (fill(sg, n_seg, seg_sizes) <= 0) return -1;
     int maxn = 0;
     for (int k = 0; k < n_seg; ++k) {
@@ -272,33 +270,30 @@ int fill_adam(Segs& sg, int n_seg, const int* seg_sizes, const float* w, const f
         if (sg.n[k] > maxn) maxn = sg.n[k];
     }
     *maxn_out = maxn;
-    int w2o[MAXSEG], nn = 0;
-    float* cw = nullptr;
-    if (weight_cache_info(w, &cw, w2o, &nn) && nn == n_seg) {
-        sg.cache_w = cw;
-        for (int k = 0; k < n_seg; ++k) sg.w2_off[k] = w2o[k] - sg.off[k];
-        float* ct = nullptr;
-        int w2t[MAXSEG], nt = 0;
-        if (target && weight_cache_info(target, &ct, w2t, &nt) && nt == n_seg) sg.cache_t = ct;
-    } else if (target) {
-        float* ct = nullptr;
-        int w2t[MAXSEG], nt = 0;
-        if (weight_cache_info(target, &ct, w2t, &nt) && nt == n_seg) {
-            sg.cache_t = ct;
-            for (int k = 0; k < n_seg; ++k) sg.w2_off[k] = w2t[k] - sg.off[k];
-        }
-    }
+    // a descriptor is honoured only if it describes exactly this buffer and this segmentation
+    auto usable = [&](const mpg_wcache_t* wc, const float* base) {
+        if (!wc || !base || wc->params != base || !wc->packed || wc->n_nets != n_seg) return false;
+        for (int k = 0; k < n_seg; ++k)
+            if (mlp::net_size(wc->in_dim[k], wc->out_dim[k]) != sg.n[k]) return false;
+        return true;
+    };
+    const mpg_wcache_t* ref = usable(wc_w, w) ? wc_w : (usable(wc_t, target) ? wc_t : nullptr);
+    if (usable(wc_w, w)) sg.cache_w = wc_w->packed;
+    if (usable(wc_t, target)) sg.cache_t = wc_t->packed;
+    if (ref)
+        for (int k = 0; k < n_seg; ++k) sg.w2_off[k] = mlp::wcache_w2_offset(ref, k) - sg.off[k];
     return 0;
 }
 }  // namespace
 
 extern "C" int mpg_adam_polyak(float* w, float* m, float* v, float* target, const float* grad, const int* seg_sizes,
                                int n_seg, const float* lr_t, const int* do_adam, const int* do_polyak, float tau,
-                               const int* skip_flags, int n_skip_flags, mpg_stream_t stream) {
+                               const int* skip_flags, int n_skip_flags, const mpg_wcache_t* wc_w,
+                               const mpg_wcache_t* wc_target, mpg_stream_t stream) {
     Segs sg;
     int maxn = 0;
     MPG_REQUIRE(w && m && v && grad && lr_t && do_adam && do_polyak &&
-                    fill_adam(sg, n_seg, seg_sizes, w, target, lr_t, do_adam, do_polyak, &maxn) == 0,
+                    fill_adam(sg, n_seg, seg_sizes, w, target, lr_t, do_adam, do_polyak, wc_w, wc_target, &maxn) == 0,
                 "mpg_adam_polyak: bad argument");
     hipLaunchKernelGGL(k_adam_polyak, dim3((maxn + 255) / 256, n_seg), dim3(256), 0, mpg_stream(stream), sg, w, m, v,
                        target, grad, tau, skip_flags, skip_flags ? n_skip_flags : 0);
@@ -316,11 +311,12 @@ extern "C" int mpg_sq_partials(const float* grad, const int* seg_sizes, int n_se
 
 extern "C" int mpg_clip_adam_polyak(float* w, float* m, float* v, float* target, float* grad, const float* sq_part,
                                     const int* seg_sizes, int n_seg, float clip, const float* lr_t, const int* do_adam,
-                                    const int* do_polyak, float tau, float* norms, int* nonfinite_flags, mpg_stream_t stream) {
+                                    const int* do_polyak, float tau, float* norms, int* nonfinite_flags,
+                                    const mpg_wcache_t* wc_w, const mpg_wcache_t* wc_target, mpg_stream_t stream) {
     Segs sg;
     int maxn = 0;
     MPG_REQUIRE(w && m && v && grad && sq_part && norms && lr_t && do_adam && do_polyak && clip > 0.f &&
-                    fill_adam(sg, n_seg, seg_sizes, w, target, lr_t, do_adam, do_polyak, &maxn) == 0,
+                    fill_adam(sg, n_seg, seg_sizes, w, target, lr_t, do_adam, do_polyak, wc_w, wc_target, &maxn) == 0,
                 "mpg_clip_adam_polyak: bad argument");
     hipLaunchKernelGGL(k_clip_adam_polyak, dim3((maxn + 255) / 256, n_seg), dim3(256), 0, mpg_stream(stream), sg, w, m, v,
                        target, grad, sq_part, clip, tau, norms, nonfinite_flags);

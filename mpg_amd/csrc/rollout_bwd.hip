@@ -148,7 +148,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_bwd(const RollBwdArgs a)
 
 }  // namespace
 
-int launch_rollout_bwd(const RollBwdArgs& ba_in, int env_kind, long ngroups, int n, hipStream_t s) {
+int launch_rollout_bwd(const RollBwdArgs& ba_in, int env_kind, long ngroups, int n, hipStream_t s, mpg_prof_t* prof) {
     RollBwdArgs ba = ba_in;
     ba.dbg = nullptr;
 #ifdef MPG_STAMP
@@ -157,12 +157,12 @@ int launch_rollout_bwd(const RollBwdArgs& ba_in, int env_kind, long ngroups, int
     if (!s_dbg_b) (void)hipMalloc(&s_dbg_b, 256 * 8 * 8 * sizeof(float));
     ba.dbg = s_dbg_b;
 #endif
-    mpg_prof_begin(1, s);
+    mpg_prof_begin(prof, 1, s);
     if (env_kind == MPG_ENV_PATH_TRACKING)
         hipLaunchKernelGGL((k_rollout_bwd<PathTracking>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, ba);
     else
         hipLaunchKernelGGL((k_rollout_bwd<Pendulum>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, ba);
-    mpg_prof_end(1, s);
+    mpg_prof_end(prof, 1, s);
     MPG_CHECK_LAUNCH("k_rollout_bwd");
 #ifdef MPG_STAMP
     if (++s_calls_b % 50 == 0) {

@@ -234,13 +234,14 @@ inline void fill_roll(RollArgs& a, const mpg_cfg_t* cfg, const float* policy, in
     const bool ranged = cfg->action_range > 0.f;
     a.out_tanh = (cfg->policy_out_act == MPG_ACT_TANH || ranged) ? 1 : 0;
     a.out_scale = ranged ? cfg->action_range : 1.f;
-    a.pack = weight_cache_lookup(make_net(policy, cfg->obs_dim, 2 * cfg->act_dim).W2, 0);
+    a.pack = weight_cache_lookup(cfg, make_net(policy, cfg->obs_dim, 2 * cfg->act_dim).W2, 0);
 }
 
 inline int grid_for(long ngroups) { return (int)(ngroups < 256 ? ngroups : 256); }
 
 // launch of the forward / reverse sweep kernel for the environment `env_kind` (n: horizon, only for the diagnostics)
-int launch_rollout_fwd(const RollArgs& a, int env_kind, long ngroups, int n, hipStream_t s, bool timed);
-int launch_rollout_bwd(const RollBwdArgs& a, int env_kind, long ngroups, int n, hipStream_t s);
+// prof (nullable): the caller's kernel timer
+int launch_rollout_fwd(const RollArgs& a, int env_kind, long ngroups, int n, hipStream_t s, mpg_prof_t* prof);
+int launch_rollout_bwd(const RollBwdArgs& a, int env_kind, long ngroups, int n, hipStream_t s, mpg_prof_t* prof);
 
 }  // namespace rollout

@@ -147,7 +147,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_fwd(const RollArgs a) {
 
 }  // namespace
 
-int launch_rollout_fwd(const RollArgs& fa_in, int env_kind, long ngroups, int n, hipStream_t s, bool timed) {
+int launch_rollout_fwd(const RollArgs& fa_in, int env_kind, long ngroups, int n, hipStream_t s, mpg_prof_t* prof) {
     RollArgs fa = fa_in;
     fa.dbg = nullptr;
 #ifdef MPG_STAMP
@@ -156,12 +156,12 @@ int launch_rollout_fwd(const RollArgs& fa_in, int env_kind, long ngroups, int n,
     if (!s_dbg) (void)hipMalloc(&s_dbg, 256 * 8 * 8 * sizeof(float));
     fa.dbg = s_dbg;
 #endif
-    if (timed) mpg_prof_begin(0, s);
+    mpg_prof_begin(prof, 0, s);
     if (env_kind == MPG_ENV_PATH_TRACKING)
         hipLaunchKernelGGL((k_rollout_fwd<PathTracking>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, fa);
     else
         hipLaunchKernelGGL((k_rollout_fwd<Pendulum>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, fa);
-    if (timed) mpg_prof_end(0, s);
+    mpg_prof_end(prof, 0, s);
     MPG_CHECK_LAUNCH("k_rollout_fwd");
 #ifdef MPG_STAMP
     if (++s_calls % 50 == 0) {

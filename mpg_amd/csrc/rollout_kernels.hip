@@ -89,7 +89,8 @@ inline size_t pad256(size_t nfloat) { return ((nfloat * sizeof(float) + 255) & ~
 
 inline bool cfg_ok(const mpg_cfg_t* c) {
     return c && ((c->obs_dim == 6 && c->act_dim == 2 && c->env_kind == MPG_ENV_PATH_TRACKING) ||
-                 (c->obs_dim == 4 && c->act_dim == 1 && c->env_kind == MPG_ENV_INVERTED_PENDULUM));
+                 (c->obs_dim == 4 && c->act_dim == 1 && c->env_kind == MPG_ENV_INVERTED_PENDULUM)) &&
+           !(c->policy_out_act == MPG_ACT_TANH && c->action_range > 0.f);   // see learner_api.hip:cfg_ok
 }
 
 
@@ -150,7 +151,7 @@ int run_rollout_fwd(const mpg_cfg_t* cfg, const float* policy_params, int rows, 
     for (int k = 0; k < MAXSEL; ++k) fa.sel[k] = k < n_select ? select[k] : -1;
     fa.XQ = XQ; fa.GK = GK;
     const long ngroups = (R + GROUP - 1) / GROUP;
-    return launch_rollout_fwd(fa, cfg->env_kind, ngroups, n, s, true);
+    return launch_rollout_fwd(fa, cfg->env_kind, ngroups, n, s, cfg->prof);
 }
 
 int run_rollout_bwd(const mpg_cfg_t* cfg, const float* policy_params, int rows, int M, int n, const int* select, int n_select,
@@ -173,8 +174,8 @@ int run_rollout_bwd(const mpg_cfg_t* cfg, const float* policy_params, int rows, 
     for (int t = 0; t < MAXN; ++t) ba.rho[t] = rho[t];
     ba.stash_all = all_steps_param_grad ? 1 : 0;
     ba.DZ1 = DZ1; ba.DZ2 = DZ2; ba.DZ3 = DZ3;
-    ba.pack = weight_cache_lookup(make_net(policy_params, od, 2 * ad).W2, 1);
-    return launch_rollout_bwd(ba, cfg->env_kind, ngroups, n, s);
+    ba.pack = weight_cache_lookup(cfg, make_net(policy_params, od, 2 * ad).W2, 1);
+    return launch_rollout_bwd(ba, cfg->env_kind, ngroups, n, s, cfg->prof);
 }
 
 }  // namespace
@@ -221,14 +222,14 @@ extern "C" int mpg_rollout_pg(const mpg_cfg_t* cfg, const float* policy_params, 
     // ---- critic at the selected slices: values, returns, input gradients ----
     OutSpec lin; lin.out_tanh = 0; lin.out_scale = 1.f; lin.sigma = 0.f; lin.seed = lin.ctr = 0;
     const int RQ = (int)(n_select * R);
-    rc = launch_forward(q1_params, qin, 1, 1, RQ, xspec(XQ, qin, nullptr, 0, nullptr, 0), lin, Q, 1, HQ1, HQ2, s);
+    rc = launch_forward(cfg, q1_params, qin, 1, 1, RQ, xspec(XQ, qin, nullptr, 0, nullptr, 0), lin, Q, 1, HQ1, HQ2, s);
     if (rc) return rc;
     const Coefs cf = make_coefs(cfg, select, n_select, w, inv_b_global, M);
     RetCoef rcf;
     for (int k = 0; k < MAXSEL; ++k) { rcf.gpow[k] = cf.gpow[k]; rcf.coef[k] = cf.coef[k]; }
     hipLaunchKernelGGL(k_returns, dim3(1), dim3(1024), 0, s, rows, M, n_select, rcf, Q, GK, DYQ, ret_sum, ret_sqsum);
     MPG_CHECK_LAUNCH("k_returns");
-    rc = launch_backward(q1_params, qin, 1, 1, RQ, DYQ, 1, nullptr, 0, 0, 1.f, HQ1, HQ2, nullptr, nullptr, nullptr, GXQ, qin, s);
+    rc = launch_backward(cfg, q1_params, qin, 1, 1, RQ, DYQ, 1, nullptr, 0, 0, 1.f, HQ1, HQ2, nullptr, nullptr, nullptr, GXQ, qin, s);
     if (rc) return rc;
 
     // ---- reverse sweep ----
@@ -240,7 +241,7 @@ extern "C" int mpg_rollout_pg(const mpg_cfg_t* cfg, const float* policy_params, 
     const int T = all_steps_param_grad ? n + 1 : 1;
     XSpec xs = xspec(SA, od, nullptr, 0, cfg->obs_scale, od);
     xs.ld0 = SAW;
-    return launch_wgrad(od, 2 * ad, ad, (int)(T * R), xs, H1, H2, DZ1, DZ2, DZ3, grad, slabs, s);
+    return launch_wgrad(cfg, od, 2 * ad, ad, (int)(T * R), xs, H1, H2, DZ1, DZ2, DZ3, grad, slabs, s);
 }
 
 extern "C" size_t mpg_rollout_q_target_workspace_bytes(const mpg_cfg_t* cfg, int rows) {
@@ -270,11 +271,11 @@ extern "C" int mpg_rollout_q_target(const mpg_cfg_t* cfg, const float* policy_pa
     fa.XQ = XQ; fa.GK = GK;
     const long ngroups = (rows + GROUP - 1) / GROUP;
     {
-        int rcq = launch_rollout_fwd(fa, cfg->env_kind, ngroups, n, s, false);
+        int rcq = launch_rollout_fwd(fa, cfg->env_kind, ngroups, n, s, nullptr);
         if (rcq) return rcq;
     }
     OutSpec lin; lin.out_tanh = 0; lin.out_scale = 1.f; lin.sigma = 0.f; lin.seed = lin.ctr = 0;
-    int rc = launch_forward(q1t, qin, 1, 1, rows, xspec(XQ, qin, nullptr, 0, nullptr, 0), lin, Q, 1, nullptr, nullptr, s);
+    int rc = launch_forward(cfg, q1t, qin, 1, 1, rows, xspec(XQ, qin, nullptr, 0, nullptr, 0), lin, Q, 1, nullptr, nullptr, s);
     if (rc) return rc;
     hipLaunchKernelGGL(k_gq, dim3((rows + 255) / 256), dim3(256), 0, s, rows, GK, Q, powf(cfg->gamma, (float)n), y);
     MPG_CHECK_LAUNCH("k_gq");
@@ -320,7 +321,8 @@ MgLayout mg_layout(const mpg_cfg_t* cfg, int rows, int M, int n, int n_sel, int 
 }  // namespace
 
 extern "C" size_t mpg_mpg_gradients_workspace_bytes(const mpg_cfg_t* cfg, int rows, int M, int n, int n_select, int n_q) {
-    if (!cfg_ok(cfg) || rows <= 0 || M <= 0 || n <= 0 || n >= MAXN || n_select <= 0 || n_select > MAXSEL || n_q < 1 || n_q > 2)
+    if (!cfg_ok(cfg) || rows <= 0 || M <= 0 || n <= 0 || n >= MAXN || n_select <= 0 || n_select > MAXSEL || n_q < 1 || n_q > 2 ||
+        n_q + 2 * n_select > 8)
         return 0;
     const MgLayout l = mg_layout(cfg, rows, M, n, n_select, n_q);
     return std::max(l.fused_total, l.fallback0 + l.fallback1 + 512);
@@ -337,6 +339,8 @@ extern "C" int mpg_mpg_gradients(const mpg_cfg_t* cfg, int n_q, const float* par
     MPG_REQUIRE(y_in || (target_params && rew && obs_tp1), "mpg_mpg_gradients: either y_in or the target inputs are required");
     MPG_REQUIRE(rows > 0 && M > 0 && n > 0 && n < MAXN && n_select > 0 && n_select <= MAXSEL, "mpg_mpg_gradients: bad sizes");
     for (int k = 0; k < n_select; ++k) MPG_REQUIRE(select[k] >= 0 && select[k] <= n, "mpg_mpg_gradients: slice out of range");
+    // the statistics block holds n_q losses + 2 sums per slice in 8 reduction jobs: checked before anything is enqueued
+    MPG_REQUIRE(n_q + 2 * n_select <= 8, "mpg_mpg_gradients: too many statistics (n_select <= 3 with two critics)");
     if (ws_bytes < mpg_mpg_gradients_workspace_bytes(cfg, rows, M, n, n_select, n_q)) {
         mpg_set_error("mpg_mpg_gradients: workspace too small");
         return MPG_EWORKSPACE;
@@ -405,8 +409,7 @@ extern "C" int mpg_mpg_gradients(const mpg_cfg_t* cfg, int n_q, const float* par
     }
     int rc;
     const Coefs cf = make_coefs(cfg, select, n_select, w, inv_b_global, 1);
-    static const bool merged_critic = getenv("MPG_NO_CRITIC_FUSED") == nullptr;    // A/B switch (tools only)
-    if (n_select == 2 && merged_critic) {
+    if (n_select == 2) {
         // 2. rollout forward sweep
         rc = run_rollout_fwd(cfg, policy, rows, 1, n, select, n_select, obs, eps, noise_seed, noise_ctr, H1, H2, SA, XQ, GK, s);
         if (rc) return rc;
@@ -423,7 +426,7 @@ extern "C" int mpg_mpg_gradients(const mpg_cfg_t* cfg, int n_q, const float* par
         rc = run_rollout_fwd(cfg, policy, rows, 1, n, select, n_select, obs, eps, noise_seed, noise_ctr, H1, H2, SA, XQ, GK, s);
         if (rc) return rc;
         // 4. critic at the selected slices: returns and input gradients
-        rc = launch_qslice_fused(qp[0], qin, rows, n_select, XQ, GK, cf.gpow, cf.coef, ret_part, GXQ, s);
+        rc = launch_qslice_fused(cfg, qp[0], qin, rows, n_select, XQ, GK, cf.gpow, cf.coef, ret_part, GXQ, s);
         if (rc) return rc;
     }
     // 5. reverse sweep
@@ -450,6 +453,5 @@ extern "C" int mpg_mpg_gradients(const mpg_cfg_t* cfg, int n_q, const float* par
         sums[ns].src = ret_part + (size_t)k * ngroups * 2; sums[ns].n = ngroups; sums[ns].stride = 2; sums[ns].dst = stats + 2 + k; ++ns;
         sums[ns].src = ret_part + (size_t)k * ngroups * 2 + 1; sums[ns].n = ngroups; sums[ns].stride = 2; sums[ns].dst = stats + 2 + n_select + k; ++ns;
     }
-    MPG_REQUIRE(n_q + 2 * n_select <= 8, "mpg_mpg_gradients: too many statistics (n_select <= 3 with two critics)");
-    return launch_wgrad_multi(jobs, n_q + 1, sums, ns, sq_part, s);
+    return launch_wgrad_multi(cfg, jobs, n_q + 1, sums, ns, sq_part, s);
 }

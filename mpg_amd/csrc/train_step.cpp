@@ -59,9 +59,11 @@ double polynomial_decay(const float* sched, long long step) {       // policy.py
         if (rc_) return rc_; \
     } while (0)
 
+inline bool exchanged(const mpg_train_ctx_t* c) { return c->world_size > 1 || c->grads_exchanged != 0; }
+
 bool ctx_ok(const mpg_train_ctx_t* c) {
     return c && (c->learner_version == 1 || c->learner_version == 2) && c->num_agent > 0 && c->batch > 0 && c->n > 0 &&
-           c->M > 0 && c->n_select > 0 && c->n_select <= 4 && c->world_size > 0 && c->sampling_interval > 0 &&
+           c->M > 0 && c->n_select > 0 && c->n_select <= 4 && (c->learner_version == 2 ? 2 : 1) + 2 * c->n_select <= 8 && c->world_size > 0 && c->sampling_interval > 0 &&
            c->num_batch_reuse > 0 && c->ring_capacity > 0 && c->params && c->targets && c->grad && c->ws0 && c->ws1;
 }
 
@@ -88,9 +90,11 @@ extern "C" int mpg_step_begin(mpg_train_ctx_t* c, int iteration, mpg_stream_t s)
                                   c->w_act, s));
             MPG_REQUIRE(c->num_agent <= c->ring_capacity, "mpg_step_begin: ring smaller than one sample");
             // env.step -> ring slot (next + i) % capacity -> env.reset of the done agents, one launch
+            mpg_prof_begin(c->cfg.prof, 2, mpg_stream(s));
             TRY(mpg_env_step_store_reset(kind, c->num_agent, c->env_state, c->w_act, c->ring_capacity, c->ring_next, c->ring_obs,
                                          c->ring_act, c->ring_rew, c->ring_obs2, c->ring_done, c->env_seed, c->env_ctr++, c->w_obs,
                                          c->w_done, s));
+            mpg_prof_end(c->cfg.prof, 2, mpg_stream(s));
             c->ring_next = (c->ring_next + c->num_agent) % c->ring_capacity;
             c->ring_size = std::min(c->ring_size + c->num_agent, c->ring_capacity);
         }
@@ -136,7 +140,7 @@ extern "C" int mpg_step_begin(mpg_train_ctx_t* c, int iteration, mpg_stream_t s)
     const float* y_in = (c->learner_version == 2 && fresh) ? nullptr : c->b_targets;
     TRY(mpg_mpg_gradients(&c->cfg, l.n_nets - 1, c->params, c->targets, c->batch, c->b_obs, c->b_act, c->b_rew, c->b_obs2, y_in,
                           c->M, c->n, c->select, c->n_select, w, nullptr, c->learner_seed, c->learner_counter, inv_b, c->grad,
-                          c->grad + l.n_grad, c->b_targets, c->world_size == 1 ? c->clip_scratch : nullptr,
+                          c->grad + l.n_grad, c->b_targets, exchanged(c) ? nullptr : c->clip_scratch,
                           draw_in_gradients ? &draw : nullptr, c->ws1, c->ws1_bytes, s));
     return MPG_OK;
 }
@@ -146,7 +150,7 @@ extern "C" int mpg_step_end(mpg_train_ctx_t* c, int iteration, mpg_stream_t s) {
     const Layout l = layout(c);
     // per-network clip_by_global_norm (mpg_learner.py:415-431): on one GPU the partial sums of squares were left in
     // clip_scratch by mpg_mpg_gradients; after an all-reduce they are recomputed from the reduced gradient
-    if (c->world_size > 1) TRY(mpg_sq_partials(c->grad, l.sizes, l.n_nets, c->clip_scratch, s));
+    if (exchanged(c)) TRY(mpg_sq_partials(c->grad, l.sizes, l.n_nets, c->clip_scratch, s));
     // PolicyWithQs.apply_gradients, policy.py:123-156
     const bool delayed = iteration % c->delay_update == 0;
     float lr_t[3];
@@ -162,5 +166,5 @@ extern "C" int mpg_step_end(mpg_train_ctx_t* c, int iteration, mpg_stream_t s) {
         if (upd) c->opt_steps[k] = t;
     }
     return mpg_clip_adam_polyak(c->params, c->adam_m, c->adam_v, c->targets, c->grad, c->clip_scratch, l.sizes, l.n_nets, c->clip,
-                                lr_t, do_adam, do_polyak, c->tau, c->norms, c->nonfinite, s);
+                                lr_t, do_adam, do_polyak, c->tau, c->norms, c->nonfinite, c->cfg.wcache[0], c->cfg.wcache[1], s);
 }

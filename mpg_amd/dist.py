@@ -12,7 +12,7 @@ def init_from_env(backend=None):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or backend is not None) and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend is None:
@@ -25,13 +25,18 @@ def init_from_env(backend=None):
     return rank, world, local
 
 
+def backend():
+    return dist.get_backend() if dist.is_initialized() else None
+
+
 def world_size():
     return dist.get_world_size() if dist.is_initialized() else 1
 
 
-def all_reduce_sum_(flat):
-    """In-place sum over ranks of one flat float32 buffer (no-op on a single process)."""
-    if dist.is_initialized() and dist.get_world_size() > 1:
+def all_reduce_sum_(flat, force=False):
+    """In-place sum over ranks of one flat float32 buffer (no-op on a single process unless `force`: a one-rank group
+    still runs the collective - the way the RCCL path is exercised on a 1-GPU box)."""
+    if dist.is_initialized() and (dist.get_world_size() > 1 or force):
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     return flat
 

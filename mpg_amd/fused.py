@@ -1,6 +1,7 @@
 """Native step driver binding (mpg_step_begin / mpg_step_end): one optimizer iteration enqueued from C++ so that the
 Python interpreter is not on the launch path.  Built from - and kept in sync with - the stock worker / buffer / learner
-objects, whose methods remain usable at any time (counters are written back after every step)."""
+objects, whose methods remain usable at any time: every fused step starts by reading their counters and buffers
+(sync_in) and ends by writing them back (push)."""
 import ctypes
 
 import torch
@@ -19,7 +20,7 @@ class TrainCtx(ctypes.Structure):
         ('sampling_interval', ctypes.c_int), ('batch', ctypes.c_int), ('n', ctypes.c_int), ('M', ctypes.c_int),
         ('n_select', ctypes.c_int), ('select', ctypes.c_int * 4), ('eta', ctypes.c_float), ('total_ite', ctypes.c_int),
         ('clip', ctypes.c_float), ('tau', ctypes.c_float), ('delay_update', ctypes.c_int), ('num_batch_reuse', ctypes.c_int),
-        ('world_size', ctypes.c_int), ('explore_sigma', ctypes.c_float), ('value_lr', ctypes.c_float * 3),
+        ('world_size', ctypes.c_int), ('grads_exchanged', ctypes.c_int), ('explore_sigma', ctypes.c_float), ('value_lr', ctypes.c_float * 3),
         ('policy_lr', ctypes.c_float * 3),
         ('worker_seed', ctypes.c_uint64), ('noise_ctr', ctypes.c_uint64), ('env_seed', ctypes.c_uint64),
         ('env_ctr', ctypes.c_uint64), ('replay_seed', ctypes.c_uint64), ('replay_times', ctypes.c_uint64),
@@ -38,7 +39,7 @@ class FusedMPGStep(object):
     """step(iteration) == SingleProcessOffPolicyOptimizer.step for (OffPolicyWorker, ReplayBuffer, MPGLearner) sharing
     one PolicyWithQs."""
 
-    def __init__(self, worker, learner, rb, sampling_interval):
+    def __init__(self, worker, learner, rb, sampling_interval, always_exchange=False):
         from .buffer import PrioritizedReplayBuffer
         assert not isinstance(rb, PrioritizedReplayBuffer) and learner.args.buffer_type == 'normal'
         assert learner.policy_with_value is worker.policy_with_value
@@ -57,6 +58,9 @@ class FusedMPGStep(object):
         c.eta, c.total_ite = a.eta, a.rule_based_bias_total_ite
         c.clip, c.tau, c.delay_update = float(a.gradient_clip_norm), pw.tau, pw.delay_update
         c.num_batch_reuse, c.world_size = learner.num_batch_reuse, D.world_size()
+        # always_exchange: run the collective (and the exchanged-gradient form of the clip) even in a one-process group
+        self.always_exchange = bool(always_exchange)
+        c.grads_exchanged = 1 if (c.world_size > 1 or self.always_exchange) else 0
         c.explore_sigma = float(worker.explore_sigma or 0.)
         for i in range(3):
             c.value_lr[i], c.policy_lr[i] = pw.schedules['Q1'][i], pw.schedules['policy'][i]
@@ -115,19 +119,26 @@ class FusedMPGStep(object):
         w.env.done = self.t['w_done']
         w.env._initialised = True
 
-    def reload(self):
-        """after the python objects were restored from a checkpoint: refresh the driver's own buffers and counters"""
+    def sync_in(self):
+        """python objects -> driver (counters, and the worker's observation / done buffers if they were re-bound):
+        whatever the stock methods did since the last fused step - worker.sample(), rb.add_batch(), rb.replay(),
+        learner.compute_gradient(), a checkpoint restore - is what the next fused step continues from."""
         w = self.worker
         if w.obs is not self.t['w_obs']:
             self.t['w_obs'].copy_(w.obs)
         if w.env.done is not self.t['w_done']:
             self.t['w_done'].copy_(w.env.done)
         self.pull()
+
+    def reload(self):
+        """after the python objects were restored from a checkpoint: refresh the driver's own buffers and counters"""
+        self.sync_in()
         self.push()
 
     def step(self, iteration):
+        self.sync_in()           # a few host scalar copies; the tensor copies only happen after a stock-method call
         s = L.stream()
         L.check(self._lib.mpg_step_begin(self._ref, ctypes.c_int(iteration), s), 'mpg_step_begin')
-        D.all_reduce_sum_(self.learner.flat)                     # the ONE exchange step (no-op on a single GPU)
+        D.all_reduce_sum_(self.learner.flat, force=self.always_exchange)   # the ONE exchange step (no-op on a single GPU)
         L.check(self._lib.mpg_step_end(self._ref, ctypes.c_int(iteration), s), 'mpg_step_end')
         self.push()

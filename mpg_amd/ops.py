@@ -9,12 +9,84 @@ ACT_LINEAR, ACT_TANH = 0, 1
 HIDDEN = 256
 
 
+class WCacheStruct(ctypes.Structure):
+    """mpg_wcache_t: caller-owned descriptor of the packed W2 images of one flat parameter vector"""
+    _fields_ = [('params', ctypes.c_void_p), ('packed', ctypes.c_void_p), ('n_nets', ctypes.c_int),
+                ('in_dim', ctypes.c_int * 8), ('out_dim', ctypes.c_int * 8)]
+
+
 class CfgStruct(ctypes.Structure):
     """mpg_cfg_t"""
     _fields_ = [('obs_dim', ctypes.c_int), ('act_dim', ctypes.c_int), ('policy_out_act', ctypes.c_int),
                 ('action_range', ctypes.c_float), ('obs_scale', ctypes.c_float * 8),
                 ('rew_scale', ctypes.c_float), ('rew_shift', ctypes.c_float), ('gamma', ctypes.c_float),
-                ('env_kind', ctypes.c_int)]
+                ('env_kind', ctypes.c_int),
+                ('wcache', ctypes.POINTER(WCacheStruct) * 2), ('prof', ctypes.c_void_p)]
+
+
+class WeightCache(object):
+    """Owns the packed images of one flat [net0 | net1 | ...] tensor (mpg_wcache_t + the device array).  Keep the object
+    alive for as long as a cfg points at it; call pack() after writing `params` by anything but the Adam entry points."""
+
+    def __init__(self, params, dims):
+        k = len(dims)
+        self.params = params
+        self.packed = torch.empty(L.lib().mpg_weight_cache_floats(L.c_int(k)), dtype=torch.float32, device=params.device)
+        self.desc = WCacheStruct()
+        self.desc.params, self.desc.packed, self.desc.n_nets = params.data_ptr(), self.packed.data_ptr(), k
+        for i, (ind, outd) in enumerate(dims):
+            self.desc.in_dim[i], self.desc.out_dim[i] = ind, outd
+        self.pack()
+
+    def pack(self):
+        L.call('mpg_weight_cache_pack', ctypes.byref(self.desc), L.stream())
+
+    @property
+    def ref(self):
+        return ctypes.byref(self.desc)
+
+    @property
+    def pointer(self):
+        return ctypes.pointer(self.desc)
+
+
+def _wc(cache):
+    return cache.ref if cache is not None else None
+
+
+class Profiler(object):
+    """mpg_prof_t: caller-owned kernel timer; attach() makes the calls issued with that cfg report to it."""
+
+    def __init__(self, max_samples=4096):
+        self.h = ctypes.c_void_p(0)
+        L.call('mpg_prof_create', L.c_int(max_samples), ctypes.byref(self.h))
+
+    def attach(self, *cfgs):
+        for c in cfgs:
+            c.prof = self.h.value
+
+    def start(self, every):
+        L.call('mpg_prof_start', self.h, L.c_int(every))
+
+    def stop(self):
+        L.call('mpg_prof_start', self.h, L.c_int(0))
+
+    def read(self, slot):
+        """(average ms per timed launch or None, number of timed launches)"""
+        ms, cnt = ctypes.c_double(0), ctypes.c_int(0)
+        L.call('mpg_prof_read', self.h, L.c_int(slot), ctypes.byref(ms), ctypes.byref(cnt))
+        return (ms.value / cnt.value if cnt.value else None), cnt.value
+
+    def close(self):
+        if self.h:
+            L.lib().mpg_prof_destroy(self.h)
+            self.h = ctypes.c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def make_cfg(env_id='PathTracking-v0', obs_scale=None, rew_scale=None, rew_shift=0.0, gamma=0.98,
@@ -79,12 +151,12 @@ def _f32(t):
     return t
 
 
-def mlp_forward(params, in_dim, out_dim, out_used, out_act, x, in_scale=None, n_scaled=0):
+def mlp_forward(params, in_dim, out_dim, out_used, out_act, x, in_scale=None, n_scaled=0, wcache=None):
     rows = x.shape[0]
     y = torch.empty(rows, out_used, dtype=torch.float32, device=x.device)
     sc = (ctypes.c_float * 8)(*([float(v) for v in in_scale] + [1.0] * (8 - len(in_scale)))) if in_scale is not None else None
     L.call('mpg_mlp_forward', L.ptr(_f32(params)), L.c_int(in_dim), L.c_int(out_dim), L.c_int(out_used),
-           L.c_int(out_act), L.c_int(rows), L.ptr(_f32(x)), sc, L.c_int(n_scaled), L.ptr(y), L.stream())
+           L.c_int(out_act), L.c_int(rows), L.ptr(_f32(x)), sc, L.c_int(n_scaled), L.ptr(y), _wc(wcache), L.stream())
     return y
 
 
@@ -169,7 +241,8 @@ def sq_partials(grad, seg_sizes, sq_part=None):
     return part
 
 
-def clip_adam_polyak(w, m, v, target, grad, sq_part, seg_sizes, clip, lr_t, do_adam, do_polyak, tau, norms, nonfinite=None):
+def clip_adam_polyak(w, m, v, target, grad, sq_part, seg_sizes, clip, lr_t, do_adam, do_polyak, tau, norms, nonfinite=None,
+                     wc_w=None, wc_target=None):
     """mpg_clip_adam_polyak: second half of the clip + Adam + Polyak in one launch"""
     ns = len(seg_sizes)
     segs = (ctypes.c_int * ns)(*[int(s) for s in seg_sizes])
@@ -178,7 +251,7 @@ def clip_adam_polyak(w, m, v, target, grad, sq_part, seg_sizes, clip, lr_t, do_a
     dp = (ctypes.c_int * ns)(*[int(x) for x in do_polyak])
     L.call('mpg_clip_adam_polyak', L.ptr(_f32(w)), L.ptr(_f32(m)), L.ptr(_f32(v)), L.ptr(target), L.ptr(_f32(grad)),
            L.ptr(_f32(sq_part)), segs, L.c_int(ns), L.c_float(clip), lr, da, dp, L.c_float(tau), L.ptr(norms), L.ptr(nonfinite),
-           L.stream())
+           _wc(wc_w), _wc(wc_target), L.stream())
 
 
 def clip_by_global_norm(grad, seg_sizes, clip, norms_out=None, nonfinite=None, scratch=None):
@@ -190,7 +263,7 @@ def clip_by_global_norm(grad, seg_sizes, clip, norms_out=None, nonfinite=None, s
     return norms
 
 
-def adam_polyak(w, m, v, target, grad, seg_sizes, lr_t, do_adam, do_polyak, tau, skip_flag=None):
+def adam_polyak(w, m, v, target, grad, seg_sizes, lr_t, do_adam, do_polyak, tau, skip_flag=None, wc_w=None, wc_target=None):
     ns = len(seg_sizes)
     segs = (ctypes.c_int * ns)(*[int(s) for s in seg_sizes])
     lr = (ctypes.c_float * ns)(*[float(x) for x in lr_t])
@@ -198,7 +271,7 @@ def adam_polyak(w, m, v, target, grad, seg_sizes, lr_t, do_adam, do_polyak, tau,
     dp = (ctypes.c_int * ns)(*[int(x) for x in do_polyak])
     L.call('mpg_adam_polyak', L.ptr(_f32(w)), L.ptr(_f32(m)), L.ptr(_f32(v)), L.ptr(target), L.ptr(_f32(grad)), segs,
            L.c_int(ns), lr, da, dp, L.c_float(tau), L.ptr(skip_flag),
-           L.c_int(skip_flag.numel() if skip_flag is not None else 0), L.stream())
+           L.c_int(skip_flag.numel() if skip_flag is not None else 0), _wc(wc_w), _wc(wc_target), L.stream())
 
 
 def rollout_q_target(cfg, policy_params, q1t, obs0, act0, eps, n=None, noise_seed=0, noise_ctr=0):

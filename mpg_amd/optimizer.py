@@ -1,13 +1,24 @@
 """SingleProcessOffPolicyOptimizer - mirror of optimizer.py:286-397: the per-iteration order
 (sample every 10th iteration -> replay -> set_weights -> compute_gradient -> (priorities) -> NaN guard ->
 apply_gradients) is the contract; Ray / TensorBoard plumbing is out of scope.  One instance per GPU process."""
+import gc
 import logging
 
 logger = logging.getLogger(__name__)
 
 
+def quiesce_gc():
+    """Collect once, then move everything alive into the permanent generation (gc.freeze).  `import torch` leaves ~10^6
+    container objects behind; a generation-2 pass over them takes 40-100 ms and the step loop's own small allocations
+    trigger one every few thousand iterations - 10 % of a 0.45 ms step (tools/stall_scan.py).  After the freeze the
+    collector only ever walks what the loop itself allocates.  Call it once after the training stack is built."""
+    gc.collect()
+    gc.freeze()
+
+
 class SingleProcessOffPolicyOptimizer(object):
-    def __init__(self, worker, learner, replay_buffer, evaluator, args, sampling_interval=10, fused=True):
+    def __init__(self, worker, learner, replay_buffer, evaluator, args, sampling_interval=10, fused=True,
+                 always_exchange=False):
         self.args = args
         self.worker, self.learner, self.replay_buffer, self.evaluator = worker, learner, replay_buffer, evaluator
         self.num_sampled_steps = 0
@@ -29,7 +40,15 @@ class SingleProcessOffPolicyOptimizer(object):
             if type(learner) is MPGLearner and not isinstance(replay_buffer, PrioritizedReplayBuffer) and \
                     getattr(args, 'buffer_type', 'normal') == 'normal' and not learner.deriv_interval_policy:
                 from .fused import FusedMPGStep
-                self._fused = FusedMPGStep(worker, learner, replay_buffer, sampling_interval)
+                self._fused = FusedMPGStep(worker, learner, replay_buffer, sampling_interval, always_exchange=always_exchange)
+
+    def set_profiler(self, prof):
+        """attach an ops.Profiler (or None) to every cfg this optimizer launches with"""
+        h = prof.h.value if prof is not None else None
+        self.worker.policy_with_value.cfg.prof = h
+        self.learner.policy_with_value.cfg.prof = h
+        if self._fused is not None:
+            self._fused.c.cfg.prof = h
 
     def get_stats(self):
         self.stats.update(dict(num_sampled_steps=self.num_sampled_steps, iteration=self.iteration))

@@ -73,28 +73,18 @@ class PolicyWithQs(object):
         self.nonfinite = torch.zeros(len(self.names), dtype=torch.int32, device=self.device)
         self._bind_weight_cache()
 
-    # ---- weight cache (packed register images of the hidden kernels; see include/mpg_hip.h) ----
+    # ---- weight cache (packed register images of the hidden kernels; caller-owned, see include/mpg_hip.h) ----
     def _bind_weight_cache(self):
-        k = len(self.names)
-        nf = L.lib().mpg_weight_cache_floats(L.c_int(k))
-        ind = (ctypes.c_int * k)(*[self.dims[n][0] for n in self.names])
-        outd = (ctypes.c_int * k)(*[self.dims[n][1] for n in self.names])
-        self._cache = [torch.empty(nf, dtype=torch.float32, device=self.device) for _ in range(2)]
-        self._bound = [self.params.data_ptr(), self.targets.data_ptr()]
-        for buf, cache in zip((self.params, self.targets), self._cache):
-            L.call('mpg_weight_cache_bind', L.ptr(buf), ind, outd, L.c_int(k), L.ptr(cache), L.stream())
+        dims = [self.dims[n] for n in self.names]
+        self.wc_params = ops.WeightCache(self.params, dims)
+        self.wc_targets = ops.WeightCache(self.targets, dims)
+        self.cfg.wcache[0] = self.wc_params.pointer
+        self.cfg.wcache[1] = self.wc_targets.pointer
 
     def refresh_weight_cache(self):
         """call after writing params/targets by anything other than apply_gradients"""
-        for buf in (self.params, self.targets):
-            L.call('mpg_weight_cache_refresh', L.ptr(buf), L.stream())
-
-    def __del__(self):
-        try:
-            for p in getattr(self, '_bound', []):
-                L.lib().mpg_weight_cache_unbind(ctypes.c_void_p(p))
-        except Exception:
-            pass
+        self.wc_params.pack()
+        self.wc_targets.pack()
 
     def sync_from_rank0(self):
         """Data-parallel start-up: every replica takes rank 0's parameters / targets / optimizer state."""
@@ -119,8 +109,10 @@ class PolicyWithQs(object):
         return out
 
     def get_weights(self):
-        """[models..., target_models...] each a list of 6 arrays (policy.py:112-114); device tensors (views)."""
-        return [self._as_list(self.net(n), n) for n in self.names] + [self._as_list(self.net(n, True), n) for n in self.names]
+        """[models..., target_models...] each a list of 6 arrays (policy.py:112-114).  COPIES, like Keras' get_weights():
+        writing into them does not touch the live parameters (whose packed images would otherwise go stale)."""
+        return [self._as_list(self.net(n).clone(), n) for n in self.names] + \
+               [self._as_list(self.net(n, True).clone(), n) for n in self.names]
 
     def set_weights(self, weights):
         """policy.py:116-121"""
@@ -152,7 +144,7 @@ class PolicyWithQs(object):
         x = torch.cat([obs, act], 1).contiguous()
         sc = [self.cfg.obs_scale[i] for i in range(self.obs_dim)]
         return ops.mlp_forward(self.net(name, target), self.obs_dim + self.act_dim, 1, 1, ops.ACT_LINEAR, x, in_scale=sc,
-                               n_scaled=self.obs_dim)[:, 0]
+                               n_scaled=self.obs_dim, wcache=self.wc_targets if target else self.wc_params)[:, 0]
 
     def compute_Q1(self, obs, act):
         return self._q('Q1', False, obs, act)
@@ -185,7 +177,7 @@ class PolicyWithQs(object):
             if upd:
                 self.opt_steps[n] = t
         ops.adam_polyak(self.params, self.m, self.v, self.targets, grads, self.sizes, lr_t, do_adam, do_polyak, self.tau,
-                        skip_flag=self.nonfinite)
+                        skip_flag=self.nonfinite, wc_w=self.wc_params, wc_target=self.wc_targets)
 
     # ---- checkpoint (flat blob) ----
     def state_dict(self):

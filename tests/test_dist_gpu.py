@@ -120,3 +120,59 @@ def test_native_step_driver_keeps_two_replicas_bit_identical():
     out = _run(_driver_worker)
     assert np.array_equal(out[0][1], out[1][1]) and np.isfinite(out[0][1]).all()
     assert not np.array_equal(out[0][2], out[1][2])               # the ranks really saw different data
+
+
+def _rccl_worker(rank, world, port, q):
+    """One rank, backend 'nccl' (= RCCL): the collective really runs between mpg_step_begin and mpg_step_end, on the
+    stream the library launches on, and mpg_step_end takes the exchanged-gradient branch (mpg_sq_partials)."""
+    os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                      HSA_ENABLE_IPC_MODE_LEGACY='0')
+    from mpg_amd import dist as D
+    D.init_from_env(backend='nccl')
+    assert torch.distributed.is_initialized() and torch.distributed.get_backend() == 'nccl'
+    from mpg_amd.buffer import ReplayBuffer
+    from mpg_amd.config import default_args
+    from mpg_amd.learners import MPGLearner
+    from mpg_amd.optimizer import SingleProcessOffPolicyOptimizer
+    from mpg_amd.policy import PolicyWithQs
+    from mpg_amd.worker import OffPolicyWorker
+
+    def run(always_exchange):
+        args = default_args('MPG-v2', num_agent=256, batch_size=256, replay_batch_size=256, replay_starts=512,
+                            max_buffer_size=4096, seed=0, init_seed=0)
+        worker = OffPolicyWorker(PolicyWithQs, args.env_id, args, 0)
+        opt = SingleProcessOffPolicyOptimizer(worker, MPGLearner(PolicyWithQs, args), ReplayBuffer(args, 0), None, args,
+                                              sampling_interval=1, always_exchange=always_exchange)
+        assert opt._fused is not None and opt._fused.c.grads_exchanged == int(always_exchange)
+        for _ in range(30):
+            opt.step()
+        torch.cuda.synchronize()
+        pw = worker.policy_with_value
+        return torch.cat([pw.params, pw.targets, pw.m, pw.v]).cpu().numpy(), opt.learner.norms.cpu().numpy()
+    a, na = run(True)          # RCCL all-reduce (identity in a one-rank group) + clip partials from the reduced buffer
+    b, nb = run(False)         # no collective, clip partials as a by-product of the gradient launch
+    # a second stream user: the collective must also be ordered against the library when it is NOT torch's default stream
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        c, nc = run(True)
+    q.put((0, a, b, c, na, nb, nc))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_rccl_all_reduce_between_step_begin_and_step_end():
+    """backend='nccl' IS RCCL on ROCm.  A one-rank group on the one GPU of the test box: 30 native steps with the flat
+    [gradients | statistics] buffer all-reduced by RCCL between mpg_step_begin and mpg_step_end end in bit-identical
+    parameters / targets / Adam moments to 30 steps without the collective - i.e. RCCL loads, the collective is ordered
+    correctly against the library's launches on the current stream (default and non-default), and the
+    exchanged-gradient branch of the clip (mpg_sq_partials after the reduce) yields the same norms as the fused one."""
+    port = _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(0, 1, port, q))
+    p.start()
+    _, a, b, c, na, nb, nc = q.get(timeout=500)
+    p.join(60)
+    assert p.exitcode == 0
+    assert np.isfinite(a).all() and np.array_equal(a, b) and np.array_equal(a, c)
+    assert np.array_equal(na, nb) and np.array_equal(na, nc)

@@ -167,6 +167,42 @@ def test_native_step_driver_equals_method_by_method_path(alg):
     assert ((g1 - g2).norm() / g2.norm()).item() < 1e-5
 
 
+def test_stock_methods_interleaved_with_native_steps():
+    """The stock worker / buffer methods may be called between native steps (mpg_amd/fused.py: sync_in / push): a run that
+    interleaves `worker.sample()` + `rb.add_batch()` with fused steps ends in the same ring, counters and parameters as
+    the pure method-by-method path doing the same calls - no ring slot is overwritten, no Philox (seed, counter) pair is
+    used twice."""
+    from mpg_amd.buffer import ReplayBuffer
+    from mpg_amd.config import default_args
+    from mpg_amd.learners import MPGLearner
+    from mpg_amd.optimizer import SingleProcessOffPolicyOptimizer
+    from mpg_amd.policy import PolicyWithQs
+    from mpg_amd.worker import OffPolicyWorker
+
+    def run(fused):
+        args = default_args('MPG-v2', num_agent=64, batch_size=64, replay_batch_size=96, replay_starts=256, max_buffer_size=700)
+        worker = OffPolicyWorker(PolicyWithQs, args.env_id, args, 0)
+        learner = MPGLearner(PolicyWithQs, args)
+        rb = ReplayBuffer(args, 0)
+        opt = SingleProcessOffPolicyOptimizer(worker, learner, rb, None, args, sampling_interval=2, fused=fused)
+        assert (opt._fused is not None) == fused
+        for it in range(12):
+            opt.step()
+            if it % 3 == 1:                      # extra samples through the stock methods (wraps the 700-slot ring)
+                batch, n = worker.sample_with_count()
+                rb.add_batch(batch)
+        pw = worker.policy_with_value
+        return [pw.params.clone(), pw.targets.clone(), rb.obs.clone(), rb.act.clone(), worker.obs.clone()], \
+            (dict(pw.opt_steps), rb._next_idx, len(rb), rb.replay_times, worker._noise_ctr, worker.env._ctr)
+    a, ca = run(True)
+    b, cb = run(False)
+    assert ca == cb, (ca, cb)
+    assert torch.equal(a[2], b[2]) and torch.equal(a[4], b[4])          # ring observations and the worker's current obs
+    assert (a[3] - b[3]).abs().max().item() < 1e-4                      # stored actions depend on the policy (rounding)
+    for x, y in zip(a[:2], b[:2]):
+        assert (x - y).abs().max().item() <= 1e-6 * max(1.0, y.abs().max().item())
+
+
 def test_replay_sample_uniform_equals_indices_plus_gather():
     import mpg_amd._lib as L
     from mpg_amd.buffer import ReplayBuffer

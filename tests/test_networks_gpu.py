@@ -174,15 +174,14 @@ def test_nstep_target_vs_golden(golden):
 
 
 def test_weight_cache_is_bit_identical_to_the_strided_path():
-    """mpg_weight_cache_*: packed register images are an acceleration only - forward, backward and rollout results are
-    bit-identical with and without a binding, and stay so after mpg_adam_polyak rewrites the bound buffer."""
-    import ctypes
-    import mpg_amd._lib as L
+    """mpg_wcache_t: packed register images are an acceleration only - forward, backward and rollout results are
+    bit-identical with and without a descriptor in the cfg, and stay so after mpg_adam_polyak (which is handed the
+    descriptor) rewrites the buffer.  The descriptor is a caller-owned object: a cfg without it never sees the images."""
     from mpg_amd import ops
     from tests.golden_inputs import mlp_weights_flat, reset_law_obs
     rng = np.random.Generator(np.random.PCG64(17))
-    cfg = ops.make_cfg()
-    nq, npol = ops.q_size(cfg), ops.policy_size(cfg)
+    plain, cached = ops.make_cfg(), ops.make_cfg()
+    nq, npol = ops.q_size(plain), ops.policy_size(plain)
     flat = dev(np.concatenate([mlp_weights_flat(rng, 8, 1), mlp_weights_flat(rng, 6, 4)]))
     q1, pol = flat[:nq], flat[nq:]
     B = 100
@@ -190,27 +189,47 @@ def test_weight_cache_is_bit_identical_to_the_strided_path():
     y = dev(rng.standard_normal(B))
     eps = dev(rng.standard_normal((25, B)))
 
-    def run():
+    def run(cfg):
         a = ops.policy_action(cfg, pol, obs)
         _, g, _ = ops.q_loss_grad(cfg, q1, obs, act, y)
         _, _, pg = ops.rollout_pg(cfg, pol, q1, obs, eps, [0, 25], [0.5, 0.5])
         return a.clone(), g.clone(), pg.clone()
-    ref = run()
-    cache = torch.empty(L.lib().mpg_weight_cache_floats(L.c_int(2)), dtype=torch.float32, device=DEV)
-    ind, outd = (ctypes.c_int * 2)(8, 6), (ctypes.c_int * 2)(1, 4)
-    L.call('mpg_weight_cache_bind', L.ptr(flat), ind, outd, L.c_int(2), L.ptr(cache), L.stream())
-    try:
-        got = run()
-        for r, g in zip(ref, got):
-            assert torch.equal(r, g)
-        # an Adam step through the ABI refreshes the packed images by itself
-        m, v = torch.zeros_like(flat), torch.zeros_like(flat)
-        grad = dev(rng.standard_normal(nq + npol) * 0.01)
-        ops.adam_polyak(flat, m, v, None, grad, [nq, npol], [1e-2, 1e-2], [1, 1], [0, 0], 0.005)
-        got2 = run()
-    finally:
-        L.call('mpg_weight_cache_unbind', L.ptr(flat))
-    ref2 = run()                                   # unbound again: strided loads from the updated weights
+    ref = run(plain)
+    wc = ops.WeightCache(flat, [(8, 1), (6, 4)])
+    cached.wcache[0] = wc.pointer
+    got = run(cached)
+    for r, g in zip(ref, got):
+        assert torch.equal(r, g)
+    # an Adam step through the ABI keeps the packed images current by itself when it is given the descriptor
+    m, v = torch.zeros_like(flat), torch.zeros_like(flat)
+    grad = dev(rng.standard_normal(nq + npol) * 0.01)
+    ops.adam_polyak(flat, m, v, None, grad, [nq, npol], [1e-2, 1e-2], [1, 1], [0, 0], 0.005, wc_w=wc)
+    got2 = run(cached)
+    ref2 = run(plain)                              # strided loads from the updated weights
     for r, g in zip(ref2, got2):
         assert torch.equal(r, g)
     assert not torch.equal(ref[0], ref2[0])
+    # mpg_mlp_forward takes the descriptor as an explicit argument
+    x = torch.cat([obs, act], 1).contiguous()
+    qa = ops.mlp_forward(q1, 8, 1, 1, ops.ACT_LINEAR, x)
+    qb = ops.mlp_forward(q1, 8, 1, 1, ops.ACT_LINEAR, x, wcache=wc)
+    assert torch.equal(qa, qb)
+    # a write that by-passes the ABI leaves the images stale until the owner re-packs them
+    flat.mul_(1.5)
+    stale = ops.policy_action(cached, pol, obs)
+    wc.pack()
+    fresh = ops.policy_action(cached, pol, obs)
+    assert torch.equal(fresh, ops.policy_action(plain, pol, obs)) and not torch.equal(stale, fresh)
+
+
+def test_tanh_policy_with_action_range_is_refused():
+    """policy_out_activation='tanh' together with an action_range would be range*tanh(tanh(z)) in the reference
+    (policy.py:176-177,197-199); the kernels only implement z / tanh(z) / range*tanh(z), so the ABI rejects the
+    combination instead of silently computing something else."""
+    import mpg_amd._lib as L
+    from mpg_amd import ops
+    from tests.golden_inputs import mlp_weights_flat
+    rng = np.random.Generator(np.random.PCG64(3))
+    cfg = ops.make_cfg('PathTracking-v0', policy_out_activation='tanh', action_range=2.0)
+    with pytest.raises(L.MpgError):
+        ops.policy_action(cfg, dev(mlp_weights_flat(rng, 6, 4)), dev(rng.standard_normal((16, 6))))
