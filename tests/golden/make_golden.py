@@ -19,6 +19,13 @@ same float32-rounded inputs - the error yard-stick of SURVEY.md §8c):
   nadp_H{H}_B{B}.npz     NADPLearner.compute_gradient on the pendulum model (a18)
   td3_H{H}_B{B}.npz      TD3Learner.compute_gradient with recorded smoothing noise (a19)
   segment_tree_ref.npz   SumSegmentTree / MinSegmentTree primitives (a22)
+  bench_c2_mpg_v2_B4096.npz, bench_c3_nadp_B8192.npz, bench_c4_td3_B65536.npz
+                         the three learners at the BASELINE.json batch sizes; inputs are seeded draws regenerated on
+                         both sides (tests/golden_inputs.py), the fixture holds the reference's outputs only
+  replay_buffer_ref.npz  the reference's own ReplayBuffer (buffer.py imports as-is): ring wrap, _encode_sample (a21)
+  evaluator_ref.npz      Evaluator.run_n_episodes_parallel + metrics_for_an_episode over 200 steps (f2)
+  env_future_ref.npz     PathTrackingEnv with num_future_data = 3 (f3)
+  q_estimation_ref.npz   MPGLearner.model_rollout_for_q_estimation, M = 1, 2, 3 (f4)
 """
 import argparse
 import os
@@ -382,7 +389,219 @@ def fx_segment_tree(seed=5):
              edge_idx=np.array([st.find_prefixsum_idx(0.0), st.find_prefixsum_idx(total2)]))
 
 
+# ------------------------------------------------------------------------------------------------
+# round 2: bench-size cases, the reference's own ReplayBuffer / Evaluator, future-data observations, Q-estimation rollout
+# ------------------------------------------------------------------------------------------------
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+from golden_inputs import BENCH_CASES, bench_case_inputs      # noqa: E402  (seeded inputs shared with the GPU tests)
+
+
+def fx_bench_case(name):
+    """C2 / C3 / C4 at their full batch sizes.  Inputs are pure functions of the seed (tests/golden_inputs.py), so the
+    fixture carries only what the reference computed: the clipped gradient list (float32, complete), every 8th element
+    of the float64 run (yard-stick), every 8th target, and the scalar statistics."""
+    d = bench_case_inputs(name)
+    kind, B, H = d['kind'], d['B'], 256
+    nets = dict(d['nets'])
+    add_targets(nets)
+    out = dict(target_scale=TARGET_SCALE)
+    if kind == 'MPG-v2':
+        from learners.mpg_learner import MPGLearner as Learner
+        args = mpg_args('MPG-v2', B, H)
+        noise = lambda: list(d['eps'])
+        its = (100, 9000)
+        keys = ('value_mean', 'policy_total_loss', 'policy_gradient_norm', 'q_loss1', 'q_gradient_norm1', 'q_loss2',
+                'q_gradient_norm2')
+    elif kind == 'NADP':
+        from learners.nadp import NADPLearner as Learner
+        args = mpg_args('NADP', B, H, env='InvertedPendulumConti-v0')
+        args.num_rollout_list_for_policy_update = [25]
+        args.num_rollout_list_for_q_estimation = [25]
+        args.delay_update = 1
+        noise = lambda: list(d['eps_q']) + list(d['eps_pi'])
+        its = (0,)
+        keys = ('q_loss', 'policy_loss', 'value_mean', 'q_gradient_norm', 'policy_gradient_norm')
+    else:
+        from learners.td3 import TD3Learner as Learner
+        args = mpg_args('TD3', B, H)
+        noise = lambda: [d['smooth_eps']]
+        its = (0,)
+        keys = ('q_loss1', 'q_loss2', 'policy_loss', 'value_mean', 'value_var', 'q_gradient_norm1', 'q_gradient_norm2',
+                'policy_gradient_norm')
+    from policy import PolicyWithQs
+    for tag, dt in (('', torch.float32), ('_f64', torch.float64)):
+        tf.set_ref_dtype(dt)
+        learner = Learner(PolicyWithQs, args)
+        set_policy_weights(learner.policy_with_value, nets)
+        for it in its:
+            learner.counter = 0
+            tf.set_noise_source(NoiseStream(noise()))
+            grads = learner.compute_gradient(d['batch'], None, None, it)
+            st = learner.get_stats()
+            p = 'it%d_' % it
+            out[p + 'grads' + tag] = flat(grads) if tag == '' else sub64(flat(grads), H)
+            if 'batch_targets' in learner.batch_data:
+                out[p + 'targets_sub' + tag] = np.asarray(learner.batch_data['batch_targets'])[::8].astype(np.float32)
+            for key in keys:
+                out[p + key + tag] = np.asarray(st[key])
+            if 'w_list' in st:
+                out[p + 'w_list' + tag] = np.asarray(st['w_list'])
+                out[p + 'all_losses' + tag] = np.asarray(st['all_losses'])
+    tf.set_ref_dtype(torch.float32)
+    tf.set_noise_source(None)
+    np.savez_compressed(os.path.join(HERE, 'bench_%s.npz' % name), **out)
+
+
+def fx_replay_buffer(seed=40):
+    """buffer.py:21-91 imported as-is: ring wrap of add_batch, column order and dtypes of _encode_sample, replay()'s
+    gate and counter.  Transitions are what OffPolicyWorker.sample hands over: (obs, act, raw reward, obs', done)."""
+    import random
+    from buffer import ReplayBuffer
+    rng = np.random.Generator(np.random.PCG64(seed))
+    cap = 50
+    args = argparse.Namespace(max_buffer_size=cap, replay_starts=30, replay_batch_size=16, buffer_log_interval=1000)
+    rb = ReplayBuffer(args, 0)
+    sizes = [20, 7, 23, 30, 45, 5]                     # 130 transitions: wraps the 50-slot ring more than twice
+    n = sum(sizes)
+    obs = rng.standard_normal((n, 6)).astype(np.float32)
+    act = rng.uniform(-1, 1, (n, 2)).astype(np.float32)
+    rew = rng.uniform(-30, 0, n).astype(np.float32)
+    obs2 = rng.standard_normal((n, 6)).astype(np.float32)
+    done = (rng.uniform(0, 1, n) < 0.5)
+    out = dict(capacity=cap, sizes=np.array(sizes), obs=obs, act=act, rew=rew, obs2=obs2, done=done.astype(np.uint8),
+               replay_starts=30, replay_batch_size=16)
+    o = 0
+    next_idx, length, gate = [], [], []
+    idx_q = rng.integers(0, 20, (len(sizes), 12))
+    for k, m in enumerate(sizes):
+        rb.add_batch([(obs[i], act[i], rew[i], obs2[i], done[i]) for i in range(o, o + m)])
+        o += m
+        next_idx.append(rb._next_idx)
+        length.append(len(rb))
+        random.seed(k)
+        r = rb.replay()
+        gate.append(0 if r is None else 1)
+        idx = (idx_q[k] % len(rb)).astype(np.int32)
+        enc = rb.sample_with_idxes(idx)
+        for name, arr in zip(('obs', 'act', 'rew', 'obs2', 'done'), enc[:5]):
+            out['enc%d_%s' % (k, name)] = np.asarray(arr)
+        out['enc%d_idx' % k] = np.asarray(enc[5])
+        out['enc%d_dtypes' % k] = np.array([str(np.asarray(a).dtype) for a in enc[:5]])
+    out.update(next_idx=np.array(next_idx), length=np.array(length), replay_gate=np.array(gate), replay_times=rb.replay_times,
+               final_obs=np.stack([t[0] for t in rb._storage]), final_act=np.stack([t[1] for t in rb._storage]),
+               final_rew=np.array([t[2] for t in rb._storage], np.float32),
+               final_obs2=np.stack([t[3] for t in rb._storage]), final_done=np.array([t[4] for t in rb._storage], np.uint8))
+    np.savez_compressed(os.path.join(HERE, 'replay_buffer_ref.npz'), **out)
+
+
+def fx_evaluator(N=8, T=200, seed=50, H=256):
+    """Evaluator.run_n_episodes_parallel + metrics_for_an_episode (evaluator.py:118-184) on the reference's env and
+    policy, called on a bare object that carries exactly the attributes those two methods read (the constructor wants a
+    TensorBoard writer and a log directory).  The start states are the env's own reset() draw (np.random seeded)."""
+    import types
+    from envs_and_models.path_tracking_env import PathTrackingEnv
+    from evaluator import Evaluator
+    from policy import PolicyWithQs
+    from preprocessor import Preprocessor
+    rng = np.random.Generator(np.random.PCG64(seed))
+    args = mpg_args('MPG-v2', 64, H)
+    args.fixed_steps, args.eval_render, args.num_eval_agent = T, False, N
+    nets = {'policy': mlp_weights(rng, 6, H, 4), 'Q1': mlp_weights(rng, 8, H, 1), 'Q2': mlp_weights(rng, 8, H, 1)}
+    # a tame controller instead of a random one: the mean head is scaled down so that the closed loop stays inside the
+    # env's normal operating range for 200 steps (a random policy saturates steering and spins the car)
+    nets['policy'][4] = (nets['policy'][4] * np.float32(0.05)).astype(np.float32)
+    add_targets(nets)
+    out = dict(w_policy=flat(nets['policy']), N=N, T=T)
+    for tag, dt in (('', torch.float32), ('_f64', torch.float64)):
+        tf.set_ref_dtype(dt)
+        ev = types.SimpleNamespace(args=args, env=PathTrackingEnv(num_agent=N, num_future_data=0),
+                                   preprocessor=Preprocessor(**vars(args)), policy_with_value=PolicyWithQs(**vars(args)))
+        set_policy_weights(ev.policy_with_value, nets)
+        ev.metrics_for_an_episode = types.MethodType(Evaluator.metrics_for_an_episode, ev)
+        np.random.seed(seed)
+        if tag == '':
+            probe = PathTrackingEnv(num_agent=N, num_future_data=0)
+            out['init_obs'] = probe.reset().astype(np.float32)          # the same draw the evaluated env makes below
+            np.random.seed(seed)
+        metrics_list, mean = Evaluator.run_n_episodes_parallel(ev, N)
+        keys = sorted(mean.keys())
+        out['metric_keys'] = np.array(keys)
+        out['per_episode' + tag] = np.array([[float(m[k]) for k in keys] for m in metrics_list], np.float64)
+        out['mean' + tag] = np.array([float(mean[k]) for k in keys], np.float64)
+    tf.set_ref_dtype(torch.float32)
+    np.savez_compressed(os.path.join(HERE, 'evaluator_ref.npz'), **out)
+
+
+def fx_env_future(N=64, T=6, K=3, seed=60):
+    """PathTrackingEnv with num_future_data = K (path_tracking_env.py:385-402): obs = [6 base entries | K look-ahead
+    delta-y terms at x + k * v_x * 0.2]; reset(init_obs) / step like fx_env_step."""
+    from envs_and_models.path_tracking_env import PathTrackingEnv
+    rng = np.random.Generator(np.random.PCG64(seed))
+    env = PathTrackingEnv(num_agent=N, num_future_data=K)
+    obs0 = reset_law_obs(rng, N)
+    obs0[0, 5] = 1199.5
+    obs0[1, 5] = 0.3
+    obs0[2, 4] = 3.1
+    actions = rng.uniform(-1.3, 1.3, (T, N, 2)).astype(np.float32)
+    env.reset(init_obs=np.concatenate([obs0, np.zeros((N, K), np.float32)], 1))
+    obs_l, rew_l = [], []
+    for t in range(T):
+        o, r, dn, _ = env.step(actions[t])
+        obs_l.append(o.copy()), rew_l.append(r.copy())
+    # the reset() branch: obs of freshly drawn agents (np.random seeded) - the future columns are a function of the state
+    np.random.seed(seed)
+    env2 = PathTrackingEnv(num_agent=N, num_future_data=K)
+    reset_obs = env2.reset().astype(np.float32)
+    np.savez_compressed(os.path.join(HERE, 'env_future_ref.npz'), K=K, obs0=obs0, actions=actions,
+                        obs=np.stack(obs_l).astype(np.float32), reward=np.stack(rew_l).astype(np.float32),
+                        reset_obs=reset_obs, reset_full_state=env2.veh_full_state.astype(np.float32))
+
+
+def fx_q_estimation(H=256, B=64, seed=70):
+    """MPGLearner.model_rollout_for_q_estimation (mpg_learner.py:180-224): model rollout from (s, a_replay), later actions
+    from pi_theta, Q1-target bootstrap at every slice, mean over the M copies, the selected slices concatenated."""
+    from learners.mpg_learner import MPGLearner
+    from policy import PolicyWithQs
+    rng = np.random.Generator(np.random.PCG64(seed))
+    nets = {'policy': mlp_weights(rng, 6, H, 4), 'Q1': mlp_weights(rng, 8, H, 1), 'Q2': mlp_weights(rng, 8, H, 1)}
+    add_targets(nets)
+    obs = reset_law_obs(rng, B)
+    act = np.clip(rng.uniform(-1, 1, (B, 2)), -1, 1).astype(np.float32)
+    out = dict(batch_obs=obs, batch_actions=act, target_scale=TARGET_SCALE)
+    for k, v in nets.items():
+        if not k.endswith('_target'):
+            out['w_' + k] = flat(v)
+    for M, sel in ((1, [0, 5, 25]), (2, [25]), (3, [0, 10])):
+        eps = rng.standard_normal((max(sel), M * B)).astype(np.float32)
+        out['M%d_eps' % M], out['M%d_select' % M] = eps, np.array(sel)
+        for tag, dt in (('', torch.float32), ('_f64', torch.float64)):
+            tf.set_ref_dtype(dt)
+            args = mpg_args('MPG-v2', B, H)
+            args.M, args.num_rollout_list_for_q_estimation = M, sel
+            learner = MPGLearner(PolicyWithQs, args)
+            set_policy_weights(learner.policy_with_value, nets)
+            tf.set_noise_source(NoiseStream(list(eps)))
+            y = learner.model_rollout_for_q_estimation(tf.constant(obs), tf.constant(act))
+            out['M%d_returns%s' % (M, tag)] = np.asarray(y.numpy())
+    tf.set_ref_dtype(torch.float32)
+    tf.set_noise_source(None)
+    np.savez_compressed(os.path.join(HERE, 'q_estimation_ref.npz'), **out)
+
+
+ROUND2 = {'replay_buffer': fx_replay_buffer, 'evaluator': fx_evaluator, 'env_future': fx_env_future,
+          'q_estimation': fx_q_estimation}
+ROUND2.update({n: (lambda n=n: fx_bench_case(n)) for n in BENCH_CASES})
+
+
 def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--only', default='', help='comma-separated round-2 fixture names (%s); default: everything' % ', '.join(ROUND2))
+    only = [x for x in ap.parse_args().only.split(',') if x]
+    if only:
+        torch.manual_seed(0)
+        for n in only:
+            ROUND2[n]()
+        return
     torch.manual_seed(0)
     fx_mpc_rl()
     fx_segment_tree()
@@ -396,6 +615,8 @@ def main():
     fx_nadp(256, 64, seed=21)
     fx_td3(32, 64, seed=30)
     fx_td3(256, 64, seed=31)
+    for n in ROUND2:
+        ROUND2[n]()
     for f in sorted(os.listdir(HERE)):
         if f.endswith('.npz'):
             print('%-28s %8.1f KB' % (f, os.path.getsize(os.path.join(HERE, f)) / 1024))

@@ -254,3 +254,182 @@ def test_adam_restatement_cross_checked_against_an_independent_adam():
     np.testing.assert_allclose(opt.v, ref.state[p]['exp_avg_sq'].numpy(), rtol=1e-4, atol=1e-7)
     # PolynomialDecay(lr0, S, lr_end), power 1: documented closed form
     assert abs(O.polynomial_decay(sched, 50000) - (8e-5 - 8e-6) * 0.5 - 8e-6) < 1e-12 and O.polynomial_decay(sched, 10 ** 7) == 8e-6
+
+
+# ---- round 2: bench-size cases, the reference's own buffer / evaluator, future-data obs, Q-estimation rollout ---------
+from tests import yardstick as Y                          # noqa: E402
+from tests.golden_inputs import BENCH_CASES, bench_case_inputs   # noqa: E402
+
+
+def _flat_nets(nets):
+    return {k: np.concatenate([np.asarray(w).ravel() for w in v]).astype(np.float32) for k, v in nets.items()}
+
+
+@pytest.mark.parametrize('name', sorted(BENCH_CASES))
+def test_bench_size_cases(golden, name):
+    """C2 (MPG-v2, B = 4096), C3 (NADP, B = 8192), C4 (TD3, B = 65 536): the oracle on the seeded inputs against what the
+    reference computed from the same inputs, with the float64 yard-stick on every gradient array."""
+    g = golden('bench_%s.npz' % name)
+    d = bench_case_inputs(name)
+    flat = _flat_nets(d['nets'])
+    if d['kind'] == 'MPG-v2':
+        cfg, names = O.Cfg(), ['Q1', 'Q2', 'policy']
+        nets = O.Nets(cfg, flat, target_scale=g['target_scale'])
+        for it in (100, 9000):
+            grads, st = O.mpg_compute_gradient(cfg, nets, d['batch'], d['eps'], it, 'MPG-v2')
+            p = 'it%d_' % it
+            Y.check_gradients(np.concatenate([x.ravel() for x in grads]), g[p + 'grads'], g[p + 'grads_f64'],
+                              [('Q1', 8, 1), ('Q2', 8, 1), ('policy', 6, 4)], where=name + ' ' + p)
+            Y.check_values(st['targets'][::8], g[p + 'targets_sub'], g[p + 'targets_sub_f64'], what='targets')
+            for k in ('value_mean', 'policy_total_loss', 'policy_gradient_norm', 'q_loss1', 'q_gradient_norm1', 'q_loss2',
+                      'q_gradient_norm2'):
+                np.testing.assert_allclose(st[k], g[p + k], rtol=5e-5, atol=1e-7, err_msg=k)
+    elif d['kind'] == 'NADP':
+        cfg = O.Cfg(env='InvertedPendulumConti-v0', select=[25], delay_update=1)
+        nets = O.Nets(cfg, flat, target_scale=g['target_scale'])
+        grads, st = O.nadp_compute_gradient(cfg, nets, d['batch'][:2], d['eps_q'], d['eps_pi'])
+        Y.check_gradients(np.concatenate([x.ravel() for x in grads]), g['it0_grads'], g['it0_grads_f64'],
+                          [('Q1', 5, 1), ('policy', 4, 2)], where=name)
+        for k in ('q_loss', 'policy_loss', 'value_mean', 'q_gradient_norm', 'policy_gradient_norm'):
+            np.testing.assert_allclose(st[k], g['it0_' + k], rtol=2e-4, atol=1e-6, err_msg=k)
+    else:
+        cfg = O.Cfg()
+        nets = O.Nets(cfg, flat, target_scale=g['target_scale'])
+        grads, st = O.td3_compute_gradient(cfg, nets, d['batch'], d['smooth_eps'])
+        Y.check_gradients(np.concatenate([x.ravel() for x in grads]), g['it0_grads'], g['it0_grads_f64'],
+                          [('Q1', 8, 1), ('Q2', 8, 1), ('policy', 6, 4)], where=name)
+        Y.check_values(st['targets'][::8], g['it0_targets_sub'], g['it0_targets_sub_f64'], what='targets')
+        for k in ('q_loss1', 'q_loss2', 'policy_loss', 'value_mean', 'value_var', 'q_gradient_norm1', 'q_gradient_norm2',
+                  'policy_gradient_norm'):
+            np.testing.assert_allclose(st[k], g['it0_' + k], rtol=1e-4, atol=1e-7, err_msg=k)
+
+
+def test_replay_buffer_vs_reference(golden):
+    """The reference's own ReplayBuffer (buffer.py imports as-is): ring wrap, storage content, _encode_sample column order
+    and dtypes, replay()'s gate and counter - all exact."""
+    g = golden('replay_buffer_ref.npz')
+    rb = O.ReplayBufferOracle(int(g['capacity']), int(g['replay_starts']))
+    o = 0
+    for k, m in enumerate(g['sizes']):
+        sl = slice(o, o + m)
+        rb.add_batch(g['obs'][sl], g['act'][sl], g['rew'][sl], g['obs2'][sl], g['done'][sl].astype(bool))
+        o += m
+        assert rb._next_idx == g['next_idx'][k] and len(rb) == g['length'][k]
+        assert int(rb.replay_gate()) == g['replay_gate'][k]
+        enc = rb.encode_sample(g['enc%d_idx' % k])
+        for nm, arr in zip(('obs', 'act', 'rew', 'obs2', 'done'), enc):
+            ref = g['enc%d_%s' % (k, nm)]
+            assert np.array_equal(arr, ref.astype(arr.dtype)) and arr.shape == ref.shape, (k, nm)
+        assert list(g['enc%d_dtypes' % k]) == ['float32', 'float32', 'float32', 'float32', 'bool']
+    assert rb.replay_times == int(g['replay_times'])
+    n = len(rb)
+    assert np.array_equal(rb.obs[:n], g['final_obs']) and np.array_equal(rb.act[:n], g['final_act'])
+    assert np.array_equal(rb.rew[:n], g['final_rew']) and np.array_equal(rb.obs2[:n], g['final_obs2'])
+    assert np.array_equal(rb.done[:n].astype(np.uint8), g['final_done'])
+
+
+def test_evaluator_metrics_vs_reference(golden):
+    """Evaluator.run_n_episodes_parallel + metrics_for_an_episode (evaluator.py:118-184) over 200 closed-loop steps.
+    Closed loop, so rounding differences grow along the episode: the allowance is 4x the reference's own
+    float32-vs-float64 gap per metric (which is ~1e-5 relative here), not a flat number."""
+    g = golden('evaluator_ref.npz')
+    cfg = O.Cfg()
+    rng = np.random.Generator(np.random.PCG64(0))
+    from tests.golden_inputs import mlp_weights_flat
+    flat = {'policy': g['w_policy'], 'Q1': mlp_weights_flat(rng, 8, 1), 'Q2': mlp_weights_flat(rng, 8, 1)}
+    nets = O.Nets(cfg, flat, target_scale=1.0)
+    per, mean = O.run_n_episodes_parallel(cfg, nets, g['init_obs'], int(g['T']))
+    keys = [str(k) for k in g['metric_keys']]
+    got_mean = np.array([float(mean[k]) for k in keys])
+    got_per = np.array([[float(m[k]) for k in keys] for m in per])
+    for j, k in enumerate(keys):
+        gap = abs(g['mean'][j] - g['mean_f64'][j])
+        assert abs(got_mean[j] - g['mean_f64'][j]) <= 4 * gap + 1e-6 * abs(g['mean_f64'][j]) + 1e-9, (k, got_mean[j], g['mean'][j])
+        gap_e = np.abs(g['per_episode'][:, j] - g['per_episode_f64'][:, j])
+        assert (np.abs(got_per[:, j] - g['per_episode_f64'][:, j]) <= 4 * gap_e.max() + 1e-6 * np.abs(g['per_episode_f64'][:, j]) + 1e-9).all(), k
+
+
+def test_env_future_data_vs_reference(golden):
+    """num_future_data = 3 (path_tracking_env.py:385-402): obs = 6 base entries + 3 look-ahead delta-y terms."""
+    g = golden('env_future_ref.npz')
+    K, N = int(g['K']), g['obs0'].shape[0]
+    env = O.PathTrackingEnvOracle(N, num_future_data=K)
+    env.reset(init_obs=np.concatenate([g['obs0'], np.zeros((N, K), np.float32)], 1))
+    for t in range(g['actions'].shape[0]):
+        o, r, _, _ = env.step(g['actions'][t])
+        assert o.shape == (N, 6 + K)
+        np.testing.assert_allclose(o, g['obs'][t], rtol=0, atol=5e-6 * (1 + np.abs(g['obs'][t]).max()))
+        np.testing.assert_allclose(r, g['reward'][t], rtol=2e-6, atol=1e-5)
+    # reset() branch: the future columns as a function of the drawn state
+    env2 = O.PathTrackingEnvOracle(N, num_future_data=K)
+    fs = g['reset_full_state'].copy()
+    vs = fs.copy()
+    vs[:, 4] = fs[:, 4] - O.path_phi(fs[:, 5])
+    vs[:, 3] = fs[:, 3] - O.path_y(fs[:, 5])
+    np.testing.assert_allclose(env2._get_obs(vs, fs), g['reset_obs'], rtol=0, atol=2e-5)
+
+
+def test_q_estimation_rollout_vs_reference(golden):
+    """MPGLearner.model_rollout_for_q_estimation (mpg_learner.py:180-224) for M = 1, 2, 3 and several slice lists."""
+    g = golden('q_estimation_ref.npz')
+    cfg = O.Cfg()
+    for M in (1, 2, 3):
+        sel = [int(k) for k in g['M%d_select' % M]]
+        for dt, tag in ((torch.float32, ''), (torch.float64, '_f64')):
+            nets = _nets(g, cfg, ['Q1', 'Q2', 'policy'], dt)
+            y = O.model_rollout_for_q_estimation(cfg, nets, torch.as_tensor(g['batch_obs']), torch.as_tensor(g['batch_actions']),
+                                                 torch.as_tensor(g['M%d_eps' % M]), sel, M=M).numpy()
+            ref = g['M%d_returns%s' % (M, tag)]
+            assert y.shape == ref.shape == (len(sel) * g['batch_obs'].shape[0],)
+            if tag:
+                # the oracle keeps float32-rounded constants (gamma, obs_scale) in its float64 mode, the reference's
+                # float64 graph does not: 0.98f^25 alone differs by 5e-7 from 0.98^25
+                assert Y.rel_l2(y, ref) <= 1e-6
+            else:
+                Y.check_values(y, ref, g['M%d_returns_f64' % M], what='M=%d' % M)
+
+
+def test_cart_pole_env_restatement_is_self_consistent():
+    """InvertedPendulumContiOracle is restated from inverted_pendulum_conti.xml, NOT pinned by the reference (MuJoCo is
+    absent - DESIGN.md says "parity unpinned" for this row).  What can be checked without MuJoCo: the mass matrix and
+    the equations conserve energy when damping and actuation are switched off (RK4, h = 0.02: drift < 5e-5 relative over
+    2 s), the upright equilibrium is unstable with the textbook rate sqrt(m g l (M + m) / ((M + m)(I + m l^2) - m^2 l^2)),
+    reward / done follow inverted_pendulum_conti.py:12-18."""
+    E = O.InvertedPendulumContiOracle
+    c = E.constants()
+    assert abs(c['M'] - 1000 * (np.pi * 0.01 * 0.2 + 4 / 3 * np.pi * 1e-3)) < 1e-9          # cart capsule
+    env = E(3)
+    saved = (E.DAMP_X, E.DAMP_TH)
+    try:
+        E.DAMP_X = E.DAMP_TH = 0.0
+        s0 = np.array([[0., 0.1, 0., 0.], [0.2, -0.15, 0.3, -0.2], [0., 0.05, -0.1, 0.4]])
+        env.reset(init_obs=s0)
+
+        def energy(s):
+            th = s[:, 1] + c['th0']
+            v2 = s[:, 2] ** 2 + 2 * c['l'] * np.cos(th) * s[:, 2] * s[:, 3] + (c['l'] * s[:, 3]) ** 2
+            return 0.5 * c['M'] * s[:, 2] ** 2 + 0.5 * c['m'] * v2 + 0.5 * c['I'] * s[:, 3] ** 2 + c['m'] * E.G * c['l'] * np.cos(th)
+        e0 = energy(s0)
+        for _ in range(50):
+            s, r, d, _ = env.step(np.zeros(3))
+        assert (np.abs(energy(s) - e0) / np.abs(e0)).max() < 5e-5      # RK4 truncation while the pole swings through
+    finally:
+        E.DAMP_X, E.DAMP_TH = saved
+    env = E(1)
+    env.reset(init_obs=np.array([[0., 1e-6 - c['th0'], 0., 0.]]))
+    E2 = (c['M'] + c['m']) * (c['I'] + c['m'] * c['l'] ** 2) - (c['m'] * c['l']) ** 2
+    lam = np.sqrt(c['m'] * E.G * c['l'] * (c['M'] + c['m']) / E2)
+    saved = (E.DAMP_X, E.DAMP_TH)
+    try:
+        E.DAMP_X = E.DAMP_TH = 0.0
+        for _ in range(25):                                   # 1 s
+            s, r, d, _ = env.step(np.zeros(1))
+    finally:
+        E.DAMP_X, E.DAMP_TH = saved
+    growth = (s[0, 1] + c['th0']) / 1e-6
+    assert abs(growth - np.cosh(lam * 1.0)) / np.cosh(lam * 1.0) < 1e-3
+    env = E(2)
+    env.reset(init_obs=np.array([[2.05, 0.1, 0., 0.], [0., 0., 0., 0.]]))
+    s, r, d, _ = env.step(np.array([3.5, -0.2]))              # action clipped to +-3 by ctrlrange
+    assert d[0] and not d[1]
+    np.testing.assert_allclose(r, -(0.01 * s[:, 0] ** 2 + s[:, 1] ** 2) - 0.1 * (s[:, 2] ** 2 + s[:, 3] ** 2))

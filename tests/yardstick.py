@@ -1,0 +1,65 @@
+"""Tolerance rule shared by the CPU (oracle) and GPU (HIP) parity tests - SURVEY.md §8c:
+
+    a float32 implementation is accepted when its error against the float64 run of the REFERENCE graph is at most
+    4 x the error of the reference's own float32 run against that same float64 run (plus a small floor for arrays
+    the reference happens to hit exactly), AND it is within 1e-4 relative L2 of the reference's float32 result.
+
+The fixtures carry the reference's float32 result completely and, for the 256-unit nets, every 8th element of the flat
+float64 gradient vector (tests/golden/make_golden.py: sub64); the yard-stick is evaluated on that subsample."""
+import numpy as np
+
+FLOOR = 1e-6
+
+
+def rel_l2(a, b):
+    a, b = np.asarray(a, np.float64).ravel(), np.asarray(b, np.float64).ravel()
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def mlp_shapes(din, dout, H=256):
+    return [(din, H), (H,), (H, H), (H,), (H, dout), (dout,)]
+
+
+def layout(nets):
+    """nets: [(name, din, dout), ...] in the order of the flat vector -> [(name, shape, offset, n), ...]"""
+    out, o = [], 0
+    for name, din, dout in nets:
+        for shp in mlp_shapes(din, dout):
+            n = int(np.prod(shp))
+            out.append((name, shp, o, n))
+            o += n
+    return out, o
+
+
+def check_gradients(got, ref32, ref64_sub, nets, where='', bar=1e-4, factor=4.0):
+    """got / ref32: complete flat float32 gradient vectors; ref64_sub: ref64[::8] (as stored by make_golden.sub64).
+    Returns the worst (error / allowance) ratio for reporting."""
+    lay, total = layout(nets)
+    got, ref32, ref64_sub = np.asarray(got), np.asarray(ref32), np.asarray(ref64_sub)
+    assert got.size == total == ref32.size, (got.size, total, ref32.size)
+    assert ref64_sub.size == (total + 7) // 8, (ref64_sub.size, total)
+    worst = 0.0
+    for name, shp, o, n in lay:
+        r = ref32[o:o + n]
+        if np.linalg.norm(r) == 0:
+            assert np.linalg.norm(got[o:o + n]) == 0, (where, name, shp, 'reference gradient is exactly zero')
+            continue
+        e = rel_l2(got[o:o + n], r)
+        assert e <= bar, (where, name, shp, 'rel-L2 vs reference float32', e)
+        first = (o + 7) // 8 * 8                    # flat indices that are multiples of 8 inside [o, o + n)
+        idx = np.arange(first, o + n, 8)
+        if idx.size < 8:
+            continue                                # too few yard-stick samples in this array (biases of width <= 4)
+        r64 = ref64_sub[idx // 8]
+        e_ref, e_got = rel_l2(ref32[idx], r64), rel_l2(got[idx], r64)
+        allow = factor * e_ref + FLOOR
+        assert e_got <= allow, (where, name, shp, 'vs float64: got %.3e, reference float32 %.3e' % (e_got, e_ref))
+        worst = max(worst, e_got / allow)
+    return worst
+
+
+def check_values(got, ref32, ref64, what='', factor=4.0, floor=FLOOR, bar=1e-4):
+    """Same rule for a value array that is stored completely in both precisions (targets, returns)."""
+    e_ref, e_got = rel_l2(ref32, ref64), rel_l2(got, ref64)
+    assert e_got <= factor * e_ref + floor, (what, 'vs float64: got %.3e, reference float32 %.3e' % (e_got, e_ref))
+    assert rel_l2(got, ref32) <= bar, (what, rel_l2(got, ref32))
