@@ -99,31 +99,43 @@ const char* mpg_prof_slot_name(int slot);
  * Vectorised real environment (K1)
  * ---------------------------------------------------------------------------------------------- */
 
-/* PathTrackingEnv.reset(init_obs=...)  - envs_and_models/path_tracking_env.py:410-421.
- * Rebuilds the full state of all n agents from obs [n][6] (= [v_x-20, v_y, r, dy, dphi, x]). */
-int mpg_env_reset_from_obs(int env_kind, int n, float* state, const float* init_obs, mpg_stream_t stream);
+/* Two real environments sit behind these entry points, selected by env_kind:
+ *   MPG_ENV_PATH_TRACKING      PathTrackingEnv (path_tracking_env.py:356-487), act_dim 2, obs_dim = 6 + num_future_data
+ *                              (0 <= num_future_data <= MPG_ENV_MAX_FUTURE): [v_x-20, v_y, r, dy, dphi, x | look-ahead
+ *                              delta-y terms at x + k * 0.2 v_x, :385-402];
+ *   MPG_ENV_INVERTED_PENDULUM  InvertedPendulumContiEnv (inverted_pendulum_conti.py:5-30 + inverted_pendulum_conti.xml) as
+ *                              an analytic RK4 cart-pole (the reference steps it with MuJoCo, which cannot be pinned
+ *                              here: csrc/env_cart_pole.hip), act_dim 1, obs_dim 4: [p, theta, pdot, thetadot].
+ * state: the opaque block [MPG_ENV_STATE_DIM][n]. */
+enum { MPG_ENV_MAX_FUTURE = 10 };
 
-/* PathTrackingEnv.reset()  - path_tracking_env.py:423-454.  Re-draws every agent whose done_mask byte is
+/* env.reset(init_obs=...)  - path_tracking_env.py:410-421 / DummyVecEnv.reset(init_obs=) for the pendulum.
+ * Rebuilds the full state of all n agents from init_obs [n][obs_dim] (PathTracking reads its six base entries). */
+int mpg_env_reset_from_obs(int env_kind, int n, int obs_dim, float* state, const float* init_obs, mpg_stream_t stream);
+
+/* env.reset()  - path_tracking_env.py:423-454.  Re-draws every agent whose done_mask byte is
  * non-zero (done_mask == NULL: all agents) from the reset law x~U(0,600), dy~N(0,1), dphi~N(0,pi/9),
- * v_x~U(15,25), beta~N(0,.15), v_y=v_x tan(beta), r~N(0,.3) with a counter-based Philox4x32-10 stream
- * keyed by (seed, call counter ctr, agent index); writes obs [n][6] for ALL agents. */
-int mpg_env_reset(int env_kind, int n, float* state, const uint8_t* done_mask, uint64_t seed, uint64_t ctr,
+ * v_x~U(15,25), beta~N(0,.15), v_y=v_x tan(beta), r~N(0,.3) (pendulum: U(-0.01, 0.01) on all four,
+ * inverted_pendulum_conti.py:21-25) with a counter-based Philox4x32-10 stream
+ * keyed by (seed, call counter ctr, agent index); writes obs [n][obs_dim] for ALL agents. */
+int mpg_env_reset(int env_kind, int n, int obs_dim, float* state, const uint8_t* done_mask, uint64_t seed, uint64_t ctr,
                   float* obs, mpg_stream_t stream);
 
 /* PathTrackingEnv.step  - path_tracking_env.py:456-487 with VehicleDynamics.simulation :144-179 (20
  * sub-steps at 200 Hz), compute_rewards :181-199 (on the pre-step state), judge_done :474-487.
- * action [n][2] in [-1,1] (scaled by [1.2pi/9, 3] and clipped inside, :457-459); outputs obs [n][6],
+ * action [n][2] in [-1,1] (scaled by [1.2pi/9, 3] and clipped inside, :457-459); outputs obs [n][obs_dim],
  * reward [n], done [n] bytes.  done follows the reference literally and is therefore always 1
- * (SURVEY.md B-0); done_intended (nullable) receives the evidently intended |alpha| > |bound| test. */
-int mpg_env_step(int env_kind, int n, float* state, const float* action, float* obs, float* reward,
+ * (SURVEY.md B-0); done_intended (nullable) receives the evidently intended |alpha| > |bound| test.
+ * Pendulum: inverted_pendulum_conti.py:9-19, action [n][1] clipped to +-3, 2 RK4 steps of 0.02 s, real done flag. */
+int mpg_env_step(int env_kind, int n, int obs_dim, float* state, const float* action, float* obs, float* reward,
                  uint8_t* done, uint8_t* done_intended, mpg_stream_t stream);
 
 /* The inner body of OffPolicyWorker.sample after the policy (worker.py:108-112) in one launch: env.step, the
  * transition (obs, action, RAW reward, obs', done) written straight into the replay ring at (next_idx + i) % capacity
  * (ReplayBuffer.add, buffer.py:46-55), then env.reset() of the agents whose done flag is set
  * (path_tracking_env.py:445) with the Philox stream (seed, ctr).  Same results as mpg_env_step + mpg_replay_add +
- * mpg_env_reset.  obs_out [n][6]: the observations after the reset; done_out (nullable) [n]. */
-int mpg_env_step_store_reset(int env_kind, int n, float* state, const float* action, int capacity, int next_idx,
+ * mpg_env_reset.  obs_out [n][obs_dim]: the observations after the reset; done_out (nullable) [n]. */
+int mpg_env_step_store_reset(int env_kind, int n, int obs_dim, float* state, const float* action, int capacity, int next_idx,
                              float* ring_obs, float* ring_act, float* ring_rew, float* ring_obs2, uint8_t* ring_done,
                              uint64_t seed, uint64_t ctr, float* obs_out, uint8_t* done_out, mpg_stream_t stream);
 
@@ -251,6 +263,18 @@ size_t mpg_rollout_q_target_workspace_bytes(const mpg_cfg_t* cfg, int rows);
 int mpg_rollout_q_target(const mpg_cfg_t* cfg, const float* policy_params, const float* q1t, int rows, int n,
                          const float* obs0, const float* act0, const float* eps, uint64_t noise_seed,
                          uint64_t noise_ctr, float* y, void* ws, size_t ws_bytes, mpg_stream_t stream);
+
+/* MPGLearner.model_rollout_for_q_estimation  - learners/mpg_learner.py:180-224 (the heuristic-bias rollout): tile
+ * (s, a_replay) M times, roll the model max(select) steps - first action a_replay, later ones from pi_theta - and
+ * bootstrap every selected slice k with gamma^k * Q1_target(s~_k, a_k); the InvertedPendulum branch clips that Q to
+ * [-0.5, 0] for every slice but the first (:206-209).  y [n_select][rows]: mean over the M copies, slices in the order of
+ * `select` (HOST array, n_select <= 4) - the reference's concatenation.  eps [max(select)][M*rows] standard normal, or
+ * NULL for in-kernel Philox(noise_seed, noise_ctr) draws.  No gradient. */
+size_t mpg_rollout_q_estimation_workspace_bytes(const mpg_cfg_t* cfg, int rows, int M, int n_select);
+int mpg_rollout_q_estimation(const mpg_cfg_t* cfg, const float* policy_params, const float* q1t, int rows, int M,
+                             const int* select, int n_select, const float* obs0, const float* act0, const float* eps,
+                             uint64_t noise_seed, uint64_t noise_ctr, float* y, void* ws, size_t ws_bytes,
+                             mpg_stream_t stream);
 
 /* TD3Learner.policy_forward_and_backward  - learners/td3.py:120-134:
  *   loss = -mean_B min(Q1,Q2)(s~, pi(s~)); grad = flat policy gradient (unclipped, reduced over this GPU's rows,

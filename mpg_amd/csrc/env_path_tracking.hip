@@ -8,7 +8,9 @@
 // sqrt) differ from the reference's by their last-ulp behaviour.
 //
 // State block (opaque to callers): v_x, v_y, r, y, phi, x, delta_y, delta_phi.
-#include "mpg_common.h"
+// Observations carry 6 + K entries, K = num_future_data look-ahead delta-y terms (path_tracking_env.py:385-402).
+// env_kind MPG_ENV_INVERTED_PENDULUM is dispatched to env_cart_pole.hip.
+#include "env_internal.h"
 
 namespace {
 
@@ -53,10 +55,10 @@ __device__ __forceinline__ float wrap_pi(float a) {        // :168-169 / :176-17
     return a;
 }
 
-__global__ void __launch_bounds__(64) k_reset_from_obs(int n, float* __restrict__ st, const float* __restrict__ obs) {
+__global__ void __launch_bounds__(64) k_reset_from_obs(int n, int od, float* __restrict__ st, const float* __restrict__ obs) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float* o = obs + (size_t)i * 6;
+    const float* o = obs + (size_t)i * od;                                            // only the six base entries are read
     float vx = o[0] + 20.f, vy = o[1], r = o[2], dy = o[3], dphi = o[4], x = o[5];   // _get_state :404-408
     PathRef p = path_ref(x);                                                          // :415-417
     st[0 * (size_t)n + i] = vx;
@@ -92,11 +94,35 @@ __device__ __forceinline__ void store_agent(float* __restrict__ st, size_t N, in
     st[0 * N + i] = a.vx; st[1 * N + i] = a.vy; st[2 * N + i] = a.r; st[3 * N + i] = a.y;
     st[4 * N + i] = a.phi; st[5 * N + i] = a.x; st[6 * N + i] = a.dy; st[7 * N + i] = a.dphi;
 }
-__device__ __forceinline__ void write_obs(float* __restrict__ obs, int i, const Agent& a) {   // _get_obs :399-402
-    float2* o = reinterpret_cast<float2*>(obs + (size_t)i * 6);
-    o[0] = make_float2(a.vx - 20.f, a.vy);
-    o[1] = make_float2(a.r, a.dy);
-    o[2] = make_float2(a.dphi, a.x);
+// ReferencePath.compute_path_y alone (the look-ahead terms need no heading)
+__device__ __forceinline__ float path_y_only(float x) {
+    const float Amp[3] = {7.5f, 2.5f, -5.f};
+    const float T[3] = {200.f, 300.f, 400.f};
+    float y = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) y = y + Amp[i] * sinf((((x - 0.f) * 2.f) * PI_F) / T[i]);
+    return y;
+}
+
+// _get_obs, path_tracking_env.py:385-402: [v_x - 20, v_y, r, delta_y, delta_phi, x | K look-ahead delta-y terms].
+// od = 6 + K.  The look-ahead abscissa advances by v_x * 1. / 200 * 20 * 2 per entry (float32, operator by operator,
+// :394-395) and is NOT wrapped to the path period; y is the vehicle's current world-frame y.
+__device__ __forceinline__ void write_obs(float* __restrict__ obs, int i, int od, const Agent& a) {
+    if (od == 6) {
+        float2* o = reinterpret_cast<float2*>(obs + (size_t)i * 6);
+        o[0] = make_float2(a.vx - 20.f, a.vy);
+        o[1] = make_float2(a.r, a.dy);
+        o[2] = make_float2(a.dphi, a.x);
+        return;
+    }
+    float* o = obs + (size_t)i * od;
+    o[0] = a.vx - 20.f; o[1] = a.vy; o[2] = a.r; o[3] = a.dy; o[4] = a.dphi; o[5] = a.x;
+    float x_ = a.x;
+    const float adv = (((a.vx * 1.f) / 200.f) * 20.f) * 2.f;
+    for (int k = 6; k < od; ++k) {
+        x_ = x_ + adv;
+        o[k] = a.y - path_y_only(x_);
+    }
 }
 
 // PathTrackingEnv.reset() for one agent, path_tracking_env.py:423-454, on the Philox stream (i, ctr)
@@ -199,7 +225,7 @@ __device__ __forceinline__ StepOut step_agent(Agent& ag, const float2 an) {
 
 __global__ void __launch_bounds__(64) k_reset(int n, float* __restrict__ st, const uint8_t* __restrict__ mask,
                                               uint32_t k0, uint32_t k1, uint32_t c1, uint32_t c2,
-                                              float* __restrict__ obs) {
+                                              float* __restrict__ obs, int od) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Agent ag = load_agent(st, n, i);
@@ -207,12 +233,12 @@ __global__ void __launch_bounds__(64) k_reset(int n, float* __restrict__ st, con
         reset_agent(ag, i, k0, k1, c1, c2);
         store_agent(st, n, i, ag);
     }
-    write_obs(obs, i, ag);
+    write_obs(obs, i, od, ag);
 }
 
 __global__ void __launch_bounds__(64) k_step(int n, float* __restrict__ st, const float* __restrict__ action,
                                              float* __restrict__ obs, float* __restrict__ reward,
-                                             uint8_t* __restrict__ done, uint8_t* __restrict__ done_intended) {
+                                             uint8_t* __restrict__ done, uint8_t* __restrict__ done_intended, int od) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Agent ag = load_agent(st, n, i);
@@ -221,7 +247,7 @@ __global__ void __launch_bounds__(64) k_step(int n, float* __restrict__ st, cons
     done[i] = o.done ? 1 : 0;
     if (done_intended) done_intended[i] = o.done_intended ? 1 : 0;
     store_agent(st, n, i, ag);
-    write_obs(obs, i, ag);
+    write_obs(obs, i, od, ag);
 }
 
 // OffPolicyWorker.sample's inner body after the policy (worker.py:108-112) in one launch: env.step, the transition
@@ -234,65 +260,75 @@ struct RingPtrs {
 __global__ void __launch_bounds__(64) k_step_store_reset(int n, float* __restrict__ st, const float* __restrict__ action,
                                                          RingPtrs ring, int capacity, int next_idx, uint32_t k0, uint32_t k1,
                                                          uint32_t c1, uint32_t c2, float* __restrict__ obs_out,
-                                                         uint8_t* __restrict__ done_out) {
+                                                         uint8_t* __restrict__ done_out, int od) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Agent ag = load_agent(st, n, i);
     const float2 an = reinterpret_cast<const float2*>(action)[i];
     const size_t slot = (size_t)((next_idx + i) % capacity);
-    write_obs(ring.obs, (int)slot, ag);                         // obs before the step
+    write_obs(ring.obs, (int)slot, od, ag);                     // obs before the step
     reinterpret_cast<float2*>(ring.act)[slot] = an;
     const StepOut o = step_agent(ag, an);
-    write_obs(ring.obs2, (int)slot, ag);
+    write_obs(ring.obs2, (int)slot, od, ag);
     ring.rew[slot] = o.reward;
     ring.done[slot] = o.done ? 1 : 0;
     if (done_out) done_out[i] = o.done ? 1 : 0;
     if (o.done) reset_agent(ag, i, k0, k1, c1, c2);
     store_agent(st, n, i, ag);
-    write_obs(obs_out, i, ag);
+    write_obs(obs_out, i, od, ag);
 }
+
+inline bool pt_obs_dim_ok(int od) { return od >= 6 && od <= 6 + MPG_ENV_MAX_FUTURE; }
 
 }  // namespace
 
-extern "C" int mpg_env_reset_from_obs(int env_kind, int n, float* state, const float* init_obs, mpg_stream_t stream) {
-    MPG_REQUIRE(env_kind == MPG_ENV_PATH_TRACKING, "mpg_env_reset_from_obs: only PathTracking has a real env (kind %d)", env_kind);
-    MPG_REQUIRE(n > 0 && state && init_obs, "mpg_env_reset_from_obs: bad argument");
-    hipLaunchKernelGGL(k_reset_from_obs, dim3((n + 63) / 64), dim3(64), 0, mpg_stream(stream), n, state, init_obs);
+extern "C" int mpg_env_reset_from_obs(int env_kind, int n, int obs_dim, float* state, const float* init_obs, mpg_stream_t stream) {
+    if (env_kind == MPG_ENV_INVERTED_PENDULUM) return cart_pole::reset_from_obs(n, obs_dim, state, init_obs, mpg_stream(stream));
+    MPG_REQUIRE(env_kind == MPG_ENV_PATH_TRACKING, "mpg_env_reset_from_obs: unknown env kind %d", env_kind);
+    MPG_REQUIRE(n > 0 && state && init_obs && pt_obs_dim_ok(obs_dim), "mpg_env_reset_from_obs: bad argument");
+    hipLaunchKernelGGL(k_reset_from_obs, dim3((n + 63) / 64), dim3(64), 0, mpg_stream(stream), n, obs_dim, state, init_obs);
     MPG_CHECK_LAUNCH("mpg_env_reset_from_obs");
     return MPG_OK;
 }
 
-extern "C" int mpg_env_reset(int env_kind, int n, float* state, const uint8_t* done_mask, uint64_t seed, uint64_t ctr,
+extern "C" int mpg_env_reset(int env_kind, int n, int obs_dim, float* state, const uint8_t* done_mask, uint64_t seed, uint64_t ctr,
                              float* obs, mpg_stream_t stream) {
-    MPG_REQUIRE(env_kind == MPG_ENV_PATH_TRACKING, "mpg_env_reset: only PathTracking has a real env (kind %d)", env_kind);
-    MPG_REQUIRE(n > 0 && state && obs, "mpg_env_reset: bad argument");
+    if (env_kind == MPG_ENV_INVERTED_PENDULUM) return cart_pole::reset(n, obs_dim, state, done_mask, seed, ctr, obs, mpg_stream(stream));
+    MPG_REQUIRE(env_kind == MPG_ENV_PATH_TRACKING, "mpg_env_reset: unknown env kind %d", env_kind);
+    MPG_REQUIRE(n > 0 && state && obs && pt_obs_dim_ok(obs_dim), "mpg_env_reset: bad argument");
     hipLaunchKernelGGL(k_reset, dim3((n + 63) / 64), dim3(64), 0, mpg_stream(stream), n, state, done_mask,
-                       (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)ctr, (uint32_t)(ctr >> 32), obs);
+                       (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)ctr, (uint32_t)(ctr >> 32), obs, obs_dim);
     MPG_CHECK_LAUNCH("mpg_env_reset");
     return MPG_OK;
 }
 
-extern "C" int mpg_env_step(int env_kind, int n, float* state, const float* action, float* obs, float* reward,
+extern "C" int mpg_env_step(int env_kind, int n, int obs_dim, float* state, const float* action, float* obs, float* reward,
                             uint8_t* done, uint8_t* done_intended, mpg_stream_t stream) {
-    MPG_REQUIRE(env_kind == MPG_ENV_PATH_TRACKING, "mpg_env_step: only PathTracking has a real env (kind %d)", env_kind);
-    MPG_REQUIRE(n > 0 && state && action && obs && reward && done, "mpg_env_step: bad argument");
+    if (env_kind == MPG_ENV_INVERTED_PENDULUM)
+        return cart_pole::step(n, obs_dim, state, action, obs, reward, done, done_intended, mpg_stream(stream));
+    MPG_REQUIRE(env_kind == MPG_ENV_PATH_TRACKING, "mpg_env_step: unknown env kind %d", env_kind);
+    MPG_REQUIRE(n > 0 && state && action && obs && reward && done && pt_obs_dim_ok(obs_dim), "mpg_env_step: bad argument");
     hipLaunchKernelGGL(k_step, dim3((n + 63) / 64), dim3(64), 0, mpg_stream(stream), n, state, action, obs, reward,
-                       done, done_intended);
+                       done, done_intended, obs_dim);
     MPG_CHECK_LAUNCH("mpg_env_step");
     return MPG_OK;
 }
 
-extern "C" int mpg_env_step_store_reset(int env_kind, int n, float* state, const float* action, int capacity, int next_idx,
+extern "C" int mpg_env_step_store_reset(int env_kind, int n, int obs_dim, float* state, const float* action, int capacity, int next_idx,
                                         float* ring_obs, float* ring_act, float* ring_rew, float* ring_obs2, uint8_t* ring_done,
                                         uint64_t seed, uint64_t ctr, float* obs_out, uint8_t* done_out, mpg_stream_t stream) {
-    MPG_REQUIRE(env_kind == MPG_ENV_PATH_TRACKING, "mpg_env_step_store_reset: only PathTracking has a real env (kind %d)", env_kind);
     MPG_REQUIRE(n > 0 && state && action && capacity >= n && next_idx >= 0 && next_idx < capacity && ring_obs && ring_act &&
                     ring_rew && ring_obs2 && ring_done && obs_out,
                 "mpg_env_step_store_reset: bad argument");
+    if (env_kind == MPG_ENV_INVERTED_PENDULUM)
+        return cart_pole::step_store_reset(n, obs_dim, state, action, capacity, next_idx, ring_obs, ring_act, ring_rew, ring_obs2,
+                                           ring_done, seed, ctr, obs_out, done_out, mpg_stream(stream));
+    MPG_REQUIRE(env_kind == MPG_ENV_PATH_TRACKING, "mpg_env_step_store_reset: unknown env kind %d", env_kind);
+    MPG_REQUIRE(pt_obs_dim_ok(obs_dim), "mpg_env_step_store_reset: obs_dim");
     RingPtrs ring{ring_obs, ring_act, ring_rew, ring_obs2, ring_done};
     hipLaunchKernelGGL(k_step_store_reset, dim3((n + 63) / 64), dim3(64), 0, mpg_stream(stream), n, state, action, ring,
                        capacity, next_idx, (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)ctr, (uint32_t)(ctr >> 32), obs_out,
-                       done_out);
+                       done_out, obs_dim);
     MPG_CHECK_LAUNCH("mpg_env_step_store_reset");
     return MPG_OK;
 }

@@ -72,6 +72,28 @@ __global__ void k_gq(int n, const float* __restrict__ G, const float* __restrict
     if (i < n) y[i] = G[i] + gpow * Q[i];
 }
 
+// y[k][b] = mean over the M copies of G_k + gamma^k * Q_k, Q clipped to [-0.5, 0] where `clip[k]`   (mpg_learner.py:202-216)
+struct QestCoef {
+    float gpow[MAXSEL];
+    int clip[MAXSEL];
+};
+__global__ void k_qest(int rows, int M, int n_sel, const QestCoef qc, const float* __restrict__ Q,
+                       const float* __restrict__ GK, float* __restrict__ y) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= rows) return;
+    const long R = (long)rows * M;
+    for (int k = 0; k < n_sel; ++k) {
+        float m = 0.f;
+        for (int mm = 0; mm < M; ++mm) {
+            const long tr = (long)mm * rows + b;
+            float q = Q[k * R + tr];
+            if (qc.clip[k]) q = fminf(fmaxf(q, -0.5f), 0.f);
+            m += GK[k * R + tr] + qc.gpow[k] * q;
+        }
+        y[(long)k * rows + b] = m / (float)M;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------
@@ -279,6 +301,56 @@ extern "C" int mpg_rollout_q_target(const mpg_cfg_t* cfg, const float* policy_pa
     if (rc) return rc;
     hipLaunchKernelGGL(k_gq, dim3((rows + 255) / 256), dim3(256), 0, s, rows, GK, Q, powf(cfg->gamma, (float)n), y);
     MPG_CHECK_LAUNCH("k_gq");
+    return MPG_OK;
+}
+
+extern "C" size_t mpg_rollout_q_estimation_workspace_bytes(const mpg_cfg_t* cfg, int rows, int M, int n_select) {
+    if (!cfg_ok(cfg) || rows <= 0 || M <= 0 || n_select <= 0 || n_select > MAXSEL) return 0;
+    const size_t R = (size_t)rows * M;
+    return pad256(n_select * R * (cfg->obs_dim + cfg->act_dim)) + 2 * pad256(n_select * R);
+}
+
+extern "C" int mpg_rollout_q_estimation(const mpg_cfg_t* cfg, const float* policy_params, const float* q1t, int rows, int M,
+                                        const int* select, int n_select, const float* obs0, const float* act0, const float* eps,
+                                        uint64_t noise_seed, uint64_t noise_ctr, float* y, void* ws, size_t ws_bytes,
+                                        mpg_stream_t stream) {
+    MPG_REQUIRE(cfg_ok(cfg) && policy_params && q1t && select && obs0 && act0 && y && ws && rows > 0 && M > 0 && n_select > 0 &&
+                    n_select <= MAXSEL,
+                "mpg_rollout_q_estimation: bad argument");
+    int n = 0;
+    for (int k = 0; k < n_select; ++k) {
+        MPG_REQUIRE(select[k] >= 0 && select[k] < MAXN, "mpg_rollout_q_estimation: slice out of range");
+        n = std::max(n, select[k]);
+    }
+    if (ws_bytes < mpg_rollout_q_estimation_workspace_bytes(cfg, rows, M, n_select)) {
+        mpg_set_error("mpg_rollout_q_estimation: workspace too small");
+        return MPG_EWORKSPACE;
+    }
+    hipStream_t s = mpg_stream(stream);
+    const int qin = cfg->obs_dim + cfg->act_dim;
+    const long R = (long)rows * M;
+    Carver cv(ws, ws_bytes);
+    float* XQ = cv.take((size_t)n_select * R * qin); float* GK = cv.take((size_t)n_select * R); float* Q = cv.take((size_t)n_select * R);
+    RollArgs fa;
+    fill_roll(fa, cfg, policy_params, rows, M, n);
+    fa.obs0 = obs0; fa.act0 = act0; fa.eps = eps; fa.H1 = fa.H2 = nullptr; fa.SA = nullptr; fa.dbg = nullptr;
+    fa.nk0 = (uint32_t)noise_seed; fa.nk1 = (uint32_t)(noise_seed >> 32); fa.nc0 = (uint32_t)noise_ctr; fa.nc1 = (uint32_t)(noise_ctr >> 32);
+    fa.n_sel = n_select;
+    for (int k = 0; k < MAXSEL; ++k) fa.sel[k] = k < n_select ? select[k] : -1;
+    fa.XQ = XQ; fa.GK = GK;
+    int rc = launch_rollout_fwd(fa, cfg->env_kind, (R + GROUP - 1) / GROUP, n, s, nullptr);
+    if (rc) return rc;
+    OutSpec lin; lin.out_tanh = 0; lin.out_scale = 1.f; lin.sigma = 0.f; lin.seed = lin.ctr = 0;
+    rc = launch_forward(cfg, q1t, qin, 1, 1, (int)(n_select * R), xspec(XQ, qin, nullptr, 0, nullptr, 0), lin, Q, 1, nullptr, nullptr, s);
+    if (rc) return rc;
+    QestCoef qc;
+    for (int k = 0; k < MAXSEL; ++k) {
+        qc.gpow[k] = k < n_select ? powf(cfg->gamma, (float)select[k]) : 0.f;
+        // the pendulum branch clips the bootstrap of every slice but the first (all_Qs[batch_size:], :206-209)
+        qc.clip[k] = (k < n_select && cfg->env_kind == MPG_ENV_INVERTED_PENDULUM && select[k] >= 1) ? 1 : 0;
+    }
+    hipLaunchKernelGGL(k_qest, dim3((rows + 255) / 256), dim3(256), 0, s, rows, M, n_select, qc, Q, GK, y);
+    MPG_CHECK_LAUNCH("k_qest");
     return MPG_OK;
 }
 

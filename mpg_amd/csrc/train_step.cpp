@@ -91,7 +91,7 @@ extern "C" int mpg_step_begin(mpg_train_ctx_t* c, int iteration, mpg_stream_t s)
             MPG_REQUIRE(c->num_agent <= c->ring_capacity, "mpg_step_begin: ring smaller than one sample");
             // env.step -> ring slot (next + i) % capacity -> env.reset of the done agents, one launch
             mpg_prof_begin(c->cfg.prof, 2, mpg_stream(s));
-            TRY(mpg_env_step_store_reset(kind, c->num_agent, c->env_state, c->w_act, c->ring_capacity, c->ring_next, c->ring_obs,
+            TRY(mpg_env_step_store_reset(kind, c->num_agent, od, c->env_state, c->w_act, c->ring_capacity, c->ring_next, c->ring_obs,
                                          c->ring_act, c->ring_rew, c->ring_obs2, c->ring_done, c->env_seed, c->env_ctr++, c->w_obs,
                                          c->w_done, s));
             mpg_prof_end(c->cfg.prof, 2, mpg_stream(s));
@@ -116,14 +116,14 @@ extern "C" int mpg_step_begin(mpg_train_ctx_t* c, int iteration, mpg_stream_t s)
                                           c->ring_rew, c->ring_obs2, c->ring_done, c->idx, c->b_obs, c->b_act, c->b_rew, c->b_obs2,
                                           c->b_done, s));
             MPG_REQUIRE(c->l_env_state && c->l_obs && c->l_act && c->l_rewards && c->l_done, "mpg_step_begin: MPG-v1 needs the learner env buffers");
-            TRY(mpg_env_reset_from_obs(kind, c->batch, c->l_env_state, c->b_obs, s));
+            TRY(mpg_env_reset_from_obs(kind, c->batch, od, c->l_env_state, c->b_obs, s));
             for (int t = 0; t < c->n; ++t) {
                 const float* act = c->b_act;
                 if (t > 0) {
                     TRY(mpg_policy_action(&c->cfg, policy, c->batch, c->l_obs, 0.f, 0, 0, c->l_act, s));
                     act = c->l_act;
                 }
-                TRY(mpg_env_step(kind, c->batch, c->l_env_state, act, c->l_obs, c->l_rewards + (size_t)t * c->batch, c->l_done,
+                TRY(mpg_env_step(kind, c->batch, od, c->l_env_state, act, c->l_obs, c->l_rewards + (size_t)t * c->batch, c->l_done,
                                  c->l_done_intended, s));
             }
             TRY(mpg_nstep_targets(&c->cfg, policy_t, c->targets + l.off[0], c->batch, c->n, c->l_rewards, c->l_obs, c->b_targets,

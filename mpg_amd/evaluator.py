@@ -32,11 +32,16 @@ class Evaluator(object):
     def set_ppc_params(self, params):
         pass
 
-    def run_n_episodes_parallel(self, n=None):
-        """evaluator.py:118-156: reset, `fixed_steps` deterministic steps (done is ignored), metrics per episode."""
+    def run_n_episodes_parallel(self, n=None, init_obs=None):
+        """evaluator.py:118-156: reset, `fixed_steps` deterministic steps (done is ignored), metrics per episode.
+        init_obs (optional, [num_eval_agent, obs_dim]): start from these observations instead of a fresh reset() draw
+        (the parity test starts from the states the reference's own env drew)."""
         pw = self.policy_with_value
-        self.env._initialised = False                      # fresh draw of every agent
-        obses = self.env.reset()
+        if init_obs is not None:
+            obses = self.env.reset(init_obs=init_obs)
+        else:
+            self.env._initialised = False                  # fresh draw of every agent
+            obses = self.env.reset()
         obs_l, act_l, rew_l = [], [], []
         for _ in range(self.fixed_steps):
             actions = ops.policy_action(pw.cfg, pw.net('policy'), obses)      # compute_mode, policy.py:173-177
@@ -44,7 +49,8 @@ class Evaluator(object):
             act_l.append(actions)
             obses, rewards, _, _ = self.env.step(actions)
             rew_l.append(rewards)
-        obs, act, rew = torch.stack(obs_l), torch.stack(act_l), torch.stack(rew_l)      # [T, N, .]
+        # the reference accumulates in numpy: np.mean / python sum() promote to float64 (evaluator.py:141-142,172-178)
+        obs, act, rew = torch.stack(obs_l).double(), torch.stack(act_l).double(), torch.stack(rew_l).double()   # [T, N, .]
         rms = lambda x: torch.sqrt(torch.mean(torch.square(x), 0))
         per_episode = dict(                                # metrics_for_an_episode, evaluator.py:160-184
             episode_return=rew.sum(0), episode_len=torch.full_like(rew[0], float(self.fixed_steps)),

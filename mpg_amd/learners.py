@@ -124,6 +124,19 @@ class MPGLearner(_LearnerBase):
         if args.learner_version == 'MPG-v1':
             self.env = PathTrackingEnv(num_agent=self.batch_size, num_future_data=args.num_future_data, device=device)
 
+    # ---- heuristic-bias rollout (defined but never called by the reference's compute_gradient either) ----
+    def model_rollout_for_q_estimation(self, start_obses, start_actions, eps=None):
+        """mpg_learner.py:180-224: from (s, a_replay) roll the model, later actions from pi_theta, bootstrap every selected
+        slice of args.num_rollout_list_for_q_estimation with Q1_target, mean over the M copies; returns the selected
+        slices concatenated ([len(list) * B], no gradient).  eps: optional [max(list)][M*B] standard-normal model noise
+        (default: Philox draws keyed by the learner's seed and call counter)."""
+        sel = list(getattr(self.args, 'num_rollout_list_for_q_estimation', []) or [])
+        assert sel, 'args.num_rollout_list_for_q_estimation is empty'
+        pw = self.policy_with_value
+        self._qest_calls = getattr(self, '_qest_calls', 0) + 1
+        return ops.rollout_q_estimation(self.cfg, pw.net('policy'), pw.net('Q1', True), start_obses, start_actions, eps, sel,
+                                        M=self.M, noise_seed=self.seed + 7, noise_ctr=self._qest_calls)
+
     # ---- targets ----
     def compute_clipped_double_q_target(self):
         """mpg_learner.py:126-134"""

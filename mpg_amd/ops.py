@@ -286,6 +286,21 @@ def rollout_q_target(cfg, policy_params, q1t, obs0, act0, eps, n=None, noise_see
     return y
 
 
+def rollout_q_estimation(cfg, policy_params, q1t, obs0, act0, eps, select, M=1, noise_seed=0, noise_ctr=0):
+    """mpg_rollout_q_estimation -> [n_select * rows] (the reference's concatenation of the selected slices)"""
+    rows, ns = obs0.shape[0], len(select)
+    y = torch.empty(ns * rows, dtype=torch.float32, device=obs0.device)
+    sel = (ctypes.c_int * ns)(*[int(k) for k in select])
+    nb = L.lib().mpg_rollout_q_estimation_workspace_bytes(ctypes.byref(cfg), L.c_int(rows), L.c_int(M), L.c_int(ns))
+    if nb == 0:
+        raise L.MpgError('mpg_rollout_q_estimation_workspace_bytes: unsupported configuration')
+    ws = workspace(obs0.device, nb)
+    L.call('mpg_rollout_q_estimation', ctypes.byref(cfg), L.ptr(_f32(policy_params)), L.ptr(_f32(q1t)), L.c_int(rows), L.c_int(M),
+           sel, L.c_int(ns), L.ptr(_f32(obs0)), L.ptr(_f32(act0)), L.ptr(_f32(eps) if eps is not None else None),
+           L.c_u64(noise_seed), L.c_u64(noise_ctr), L.ptr(y), L.ptr(ws), L.c_size_t(ws.numel()), L.stream())
+    return y
+
+
 def td3_policy_grad(cfg, policy_params, q1, q2, obs, inv_b_global=None, grad_out=None, stats_out=None):
     rows, dev = obs.shape[0], obs.device
     grad = grad_out if grad_out is not None else torch.empty(policy_size(cfg), dtype=torch.float32, device=dev)

@@ -128,8 +128,98 @@ def test_fused_step_store_reset_equals_separate_calls():
     ring_b = [torch.zeros_like(t) for t in ring_a]
     obs_b = torch.empty(n, 6).cuda()
     done_b = torch.empty(n, dtype=torch.uint8).cuda()
-    L.call('mpg_env_step_store_reset', L.c_int(0), L.c_int(n), L.ptr(env_b._state), L.ptr(act), L.c_int(cap), L.c_int(nxt),
+    L.call('mpg_env_step_store_reset', L.c_int(0), L.c_int(n), L.c_int(6), L.ptr(env_b._state), L.ptr(act), L.c_int(cap), L.c_int(nxt),
            *[L.ptr(t) for t in ring_b], L.c_u64(env_b.seed), L.c_u64(env_b._ctr), L.ptr(obs_b), L.ptr(done_b), L.stream())
     for x, y in zip(ring_a, ring_b):
         assert torch.equal(x, y)
     assert torch.equal(obs_a, obs_b) and torch.equal(env_a._state, env_b._state) and bool(done_b.all())
+
+
+def test_future_data_observations_vs_reference_run(golden):
+    """num_future_data = 3 (path_tracking_env.py:385-402): six base entries + three look-ahead delta-y terms, against the
+    reference's own env on the same start states and actions; and the reset() branch against the oracle's statement of
+    _get_obs applied to the kernel's own drawn state."""
+    from oracle import mpg_oracle as O
+    from mpg_amd.envs import PathTrackingEnv
+    g = golden('env_future_ref.npz')
+    K, N = int(g['K']), g['obs0'].shape[0]
+    env = PathTrackingEnv(num_future_data=K, num_agent=N)
+    assert env.obs_dim == 6 + K
+    env.reset(init_obs=torch.as_tensor(np.concatenate([g['obs0'], np.zeros((N, K), np.float32)], 1)).cuda())
+    for t in range(g['actions'].shape[0]):
+        o, r, d, _ = env.step(torch.as_tensor(g['actions'][t]).cuda())
+        assert o.shape == (N, 6 + K)
+        ref = g['obs'][t]
+        tol = 5e-6 * (1.0 + np.abs(ref))            # the stated env bar: 5e-6 abs + ulp-of-x terms (x up to 1200)
+        assert (np.abs(o.cpu().numpy() - ref) <= tol + 6e-5 * (np.arange(6 + K) == 5)).all(), t
+        np.testing.assert_allclose(r.cpu().numpy(), g['reward'][t], rtol=2e-6, atol=1e-5)
+    for n in (1, 63, 4099):                          # ragged sizes, reset() branch, an odd obs stride (7)
+        env = PathTrackingEnv(num_future_data=1, num_agent=n, seed=5)
+        obs = env.reset().cpu().numpy()
+        fs = env.veh_full_state.cpu().numpy()
+        vs = env.veh_state.cpu().numpy()
+        ref = O.PathTrackingEnvOracle(n, num_future_data=1)._get_obs(vs, fs)
+        np.testing.assert_allclose(obs, ref, rtol=0, atol=2e-5)
+        plain = PathTrackingEnv(num_future_data=0, num_agent=n, seed=5)
+        assert np.array_equal(plain.reset().cpu().numpy(), obs[:, :6])      # the base entries do not depend on K
+
+
+def test_cart_pole_env_vs_float64_restatement():
+    """InvertedPendulumContiEnv (analytic RK4 statement of inverted_pendulum_conti.xml; PARITY UNPINNED - no MuJoCo).
+    The float32 kernel against the float64 restatement of the same equations: 50 steps (2 s) with random actions, each
+    step checked from the kernel's own previous state (<= 3e-6 relative-to-scale per step); reward / done / clipping /
+    reset range / fused step-store-reset."""
+    import mpg_amd._lib as L
+    from oracle import mpg_oracle as O
+    from mpg_amd.envs import InvertedPendulumContiEnv
+    rng = np.random.Generator(np.random.PCG64(11))
+    for n in (1, 64, 1000):
+        env = InvertedPendulumContiEnv(num_agent=n, seed=3)
+        obs0 = env.reset().cpu().numpy().astype(np.float64)
+        assert obs0.shape == (n, 4) and (np.abs(obs0) <= 0.01).all() and np.abs(obs0).max() > 0.005 * (n > 1)
+        ref = O.InvertedPendulumContiOracle(n)
+        prev = obs0
+        for t in range(50):
+            a = rng.uniform(-3.5, 3.5, (n, 1)).astype(np.float32)           # beyond ctrlrange: clipped inside
+            o, r, d, _ = env.step(torch.as_tensor(a).cuda())
+            # one-step error from the kernel's own previous state (open loop, a swinging pole separates two float
+            # precisions exponentially - that would measure the pendulum, not the kernel)
+            ref.reset(init_obs=prev)
+            ro, rr, rd, _ = ref.step(a[:, 0].astype(np.float64))
+            prev = o.cpu().numpy().astype(np.float64)
+            scale = 1.0 + np.abs(ro)
+            assert (np.abs(prev - ro) / scale).max() <= 3e-6, (n, t)
+            np.testing.assert_allclose(r.cpu().numpy(), rr, rtol=2e-5, atol=1e-5)
+            # done may legitimately differ for an agent sitting within rounding of a threshold
+            near = (np.abs(np.abs(ro[:, 0]) - 2.0) < 1e-4) | (np.abs(np.abs(ro[:, 1]) - 0.2) < 1e-4)
+            assert (d.cpu().numpy().astype(bool) == rd)[~near].all()
+        assert bool(env.done.any()) or n == 1        # random +-3 pushes for 2 s drop the pole for essentially every agent
+    # reset(init_obs) + reset() of the done agents only
+    env = InvertedPendulumContiEnv(num_agent=8, seed=1)
+    init = torch.as_tensor(np.array([[0., 0., 0., 0.]] * 4 + [[2.5, 0., 0., 0.]] * 4, np.float32)).cuda()
+    env.reset(init_obs=init)
+    o, r, d, _ = env.step(torch.zeros(8, 1).cuda())
+    assert d.cpu().tolist() == [0, 0, 0, 0, 1, 1, 1, 1]
+    o2 = env.reset().cpu().numpy()
+    assert np.array_equal(o2[:4], o.cpu().numpy()[:4]) and (np.abs(o2[4:]) <= 0.01).all()
+    # fused step + ring store + reset == the separate calls, bit for bit
+    n, cap, nxt = 50, 64, 40
+    act = torch.as_tensor(rng.uniform(-3, 3, (n, 1)).astype(np.float32)).cuda()
+    ea, eb = InvertedPendulumContiEnv(num_agent=n, seed=9), InvertedPendulumContiEnv(num_agent=n, seed=9)
+    start = torch.as_tensor((rng.standard_normal((n, 4)) * np.array([1.5, 0.15, 0.5, 0.5])).astype(np.float32)).cuda()
+    ea.reset(init_obs=start.clone())
+    eb.reset(init_obs=start.clone())
+    o2, r, d, _ = ea.step(act)
+    ring_a = [torch.zeros(cap, 4).cuda(), torch.zeros(cap, 1).cuda(), torch.zeros(cap).cuda(), torch.zeros(cap, 4).cuda(),
+              torch.zeros(cap, dtype=torch.uint8).cuda()]
+    L.call('mpg_replay_add', L.c_int(cap), L.c_int(nxt), L.c_int(n), L.c_int(4), L.c_int(1), L.ptr(start), L.ptr(act), L.ptr(r),
+           L.ptr(o2), L.ptr(d), *[L.ptr(t) for t in ring_a], L.stream())
+    obs_a = ea.reset()
+    ring_b = [torch.zeros_like(t) for t in ring_a]
+    obs_b, done_b = torch.empty(n, 4).cuda(), torch.empty(n, dtype=torch.uint8).cuda()
+    L.call('mpg_env_step_store_reset', L.c_int(1), L.c_int(n), L.c_int(4), L.ptr(eb._state), L.ptr(act), L.c_int(cap), L.c_int(nxt),
+           *[L.ptr(t) for t in ring_b], L.c_u64(eb.seed), L.c_u64(eb._ctr), L.ptr(obs_b), L.ptr(done_b), L.stream())
+    for x, y in zip(ring_a, ring_b):
+        assert torch.equal(x, y)
+    assert torch.equal(obs_a, obs_b) and torch.equal(ea._state[:4], eb._state[:4]) and torch.equal(done_b, d)
+    assert 0 < int(d.sum().item()) < n

@@ -168,9 +168,12 @@ def test_nstep_target_vs_golden(golden):
         obs, r, _, _ = env.step(a)
         rewards.append(r)
     rewards = torch.stack(rewards).contiguous()
-    np.testing.assert_allclose(rewards.cpu().numpy(), g['nstep_all_rewards'], rtol=2e-3, atol=2e-4)
+    # 25 closed-loop env steps: measured max relative reward error 3.7e-6 at step 24 (tools/v1_errors.py); the spread
+    # between two valid float32 evaluations of the REFERENCE itself (library vs correctly rounded sin/cos/atan) is 3.2e-6
+    np.testing.assert_allclose(rewards.cpu().numpy(), g['nstep_all_rewards'], rtol=2e-5, atol=2e-6)
     y = ops.nstep_targets(cfg, dev(targets['policy']), dev(targets['Q1']), rewards, obs).cpu().numpy()
-    np.testing.assert_allclose(y, g['it100_targets'], rtol=1e-3, atol=1e-4)
+    from tests import yardstick as Y
+    Y.check_values(y, g['it100_targets'], g['it100_targets_f64'], what='n-step targets')
 
 
 def test_weight_cache_is_bit_identical_to_the_strided_path():
