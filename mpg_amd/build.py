@@ -48,10 +48,11 @@ def _stamp(src, flags):
     return h.hexdigest()
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, jobs=None):
+    from concurrent.futures import ThreadPoolExecutor
     os.makedirs(OBJ, exist_ok=True)
     cc = hipcc()
-    objs, rebuilt = [], False
+    objs, todo = [], []
     for s in sources():
         src = os.path.join(CSRC, s)
         obj = os.path.join(OBJ, s + '.o')
@@ -59,15 +60,20 @@ def build(force=False, verbose=True):
         stamp_file = obj + '.stamp'
         stamp = _stamp(src, flags)
         if force or not os.path.exists(obj) or not os.path.exists(stamp_file) or open(stamp_file).read() != stamp:
-            cmd = [cc] + flags + ['-c', src, '-o', obj]
-            if verbose:
-                print('[mpg_amd.build]', ' '.join(cmd), flush=True)
-            subprocess.check_call(cmd)
-            with open(stamp_file, 'w') as fh:
-                fh.write(stamp)
-            rebuilt = True
+            todo.append(([cc] + flags + ['-c', src, '-o', obj], stamp_file, stamp))
         objs.append(obj)
-    if rebuilt or not os.path.exists(LIB):
+
+    def compile_one(job):
+        cmd, stamp_file, stamp = job
+        if verbose:
+            print('[mpg_amd.build]', ' '.join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        with open(stamp_file, 'w') as fh:
+            fh.write(stamp)
+    if todo:      # translation units are independent: compile them side by side
+        with ThreadPoolExecutor(max_workers=jobs or min(len(todo), os.cpu_count() or 1, 16)) as ex:
+            list(ex.map(compile_one, todo))
+    if todo or not os.path.exists(LIB):
         cmd = [cc, '-shared', '-fPIC', '--offload-arch=' + ARCH, '-o', LIB] + objs
         if verbose:
             print('[mpg_amd.build]', ' '.join(cmd), flush=True)

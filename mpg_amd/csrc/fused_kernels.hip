@@ -9,11 +9,23 @@ namespace mlp {
 
 namespace {
 
+// PK (template parameter of every kernel here): the caller handed packed images for ALL its networks - the kernel then
+// contains no strided loader at all (the uncached form costs registers the hot form cannot spare)
+template <bool PK>
 __device__ __forceinline__ void load_w2(const float* pack, const float* W2, bool bwd, const Lane& L, float (&w)[128]) {
-    if (pack) load_w2_packed(pack, L, w);
+    if constexpr (PK) load_w2_packed(pack, L, w);
     else if (bwd) load_w2_bwd(W2, L, w);
     else load_w2_fwd(W2, L, w);
 }
+
+// order of a phase's loads: the small per-lane pieces first, so that layer 1 and its barrier run while the 256 KB
+// register image is still streaming in (the vector-memory counter retires in order)
+#define MPG_UNPAREN(...) __VA_ARGS__
+#ifdef MPG_AB_IMAGE_FIRST
+#define MPG_LOAD2(SMALL, IMAGE) do { MPG_UNPAREN IMAGE; MPG_UNPAREN SMALL; } while (0)
+#else
+#define MPG_LOAD2(SMALL, IMAGE) do { MPG_UNPAREN SMALL; MPG_UNPAREN IMAGE; } while (0)
+#endif
 
 constexpr int SMEM_FLOATS = 2 * GROUP * LDA + GROUP * XS + NWAVE * GROUP * MAXOUT + GROUP * MAXOUT + NWAVE * GROUP * XS + 4 * GROUP;
 struct Smem {
@@ -49,7 +61,7 @@ struct TargetArgs {
     float *o_obs, *o_act, *o_rew, *o_obs2, *o_done;
 };
 
-template <int OBS, int ACT>
+template <int OBS, int ACT, bool PK>
 __global__ void __launch_bounds__(NTHREAD, 2) k_target_fused(const TargetArgs a) {
     constexpr int QIN = OBS + ACT;
     __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
@@ -83,8 +95,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_target_fused(const TargetArgs a)
     float w2[128], h1[2][4], h2[2][4];
     const Net pnet = make_net(a.pol, OBS, 2 * ACT);
     SmallRegs<OBS, ACT> pr;
-    load_w2(a.pk_pol, pnet.W2, false, L, w2);
-    load_small<OBS, ACT>(pnet, L, pr);
+    MPG_LOAD2((load_small<OBS, ACT>(pnet, L, pr)), (load_w2<PK>(a.pk_pol, pnet.W2, false, L, w2)));
     if (a.draw) {
         if (tid < GROUP) {
             if (drawn) {
@@ -121,13 +132,13 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_target_fused(const TargetArgs a)
         }
         lds_barrier();
     }
+#pragma unroll
     for (int qi = 0; qi < 2; ++qi) {
         const float* qp = qi == 0 ? a.q1 : a.q2;
         if (!qp) break;
         const Net net = make_net(qp, QIN, 1);
         SmallRegs<QIN, 1> r;
-        load_w2(qi == 0 ? a.pk_q1 : a.pk_q2, net.W2, false, L, w2);
-        load_small<QIN, 1>(net, L, r);
+        MPG_LOAD2((load_small<QIN, 1>(net, L, r)), (load_w2<PK>(qi == 0 ? a.pk_q1 : a.pk_q2, net.W2, false, L, w2)));
         forward_group<QIN, 1>(m.sX, m.sA, m.sPart, L, w2, r, h1, h2);
         if (tid < GROUP) m.sQ[qi * GROUP + tid] = out_preact(m.sPart, net.b3[0], tid, 0);
         lds_barrier();
@@ -154,7 +165,7 @@ struct QlossArgs {
     float* td;
 };
 
-template <int QIN>
+template <int QIN, bool PK>
 __global__ void __launch_bounds__(NTHREAD, 2) k_qloss_fused(const QlossArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
     const Smem m(smem);
@@ -169,8 +180,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_qloss_fused(const QlossArgs a) {
     lds_barrier();
     float w2[128], h1[2][4], h2[2][4], dz1[2][4], dz2[2][4];
     SmallRegs<QIN, 1> r;
-    load_w2(a.pkf[qi], net.W2, false, L, w2);
-    load_small<QIN, 1>(net, L, r);
+    MPG_LOAD2((load_small<QIN, 1>(net, L, r)), (load_w2<PK>(a.pkf[qi], net.W2, false, L, w2)));
     forward_group<QIN, 1>(m.sX, m.sA, m.sPart, L, w2, r, h1, h2);
     stash_store(st.h1, g, L, h1);
     stash_store(st.h2, g, L, h2);
@@ -185,7 +195,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_qloss_fused(const QlossArgs a) {
         m.sD3[d3_index(tid, 0)] = e * a.inv_b;
         m.sQ[tid] = e * e;
     }
-    load_w2(a.pkb[qi], net.W2, true, L, w2);     // same registers, backward image
+    load_w2<PK>(a.pkb[qi], net.W2, true, L, w2);     // same registers, backward image
     lds_barrier();
     if (tid == 0) {
         float s2 = 0.f;
@@ -208,7 +218,7 @@ struct QsliceArgs {
     float* gxq;
 };
 
-template <int QIN>
+template <int QIN, bool PK>
 __global__ void __launch_bounds__(NTHREAD, 2) k_qslice_fused(const QsliceArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
     const Smem m(smem);
@@ -225,8 +235,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_qslice_fused(const QsliceArgs a)
     lds_barrier();
     float w2[128], h1[2][4], h2[2][4], dz1[2][4], dz2[2][4];
     SmallRegs<QIN, 1> r;
-    load_w2(a.pkf, net.W2, false, L, w2);
-    load_small<QIN, 1>(net, L, r);
+    MPG_LOAD2((load_small<QIN, 1>(net, L, r)), (load_w2<PK>(a.pkf, net.W2, false, L, w2)));
     forward_group<QIN, 1>(m.sX, m.sA, m.sPart, L, w2, r, h1, h2);
     if (tid < GROUP) {
         const long gr = g * GROUP + tid;
@@ -240,7 +249,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_qslice_fused(const QsliceArgs a)
         m.sQ[tid] = ret;
         m.sQ[GROUP + tid] = (gr < total) ? (float)(gr / a.R) : -1.f;
     }
-    load_w2(a.pkb, net.W2, true, L, w2);
+    load_w2<PK>(a.pkb, net.W2, true, L, w2);
     lds_barrier();
     if (tid == 0) {   // a group may straddle two slices only when R % 16 != 0; the launcher requires R % 16 == 0
         float s1 = 0.f, s2 = 0.f;
@@ -259,7 +268,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_qslice_fused(const QsliceArgs a)
 // Two slices per workgroup (the default {0, n} selection): workgroup gb handles row group gb of BOTH slices, so each of
 // the two register images of W2 is loaded once per 32 rows instead of once per 16 (the prologue, not the MFMA work,
 // dominates these kernels at one row group per CU).
-template <int QIN>
+template <int QIN, bool PK>
 __global__ void __launch_bounds__(NTHREAD, 2) k_qslice_fused2(const QsliceArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
     __shared__ __attribute__((aligned(16))) float sX2[2 * GROUP * XS];
@@ -279,8 +288,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_qslice_fused2(const QsliceArgs a
     lds_barrier();
     float w2[128], h1[2][2][4], h2[2][2][4], dz1[2][4], dz2[2][4];
     SmallRegs<QIN, 1> r;
-    load_w2(a.pkf, net.W2, false, L, w2);
-    load_small<QIN, 1>(net, L, r);
+    MPG_LOAD2((load_small<QIN, 1>(net, L, r)), (load_w2<PK>(a.pkf, net.W2, false, L, w2)));
 #pragma unroll
     for (int sl = 0; sl < 2; ++sl) {
         forward_group<QIN, 1>(sX2 + sl * GROUP * XS, m.sA, m.sPart, L, w2, r, h1[sl], h2[sl]);
@@ -290,7 +298,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_qslice_fused2(const QsliceArgs a
             sD32[sl * GROUP * MAXOUT + d3_index(tid, 0)] = a.coef[sl];
         }
     }
-    load_w2(a.pkb, net.W2, true, L, w2);
+    load_w2<PK>(a.pkb, net.W2, true, L, w2);
     lds_barrier();
     if (tid < 2) {
         float s1 = 0.f, s2 = 0.f;
@@ -319,7 +327,7 @@ struct CriticArgs {
     QsliceArgs qs;
 };
 
-template <int QIN>
+template <int QIN, bool PK>
 __global__ void __launch_bounds__(NTHREAD, 2) k_critic_fused(const CriticArgs ca) {
     __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
     __shared__ __attribute__((aligned(16))) float sX2[2 * GROUP * XS];
@@ -345,8 +353,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_critic_fused(const CriticArgs ca
     lds_barrier();
     float w2[128], h1[3][2][4], h2[3][2][4], dz1[2][4], dz2[2][4];
     SmallRegs<QIN, 1> r;
-    load_w2(a.pkf[qi], net.W2, false, L, w2);
-    load_small<QIN, 1>(net, L, r);
+    MPG_LOAD2((load_small<QIN, 1>(net, L, r)), (load_w2<PK>(a.pkf[qi], net.W2, false, L, w2)));
     // ---- forward: replay batch group ----
     forward_group<QIN, 1>(m.sX, m.sA, m.sPart, L, w2, r, h1[0], h2[0]);
     stash_store(st.h1, g, L, h1[0]);
@@ -374,7 +381,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_critic_fused(const CriticArgs ca
             }
         }
     }
-    load_w2(a.pkb[qi], net.W2, true, L, w2);     // same registers, backward image
+    load_w2<PK>(a.pkb[qi], net.W2, true, L, w2);     // same registers, backward image
     lds_barrier();
     if (tid == 0) {
         float s2 = 0.f;
@@ -508,8 +515,8 @@ int launch_target_fused(const mpg_cfg_t* cfg, const float* policy_t, const float
     a.sigma = sigma; a.clipc = clipc; a.rshift = cfg->rew_shift; a.rscale = cfg->rew_scale; a.gamma = cfg->gamma; a.y = y;
     const int ngroups = (rows + GROUP - 1) / GROUP;
     mpg_prof_begin(mpg_prof_of(cfg), 6, s);
-    if (od == 6 && ad == 2) hipLaunchKernelGGL((k_target_fused<6, 2>), dim3(ngroups), dim3(NTHREAD), 0, s, a);
-    else if (od == 4 && ad == 1) hipLaunchKernelGGL((k_target_fused<4, 1>), dim3(ngroups), dim3(NTHREAD), 0, s, a);
+    if (od == 6 && ad == 2) { if (a.pk_pol && a.pk_q1 && (a.pk_q2 || !a.q2)) hipLaunchKernelGGL((k_target_fused<6, 2, true>), dim3(ngroups), dim3(NTHREAD), 0, s, a); else hipLaunchKernelGGL((k_target_fused<6, 2, false>), dim3(ngroups), dim3(NTHREAD), 0, s, a); }
+    else if (od == 4 && ad == 1) { if (a.pk_pol && a.pk_q1 && (a.pk_q2 || !a.q2)) hipLaunchKernelGGL((k_target_fused<4, 1, true>), dim3(ngroups), dim3(NTHREAD), 0, s, a); else hipLaunchKernelGGL((k_target_fused<4, 1, false>), dim3(ngroups), dim3(NTHREAD), 0, s, a); }
     else { mpg_set_error("launch_target_fused: unsupported dims"); return MPG_EINVAL; }
     mpg_prof_end(mpg_prof_of(cfg), 6, s);
     MPG_CHECK_LAUNCH("k_target_fused");
@@ -530,8 +537,8 @@ int launch_qloss_fused(const mpg_cfg_t* cfg, const float* const* q_params, int n
     }
     a.rows = rows; a.x = xspec(obs, od, act, ad, cfg->obs_scale, od); a.y = y; a.inv_b = inv_b; a.loss_part = loss_part; a.td = td;
     const int ngroups = (rows + GROUP - 1) / GROUP;
-    if (qin == 8) hipLaunchKernelGGL((k_qloss_fused<8>), dim3(ngroups, n_q), dim3(NTHREAD), 0, s, a);
-    else if (qin == 5) hipLaunchKernelGGL((k_qloss_fused<5>), dim3(ngroups, n_q), dim3(NTHREAD), 0, s, a);
+    if (qin == 8) { if (a.pkf[0] && a.pkb[0] && (n_q < 2 || (a.pkf[1] && a.pkb[1]))) hipLaunchKernelGGL((k_qloss_fused<8, true>), dim3(ngroups, n_q), dim3(NTHREAD), 0, s, a); else hipLaunchKernelGGL((k_qloss_fused<8, false>), dim3(ngroups, n_q), dim3(NTHREAD), 0, s, a); }
+    else if (qin == 5) { if (a.pkf[0] && a.pkb[0] && (n_q < 2 || (a.pkf[1] && a.pkb[1]))) hipLaunchKernelGGL((k_qloss_fused<5, true>), dim3(ngroups, n_q), dim3(NTHREAD), 0, s, a); else hipLaunchKernelGGL((k_qloss_fused<5, false>), dim3(ngroups, n_q), dim3(NTHREAD), 0, s, a); }
     else { mpg_set_error("launch_qloss_fused: unsupported dims"); return MPG_EINVAL; }
     MPG_CHECK_LAUNCH("k_qloss_fused");
     return MPG_OK;
@@ -548,11 +555,11 @@ int launch_qslice_fused(const mpg_cfg_t* cfg, const float* q_params, int qin, in
     for (int k = 0; k < 4; ++k) { a.gpow[k] = k < n_sel ? gpow[k] : 0.f; a.coef[k] = k < n_sel ? coef[k] : 0.f; }
     const int ngroups = n_sel * (R / GROUP);
     if (n_sel == 2) {
-        if (qin == 8) hipLaunchKernelGGL((k_qslice_fused2<8>), dim3(R / GROUP), dim3(NTHREAD), 0, s, a);
-        else if (qin == 5) hipLaunchKernelGGL((k_qslice_fused2<5>), dim3(R / GROUP), dim3(NTHREAD), 0, s, a);
+        if (qin == 8) { if (a.pkf && a.pkb) hipLaunchKernelGGL((k_qslice_fused2<8, true>), dim3(R / GROUP), dim3(NTHREAD), 0, s, a); else hipLaunchKernelGGL((k_qslice_fused2<8, false>), dim3(R / GROUP), dim3(NTHREAD), 0, s, a); }
+        else if (qin == 5) { if (a.pkf && a.pkb) hipLaunchKernelGGL((k_qslice_fused2<5, true>), dim3(R / GROUP), dim3(NTHREAD), 0, s, a); else hipLaunchKernelGGL((k_qslice_fused2<5, false>), dim3(R / GROUP), dim3(NTHREAD), 0, s, a); }
         else { mpg_set_error("launch_qslice_fused: unsupported dims"); return MPG_EINVAL; }
-    } else if (qin == 8) hipLaunchKernelGGL((k_qslice_fused<8>), dim3(ngroups), dim3(NTHREAD), 0, s, a);
-    else if (qin == 5) hipLaunchKernelGGL((k_qslice_fused<5>), dim3(ngroups), dim3(NTHREAD), 0, s, a);
+    } else if (qin == 8) { if (a.pkf && a.pkb) hipLaunchKernelGGL((k_qslice_fused<8, true>), dim3(ngroups), dim3(NTHREAD), 0, s, a); else hipLaunchKernelGGL((k_qslice_fused<8, false>), dim3(ngroups), dim3(NTHREAD), 0, s, a); }
+    else if (qin == 5) { if (a.pkf && a.pkb) hipLaunchKernelGGL((k_qslice_fused<5, true>), dim3(ngroups), dim3(NTHREAD), 0, s, a); else hipLaunchKernelGGL((k_qslice_fused<5, false>), dim3(ngroups), dim3(NTHREAD), 0, s, a); }
     else { mpg_set_error("launch_qslice_fused: unsupported dims"); return MPG_EINVAL; }
     MPG_CHECK_LAUNCH("k_qslice_fused");
     return MPG_OK;
@@ -578,8 +585,8 @@ int launch_critic_fused(const mpg_cfg_t* cfg, const float* const* q_params, int 
     for (int k = 0; k < 4; ++k) { q.gpow[k] = k < 2 ? gpow[k] : 0.f; q.coef[k] = k < 2 ? coef[k] : 0.f; }
     const int ngroups = rows / GROUP;
     mpg_prof_begin(mpg_prof_of(cfg), 7, s);
-    if (qin == 8) hipLaunchKernelGGL((k_critic_fused<8>), dim3(ngroups, n_q), dim3(NTHREAD), 0, s, c);
-    else if (qin == 5) hipLaunchKernelGGL((k_critic_fused<5>), dim3(ngroups, n_q), dim3(NTHREAD), 0, s, c);
+    if (qin == 8) { if (a.pkf[0] && a.pkb[0] && (n_q < 2 || (a.pkf[1] && a.pkb[1]))) hipLaunchKernelGGL((k_critic_fused<8, true>), dim3(ngroups, n_q), dim3(NTHREAD), 0, s, c); else hipLaunchKernelGGL((k_critic_fused<8, false>), dim3(ngroups, n_q), dim3(NTHREAD), 0, s, c); }
+    else if (qin == 5) { if (a.pkf[0] && a.pkb[0] && (n_q < 2 || (a.pkf[1] && a.pkb[1]))) hipLaunchKernelGGL((k_critic_fused<5, true>), dim3(ngroups, n_q), dim3(NTHREAD), 0, s, c); else hipLaunchKernelGGL((k_critic_fused<5, false>), dim3(ngroups, n_q), dim3(NTHREAD), 0, s, c); }
     else { mpg_set_error("launch_critic_fused: unsupported dims"); return MPG_EINVAL; }
     mpg_prof_end(mpg_prof_of(cfg), 7, s);
     MPG_CHECK_LAUNCH("k_critic_fused");

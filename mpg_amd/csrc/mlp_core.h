@@ -28,6 +28,38 @@ constexpr int MAXOUT = 2;      // outputs ever *used* (policy mean: act_dim <= 2
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// ---- arithmetic of the 256 x 256 hidden layer -------------------------------------------------------------------
+// Default: SPLIT-FP16.  Every float32 operand x of the hidden-layer product is written as hi + lo with hi = fp16(x),
+// lo = fp16(x - hi) - 22..23 significand bits, exact products - and the product is evaluated as hi*hi + hi*lo + lo*hi by
+// THREE v_mfma_f32_16x16x32_f16 per fp32-equivalent tile step into ONE float32 accumulator (the lo*lo term, 2^-22
+// relative, is dropped; the matrix pipe handles fp16 subnormals exactly - scratch/proto/denorm.hip).  The f16 matrix pipe
+// runs at 16x the rate of v_mfma_f32_16x16x4_f32, so the layer costs 3/16 of the exact-fp32 form.  Measured against
+// float64 on random data a 256-term contraction is MORE accurate than the fp32 fma chain (1.9e-7 vs 2.9e-7 rel-L2: exact
+// products, 8x fewer roundings per accumulator - scratch/proto/split.hip); what it does NOT reproduce is the last bit of
+// a quarter of the weights (a 13-bit residual in an 11-bit lo), a FIXED perturbation of <= 2^-23 relative that the 26
+// policy evaluations of a rollout see coherently: the 25-step policy gradient sits at 4e-6 of the float64 oracle instead
+// of 1.2e-6 (tools/engine_error.py; the bar is 1e-4, tests/yardstick.py states the allowance).
+// Scaling (powers of two, exact): stationary weights are carried as W * 64 and activations enter the image as x * 16 so
+// that typical magnitudes sit well inside fp16's normal range (absolute floor 2^-25/16 per element); gradients entering
+// the reverse layer are additionally scaled per row (backward_dz2).  -DMPG_F32_MFMA selects the exact fp32 engine
+// (v_mfma_f32_16x16x4_f32, k-ordered fma chain) of round 1 instead; both hold the stationary kernel in 128 registers/wave.
+#ifndef MPG_F32_MFMA
+#define MPG_SPLIT 1
+#endif
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+constexpr int LDH = 264;                 // row stride (halves) of the two fp16 LDS A images (hi, lo); 2*16*264*2 B <= GROUP*LDA*4 B
+constexpr float W_SCALE = 64.f;          // stationary weights are stored as W * 64
+constexpr float A_SCALE = 16.f;          // activations enter the LDS images as x * 16
+
+// (w0, w1) -> the two packed fp16 words: hi pair and lo pair (element 0 in the low half)
+__device__ __forceinline__ void split_pack2(float w0, float w1, float& hi_word, float& lo_word) {
+    const f16x2 hi = {(_Float16)w0, (_Float16)w1};
+    const f16x2 lo = {(_Float16)(w0 - (float)hi[0]), (_Float16)(w1 - (float)hi[1])};
+    hi_word = __builtin_bit_cast(float, hi);
+    lo_word = __builtin_bit_cast(float, lo);
+}
+
 struct Net {
     const float *W1, *b1, *W2, *b2, *W3, *b3;
     int in_dim, out_dim;
@@ -137,14 +169,88 @@ __device__ __forceinline__ float row_allreduce16(float v) {
 // for k-steps q..q+3 (k = 4q + kq) is then ONE aligned 16-byte read.
 __device__ __forceinline__ int a_index(int row, int k) { return row * LDA + (k & 3) * KS + (k >> 2); }
 
-__device__ __forceinline__ void store_c_to_a(float* sA, const Lane& L, const float (&v)[2][4]) {
+// float32 image (exact engine; always used for the small dx product of the reverse pass)
+__device__ __forceinline__ void store_c_to_a_f32(float* sA, const Lane& L, const float (&v)[2][4]) {
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int j = 0; j < 4; ++j) sA[a_index(L.row(j), L.col(t))] = v[t][j];
 }
 
+#ifdef MPG_SPLIT
+// Split engine: two fp16 images [16][LDH] (hi, then lo) in the same LDS region.  A lane owns (rows 4rg..4rg+3, column c)
+// of each tile; columns c and c^1 are adjacent k, so the pair of lanes exchanges values through one DPP quad_perm and each
+// lane writes packed (k even, k odd) words: even lanes the rows j = 0,1, odd lanes the rows j = 2,3 - 8 ds_write_b32 per
+// lane like the float32 image, and the reader's 8 consecutive k are one aligned 16-byte read per image.
+__device__ __forceinline__ void store_c_to_a(float* sA, const Lane& L, const float (&v)[2][4]) {
+    _Float16* sH = reinterpret_cast<_Float16*>(sA);
+    const bool odd = L.c & 1;
+    const int row0 = 4 * L.rg + (odd ? 2 : 0);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        float p[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) p[j] = dpp_mov<0xB1>(v[t][j]);               // partner lane (c ^ 1)
+        const int k = 32 * L.wave + 16 * t + (L.c & ~1);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const float x = odd ? p[2 + u] : v[t][u], y = odd ? v[t][2 + u] : p[u];   // (k even, k odd) of row row0 + u
+            float hi, lo;
+            split_pack2(x * A_SCALE, y * A_SCALE, hi, lo);
+            *reinterpret_cast<float*>(sH + (row0 + u) * LDH + k) = hi;
+            *reinterpret_cast<float*>(sH + GROUP * LDH + (row0 + u) * LDH + k) = lo;
+        }
+    }
+}
+#else
+__device__ __forceinline__ void store_c_to_a(float* sA, const Lane& L, const float (&v)[2][4]) { store_c_to_a_f32(sA, L, v); }
+#endif
+
 // ---- stationary hidden kernel -------------------------------------------------------------------------
+#ifdef MPG_SPLIT
+// Register image of the split engine: w[4v + r], v = (kb*2 + t)*2 + part (part 0: hi, 1: lo), r = 0..3, holds the packed
+// pair (k0, k0 + 1), k0 = 32 kb + 8 (l>>4) + 2 r, of output column n = 32 w + 16 t + (l&15): w[4v .. 4v+3] is the B
+// fragment (8 consecutive k) of v_mfma_f32_16x16x32_f16.  Stored value: W * W_SCALE, split.
+// forward:  B[k][n] = W2[k][n]
+__device__ __forceinline__ void load_w2_fwd(const float* __restrict__ W2, const Lane& L, float (&w)[128]) {
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k0 = 32 * kb + 8 * L.rg + 2 * r;
+                split_pack2(W2[k0 * H + L.col(t)] * W_SCALE, W2[(k0 + 1) * H + L.col(t)] * W_SCALE,
+                            w[4 * ((kb * 2 + t) * 2) + r], w[4 * ((kb * 2 + t) * 2 + 1) + r]);
+                if (r == 3) __builtin_amdgcn_sched_barrier(0);      // 8 loads in flight, not 256: this is the slow (uncached) path
+            }
+}
+// backward: dh1[row][k1] = sum_n dz2[row][n] W2[k1][n]  ->  B[contraction n][output k1] = W2[k1][n]
+__device__ __forceinline__ void load_w2_bwd(const float* __restrict__ W2, const Lane& L, float (&w)[128]) {
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k0 = 32 * kb + 8 * L.rg + 2 * r;
+                split_pack2(W2[L.col(t) * H + k0] * W_SCALE, W2[L.col(t) * H + k0 + 1] * W_SCALE,
+                            w[4 * ((kb * 2 + t) * 2) + r], w[4 * ((kb * 2 + t) * 2 + 1) + r]);
+                if (r == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+}
+// Same register images from the pre-packed copy kept by the weight cache (weight_cache.hip): 16-byte word index
+// (wave*32 + v)*64 + lane holds w[4v .. 4v+3] -> 32 fully coalesced 1 KiB loads per wave.
+__device__ __forceinline__ void load_w2_packed(const float* __restrict__ pack, const Lane& L, float (&w)[128]) {
+    const f32x4* p = reinterpret_cast<const f32x4*>(pack) + (L.wave * 32) * 64 + L.lane;
+#pragma unroll
+    for (int v = 0; v < 32; ++v) {
+        const f32x4 q = p[v * 64];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[4 * v + e] = q[e];
+    }
+}
+#else
 // forward:  B[k][n] = W2[k][n];  lane holds, for k-step q and tile t, W2[4q + (l>>4)][32w + 16t + (l&15)]
 __device__ __forceinline__ void load_w2_fwd(const float* __restrict__ W2, const Lane& L, float (&w)[128]) {
 #pragma unroll
@@ -173,6 +279,7 @@ __device__ __forceinline__ void load_w2_packed(const float* __restrict__ pack, c
             for (int e = 0; e < 4; ++e) w[2 * (4 * q4 + e) + t] = v[e];
         }
 }
+#endif
 
 // host side: packed copy of W2 for direction dir (0 forward, 1 backward) if `W2` is the hidden kernel of a network
 // covered by one of the caller's weight-cache descriptors (cfg->wcache[], include/mpg_hip.h), else nullptr.  Pure
@@ -181,6 +288,40 @@ const float* weight_cache_lookup(const mpg_cfg_t* cfg, const float* W2, int dir)
 const float* wcache_lookup(const mpg_wcache_t* wc, const float* W2, int dir);
 int wcache_w2_offset(const mpg_wcache_t* wc, int k);
 
+#ifdef MPG_SPLIT
+// 16 x 256 (LDS A images hi / lo) times the wave's stationary 256 x 32 slice: 8 k-blocks x 2 tiles x 3 f16 MFMAs.
+// acc0 / acc1 come in holding what is to be ADDED to the product (bias or zero) and leave holding the result.
+__device__ __forceinline__ void mfma_16x256x32(const float* sA, const Lane& L, const float (&w)[128], f32x4& acc0,
+                                               f32x4& acc1) {
+    const _Float16* bh = reinterpret_cast<const _Float16*>(sA) + L.c * LDH + 8 * L.rg;   // hi image: row l&15, k = 8 (l>>4) + ..
+    const _Float16* bl = bh + GROUP * LDH;                                               // lo image
+#ifdef MPG_AB_NOMFMA   // ablation build: one k-block instead of 8 (timing only)
+    constexpr int NKB = 1;
+#else
+    constexpr int NKB = 8;
+#endif
+    auto frag = [&](int v) {
+        return __builtin_bit_cast(f16x8, f32x4{w[4 * v], w[4 * v + 1], w[4 * v + 2], w[4 * v + 3]});
+    };
+    f32x4 m0 = {0.f, 0.f, 0.f, 0.f}, m1 = m0;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+        const f16x8 ah = *reinterpret_cast<const f16x8*>(bh + 32 * kb), al = *reinterpret_cast<const f16x8*>(bl + 32 * kb);
+        const int v0 = (kb * 2 + 0) * 2, v1 = (kb * 2 + 1) * 2;
+        m0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, frag(v0), m0, 0, 0, 0);
+        m1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, frag(v1), m1, 0, 0, 0);
+        m0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, frag(v0 + 1), m0, 0, 0, 0);
+        m1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, frag(v1 + 1), m1, 0, 0, 0);
+        m0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, frag(v0), m0, 0, 0, 0);
+        m1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, frag(v1), m1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        acc0[j] = fmaf(m0[j], 1.f / (W_SCALE * A_SCALE), acc0[j]);
+        acc1[j] = fmaf(m1[j], 1.f / (W_SCALE * A_SCALE), acc1[j]);
+    }
+}
+#else
 // 16 x 256 (LDS A image) times the wave's stationary 256 x 32 slice; 128 MFMAs, two independent accumulators.
 __device__ __forceinline__ void mfma_16x256x32(const float* sA, const Lane& L, const float (&w)[128], f32x4& acc0,
                                                f32x4& acc1) {
@@ -205,6 +346,7 @@ __device__ __forceinline__ void mfma_16x256x32(const float* sA, const Lane& L, c
         a = nxt;
     }
 }
+#endif
 
 // ---- small per-lane stationary pieces -----------------------------------------------------------------
 template <int IN, int OU>
@@ -343,6 +485,22 @@ __device__ __forceinline__ float out_preact_tree(const float* sPart, float bias,
 // one aligned 16-byte read per output and pair up for packed fmas without register shuffles
 __device__ __forceinline__ int d3_index(int row, int o) { return o * GROUP + row; }
 
+// Split engine, reverse layer: dz2 rows span many orders of magnitude (dL/dz3 carries 1/B and the slice weights), fp16
+// does not - each row of the image is scaled by 2^-e, e = exponent of max_o |dL/dz3[row][o]| (|dz2| <= ~OU |W3| |dz3|), and
+// the product is scaled back by 2^e.  Powers of two: exact.  Both halves of the pass derive e from sD3 themselves.
+template <int OU>
+__device__ __forceinline__ void row_exponents(const float* sD3, const Lane& L, int (&e)[4]) {
+    f32x4 m = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int o = 0; o < OU; ++o) {
+        const f32x4 d = *reinterpret_cast<const f32x4*>(sD3 + o * GROUP + 4 * L.rg);     // d3_index(4 rg, o)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) m[j] = fmaxf(m[j], fabsf(d[j]));
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) e[j] = __builtin_amdgcn_frexp_expf(m[j]);
+}
+
 // ---- backward through the hidden layers for one row group ---------------------------------------------
 // sD3 [16][MAXOUT] holds dL/dz3 (pre-activation of the used outputs).  h1/h2: this lane's stashed activations.
 // Produces dz2 and dz1 (C layout).  If WANT_DX, leaves per-wave partial sums of dz1*W1^T in sPartX
@@ -364,7 +522,20 @@ __device__ __forceinline__ void backward_dz2(const float* sD3, float* sA, const 
             dz2[t][j] = dh * elu_grad_from_out(h2[t][j]);
         }
     }
+#ifdef MPG_SPLIT
+    {
+        int e[4];
+        row_exponents<OU>(sD3, L, e);
+        float sc[2][4];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sc[t][j] = ldexpf(dz2[t][j], -e[j]);
+        store_c_to_a(sA, L, sc);
+    }
+#else
     store_c_to_a(sA, L, dz2);
+#endif
     MPG_STAMP_AT(1);
     lds_barrier();
     MPG_STAMP_AT(2);
@@ -376,20 +547,29 @@ __device__ __forceinline__ void backward_dz2(const float* sD3, float* sA, const 
 // sA1: a second LDS image (GROUP*LDA floats) for dz1 - every wave reads back only the columns it wrote itself, so no
 // barrier is needed around it (re-using sA would need one: other waves may still be reading dz2 from it).
 template <int IN, int OU, bool WANT_DX, bool FINAL_BARRIER = true>
-__device__ __forceinline__ void backward_rest(float* sA, float* sA1, float* sPartX, const Lane& L, const float (&w2t)[128],
-                                              const SmallRegs<IN, OU>& r, const float (&h1)[2][4], float (&dz1)[2][4]) {
+__device__ __forceinline__ void backward_rest(const float* sD3, float* sA, float* sA1, float* sPartX, const Lane& L,
+                                              const float (&w2t)[128], const SmallRegs<IN, OU>& r, const float (&h1)[2][4],
+                                              float (&dz1)[2][4]) {
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     mfma_16x256x32(sA, L, w2t, acc0, acc1);
     MPG_STAMP_AT(3);
+#ifdef MPG_SPLIT
+    int e[4];
+    row_exponents<OU>(sD3, L, e);     // sD3 is stable until the next step's barrier (not held across the MFMA block: registers)
+#endif
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
+#ifdef MPG_SPLIT
+        acc0[j] = ldexpf(acc0[j], e[j]);
+        acc1[j] = ldexpf(acc1[j], e[j]);
+#endif
         dz1[0][j] = acc0[j] * elu_grad_from_out(h1[0][j]);
         dz1[1][j] = acc1[j] * elu_grad_from_out(h1[1][j]);
     }
     if (WANT_DX) {
-        // dx partial of this wave's 32 hidden columns on the matrix pipe: A = dz1 (this wave's own columns of the
-        // second LDS image), B = W1^T.
-        store_c_to_a(sA1, L, dz1);
+        // dx partial of this wave's 32 hidden columns on the matrix pipe (exact fp32 MFMA): A = dz1 (this wave's own
+        // columns of the second LDS image, float32), B = W1^T.
+        store_c_to_a_f32(sA1, L, dz1);
         __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): this wave reads back only what it wrote itself
         __builtin_amdgcn_wave_barrier();
         const float* base = sA1 + L.c * LDA + L.rg * KS + 8 * L.wave;
@@ -418,7 +598,7 @@ __device__ __forceinline__ void backward_group(const float* sD3, float* sA, floa
                                                const float (&h1)[2][4], const float (&h2)[2][4],
                                                float (&dz1)[2][4], float (&dz2)[2][4]) {
     backward_dz2<IN, OU>(sD3, sA, L, r, h2, dz2);
-    backward_rest<IN, OU, WANT_DX>(sA, sA1, sPartX, L, w2t, r, h1, dz1);
+    backward_rest<IN, OU, WANT_DX>(sD3, sA, sA1, sPartX, L, w2t, r, h1, dz1);
 }
 
 // all XS partial sums of one row: ds_read_b128 pairs in two batches of four waves (32 VGPRs in flight; all sixteen

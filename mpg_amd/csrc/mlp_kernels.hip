@@ -20,7 +20,7 @@ struct FwdArgs {
     const float* pack;   // nullable: packed forward image of W2 (weight cache)
 };
 
-template <int IN, int OU>
+template <int IN, int OU, bool PK>
 __global__ void __launch_bounds__(NTHREAD, 2) k_forward(const FwdArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[GROUP * LDA + GROUP * XS + NWAVE * GROUP * MAXOUT];
     float* sA = smem;
@@ -30,7 +30,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_forward(const FwdArgs a) {
     const Net net = make_net(a.params, a.in_dim, a.out_dim);
     float w2[128];
     SmallRegs<IN, OU> r;
-    if (a.pack) load_w2_packed(a.pack, L, w2); else load_w2_fwd(net.W2, L, w2);
+    if constexpr (PK) load_w2_packed(a.pack, L, w2); else load_w2_fwd(net.W2, L, w2);
     load_small<IN, OU>(net, L, r);
     const long ngroups = (a.rows + GROUP - 1) / GROUP;
     for (long g = blockIdx.x; g < ngroups; g += gridDim.x) {
@@ -82,7 +82,9 @@ int launch_forward(const mpg_cfg_t* cfg, const float* params, int in_dim, int ou
     a.pack = weight_cache_lookup(cfg, make_net(params, in_dim, out_dim).W2, 0);
     const long ngroups = (rows + GROUP - 1) / GROUP;
     mpg_prof_begin(mpg_prof_of(cfg), 3, s);
-#define CALL(I, O) hipLaunchKernelGGL((k_forward<I, O>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, a)
+#define CALL(I, O)                                                                                          \
+    if (a.pack) hipLaunchKernelGGL((k_forward<I, O, true>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, a);  \
+    else hipLaunchKernelGGL((k_forward<I, O, false>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, a)
     MPG_DISPATCH_NET(in_dim, ou, CALL)
 #undef CALL
     mpg_prof_end(mpg_prof_of(cfg), 3, s);
@@ -107,7 +109,7 @@ struct BwdArgs {
     const float* pack;   // nullable: packed backward image of W2
 };
 
-template <int IN, int OU, bool WANT_DX>
+template <int IN, int OU, bool WANT_DX, bool PK>
 __global__ void __launch_bounds__(NTHREAD, 2) k_backward(const BwdArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[2 * GROUP * LDA + GROUP * MAXOUT + NWAVE * GROUP * XS];
     float* sA = smem;
@@ -118,7 +120,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_backward(const BwdArgs a) {
     const Net net = make_net(a.params, a.in_dim, a.out_dim);
     float w2t[128];
     SmallRegs<IN, OU> r;
-    if (a.pack) load_w2_packed(a.pack, L, w2t); else load_w2_bwd(net.W2, L, w2t);
+    if constexpr (PK) load_w2_packed(a.pack, L, w2t); else load_w2_bwd(net.W2, L, w2t);
     load_small<IN, OU>(net, L, r);
     const long ngroups = (a.rows + GROUP - 1) / GROUP;
     const int tid = threadIdx.x;
@@ -167,11 +169,15 @@ int launch_backward(const mpg_cfg_t* cfg, const float* params, int in_dim, int o
     const long ngroups = (rows + GROUP - 1) / GROUP;
     mpg_prof_begin(mpg_prof_of(cfg), 4, s);
     if (dx) {
-#define CALL(I, O) hipLaunchKernelGGL((k_backward<I, O, true>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, a)
+#define CALL(I, O)                                                                                                \
+    if (a.pack) hipLaunchKernelGGL((k_backward<I, O, true, true>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, a); \
+    else hipLaunchKernelGGL((k_backward<I, O, true, false>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, a)
         MPG_DISPATCH_NET(in_dim, ou, CALL)
 #undef CALL
     } else {
-#define CALL(I, O) hipLaunchKernelGGL((k_backward<I, O, false>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, a)
+#define CALL(I, O)                                                                                                 \
+    if (a.pack) hipLaunchKernelGGL((k_backward<I, O, false, true>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, a); \
+    else hipLaunchKernelGGL((k_backward<I, O, false, false>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, a)
         MPG_DISPATCH_NET(in_dim, ou, CALL)
 #undef CALL
     }

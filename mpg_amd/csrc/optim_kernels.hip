@@ -21,11 +21,27 @@ struct Segs {
 };
 
 constexpr int HH = MPG_HIDDEN * MPG_HIDDEN;
+#ifdef MPG_SPLIT
+// Packed images of the split engine (mlp_core.h / weight_cache.hip): the fp16 hi and lo halves of W2[row][col] * W_SCALE,
+// where contraction index k owns the lane group and register, output index n the lane column.  Writes both halves.
+__device__ __forceinline__ void pack_store(float* __restrict__ image, int k, int n, float w) {
+    const int wave = n >> 5, t = (n >> 4) & 1, c = n & 15, kb = k >> 5, rg = (k >> 3) & 3, r = (k >> 1) & 3, e = k & 1;
+    const int word = (((wave * 32 + (kb * 2 + t) * 2) * 64 + rg * 16 + c) << 2) + r;      // hi word; the lo word is 256 further
+    const float ws = w * mlp::W_SCALE;
+    const _Float16 hi = (_Float16)ws;
+    const _Float16 lo = (_Float16)(ws - (float)hi);
+    _Float16* p = reinterpret_cast<_Float16*>(image);
+    p[2 * word + e] = hi;
+    p[2 * (word + 256) + e] = lo;
+}
+#else
 // position of W2[row][col] in the packed image where `col`-like index n owns the lane and `row`-like index k the step
 __device__ __forceinline__ int pack_index(int k, int n) {
     const int wave = n >> 5, t = (n >> 4) & 1, c = n & 15, q = k >> 2, rg = k & 3;
     return ((((wave * 16 + (q >> 2)) * 2 + t) * 64 + rg * 16 + c) << 2) + (q & 3);
 }
+__device__ __forceinline__ void pack_store(float* __restrict__ image, int k, int n, float w) { image[pack_index(k, n)] = w; }
+#endif
 
 // Parallel form of the clip.  (1) per-network partial sums of squares, one per 256-element block, MPG_CLIP_PARTS slots
 // per network (`k_sq_blocks`; the fused gradient kernel's final slab reduction writes the SAME partials for free, see
@@ -152,16 +168,16 @@ __global__ void k_adam_polyak(const Segs sg, float* __restrict__ w, float* __res
     const bool in_w2 = e >= 0 && e < HH;
     if (in_w2 && sg.do_adam[k] && sg.cache_w) {
         const int row = e >> 8, col = e & 255;
-        sg.cache_w[(size_t)(2 * k) * HH + pack_index(row, col)] = wj;          // forward image: k = row, n = col
-        sg.cache_w[(size_t)(2 * k + 1) * HH + pack_index(col, row)] = wj;      // backward image: k = col, n = row
+        pack_store(sg.cache_w + (size_t)(2 * k) * HH, row, col, wj);           // forward image: k = row, n = col
+        pack_store(sg.cache_w + (size_t)(2 * k + 1) * HH, col, row, wj);       // backward image: k = col, n = row
     }
     if (sg.do_polyak[k] && target) {
         const float tj = tau * wj + (1.f - tau) * target[j];                     // policy.py:158-171
         target[j] = tj;
         if (in_w2 && sg.cache_t) {
             const int row = e >> 8, col = e & 255;
-            sg.cache_t[(size_t)(2 * k) * HH + pack_index(row, col)] = tj;
-            sg.cache_t[(size_t)(2 * k + 1) * HH + pack_index(col, row)] = tj;
+            pack_store(sg.cache_t + (size_t)(2 * k) * HH, row, col, tj);
+            pack_store(sg.cache_t + (size_t)(2 * k + 1) * HH, col, row, tj);
         }
     }
 }
@@ -206,16 +222,16 @@ __global__ void __launch_bounds__(256) k_clip_adam_polyak(const Segs sg, float* 
     const bool in_w2 = e >= 0 && e < HH;
     if (in_w2 && sg.do_adam[k] && sg.cache_w) {
         const int row = e >> 8, col = e & 255;
-        sg.cache_w[(size_t)(2 * k) * HH + pack_index(row, col)] = wj;
-        sg.cache_w[(size_t)(2 * k + 1) * HH + pack_index(col, row)] = wj;
+        pack_store(sg.cache_w + (size_t)(2 * k) * HH, row, col, wj);
+        pack_store(sg.cache_w + (size_t)(2 * k + 1) * HH, col, row, wj);
     }
     if (sg.do_polyak[k] && target) {
         const float tj = tau * wj + (1.f - tau) * target[j];
         target[j] = tj;
         if (in_w2 && sg.cache_t) {
             const int row = e >> 8, col = e & 255;
-            sg.cache_t[(size_t)(2 * k) * HH + pack_index(row, col)] = tj;
-            sg.cache_t[(size_t)(2 * k + 1) * HH + pack_index(col, row)] = tj;
+            pack_store(sg.cache_t + (size_t)(2 * k) * HH, row, col, tj);
+            pack_store(sg.cache_t + (size_t)(2 * k + 1) * HH, col, row, tj);
         }
     }
 }

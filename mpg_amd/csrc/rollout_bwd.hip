@@ -4,7 +4,7 @@
 namespace rollout {
 namespace {
 
-template <class ENV>
+template <class ENV, bool PK>
 __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_bwd(const RollBwdArgs a) {
     constexpr int OBS = ENV::OBS, ACT = ENV::ACT, QIN = OBS + ACT;
     __shared__ __attribute__((aligned(16))) float smem[2 * GROUP * LDA + GROUP * MAXOUT + NWAVE * GROUP * XS];
@@ -20,7 +20,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_bwd(const RollBwdArgs a)
     const Net net = make_net(a.policy, OBS, 2 * ACT);
     float w2t[128];
     SmallRegs<OBS, ACT> r;
-    if (a.pack) load_w2_packed(a.pack, L, w2t); else load_w2_bwd(net.W2, L, w2t);
+    if constexpr (PK) load_w2_packed(a.pack, L, w2t); else load_w2_bwd(net.W2, L, w2t);
     load_small<OBS, ACT>(net, L, r);
     const long R = (long)a.rows * a.M;
     const long ngroups = (R + GROUP - 1) / GROUP;
@@ -109,9 +109,9 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_bwd(const RollBwdArgs a)
                 stash_load(a.H2, (long)(t - 1) * ngroups + g, L, h2_pre);
             }
             if (t > 0)
-                backward_rest<OBS, ACT, true>(sA, sA1, sPartX, L, w2t, r, h1, dz1);
+                backward_rest<OBS, ACT, true>(sD3, sA, sA1, sPartX, L, w2t, r, h1, dz1);
             else
-                backward_rest<OBS, ACT, false>(sA, sA1, sPartX, L, w2t, r, h1, dz1);
+                backward_rest<OBS, ACT, false>(sD3, sA, sA1, sPartX, L, w2t, r, h1, dz1);
             if (a.DZ1 && (a.stash_all || t == 0)) {
                 const long sg = (long)(a.stash_all ? t : 0) * ngroups + g;
                 stash_store(a.DZ1, sg, L, dz1);
@@ -159,9 +159,9 @@ int launch_rollout_bwd(const RollBwdArgs& ba_in, int env_kind, long ngroups, int
 #endif
     mpg_prof_begin(prof, 1, s);
     if (env_kind == MPG_ENV_PATH_TRACKING)
-        hipLaunchKernelGGL((k_rollout_bwd<PathTracking>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, ba);
+        { if (ba.pack) hipLaunchKernelGGL((k_rollout_bwd<PathTracking, true>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, ba); else hipLaunchKernelGGL((k_rollout_bwd<PathTracking, false>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, ba); }
     else
-        hipLaunchKernelGGL((k_rollout_bwd<Pendulum>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, ba);
+        { if (ba.pack) hipLaunchKernelGGL((k_rollout_bwd<Pendulum, true>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, ba); else hipLaunchKernelGGL((k_rollout_bwd<Pendulum, false>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, ba); }
     mpg_prof_end(prof, 1, s);
     MPG_CHECK_LAUNCH("k_rollout_bwd");
 #ifdef MPG_STAMP

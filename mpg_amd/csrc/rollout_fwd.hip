@@ -4,7 +4,7 @@
 namespace rollout {
 namespace {
 
-template <class ENV>
+template <class ENV, bool PK>
 __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_fwd(const RollArgs a) {
     constexpr int OBS = ENV::OBS, ACT = ENV::ACT, QIN = OBS + ACT;
     __shared__ __attribute__((aligned(16))) float smem[GROUP * LDA + GROUP * XS + NWAVE * GROUP * MAXOUT + MAXN * GROUP];
@@ -19,7 +19,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_fwd(const RollArgs a) {
     const Net net = make_net(a.policy, OBS, 2 * ACT);
     float w2[128];
     SmallRegs<OBS, ACT> r;
-    if (a.pack) load_w2_packed(a.pack, L, w2); else load_w2_fwd(net.W2, L, w2);
+    if constexpr (PK) load_w2_packed(a.pack, L, w2); else load_w2_fwd(net.W2, L, w2);
     load_small<OBS, ACT>(net, L, r);
     float b3r[2] = {0.f, 0.f};                         // output bias in registers: no global load on the serial chain
 #pragma unroll
@@ -158,9 +158,9 @@ int launch_rollout_fwd(const RollArgs& fa_in, int env_kind, long ngroups, int n,
 #endif
     mpg_prof_begin(prof, 0, s);
     if (env_kind == MPG_ENV_PATH_TRACKING)
-        hipLaunchKernelGGL((k_rollout_fwd<PathTracking>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, fa);
+        { if (fa.pack) hipLaunchKernelGGL((k_rollout_fwd<PathTracking, true>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, fa); else hipLaunchKernelGGL((k_rollout_fwd<PathTracking, false>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, fa); }
     else
-        hipLaunchKernelGGL((k_rollout_fwd<Pendulum>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, fa);
+        { if (fa.pack) hipLaunchKernelGGL((k_rollout_fwd<Pendulum, true>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, fa); else hipLaunchKernelGGL((k_rollout_fwd<Pendulum, false>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, fa); }
     mpg_prof_end(prof, 0, s);
     MPG_CHECK_LAUNCH("k_rollout_fwd");
 #ifdef MPG_STAMP
