@@ -13,6 +13,10 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_fwd(const RollArgs a) {
     float* sPart = sX + GROUP * XS;
     float* sEps = sPart + NWAVE * GROUP * MAXOUT;
     __shared__ float sGp[MAXN];
+    constexpr int TRAJ_STRIDE = 12, PRE_STRIDE = 12;              // floats per trajectory: (obs[8] | act[2] | rew | -), ENV::pre's values
+    static_assert(ENV::NPRE <= PRE_STRIDE, "sPre row too short");
+    __shared__ __attribute__((aligned(16))) float sTraj[GROUP * TRAJ_STRIDE];
+    __shared__ __attribute__((aligned(16))) float sPre[GROUP * PRE_STRIDE];
     const Lane L;
     const int tid = threadIdx.x;
     if (tid <= a.n) sGp[tid] = powf(a.gamma, (float)tid);     // tf.pow(gamma, ri) in float32, mpg_learner.py:245
@@ -33,10 +37,20 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_fwd(const RollArgs a) {
     }
 #endif
     for (long g = blockIdx.x; g < ngroups; g += gridDim.x) {
-        const long tr = g * GROUP + tid;               // this lane's trajectory (tid < 16 only)
-        const bool own = tid < GROUP, live = own && tr < R;
-        float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        float G = 0.f;
+        // Two sets of trajectory lanes (one lane = one trajectory each):
+        //   chain lanes  (first 16 lanes of wave 0): only what is serial - output activation, the action-dependent half of
+        //                the model step, the next network input;
+        //   book lanes   (first 16 lanes of wave 1): everything else - the action-independent half of the model step
+        //                (ENV::pre: sincos, reciprocals), the discounted reward sum, all records for the reverse sweep and
+        //                the critic.  Wave 1 is an older wave: it leaves the matrix block early and would otherwise wait
+        //                ~1300 cycles at the step's second barrier, while this work on wave 0 kept every other wave waiting.
+        // The two exchange through sTraj (state, action, reward: chain -> book) and sPre (book -> chain).
+        const bool chain = tid < GROUP, booker = tid >= 64 && tid < 64 + GROUP;
+        const int lt = tid & 63;
+        const long tr = g * GROUP + lt;                // this lane's trajectory (chain / book lanes only)
+        const bool live = (chain || booker) && tr < R;
+        float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};        // book lanes: the model state (as observation)
+        float G = 0.f;                                                  // book lanes: discounted reward sum so far
         float act_first[2] = {0.f, 0.f};
         if (live) {
             const float* src = a.obs0 + (tr % a.rows) * OBS;
@@ -48,7 +62,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_fwd(const RollArgs a) {
             }
         }
         // the whole group's model noise goes to LDS up front (one value per thread), off the serial chain: either the
-        // caller's eps or Philox draws.  Visible to the dynamics lanes after the first barrier of the step loop.
+        // caller's eps or Philox draws.  Visible to the book lanes after the first barrier of the step loop.
         for (int idx = tid; idx < a.n * GROUP; idx += NTHREAD) {
             const int t = idx / GROUP;
             const long trj = g * GROUP + (idx % GROUP);
@@ -61,21 +75,21 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_fwd(const RollArgs a) {
             }
             sEps[idx] = z;
         }
-        // Per step: B0 (input published) -> layer 1 -> barrier -> layer-2 MFMA block -> output partials -> B2 -> the
-        // trajectory lanes' serial chain (tanh, action-dependent part of the model step, publish the next input).
-        // Everything the chain does not strictly need sits in the trajectory wave's idle time before B2: it is the
-        // older wave of its SIMD and leaves the MFMA block ~4000 cycles before the younger ones.
-        float act[2] = {0.f, 0.f}, rew = 0.f;
-        // record the action of step tb, its critic-input part and the discounted reward (late by one step: off the chain)
-        auto book = [&](int tb) {
+        // Per step: B0 (input published) -> layer 1 -> barrier -> layer-2 MFMA block -> output partials -> [book lanes: records
+        // of this step, ENV::pre] -> B2 -> [chain lanes: tanh, ENV::finish, publish the next input and sTraj].
+        // record the action of step tb, its critic-input part and the discounted reward (book lanes, one step late)
+        auto book = [&](int tb, const float (&act)[2], float rew) {
             if (live) {
                 if (a.SA) {
                     float* rec = a.SA + ((long)tb * R + tr) * SAW + OBS;
 #pragma unroll
                     for (int k = 0; k < ACT; ++k) rec[k] = act[k];
                 }
-                for (int ks = 0; ks < a.n_sel; ++ks)
-                    if (a.sel[ks] == tb) {
+                // constant indices only: a dynamically indexed kernel-argument array is re-read from memory by a scalar load
+                // (+ wait) on every use - ~200 cycles each
+#pragma unroll
+                for (int ks = 0; ks < MAXSEL; ++ks)
+                    if (ks < a.n_sel && a.sel[ks] == tb) {
                         float* xq = a.XQ + ((long)ks * R + tr) * QIN + OBS;
 #pragma unroll
                         for (int k = 0; k < ACT; ++k) xq[k] = act[k];
@@ -83,7 +97,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_fwd(const RollArgs a) {
             }
             if (tb < a.n) G += sGp[tb] * ((rew + a.rew_shift) * a.rew_scale);                 // mpg_learner.py:245
         };
-        if (own) {
+        if (chain) {
 #pragma unroll
             for (int i = 0; i < XS; ++i) sX[tid * XS + i] = i < OBS ? o[i] * a.obs_scale[i] : 0.f;
         }
@@ -93,29 +107,29 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_fwd(const RollArgs a) {
             float h1[2][4], h2[2][4];
             forward_group<OBS, ACT, false>(sX, sA, sPart, L, w2, r, h1, h2, a.H1, (long)t * ngroups + g);
             if (a.H1) stash_store(a.H2, (long)t * ngroups + g, L, h2);
-            float pre[ENV::NPRE];
-            if (own) {
-                if (t > 0) book(t - 1);
-                if (live) {
-                    if (a.SA) {
-                        float* rec = a.SA + ((long)t * R + tr) * SAW;
+            // book lanes, before B2: fetch what the chain lanes left in sTraj (they overwrite it right after B2) and prepare
+            // the action-independent half of this step's model step - the only part of their work the chain waits for
+            float pa[2] = {0.f, 0.f}, prew = 0.f;
+            if (booker) {
+                if (t > 0) {       // the state of step t, the action and reward of step t-1
+                    const f32x4* tp = reinterpret_cast<const f32x4*>(sTraj + lt * TRAJ_STRIDE);
+                    const f32x4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
 #pragma unroll
-                        for (int i = 0; i < OBS; ++i) rec[i] = o[i];
-                    }
-                    for (int ks = 0; ks < a.n_sel; ++ks)
-                        if (a.sel[ks] == t) {
-                            float* xq = a.XQ + ((long)ks * R + tr) * QIN;
-#pragma unroll
-                            for (int i = 0; i < OBS; ++i) xq[i] = o[i] * a.obs_scale[i];
-                            a.GK[(long)ks * R + tr] = G;
-                        }
+                    for (int i = 0; i < 4; ++i) { o[i] = q0[i]; o[4 + i] = q1[i]; }
+                    pa[0] = q2[0]; pa[1] = q2[1]; prew = q2[2];
                 }
-                if (t < a.n) ENV::pre(o, sEps[t * GROUP + tid], pre);
+                if (t < a.n) {
+                    float pre[ENV::NPRE];
+                    ENV::pre(o, sEps[t * GROUP + lt], pre);
+#pragma unroll
+                    for (int i = 0; i < ENV::NPRE; ++i) sPre[lt * PRE_STRIDE + i] = pre[i];
+                }
             }
             MPG_STAMP_AT(6);
             lds_barrier();
             MPG_STAMP_AT(5);
-            if (own) {
+            if (chain) {
+                float act[2] = {0.f, 0.f};
 #pragma unroll
                 for (int k = 0; k < ACT; ++k) {
                     const float z = out_preact_tree(sPart, b3r[k], tid, k);
@@ -125,19 +139,48 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_fwd(const RollArgs a) {
 #pragma unroll
                     for (int k = 0; k < ACT; ++k) act[k] = act_first[k];
                 }
+                float on[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, rew = 0.f;
                 if (t < a.n) {
-                    float on[8];
+                    float pre[ENV::NPRE];
+#pragma unroll
+                    for (int i = 0; i < ENV::NPRE; ++i) pre[i] = sPre[tid * PRE_STRIDE + i];
                     ENV::finish(pre, act, on, rew);
 #pragma unroll
                     for (int i = 0; i < XS; ++i) sX[tid * XS + i] = i < OBS ? on[i] * a.obs_scale[i] : 0.f;
+                }
+                f32x4* tp = reinterpret_cast<f32x4*>(sTraj + tid * TRAJ_STRIDE);
+                tp[0] = f32x4{on[0], on[1], on[2], on[3]};
+                tp[1] = f32x4{on[4], on[5], on[6], on[7]};
+                tp[2] = f32x4{act[0], act[1], rew, 0.f};
+            }
+            // book lanes, behind B2 (while every other wave waits for the chain lanes): the records of this step
+            if (booker) {
+                if (t > 0) book(t - 1, pa, prew);
+                if (live) {
+                    if (a.SA) {
+                        float* rec = a.SA + ((long)t * R + tr) * SAW;
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) o[i] = on[i];
+                        for (int i = 0; i < OBS; ++i) rec[i] = o[i];
+                    }
+#pragma unroll
+                    for (int ks = 0; ks < MAXSEL; ++ks)
+                        if (ks < a.n_sel && a.sel[ks] == t) {
+                            float* xq = a.XQ + ((long)ks * R + tr) * QIN;
+#pragma unroll
+                            for (int i = 0; i < OBS; ++i) xq[i] = o[i] * a.obs_scale[i];
+                            a.GK[(long)ks * R + tr] = G;
+                        }
                 }
             }
-            // sX of the next step is ordered behind this step's reads by the two barriers above
+            // sX / sTraj of the next step are ordered behind this step's reads by the two barriers above
             MPG_STAMP_AT(7);
         }
-        if (own) book(a.n);
+        lds_barrier();                                  // the last action (sTraj) for the book lanes
+        if (booker) {
+            const f32x4 q2 = reinterpret_cast<const f32x4*>(sTraj + lt * TRAJ_STRIDE)[2];
+            const float pa[2] = {q2[0], q2[1]};
+            book(a.n, pa, q2[2]);
+        }
 #ifdef MPG_STAMP
         if ((tid & 63) == 0 && a.dbg)
             for (int k = 0; k < 8; ++k) a.dbg[((long)blockIdx.x * NWAVE + (tid >> 6)) * 8 + k] = (float)g_st_acc[tid >> 6][k];
