@@ -42,12 +42,22 @@ sys.path.insert(0, ROOT)
 B_PER_GPU = 4096
 N_STEP = 25
 BURN_IN_STEPS = 200
-# algorithmic work of the dominant kernel: forward rollout = 26 policy evaluations per start
-# state, each 2*(6*256 + 256*256 + 256*2) flop (mean half of the output layer only), + 25 model steps of ~100 flop
-FWD_FLOP_PER_STATE = 26 * 2 * (6 * 256 + 256 * 256 + 256 * 2) + 25 * 100
-# reverse sweep = 26 input-side backward passes through the same policy (W3^T, W2^T, W1^T) + 25 model adjoints
-BWD_FLOP_PER_STATE = 26 * 2 * (2 * 256 + 256 * 256 + 256 * 6) + 25 * 200
+# Algorithmic work of the two rollout sweeps per start state (n = 25 -> 26 policy evaluations), DESIGN.md §4.
+#   bytes (HBM): every evaluation stashes / re-reads the two 256-wide hidden activations in float32 (2 x 1 KiB) plus a
+#                32 B (obs | action) record; the reverse sweep also reads 2 x 32 B of critic input gradients and writes the
+#                step-0 dz1 / dz2 stash (2 KiB) + dz3 (8 B); the forward sweep reads the 24 B start state and writes 2 x (32 +
+#                4) B of critic inputs / reward sums.
+#   flops:       2*(6*256 + 256*256 + 256*2) per evaluation forward, 2*(2*256 + 256*256 + 256*6) reverse (+ ~100 / ~200 per
+#                model step / adjoint).  The 256 x 256 product runs as THREE f16 MFMAs per fp32-equivalent tile step
+#                (split-fp16 engine, csrc/mlp_core.h), i.e. 3x these flops are executed on the f16 pipe.
+N_EVAL = N_STEP + 1
+FWD_BYTES_PER_STATE = N_EVAL * (2 * 1024 + 32) + 24 + 2 * 36
+BWD_BYTES_PER_STATE = N_EVAL * (2 * 1024 + 32) + 2 * 32 + 2 * 1024 + 8
+FWD_FLOP_PER_STATE = N_EVAL * 2 * (6 * 256 + 256 * 256 + 256 * 2) + 25 * 100
+BWD_FLOP_PER_STATE = N_EVAL * 2 * (2 * 256 + 256 * 256 + 256 * 6) + 25 * 200
+HIDDEN_FLOP_PER_STATE = N_EVAL * 2 * 256 * 256          # the part that runs (3x) on the f16 matrix pipe
 FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+F16_MFMA_PEAK_TFLOPS = 2500.0          # MI355X_MICROARCH.md: f16 / bf16 dense peak
 HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 # The kernel durations behind `roofline` are measured live, with HIP events on the launch stream, on every PROF_EVERY-th
 # launch of the timed region: an event record is a stream packet of its own (~4-5 us between two otherwise back-to-back
@@ -257,18 +267,28 @@ def main():
         with open(tpath) as fh:
             traffic = json.load(fh).get('bytes_per_launch', {})
 
-    def roof(kernel, flop, ms, n):
-        tf = flop * B_PER_GPU / (ms * 1e-3) / 1e12
+    def roof(kernel, nbytes, flop, ms, n):
+        """Both roofs of a rollout sweep.  With the split-fp16 engine the sweeps sit closer to the HBM roof (the activation
+        stash) than to the matrix roof, so `bound` is "hbm": achieved = algorithmic bytes per launch / average launch
+        duration; the matrix view (executed f16 MFMA flop/s against the f16 dense peak, and the algorithmic flop/s against
+        the fp32 MFMA peak it replaced) is reported beside it."""
+        sec = ms * 1e-3
+        gbs = nbytes * B_PER_GPU / sec / 1e9
         tr = traffic.get(kernel.split('<')[0])
-        return {'kernel': kernel, 'bound': 'mfma', 'achieved': tf, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': tf / FP32_MFMA_PEAK_TFLOPS, 'traffic': tr, 'avg_ms': ms, 'launches': n,
+        executed = (flop + 2 * HIDDEN_FLOP_PER_STATE) * B_PER_GPU / sec / 1e12      # hidden layer counted 3x
+        algorithmic = flop * B_PER_GPU / sec / 1e12
+        return {'kernel': kernel, 'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                'frac': gbs / HBM_PEAK_GBS, 'traffic': tr, 'avg_ms': ms, 'launches': n,
                 'timed_with': 'HIP events on the launch stream around every %d-th launch of the timed region' % PROF_EVERY,
-                'algorithmic_flop_per_launch': flop * B_PER_GPU,
-                # the north star asks for the HBM side of the rollout kernel too: PMC bytes per launch / kernel time
-                'hbm_gbs': (tr / (ms * 1e-3) / 1e9) if tr else None,
-                'hbm_frac_of_peak': (tr / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if tr else None}
-    r_fwd = roof('k_rollout_fwd<PathTracking>', FWD_FLOP_PER_STATE, fwd_ms, fwd_n)
-    r_bwd = roof('k_rollout_bwd<PathTracking>', BWD_FLOP_PER_STATE, bwd_ms, bwd_n)
+                'algorithmic_bytes_per_launch': nbytes * B_PER_GPU,
+                'traffic_gbs': (tr / sec / 1e9) if tr else None,
+                'mfma_view': {'executed_f16_tflops': executed, 'peak_f16_tflops': F16_MFMA_PEAK_TFLOPS,
+                              'frac_f16': executed / F16_MFMA_PEAK_TFLOPS,
+                              'algorithmic_tflops': algorithmic, 'peak_fp32_mfma_tflops': FP32_MFMA_PEAK_TFLOPS,
+                              'algorithmic_over_fp32_mfma_peak': algorithmic / FP32_MFMA_PEAK_TFLOPS,
+                              'algorithmic_flop_per_launch': flop * B_PER_GPU}}
+    r_fwd = roof('k_rollout_fwd<PathTracking>', FWD_BYTES_PER_STATE, FWD_FLOP_PER_STATE, fwd_ms, fwd_n)
+    r_bwd = roof('k_rollout_bwd<PathTracking>', BWD_BYTES_PER_STATE, BWD_FLOP_PER_STATE, bwd_ms, bwd_n)
     dominant, other = (r_bwd, r_fwd) if bwd_ms >= fwd_ms else (r_fwd, r_bwd)   # the dominant kernel of the step
     out = {
         'metric': 'env-steps/sec + grad-steps/sec, PathTrackingEnv MPG n=25 batch=4096',
@@ -281,6 +301,7 @@ def main():
         'step_ms_median': per_step[len(per_step) // 2], 'step_ms_min': per_step[0], 'step_ms_max': per_step[-1],
         'step_ms_from': 'second pass of the same %d steps, one HIP event per step (not part of value)' % a.steps,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'dtype_note': 'float32 data and accumulation; the 256x256 hidden-layer products run as fp16 hi/lo split operands on the f16 matrix pipe (3 MFMAs per fp32-equivalent step, more accurate than the fp32 fma chain on a single layer; csrc/mlp_core.h)',
         'config': {'workload': 'PathTrackingEnv, MPG-v2 learner, n=25, M=1, 4096 vectorised envs + replay batch 4096 per '
                                'GPU; step = worker.sample(4096 env-steps) + add_batch + replay + compute_gradient + '
                                '(all-reduce) + apply_gradients',

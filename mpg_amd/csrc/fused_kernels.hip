@@ -27,13 +27,13 @@ __device__ __forceinline__ void load_w2(const float* pack, const float* W2, bool
 #define MPG_LOAD2(SMALL, IMAGE) do { MPG_UNPAREN SMALL; MPG_UNPAREN IMAGE; } while (0)
 #endif
 
-constexpr int SMEM_FLOATS = 2 * GROUP * LDA + GROUP * XS + NWAVE * GROUP * MAXOUT + GROUP * MAXOUT + NWAVE * GROUP * XS + 4 * GROUP;
+constexpr int SMEM_FLOATS = 2 * A_IMG + GROUP * XS + NWAVE * GROUP * MAXOUT + GROUP * MAXOUT + NWAVE * GROUP * XS + 4 * GROUP;
 struct Smem {
     float *sA, *sA1, *sX, *sPart, *sD3, *sPartX, *sQ;
     __device__ explicit Smem(float* base) {
         sA = base;
-        sA1 = sA + GROUP * LDA;
-        sX = sA1 + GROUP * LDA;
+        sA1 = sA + A_IMG;
+        sX = sA1 + A_IMG;
         sPart = sX + GROUP * XS;
         sD3 = sPart + NWAVE * GROUP * MAXOUT;
         sPartX = sD3 + GROUP * MAXOUT;

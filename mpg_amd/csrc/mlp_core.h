@@ -21,7 +21,8 @@ constexpr int H = 256;
 constexpr int NTHREAD = 512;
 constexpr int NWAVE = 8;
 constexpr int GROUP = 16;      // rows per row group
-constexpr int LDA = 280;       // row stride (floats) of the LDS A image
+constexpr int A_IMG = 4608;    // floats reserved per LDS A image region: >= GROUP*LDA (float32 image) and = 2 split-fp16 images
+constexpr int LDA = 280;       // row stride (floats) of the float32 LDS A image
 constexpr int KS = 68;         // stride between the 4 k-phases of a row; (LDA, KS) = (280, 68): b128 reads conflict-free, b32 writes 2-way (free)
 constexpr int XS = 8;          // row stride of the small LDS input block
 constexpr int MAXOUT = 2;      // outputs ever *used* (policy mean: act_dim <= 2; critic: 1)
@@ -48,7 +49,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #endif
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-constexpr int LDH = 264;                 // row stride (halves) of the two fp16 LDS A images (hi, lo); 2*16*264*2 B <= GROUP*LDA*4 B
+// LDS image of the split engine (halves): element (row, k), k = 32 kb + 8 kg + j, lives at kg*PLANE_H + row*ROW_H + 8 kb + j -
+// four planes by kg (plane stride = 0 mod 64 dwords), rows 36 dwords apart (9 mod 16 in units of 4 banks): the reader's
+// ds_read_b128 (lane = (row, kg), 8 consecutive k) is conflict-free in each of the instruction's four 16-lane groups (every
+// group holds each row once: MI355X_MICROARCH.md §LDS), the writer's ds_write_b32 pairs are 2-way (free).  Two images: hi, lo.
+constexpr int ROW_H = 72, PLANE_H = GROUP * ROW_H, IMG_H = 4 * PLANE_H;      // 4608 halves = 9216 B per image
+__device__ __forceinline__ int h_index(int row, int k) { return ((k >> 3) & 3) * PLANE_H + row * ROW_H + 8 * (k >> 5) + (k & 7); }
 constexpr float W_SCALE = 64.f;          // stationary weights are stored as W * 64
 constexpr float A_SCALE = 16.f;          // activations enter the LDS images as x * 16
 
@@ -178,7 +184,7 @@ __device__ __forceinline__ void store_c_to_a_f32(float* sA, const Lane& L, const
 }
 
 #ifdef MPG_SPLIT
-// Split engine: two fp16 images [16][LDH] (hi, then lo) in the same LDS region.  A lane owns (rows 4rg..4rg+3, column c)
+// Split engine: two fp16 images (hi, then lo; layout h_index) in the same LDS region.  A lane owns (rows 4rg..4rg+3, column c)
 // of each tile; columns c and c^1 are adjacent k, so the pair of lanes exchanges values through one DPP quad_perm and each
 // lane writes packed (k even, k odd) words: even lanes the rows j = 0,1, odd lanes the rows j = 2,3 - 8 ds_write_b32 per
 // lane like the float32 image, and the reader's 8 consecutive k are one aligned 16-byte read per image.
@@ -197,8 +203,8 @@ __device__ __forceinline__ void store_c_to_a(float* sA, const Lane& L, const flo
             const float x = odd ? p[2 + u] : v[t][u], y = odd ? v[t][2 + u] : p[u];   // (k even, k odd) of row row0 + u
             float hi, lo;
             split_pack2(x * A_SCALE, y * A_SCALE, hi, lo);
-            *reinterpret_cast<float*>(sH + (row0 + u) * LDH + k) = hi;
-            *reinterpret_cast<float*>(sH + GROUP * LDH + (row0 + u) * LDH + k) = lo;
+            *reinterpret_cast<float*>(sH + h_index(row0 + u, k)) = hi;
+            *reinterpret_cast<float*>(sH + IMG_H + h_index(row0 + u, k)) = lo;
         }
     }
 }
@@ -293,8 +299,8 @@ int wcache_w2_offset(const mpg_wcache_t* wc, int k);
 // acc0 / acc1 come in holding what is to be ADDED to the product (bias or zero) and leave holding the result.
 __device__ __forceinline__ void mfma_16x256x32(const float* sA, const Lane& L, const float (&w)[128], f32x4& acc0,
                                                f32x4& acc1) {
-    const _Float16* bh = reinterpret_cast<const _Float16*>(sA) + L.c * LDH + 8 * L.rg;   // hi image: row l&15, k = 8 (l>>4) + ..
-    const _Float16* bl = bh + GROUP * LDH;                                               // lo image
+    const _Float16* bh = reinterpret_cast<const _Float16*>(sA) + L.rg * PLANE_H + L.c * ROW_H;   // hi image: row l&15, k = 8 (l>>4) + ..
+    const _Float16* bl = bh + IMG_H;                                                             // lo image
 #ifdef MPG_AB_NOMFMA   // ablation build: one k-block instead of 8 (timing only)
     constexpr int NKB = 1;
 #else
@@ -306,7 +312,7 @@ __device__ __forceinline__ void mfma_16x256x32(const float* sA, const Lane& L, c
     f32x4 m0 = {0.f, 0.f, 0.f, 0.f}, m1 = m0;
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
-        const f16x8 ah = *reinterpret_cast<const f16x8*>(bh + 32 * kb), al = *reinterpret_cast<const f16x8*>(bl + 32 * kb);
+        const f16x8 ah = *reinterpret_cast<const f16x8*>(bh + 8 * kb), al = *reinterpret_cast<const f16x8*>(bl + 8 * kb);
         const int v0 = (kb * 2 + 0) * 2, v1 = (kb * 2 + 1) * 2;
         m0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, frag(v0), m0, 0, 0, 0);
         m1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, frag(v1), m1, 0, 0, 0);
@@ -398,12 +404,13 @@ template <int IN, int OU, bool FINAL_BARRIER = true>
 __device__ __forceinline__ void forward_group(const float* sX, float* sA, float* sPart, const Lane& L,
                                               const float (&w2)[128], const SmallRegs<IN, OU>& r,
                                               float (&h1)[2][4], float (&h2)[2][4], float* h1_stash = nullptr,
-                                              long stash_group = 0) {
-    {   // layer 1 on the matrix pipe too: K = IN <= 8 zero-padded = 2 k-steps (sX rows are zero beyond IN)
+                                              long stash_group = 0, const float* xa_regs = nullptr) {
+    {   // layer 1 on the matrix pipe too: K = IN <= 8 zero-padded = 2 k-steps (sX rows are zero beyond IN).
+        // xa_regs (optional, 2 floats): this lane's A operand x[row l&15][4q + (l>>4)] already in registers (no LDS round trip)
         f32x4 z0 = {r.b1[0], r.b1[0], r.b1[0], r.b1[0]}, z1 = {r.b1[1], r.b1[1], r.b1[1], r.b1[1]};
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const float xa = sX[L.c * XS + 4 * q + L.rg];
+            const float xa = xa_regs ? xa_regs[q] : sX[L.c * XS + 4 * q + L.rg];
             z0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, r.w1p[q][0], z0, 0, 0, 0);
             z1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, r.w1p[q][1], z1, 0, 0, 0);
         }

@@ -22,9 +22,9 @@ struct FwdArgs {
 
 template <int IN, int OU, bool PK>
 __global__ void __launch_bounds__(NTHREAD, 2) k_forward(const FwdArgs a) {
-    __shared__ __attribute__((aligned(16))) float smem[GROUP * LDA + GROUP * XS + NWAVE * GROUP * MAXOUT];
+    __shared__ __attribute__((aligned(16))) float smem[A_IMG + GROUP * XS + NWAVE * GROUP * MAXOUT];
     float* sA = smem;
-    float* sX = sA + GROUP * LDA;
+    float* sX = sA + A_IMG;
     float* sPart = sX + GROUP * XS;
     const Lane L;
     const Net net = make_net(a.params, a.in_dim, a.out_dim);
@@ -111,10 +111,10 @@ struct BwdArgs {
 
 template <int IN, int OU, bool WANT_DX, bool PK>
 __global__ void __launch_bounds__(NTHREAD, 2) k_backward(const BwdArgs a) {
-    __shared__ __attribute__((aligned(16))) float smem[2 * GROUP * LDA + GROUP * MAXOUT + NWAVE * GROUP * XS];
+    __shared__ __attribute__((aligned(16))) float smem[2 * A_IMG + GROUP * MAXOUT + NWAVE * GROUP * XS];
     float* sA = smem;
-    float* sA1 = sA + GROUP * LDA;
-    float* sD3 = sA1 + GROUP * LDA;
+    float* sA1 = sA + A_IMG;
+    float* sD3 = sA1 + A_IMG;
     float* sPartX = sD3 + GROUP * MAXOUT;
     const Lane L;
     const Net net = make_net(a.params, a.in_dim, a.out_dim);

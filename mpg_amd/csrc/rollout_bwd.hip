@@ -7,10 +7,10 @@ namespace {
 template <class ENV, bool PK>
 __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_bwd(const RollBwdArgs a) {
     constexpr int OBS = ENV::OBS, ACT = ENV::ACT, QIN = OBS + ACT;
-    __shared__ __attribute__((aligned(16))) float smem[2 * GROUP * LDA + GROUP * MAXOUT + NWAVE * GROUP * XS];
+    __shared__ __attribute__((aligned(16))) float smem[2 * A_IMG + GROUP * MAXOUT + NWAVE * GROUP * XS];
     float* sA = smem;
-    float* sA1 = sA + GROUP * LDA;
-    float* sD3 = sA1 + GROUP * LDA;
+    float* sA1 = sA + A_IMG;
+    float* sD3 = sA1 + A_IMG;
     float* sPartX = sD3 + GROUP * MAXOUT;
     // carry state of the 16 trajectory lanes between steps (adjoint of the next obs, record of the next step): kept in
     // LDS because registers are allocated for all 512 lanes while only 16 use them (the kernel sits at the 256 VGPR limit)

@@ -7,9 +7,9 @@ namespace {
 template <class ENV, bool PK>
 __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_fwd(const RollArgs a) {
     constexpr int OBS = ENV::OBS, ACT = ENV::ACT, QIN = OBS + ACT;
-    __shared__ __attribute__((aligned(16))) float smem[GROUP * LDA + GROUP * XS + NWAVE * GROUP * MAXOUT + MAXN * GROUP];
+    __shared__ __attribute__((aligned(16))) float smem[A_IMG + GROUP * XS + NWAVE * GROUP * MAXOUT + MAXN * GROUP];
     float* sA = smem;
-    float* sX = sA + GROUP * LDA;
+    float* sX = sA + A_IMG;
     float* sPart = sX + GROUP * XS;
     float* sEps = sPart + NWAVE * GROUP * MAXOUT;
     __shared__ float sGp[MAXN];

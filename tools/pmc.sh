@@ -20,7 +20,7 @@ import csv, glob, collections, json
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for p in sorted(glob.glob('$OUT/pass*/*/*counter_collection.csv')):
     for r in csv.DictReader(open(p)):
-        k = r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '')
+        k = r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '').replace('rollout::', '').replace('mlp::', '')
         k = k.split('(')[0]
         agg[k][r['Counter_Name']].append(float(r['Counter_Value']))
 names = sorted({c for d in agg.values() for c in d})
@@ -35,7 +35,7 @@ traffic = {}
 for k, d in agg.items():
     if 'FETCH_SIZE' in d and 'WRITE_SIZE' in d:
         f, wr = sum(d['FETCH_SIZE']) / len(d['FETCH_SIZE']), sum(d['WRITE_SIZE']) / len(d['WRITE_SIZE'])
-        traffic[k.split('<')[0].replace('mlp::', '')] = int((2 * f + wr) * 1024)
+        traffic[k.split('<')[0]] = int((2 * f + wr) * 1024)
 json.dump({'unit': 'bytes per launch', 'formula': '(2*FETCH_SIZE + WRITE_SIZE) KB, gfx950 correction for wide coalesced reads',
            'workload': 'bench.py N=1 B=4096 n=25', 'bytes_per_launch': traffic}, open('$OUT/pmc_traffic.json', 'w'), indent=1)
 for k in ('k_rollout_fwd', 'k_rollout_bwd', 'k_wgrad_multi'):
