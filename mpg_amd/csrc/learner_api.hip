@@ -252,7 +252,7 @@ extern "C" int mpg_q_loss_grad(const mpg_cfg_t* cfg, const float* q_params, int 
     MPG_CHECK_LAUNCH("k_q_err");
     rc = launch_backward(cfg, q_params, in, 1, 1, rows, dz3, 1, nullptr, 0, 0, 1.f, h1, h2, dz1, dz2, nullptr, nullptr, 0, s);
     if (rc) return rc;
-    return launch_wgrad(cfg, in, 1, 1, rows, xq, h1, h2, dz1, dz2, dz3, grad, slabs, s);
+    return launch_wgrad(cfg, in, 1, 1, rows, xq, h1, h2, dz1, dz2, dz3, inv_b_global, grad, slabs, s);
 }
 
 extern "C" size_t mpg_td3_policy_grad_workspace_bytes(const mpg_cfg_t* cfg, int rows) {
@@ -303,5 +303,5 @@ extern "C" int mpg_td3_policy_grad(const mpg_cfg_t* cfg, const float* policy_par
     rc = launch_backward(cfg, policy_params, od, 2 * ad, ad, rows, ga, ad, a, ad, po.out_tanh, po.out_scale, hp1, hp2, dz1, dz2, dz3,
                          nullptr, 0, s);
     if (rc) return rc;
-    return launch_wgrad(cfg, od, 2 * ad, ad, rows, xp, hp1, hp2, dz1, dz2, dz3, grad, slabs, s);
+    return launch_wgrad(cfg, od, 2 * ad, ad, rows, xp, hp1, hp2, dz1, dz2, dz3, inv_b_global, grad, slabs, s);
 }

@@ -8,6 +8,7 @@ namespace mlp {
 
 struct WgradArgs {
     int in_dim, out_dim, rows, groups_per_chunk;
+    float dz_scale;         // split engine: power of two that brings dz2 to O(1) (wgrad_dz_scale)
     XSpec x;
     const float *h1, *h2, *dz1, *dz2, *dz3;
     float* slabs;
@@ -82,19 +83,28 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int sl, con
             for (int i = 0; i < IN; ++i) x[i] = rowp[i];
 #pragma unroll
             for (int o = 0; o < OU; ++o) d3[o] = rowp[8 + o];
-            gb1[0] += t.d10[j]; gb1[1] += t.d11[j];
-            gb2[0] += t.d20[j]; gb2[1] += t.d21[j];
+            // Every multiply-add of this block is ONE hand-written single-precision instruction.  Left to the compiler
+            // they become packed v_pk_fma_f32 / v_pk_add_f32 (op_sel forms), and in k_wgrad_multi single products were then
+            // lost nondeterministically: first the (row 13, even i) terms of dW1 in ~85 % of launches, after dW1 was
+            // unpacked the t = 1 half of dW3 in ~5 % (found by the repeated-launch determinism
+            // check, not reproduced in isolation by tools/proto/pk_hazard.hip; a build without packed fp32 is clean).
+#define MPG_FMAC(acc, a_, b_) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(acc) : "v"(a_), "v"(b_))
+#define MPG_ADD(acc, a_) asm volatile("v_add_f32 %0, %0, %1" : "+v"(acc) : "v"(a_))
+            MPG_ADD(gb1[0], t.d10[j]); MPG_ADD(gb1[1], t.d11[j]);
+            MPG_ADD(gb2[0], t.d20[j]); MPG_ADD(gb2[1], t.d21[j]);
 #pragma unroll
             for (int i = 0; i < IN; ++i) {
-                gW1[0][i] = fmaf(x[i], t.d10[j], gW1[0][i]);
-                gW1[1][i] = fmaf(x[i], t.d11[j], gW1[1][i]);
+                MPG_FMAC(gW1[0][i], x[i], t.d10[j]);
+                MPG_FMAC(gW1[1][i], x[i], t.d11[j]);
             }
 #pragma unroll
             for (int o = 0; o < OU; ++o) {
-                gW3[0][o] = fmaf(t.h20[j], d3[o], gW3[0][o]);
-                gW3[1][o] = fmaf(t.h21[j], d3[o], gW3[1][o]);
+                MPG_FMAC(gW3[0][o], t.h20[j], d3[o]);
+                MPG_FMAC(gW3[1][o], t.h21[j], d3[o]);
                 if (L.c == 0) gb3[o] += d3[o];
             }
+#undef MPG_FMAC
+#undef MPG_ADD
         }
         __builtin_amdgcn_wave_barrier();
     };
@@ -106,10 +116,105 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int sl, con
 #endif
 
     // ---- dW2 on the matrix pipe.  A operand: this wave's 32 rows of dW2 = 2 fragments of H1 per row group, straight
-    //      from the stash (HBM / Infinity Cache, ~1.5 us away: a ring of 2 groups per wave x 4 resident waves per SIMD
-    //      keeps 8 groups in flight).  B operand: the workgroup's 32-column slice of DZ2 - the SAME two fragments for
-    //      all eight waves, so they go through LDS: each wave fetches them for one group of an 8-group tile and every
-    //      wave reads the tile back (the kernel is bound by L2 -> CU traffic: this removes 7/16 of it). ----
+    //      from the stash (HBM / Infinity Cache, ~1.5 us away).  B operand: the workgroup's 32-column slice of DZ2 - the
+    //      SAME two fragments for all eight waves, so they go through LDS: each wave fetches them for one group of an
+    //      8-group tile and every wave reads the tile back (this removes 7/16 of the L2 -> CU traffic). ----
+#ifdef MPG_SPLIT
+    // Split-fp16 form (mlp_core.h): the contraction index is the batch row, 32 rows = TWO row groups per
+    // v_mfma_f32_16x16x32_f16: lane (c, rg) supplies rows 4rg..4rg+3 of both groups of a pair - exactly the two float4 it
+    // loads from the G16 stash - as hi/lo halves; three MFMAs (hi*hi, hi*lo, lo*hi) per tile pair.  H1 enters as x*16, DZ2 as
+    // dz * dz_scale (a power of two from the launcher, ~1/inv_b: dz carries the 1/B of the mean), undone at the end.
+    auto split8 = [](const f32x4& u, const f32x4& v, float sc, f16x8& hi, f16x8& lo) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float a = u[j] * sc, b = v[j] * sc;
+            hi[j] = (_Float16)a; hi[4 + j] = (_Float16)b;
+            lo[j] = (_Float16)(a - (float)hi[j]); lo[4 + j] = (_Float16)(b - (float)hi[4 + j]);
+        }
+    };
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 fa[2][2];                                       // [group of the pair][A tile]: raw floats of the NEXT pair
+    auto a_load = [&](long g) {                            // pair (g, g + 1)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const bool ok = g + e < g1;
+            fa[e][0] = ok ? H1[((g + e) * 16 + 2 * L.wave) * 64 + L.lane] : zero4;
+            fa[e][1] = ok ? H1[((g + e) * 16 + 2 * L.wave + 1) * 64 + L.lane] : zero4;
+        }
+    };
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2* sB2 = reinterpret_cast<f32x2*>(sRed);          // 8-byte slots: (((pair*2 + tile)*2 + part)*64 + lane)*2 + (group & 1)
+    a_load(g0);
+#ifdef MPG_AB_WG_NOMFMA
+    for (long tile = g0; tile < g0; tile += NWAVE) {
+#else
+    for (long tile = g0; tile < g1; tile += NWAVE) {
+#endif
+        const long gb = tile + L.wave;
+        f32x4 b0 = zero4, b1 = zero4;
+        if (gb < g1) {
+            b0 = DZ2[(gb * 16 + 2 * sl) * 64 + L.lane];
+            b1 = DZ2[(gb * 16 + 2 * sl + 1) * 64 + L.lane];
+        }
+        // this wave's group of the tile, split once for all eight readers
+        f32x2 bh[2], bl[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const f32x4& b = t == 0 ? b0 : b1;
+            _Float16 h[4], l[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float x = b[j] * a.dz_scale;
+                h[j] = (_Float16)x;
+                l[j] = (_Float16)(x - (float)h[j]);
+            }
+            typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+            bh[t] = __builtin_bit_cast(f32x2, f16x4{h[0], h[1], h[2], h[3]});
+            bl[t] = __builtin_bit_cast(f32x2, f16x4{l[0], l[1], l[2], l[3]});
+        }
+        __syncthreads();                                  // the previous tile has been read by every wave
+        {
+            const int pr = L.wave >> 1, e = L.wave & 1;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                sB2[(((pr * 2 + t) * 2 + 0) * 64 + L.lane) * 2 + e] = bh[t];
+                sB2[(((pr * 2 + t) * 2 + 1) * 64 + L.lane) * 2 + e] = bl[t];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int pr = 0; pr < NWAVE / 2; ++pr) {
+            const long g = tile + 2 * pr;
+            if (g < g1) {
+                f16x8 ah[2], al[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) split8(fa[0][u], fa[1][u], A_SCALE, ah[u], al[u]);
+                a_load(g + 2);                             // the next pair (zeros beyond the chunk)
+                const f32x4* sB4 = reinterpret_cast<const f32x4*>(sRed);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const f16x8 fbh = __builtin_bit_cast(f16x8, sB4[((pr * 2 + t) * 2 + 0) * 64 + L.lane]);
+                    const f16x8 fbl = __builtin_bit_cast(f16x8, sB4[((pr * 2 + t) * 2 + 1) * 64 + L.lane]);
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[u], fbh, acc[u][t], 0, 0, 0);
+                        acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[u], fbl, acc[u][t], 0, 0, 0);
+                        acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[u], fbh, acc[u][t], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    {
+        const float un = 1.f / (A_SCALE * a.dz_scale);
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[u][t][j] *= un;
+    }
+#else
     constexpr int DEPTH = 2;
     f32x4 fa0[DEPTH], fa1[DEPTH];
     auto a_load = [&](long g, int slot) {
@@ -152,6 +257,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int sl, con
             }
         }
     }
+#endif
     __syncthreads();                                      // the staging corners of the thin part alias the B tile
     // thin pieces after the matrix loop (their registers are then free): the chunk's groups are dealt round-robin to
     // the 8 waves; the load latency is covered by the other resident waves
@@ -238,6 +344,14 @@ __device__ __forceinline__ void wgrad_map(int b, int nch, int& chunk, int& sl) {
         chunk = b >> 3;
         sl = b & 7;
     }
+}
+
+// dz carries the 1/B_global of the loss mean (and the 1/M of the tile mean): the power of two next to its inverse brings the
+// fp16 split operands of the weight-gradient product to O(1)
+inline float wgrad_dz_scale(float inv_b) {
+    float s = 1.f;
+    while (s * inv_b < 1.f && s < 1073741824.f) s *= 2.f;
+    return s;
 }
 
 constexpr int WGRAD_MAX_CHUNKS = 32;      // chunk slabs per network (16 and 64 measure the same, tools/ab_wgrad.sh history)

@@ -263,7 +263,7 @@ extern "C" int mpg_rollout_pg(const mpg_cfg_t* cfg, const float* policy_params, 
     const int T = all_steps_param_grad ? n + 1 : 1;
     XSpec xs = xspec(SA, od, nullptr, 0, cfg->obs_scale, od);
     xs.ld0 = SAW;
-    return launch_wgrad(cfg, od, 2 * ad, ad, (int)(T * R), xs, H1, H2, DZ1, DZ2, DZ3, grad, slabs, s);
+    return launch_wgrad(cfg, od, 2 * ad, ad, (int)(T * R), xs, H1, H2, DZ1, DZ2, DZ3, inv_b_global / (float)M, grad, slabs, s);
 }
 
 extern "C" size_t mpg_rollout_q_target_workspace_bytes(const mpg_cfg_t* cfg, int rows) {
@@ -510,13 +510,14 @@ extern "C" int mpg_mpg_gradients(const mpg_cfg_t* cfg, int n_q, const float* par
     for (int k = 0; k < n_q; ++k) {
         jobs[k].in_dim = qin; jobs[k].out_dim = 1; jobs[k].ou = 1; jobs[k].rows = rows; jobs[k].x = xq;
         jobs[k].h1 = st[k].h1; jobs[k].h2 = st[k].h2; jobs[k].dz1 = st[k].dz1; jobs[k].dz2 = st[k].dz2; jobs[k].dz3 = st[k].dz3;
+        jobs[k].inv_b = inv_b_global;
         jobs[k].grad = gq[k]; jobs[k].slabs = slab_q[k];
     }
     WgradJob& jp = jobs[n_q];
     jp.in_dim = od; jp.out_dim = 2 * ad; jp.ou = ad; jp.rows = rows;
     jp.x = xspec(SA, od, nullptr, 0, cfg->obs_scale, od);
     jp.x.ld0 = SAW;
-    jp.h1 = H1; jp.h2 = H2; jp.dz1 = DZ1; jp.dz2 = DZ2; jp.dz3 = DZ3; jp.grad = gp; jp.slabs = slab_p;
+    jp.h1 = H1; jp.h2 = H2; jp.dz1 = DZ1; jp.dz2 = DZ2; jp.dz3 = DZ3; jp.inv_b = inv_b_global; jp.grad = gp; jp.slabs = slab_p;
     const int ngroups = rows / GROUP;
     SumJob sums[8];
     int ns = 0;

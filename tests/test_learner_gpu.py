@@ -172,6 +172,37 @@ def test_bench_size_cases_vs_reference(golden, name):
         assert int(pw.nonfinite.sum().item()) == 0
 
 
+@pytest.mark.parametrize('name,reps', [('c2_mpg_v2_B4096', 3000), ('c3_nadp_B8192', 600), ('c4_td3_B65536', 200)])
+def test_repeated_launches_are_bit_identical(name, reps):
+    """The same gradient computation launched `reps` times must return the same bits every time.  This is the check that
+    exposed the lost packed-FMA products of the round-2 weight-gradient kernel (one 16-column run of
+    dW1 off by a single row's product in most launches, invisible to a tolerance of 1e-4 and to a two-launch comparison)."""
+    from mpg_amd.config import default_args
+    from mpg_amd.learners import MPGLearner, NADPLearner, TD3Learner
+    from mpg_amd.policy import PolicyWithQs
+    from tests.golden_inputs import bench_case_inputs
+    d = bench_case_inputs(name)
+    B = d['B']
+    flat = {k: np.concatenate([np.asarray(w).ravel() for w in v]).astype(np.float32) for k, v in d['nets'].items()}
+    batch = [dev(x) for x in d['batch']]
+    if d['kind'] == 'MPG-v2':
+        learner, it, kw = MPGLearner(PolicyWithQs, default_args('MPG-v2', replay_batch_size=B, num_batch_reuse=1)), 100, dict(eps=dev(d['eps']))
+    elif d['kind'] == 'NADP':
+        learner, it, kw = NADPLearner(PolicyWithQs, default_args('NADP', replay_batch_size=B)), 0, dict(eps_q=dev(d['eps_q']), eps_pi=dev(d['eps_pi']))
+    else:
+        learner, it, kw = TD3Learner(PolicyWithQs, default_args('TD3', replay_batch_size=B)), 0, dict(smooth_eps=dev(d['smooth_eps']))
+    pw = learner.policy_with_value
+    w = np.concatenate([flat[n] for n in pw.names])
+    pw.set_flat(w, (w * np.float32(0.97)).astype(np.float32))
+
+    def run():
+        learner.counter = 0
+        return torch.cat([x.reshape(-1) for x in learner.compute_gradient(batch, None, None, it, **kw)])
+    ref = torch.stack([run().clone() for _ in range(5)]).median(0).values
+    differing = torch.stack([(run() != ref).any() for _ in range(reps)]).sum().item()
+    assert differing == 0, '%d of %d launches differ from the majority result' % (differing, reps)
+
+
 def test_replay_buffer_ring_and_gather_bit_exact():
     from mpg_amd.buffer import ReplayBuffer
     from mpg_amd.config import default_args
