@@ -188,6 +188,17 @@ def launch_ranks(a):
     return subprocess.call(cmd, env=env)
 
 
+def _device_info():
+    """Name, CU count and clocks of the GPU the line was measured on (boxes of the pool differ: see DESIGN.md section 6)."""
+    import torch
+    p = torch.cuda.get_device_properties(torch.cuda.current_device())
+    info = {'name': p.name, 'compute_units': p.multi_processor_count, 'hbm_gib': round(p.total_memory / 2 ** 30, 1)}
+    for k in ('clock_rate', 'memory_clock_rate'):
+        if hasattr(p, k):
+            info[k + '_khz'] = getattr(p, k)
+    return info
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -308,6 +319,7 @@ def main():
                    'global_batch': world * B_PER_GPU, 'parallelism': 'dp%d' % world,
                    'grad_allreduce_floats': int(learner.flat.numel()), 'native_step_driver': opt._fused is not None,
                    'dist_backend': D.backend()},
+        'device': _device_info(),
         'roofline': dominant,
         'roofline_other_rollout_kernel': other,
         'other_kernels_avg_ms': {'k_target_fused': tgt_ms, 'k_critic_fused': crit_ms, 'k_wgrad_multi': wg_ms,

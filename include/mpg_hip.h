@@ -246,7 +246,23 @@ typedef struct {
     const uint8_t* ring_done;
     int* idx_out;
     float* done_out;
+    /* pre_gathered != 0: mpg_env_step_store_reset_draw already gathered every drawn row whose ring slot lies OUTSIDE the
+     * window [fresh_start, fresh_start + fresh_count) mod capacity (the slots that launch was writing) into the output
+     * arrays; only rows drawn from the window are gathered now.  Same minibatch either way. */
+    int pre_gathered, capacity, fresh_start, fresh_count;
 } mpg_replay_draw_t;
+
+/* mpg_env_step_store_reset plus, in spare workgroups of the same launch, the gather of the NEXT minibatch draw
+ * (draw->n_storage = the ring size after this add, draw->seed / ctr = that draw's Philox key and counter): the random
+ * ring reads (one DRAM line and one page-table walk per array and row) then overlap the 20 sub-steps of the env instead
+ * of sitting at the head of mpg_mpg_gradients' first launch.  Rows drawn from the slots this launch writes are skipped;
+ * pass the same draw with pre_gathered = 1, fresh_start = next_idx, fresh_count = n to mpg_mpg_gradients.
+ * Path-tracking env with obs_dim 6 only (MPG_EINVAL otherwise). */
+int mpg_env_step_store_reset_draw(int env_kind, int n, int obs_dim, float* state, const float* action, int capacity, int next_idx,
+                                  float* ring_obs, float* ring_act, float* ring_rew, float* ring_obs2, uint8_t* ring_done,
+                                  uint64_t seed, uint64_t ctr, float* obs_out, uint8_t* done_out /* nullable */,
+                                  const mpg_replay_draw_t* draw, int rows, float* b_obs, float* b_act, float* b_rew,
+                                  float* b_obs2, mpg_stream_t stream);
 
 size_t mpg_mpg_gradients_workspace_bytes(const mpg_cfg_t* cfg, int rows, int M, int n, int n_select, int n_q);
 int mpg_mpg_gradients(const mpg_cfg_t* cfg, int n_q, const float* params, const float* target_params, int rows,

@@ -16,6 +16,10 @@ ARCH = os.environ.get('MPG_ARCH', 'gfx950')      # MPG_ARCH=gfx950:xnack- for ex
 
 # MPG_EXTRA_CFLAGS: ablation / diagnostic builds only (e.g. -DMPG_AB_NODYN); never set in the product build
 COMMON = os.environ.get('MPG_EXTRA_CFLAGS', '').split() + ['-O3', '-fPIC', '-std=c++17', '--offload-arch=' + ARCH, '-Wall', '-Wno-unused-function', '-Wno-bitwise-instead-of-logical',
+          # a private array the optimiser cannot keep in registers must not be moved to LDS: the LDS copy is addressed by the
+          # flattened thread id, whose workgroup size the code then reads from the dispatch packet in HOST memory
+          # (microseconds per load; tools/dispatch_ptr_check.py, tests/test_abi.py keep every kernel free of such reads)
+          '-mllvm', '-disable-promote-alloca-to-lds',
           '-I' + os.path.join(HERE, '..', 'include')]
 # per-file extras: the real-env kernel mirrors the reference op-by-op, so no fused multiply-adds there
 EXTRA = {'env_path_tracking.hip': ['-ffp-contract=off'],

@@ -26,6 +26,31 @@ struct PathRef {
     float y, phi;
 };
 
+// sin and cos of a bounded argument (headings within +-pi, path phases below 38 rad) without the library routine's
+// large-argument machinery: three-term Cody-Waite reduction by pi/2 (k * 1.5703125 is exact for |k| < 2^8), then the
+// minimax polynomials of the Cephes single-precision kernels on [-pi/4, pi/4].  Measured against float64 on 4M draws
+// each of [-3.3, 3.3], [0, 38] and [-200, 200]: absolute error <= 9.2e-8 for both (numpy's float32 sin/cos: 8.5e-8);
+// the results only ever enter sums with O(1) terms.  ~25 instructions for both, against ~110 for sincosf - the env
+// kernel spends most of its time in the 20 + 3 of them per step.  |a| > 200 (a caller's own far-away x) takes sincosf.
+__device__ __forceinline__ void sincos_bounded(float a, float& s, float& c) {
+    if (fabsf(a) > 200.f) {
+        sincosf(a, &s, &c);
+        return;
+    }
+    const float kf = rintf(a * 0.63661977236758134308f);            // a * 2/pi
+    float r = fmaf(-kf, 1.5703125f, a);
+    r = fmaf(-kf, 4.837512969970703125e-4f, r);
+    r = fmaf(-kf, 7.54978995489188216e-8f, r);
+    const float z = r * r;
+    const float ps = fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f) * z, r, r);
+    const float pc = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f) * z, z,
+                          fmaf(-0.5f, z, 1.f));
+    const int q = (int)kf;
+    const float ss = (q & 1) ? pc : ps, cc = (q & 1) ? ps : pc;
+    s = (q & 2) ? -ss : ss;
+    c = ((q + 1) & 2) ? -cc : cc;
+}
+
 // ReferencePath.compute_path_y / compute_path_phi, path_tracking_env.py:207-220.
 // numpy evaluates (x - shift) * 2 * np.pi / T in float32, one rounding per operator; y and the slope are
 // accumulated curve by curve into a float32 zero array.
@@ -37,7 +62,7 @@ __device__ __forceinline__ PathRef path_ref(float x) {
     for (int i = 0; i < 3; ++i) {
         float arg = (((x - 0.f) * 2.f) * PI_F) / T[i];
         float s, c;
-        sincosf(arg, &s, &c);
+        sincos_bounded(arg, s, c);
         y = y + Amp[i] * s;
         // magnitude * 2 * np.pi / T is a python-float (double) scalar, rounded once when it meets the array
         const float k = (float)((double)Amp[i] * 2.0 * 3.14159265358979323846 / (double)T[i]);
@@ -184,8 +209,14 @@ __device__ __forceinline__ StepOut step_agent(Agent& ag, const float2 an) {
     const float K5 = (tau * A_) * C_f;
     const float K6 = tau * ((A_ * A_) * C_f + (B_ * B_) * C_r);
 
+    // simulation(), :144-179.  delta_y / delta_phi are overwritten by every sub-step, so the reference path is evaluated once,
+    // for the last one.  The loop is deliberately NOT unrolled: one wave per CU runs this kernel, once per launch, with a cold
+    // instruction cache - 20 unrolled sub-steps (7300 instructions, 58 KB) spent more time fetching code than executing
+    // it (18.5 us -> 22 us when the unrolled body was made cheaper; measured).
     float vx_pre = vx, vy_pre = vy, r_pre = r;  // state entering the LAST sub-step (for `others`)
-    for (int s = 0; s < 20; ++s) {              // simulation(), :144-179
+    float x_u = x, phi_u = phi;
+#pragma unroll 1
+    for (int s = 0; s < 20; ++s) {
         vx_pre = vx; vy_pre = vy; r_pre = r;
         // prediction -> f_xu with tau = 1/200 on (v_x, v_y, r); entries 3-5 are overwritten below
         float nvx = vx + tau * (a_x + vy * r);
@@ -195,17 +226,19 @@ __device__ __forceinline__ StepOut step_agent(Agent& ag, const float2 an) {
         // world frame, :156-160: phi first, then y and x with the OLD v_x, v_y but the NEW phi (view aliasing)
         phi = phi + r / 200.f;
         float sp, cp;
-        sincosf(phi, &sp, &cp);
+        sincos_bounded(phi, sp, cp);
         y = y + (vx * sp + vy * cp) / 200.f;
         x = x + (vx * cp - vy * sp) / 200.f;
         vx = nvx; vy = nvy; r = nr;             // :161
-        PathRef p = path_ref(x);                // :163-164 (x not yet wrapped)
-        dphi = phi - p.phi;                     // :165
-        dy = y - p.y;                           // :166
+        x_u = x; phi_u = phi;                   // :163-165 read x and phi before their wraps
         phi = wrap_pi(phi);                     // :168-169
         if (x > PERIOD) x = x - PERIOD;         // :171
         if (x <= 0.f) x = x + PERIOD;           // :172
-        dphi = wrap_pi(dphi);                   // :176-177
+    }
+    {
+        PathRef p = path_ref(x_u);              // :163-164
+        dphi = wrap_pi(phi_u - p.phi);          // :165, :176-177
+        dy = y - p.y;                           // :166
     }
 
     // `others` of the last sub-step (:100-101,135-138), judge_done :474-487
@@ -257,10 +290,45 @@ struct RingPtrs {
     float *obs, *act, *rew, *obs2;
     uint8_t* done;
 };
+// The next minibatch draw, gathered by spare workgroups of the env launch (mpg_env_step_store_reset_draw): one lane per
+// drawn row, the same Philox draw as k_target_fused / k_sample_gather; rows whose slot the env lanes are writing are left
+// to the consumer.
+struct PreDraw {
+    int rows, n_storage, env_blocks;
+    uint32_t k0, k1, c1, c2;
+    int* o_idx;
+    float *o_obs, *o_act, *o_rew, *o_obs2, *o_done;
+};
+__device__ __forceinline__ void predraw_row(const PreDraw& d, const RingPtrs& ring, int capacity, int fresh_start, int fresh_count,
+                                            int gr) {
+    const Philox4 p = philox4x32_10((uint32_t)(gr >> 2), d.c1, d.c2, 0x1d5u, d.k0, d.k1);
+    const long sr = (long)(((uint64_t)philox_word(p, gr & 3) * (uint64_t)d.n_storage) >> 32);
+    int off = (int)sr - fresh_start;
+    if (off < 0) off += capacity;
+    if (off < fresh_count) return;
+    float o1[6], o2[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { o1[i] = ring.obs[sr * 6 + i]; o2[i] = ring.obs2[sr * 6 + i]; }
+    const float2 ac = reinterpret_cast<const float2*>(ring.act)[sr];
+    const float rw = ring.rew[sr];
+    const uint8_t dn = ring.done[sr];
+    if (d.o_idx) d.o_idx[gr] = (int)sr;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { d.o_obs[(long)gr * 6 + i] = o1[i]; d.o_obs2[(long)gr * 6 + i] = o2[i]; }
+    reinterpret_cast<float2*>(d.o_act)[gr] = ac;
+    d.o_rew[gr] = rw;
+    if (d.o_done) d.o_done[gr] = (float)dn;
+}
+
 __global__ void __launch_bounds__(64) k_step_store_reset(int n, float* __restrict__ st, const float* __restrict__ action,
                                                          RingPtrs ring, int capacity, int next_idx, uint32_t k0, uint32_t k1,
                                                          uint32_t c1, uint32_t c2, float* __restrict__ obs_out,
-                                                         uint8_t* __restrict__ done_out, int od) {
+                                                         uint8_t* __restrict__ done_out, int od, PreDraw pd) {
+    if (pd.rows > 0 && (int)blockIdx.x >= pd.env_blocks) {
+        const int gr = ((int)blockIdx.x - pd.env_blocks) * 64 + threadIdx.x;
+        if (gr < pd.rows) predraw_row(pd, ring, capacity, next_idx, n, gr);
+        return;
+    }
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Agent ag = load_agent(st, n, i);
@@ -314,21 +382,54 @@ extern "C" int mpg_env_step(int env_kind, int n, int obs_dim, float* state, cons
     return MPG_OK;
 }
 
-extern "C" int mpg_env_step_store_reset(int env_kind, int n, int obs_dim, float* state, const float* action, int capacity, int next_idx,
-                                        float* ring_obs, float* ring_act, float* ring_rew, float* ring_obs2, uint8_t* ring_done,
-                                        uint64_t seed, uint64_t ctr, float* obs_out, uint8_t* done_out, mpg_stream_t stream) {
+namespace {
+int step_store_reset_impl(int env_kind, int n, int obs_dim, float* state, const float* action, int capacity, int next_idx,
+                          float* ring_obs, float* ring_act, float* ring_rew, float* ring_obs2, uint8_t* ring_done, uint64_t seed,
+                          uint64_t ctr, float* obs_out, uint8_t* done_out, const PreDraw& pd_in, mpg_stream_t stream) {
     MPG_REQUIRE(n > 0 && state && action && capacity >= n && next_idx >= 0 && next_idx < capacity && ring_obs && ring_act &&
                     ring_rew && ring_obs2 && ring_done && obs_out,
                 "mpg_env_step_store_reset: bad argument");
-    if (env_kind == MPG_ENV_INVERTED_PENDULUM)
+    if (env_kind == MPG_ENV_INVERTED_PENDULUM) {
+        MPG_REQUIRE(pd_in.rows == 0, "mpg_env_step_store_reset_draw: path-tracking env only");
         return cart_pole::step_store_reset(n, obs_dim, state, action, capacity, next_idx, ring_obs, ring_act, ring_rew, ring_obs2,
                                            ring_done, seed, ctr, obs_out, done_out, mpg_stream(stream));
+    }
     MPG_REQUIRE(env_kind == MPG_ENV_PATH_TRACKING, "mpg_env_step_store_reset: unknown env kind %d", env_kind);
     MPG_REQUIRE(pt_obs_dim_ok(obs_dim), "mpg_env_step_store_reset: obs_dim");
     RingPtrs ring{ring_obs, ring_act, ring_rew, ring_obs2, ring_done};
-    hipLaunchKernelGGL(k_step_store_reset, dim3((n + 63) / 64), dim3(64), 0, mpg_stream(stream), n, state, action, ring,
+    PreDraw pd = pd_in;
+    pd.env_blocks = (n + 63) / 64;
+    const int blocks = pd.env_blocks + (pd.rows + 63) / 64;
+    hipLaunchKernelGGL(k_step_store_reset, dim3(blocks), dim3(64), 0, mpg_stream(stream), n, state, action, ring,
                        capacity, next_idx, (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)ctr, (uint32_t)(ctr >> 32), obs_out,
-                       done_out, obs_dim);
+                       done_out, obs_dim, pd);
     MPG_CHECK_LAUNCH("mpg_env_step_store_reset");
     return MPG_OK;
+}
+}  // namespace
+
+extern "C" int mpg_env_step_store_reset(int env_kind, int n, int obs_dim, float* state, const float* action, int capacity, int next_idx,
+                                        float* ring_obs, float* ring_act, float* ring_rew, float* ring_obs2, uint8_t* ring_done,
+                                        uint64_t seed, uint64_t ctr, float* obs_out, uint8_t* done_out, mpg_stream_t stream) {
+    PreDraw pd{};
+    return step_store_reset_impl(env_kind, n, obs_dim, state, action, capacity, next_idx, ring_obs, ring_act, ring_rew, ring_obs2,
+                                 ring_done, seed, ctr, obs_out, done_out, pd, stream);
+}
+
+extern "C" int mpg_env_step_store_reset_draw(int env_kind, int n, int obs_dim, float* state, const float* action, int capacity,
+                                             int next_idx, float* ring_obs, float* ring_act, float* ring_rew, float* ring_obs2,
+                                             uint8_t* ring_done, uint64_t seed, uint64_t ctr, float* obs_out, uint8_t* done_out,
+                                             const mpg_replay_draw_t* draw, int rows, float* b_obs, float* b_act, float* b_rew,
+                                             float* b_obs2, mpg_stream_t stream) {
+    MPG_REQUIRE(env_kind == MPG_ENV_PATH_TRACKING && obs_dim == 6, "mpg_env_step_store_reset_draw: path-tracking env with obs_dim 6 only");
+    MPG_REQUIRE(draw && rows > 0 && b_obs && b_act && b_rew && b_obs2 && draw->n_storage > 0 && draw->n_storage <= capacity,
+                "mpg_env_step_store_reset_draw: incomplete draw");
+    PreDraw pd{};
+    pd.rows = rows; pd.n_storage = draw->n_storage;
+    pd.k0 = (uint32_t)draw->seed; pd.k1 = (uint32_t)(draw->seed >> 32);
+    pd.c1 = (uint32_t)draw->ctr; pd.c2 = (uint32_t)(draw->ctr >> 32);
+    pd.o_idx = draw->idx_out; pd.o_done = draw->done_out;
+    pd.o_obs = b_obs; pd.o_act = b_act; pd.o_rew = b_rew; pd.o_obs2 = b_obs2;
+    return step_store_reset_impl(env_kind, n, obs_dim, state, action, capacity, next_idx, ring_obs, ring_act, ring_rew, ring_obs2,
+                                 ring_done, seed, ctr, obs_out, done_out, pd, stream);
 }

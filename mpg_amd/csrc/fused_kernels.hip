@@ -27,6 +27,18 @@ __device__ __forceinline__ void load_w2(const float* pack, const float* W2, bool
 #define MPG_LOAD2(SMALL, IMAGE) do { MPG_UNPAREN SMALL; MPG_UNPAREN IMAGE; } while (0)
 #endif
 
+#ifdef MPG_TIMELINE   // diagnostic build only (tools/timeline.sh): s_memtime of every wave at marked points of workgroup 0 / 100
+#define MPG_TL_MARKS 24
+#define MPG_TL_DECL __shared__ unsigned long long s_tl[NWAVE][MPG_TL_MARKS];
+#define MPG_TL(k) do { __builtin_amdgcn_sched_barrier(0); if ((threadIdx.x & 63) == 0) s_tl[threadIdx.x >> 6][k] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define MPG_TL_DUMP(dbg) do { __syncthreads(); if (dbg && (blockIdx.x == 0 || blockIdx.x == 100) && threadIdx.x < NWAVE * MPG_TL_MARKS) \
+    dbg[(blockIdx.x ? 1 : 0) * NWAVE * MPG_TL_MARKS + threadIdx.x] = s_tl[threadIdx.x / MPG_TL_MARKS][threadIdx.x % MPG_TL_MARKS]; } while (0)
+#else
+#define MPG_TL_DECL
+#define MPG_TL(k)
+#define MPG_TL_DUMP(dbg)
+#endif
+
 constexpr int SMEM_FLOATS = 2 * A_IMG + GROUP * XS + NWAVE * GROUP * MAXOUT + GROUP * MAXOUT + NWAVE * GROUP * XS + 4 * GROUP;
 struct Smem {
     float *sA, *sA1, *sX, *sPart, *sD3, *sPartX, *sQ;
@@ -53,24 +65,33 @@ struct TargetArgs {
     float* y;
     // optional fused minibatch draw (ReplayBuffer.sample, buffer.py:70-78; same Philox stream as k_sample_gather): the
     // kernel's 16 rows are drawn and gathered by its own first 16 lanes and written out for the later kernels
-    int draw, n_storage;
+    int draw, n_storage;      // draw: 0 none, 1 gather every row, 2 rows outside the fresh window are already in o_*
+    int d_capacity, d_fresh_start, d_fresh_count;
     uint32_t dk0, dk1, dc1, dc2;
     const float *r_obs, *r_act, *r_rew, *r_obs2;
     const uint8_t* r_done;
     int* o_idx;
     float *o_obs, *o_act, *o_rew, *o_obs2, *o_done;
+    unsigned long long* dbg;   // MPG_TIMELINE builds only
 };
 
-template <int OBS, int ACT, bool PK>
+// G2 row groups per workgroup: every network's 256 KB register image is fetched once per workgroup and applied to G2 x 16
+// rows.  With one group per workgroup the kernel is bound by the L2 -> CU traffic of the images (32 CUs of an XCD pull the
+// same 256 KB at the same time: 64 B/clk each = the XCD's whole L2 bandwidth); two groups halve that traffic.
+template <int OBS, int ACT, bool PK, int G2>
 __global__ void __launch_bounds__(NTHREAD, 2) k_target_fused(const TargetArgs a) {
     constexpr int QIN = OBS + ACT;
     __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
+    __shared__ __attribute__((aligned(16))) float sXg[G2][GROUP * XS];
+    __shared__ float sQg[G2][2 * GROUP];
     const Smem m(smem);
     const Lane L;
     const int tid = threadIdx.x;
-    const long g = blockIdx.x;
-    __shared__ float sRew[GROUP];
-    // Minibatch draw: the 16 trajectory lanes issue their (random-access) ring reads FIRST, then every wave requests the
+    const long g0 = (long)blockIdx.x * G2;
+    __shared__ float sRew[G2 * GROUP];
+    MPG_TL_DECL
+    MPG_TL(0);
+    // Minibatch draw: the trajectory lanes issue their (random-access) ring reads FIRST, then every wave requests the
     // policy's weights, and only then are the gathered values consumed - the vector-memory counter retires in order, so
     // this is the order in which the two latencies overlap instead of adding up.
     float o1[OBS], o2[OBS], ac[ACT], rw = 0.f;
@@ -80,26 +101,40 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_target_fused(const TargetArgs a)
     for (int i = 0; i < OBS; ++i) o1[i] = o2[i] = 0.f;
 #pragma unroll
     for (int k = 0; k < ACT; ++k) ac[k] = 0.f;
-    const bool drawn = a.draw && tid < GROUP && g * GROUP + tid < a.rows;
+    const bool drawn = a.draw && tid < G2 * GROUP && g0 * GROUP + tid < a.rows;
+    bool gather = drawn;
     if (drawn) {
-        const long gr = g * GROUP + tid;
+        const long gr = g0 * GROUP + tid;
         const Philox4 p = philox4x32_10((uint32_t)(gr >> 2), a.dc1, a.dc2, 0x1d5u, a.dk0, a.dk1);
-        sr = (long)(((uint64_t)p.v[gr & 3] * (uint64_t)a.n_storage) >> 32);
+        sr = (long)(((uint64_t)philox_word(p, (int)(gr & 3)) * (uint64_t)a.n_storage) >> 32);
+        if (a.draw == 2) {     // gathered ahead of time by the env launch unless the slot was being written then
+            int off = (int)sr - a.d_fresh_start;
+            if (off < 0) off += a.d_capacity;
+            gather = off < a.d_fresh_count;
+        }
+        if (gather) {
 #pragma unroll
-        for (int i = 0; i < OBS; ++i) { o1[i] = a.r_obs[sr * OBS + i]; o2[i] = a.r_obs2[sr * OBS + i]; }
+            for (int i = 0; i < OBS; ++i) { o1[i] = a.r_obs[sr * OBS + i]; o2[i] = a.r_obs2[sr * OBS + i]; }
 #pragma unroll
-        for (int k = 0; k < ACT; ++k) ac[k] = a.r_act[sr * ACT + k];
-        rw = a.r_rew[sr];
-        dn = a.r_done[sr];
+            for (int k = 0; k < ACT; ++k) ac[k] = a.r_act[sr * ACT + k];
+            rw = a.r_rew[sr];
+            dn = a.r_done[sr];
+        } else {
+#pragma unroll
+            for (int i = 0; i < OBS; ++i) o2[i] = a.o_obs2[gr * OBS + i];
+            rw = a.o_rew[gr];
+        }
     }
     float w2[128], h1[2][4], h2[2][4];
     const Net pnet = make_net(a.pol, OBS, 2 * ACT);
     SmallRegs<OBS, ACT> pr;
+    MPG_TL(1);
     MPG_LOAD2((load_small<OBS, ACT>(pnet, L, pr)), (load_w2<PK>(a.pk_pol, pnet.W2, false, L, w2)));
+    MPG_TL(2);
     if (a.draw) {
-        if (tid < GROUP) {
-            if (drawn) {
-                const long gr = g * GROUP + tid;
+        if (tid < G2 * GROUP) {
+            if (gather) {
+                const long gr = g0 * GROUP + tid;
                 if (a.o_idx) a.o_idx[gr] = (int)sr;
 #pragma unroll
                 for (int i = 0; i < OBS; ++i) { a.o_obs[gr * OBS + i] = o1[i]; a.o_obs2[gr * OBS + i] = o2[i]; }
@@ -110,27 +145,32 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_target_fused(const TargetArgs a)
             }
             sRew[tid] = rw;
 #pragma unroll
-            for (int i = 0; i < XS; ++i) m.sX[tid * XS + i] = i < OBS ? o2[i < OBS ? i : 0] * a.scale[i] : 0.f;
+            for (int i = 0; i < XS; ++i) sXg[tid / GROUP][(tid % GROUP) * XS + i] = i < OBS ? o2[i < OBS ? i : 0] * a.scale[i] : 0.f;
         }
-    } else if (tid < GROUP * XS) {
-        const int row = tid / XS, i = tid % XS;
-        const long gr = g * GROUP + row;
-        m.sX[tid] = (gr < a.rows && i < OBS) ? a.obs2[gr * OBS + i] * a.scale[i] : 0.f;
-        if (i == 0) sRew[row] = gr < a.rows ? a.rew[gr] : 0.f;
+    } else if (tid < G2 * GROUP * XS) {
+        const int g2 = tid / (GROUP * XS), e = tid % (GROUP * XS), row = e / XS, i = e % XS;
+        const long gr = (g0 + g2) * GROUP + row;
+        sXg[g2][e] = (gr < a.rows && i < OBS) ? a.obs2[gr * OBS + i] * a.scale[i] : 0.f;
+        if (i == 0) sRew[g2 * GROUP + row] = gr < a.rows ? a.rew[gr] : 0.f;
     }
+    MPG_TL(3);
     lds_barrier();
-    {   // a' = pi_target(s~')  (+ clip(sigma*eps, +-c), td3.py:74-76)
+    MPG_TL(4);
+#pragma unroll
+    for (int g2 = 0; g2 < G2; ++g2) {   // a' = pi_target(s~')  (+ clip(sigma*eps, +-c), td3.py:74-76)
         const Net& net = pnet;
-        forward_group<OBS, ACT>(m.sX, m.sA, m.sPart, L, w2, pr, h1, h2);
+        forward_group<OBS, ACT>(sXg[g2], m.sA, m.sPart, L, w2, pr, h1, h2);
         if (tid < GROUP * ACT) {
             const int row = tid / ACT, k = tid % ACT;
-            const long gr = g * GROUP + row;
+            const long gr = (g0 + g2) * GROUP + row;
             const float z = out_preact(m.sPart, net.b3[k], row, k);
             float act = a.out_tanh ? a.out_scale * tanhf(z) : z;
             if (a.smooth_eps && gr < a.rows) act += fminf(fmaxf(a.sigma * a.smooth_eps[gr * ACT + k], -a.clipc), a.clipc);
-            m.sX[row * XS + OBS + k] = act;
+            sXg[g2][row * XS + OBS + k] = act;
         }
+        MPG_TL(5 + 2 * g2);
         lds_barrier();
+        MPG_TL(6 + 2 * g2);
     }
 #pragma unroll
     for (int qi = 0; qi < 2; ++qi) {
@@ -139,17 +179,27 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_target_fused(const TargetArgs a)
         const Net net = make_net(qp, QIN, 1);
         SmallRegs<QIN, 1> r;
         MPG_LOAD2((load_small<QIN, 1>(net, L, r)), (load_w2<PK>(qi == 0 ? a.pk_q1 : a.pk_q2, net.W2, false, L, w2)));
-        forward_group<QIN, 1>(m.sX, m.sA, m.sPart, L, w2, r, h1, h2);
-        if (tid < GROUP) m.sQ[qi * GROUP + tid] = out_preact(m.sPart, net.b3[0], tid, 0);
-        lds_barrier();
+        MPG_TL(10 + 6 * qi);
+#pragma unroll
+        for (int g2 = 0; g2 < G2; ++g2) {
+            forward_group<QIN, 1>(sXg[g2], m.sA, m.sPart, L, w2, r, h1, h2);
+            if (tid < GROUP) sQg[g2][qi * GROUP + tid] = out_preact(m.sPart, net.b3[0], tid, 0);
+            MPG_TL(11 + 6 * qi + 2 * g2);
+            lds_barrier();
+            MPG_TL(12 + 6 * qi + 2 * g2);
+        }
     }
-    if (tid < GROUP) {
-        const long gr = g * GROUP + tid;
+    MPG_TL(22);
+    if (tid < G2 * GROUP) {
+        const int g2 = tid / GROUP, row = tid % GROUP;
+        const long gr = (g0 + g2) * GROUP + row;
         if (gr < a.rows) {
-            const float q = a.q2 ? fminf(m.sQ[tid], m.sQ[GROUP + tid]) : m.sQ[tid];
+            const float q = a.q2 ? fminf(sQg[g2][row], sQg[g2][GROUP + row]) : sQg[g2][row];
             a.y[gr] = (sRew[tid] + a.rshift) * a.rscale + a.gamma * q;      // mpg_learner.py:132-133
         }
     }
+    MPG_TL(23);
+    MPG_TL_DUMP(a.dbg);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -490,13 +540,18 @@ int launch_target_fused(const mpg_cfg_t* cfg, const float* policy_t, const float
     const int od = cfg->obs_dim, ad = cfg->act_dim;
     TargetArgs a;
     a.draw = 0; a.n_storage = 0; a.dk0 = a.dk1 = a.dc1 = a.dc2 = 0;
+    a.d_capacity = a.d_fresh_start = a.d_fresh_count = 0;
     a.r_obs = a.r_act = a.r_rew = a.r_obs2 = nullptr; a.r_done = nullptr; a.o_idx = nullptr;
     a.o_obs = a.o_act = a.o_rew = a.o_obs2 = a.o_done = nullptr;
     if (draw) {
         MPG_REQUIRE(draw_out && draw->n_storage > 0 && draw->ring_obs && draw->ring_act && draw->ring_rew && draw->ring_obs2 &&
                         draw->ring_done && draw_out->obs && draw_out->act && draw_out->rew && draw_out->obs2,
                     "launch_target_fused: incomplete replay draw");
-        a.draw = 1; a.n_storage = draw->n_storage;
+        a.draw = draw->pre_gathered ? 2 : 1; a.n_storage = draw->n_storage;
+        a.d_capacity = draw->capacity; a.d_fresh_start = draw->fresh_start; a.d_fresh_count = draw->fresh_count;
+        MPG_REQUIRE(!draw->pre_gathered || (draw->capacity > 0 && draw->fresh_start >= 0 && draw->fresh_start < draw->capacity &&
+                                            draw->fresh_count >= 0 && draw->fresh_count <= draw->capacity),
+                    "launch_target_fused: bad pre-gathered window");
         a.dk0 = (uint32_t)draw->seed; a.dk1 = (uint32_t)(draw->seed >> 32);
         a.dc1 = (uint32_t)draw->ctr; a.dc2 = (uint32_t)(draw->ctr >> 32);
         a.r_obs = draw->ring_obs; a.r_act = draw->ring_act; a.r_rew = draw->ring_rew; a.r_obs2 = draw->ring_obs2;
@@ -514,11 +569,47 @@ int launch_target_fused(const mpg_cfg_t* cfg, const float* policy_t, const float
     a.out_scale = ranged ? cfg->action_range : 1.f;
     a.sigma = sigma; a.clipc = clipc; a.rshift = cfg->rew_shift; a.rscale = cfg->rew_scale; a.gamma = cfg->gamma; a.y = y;
     const int ngroups = (rows + GROUP - 1) / GROUP;
+    a.dbg = nullptr;
+#ifdef MPG_TIMELINE
+    static unsigned long long* s_dbg = nullptr;
+    static int s_calls = 0;
+    if (!s_dbg) (void)hipMalloc(&s_dbg, 2 * NWAVE * MPG_TL_MARKS * sizeof(unsigned long long));
+    a.dbg = s_dbg;
+#endif
     mpg_prof_begin(mpg_prof_of(cfg), 6, s);
-    if (od == 6 && ad == 2) { if (a.pk_pol && a.pk_q1 && (a.pk_q2 || !a.q2)) hipLaunchKernelGGL((k_target_fused<6, 2, true>), dim3(ngroups), dim3(NTHREAD), 0, s, a); else hipLaunchKernelGGL((k_target_fused<6, 2, false>), dim3(ngroups), dim3(NTHREAD), 0, s, a); }
-    else if (od == 4 && ad == 1) { if (a.pk_pol && a.pk_q1 && (a.pk_q2 || !a.q2)) hipLaunchKernelGGL((k_target_fused<4, 1, true>), dim3(ngroups), dim3(NTHREAD), 0, s, a); else hipLaunchKernelGGL((k_target_fused<4, 1, false>), dim3(ngroups), dim3(NTHREAD), 0, s, a); }
+    // two row groups per workgroup once there is at least one 16-row group per CU (see k_target_fused)
+#ifndef MPG_TARGET_G2_MIN_GROUPS
+#define MPG_TARGET_G2_MIN_GROUPS 256
+#endif
+    const bool pk = a.pk_pol && a.pk_q1 && (a.pk_q2 || !a.q2);
+    const bool two = ngroups >= MPG_TARGET_G2_MIN_GROUPS;
+    const dim3 grid(two ? (ngroups + 1) / 2 : ngroups), block(NTHREAD);
+#define MPG_TARGET_LAUNCH(O_, A_) \
+    do { \
+        if (pk && two) hipLaunchKernelGGL((k_target_fused<O_, A_, true, 2>), grid, block, 0, s, a); \
+        else if (pk) hipLaunchKernelGGL((k_target_fused<O_, A_, true, 1>), grid, block, 0, s, a); \
+        else if (two) hipLaunchKernelGGL((k_target_fused<O_, A_, false, 2>), grid, block, 0, s, a); \
+        else hipLaunchKernelGGL((k_target_fused<O_, A_, false, 1>), grid, block, 0, s, a); \
+    } while (0)
+    if (od == 6 && ad == 2) MPG_TARGET_LAUNCH(6, 2);
+    else if (od == 4 && ad == 1) MPG_TARGET_LAUNCH(4, 1);
+#undef MPG_TARGET_LAUNCH
     else { mpg_set_error("launch_target_fused: unsupported dims"); return MPG_EINVAL; }
     mpg_prof_end(mpg_prof_of(cfg), 6, s);
+#ifdef MPG_TIMELINE
+    if (++s_calls % 100 == 0) {
+        static unsigned long long h[2 * NWAVE * MPG_TL_MARKS];
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(h, s_dbg, sizeof(h), hipMemcpyDeviceToHost);
+        for (int b = 0; b < 2; ++b)
+            for (int w = 0; w < NWAVE; w += 7) {
+                fprintf(stderr, "timeline target wg%d wave%d:", b ? 100 : 0, w);
+                const unsigned long long* t = h + (b * NWAVE + w) * MPG_TL_MARKS;
+                for (int k = 1; k < MPG_TL_MARKS; ++k) fprintf(stderr, " %d:%lld", k, t[k] ? (long long)(t[k] - t[0]) : -1LL);
+                fprintf(stderr, "\n");
+            }
+    }
+#endif
     MPG_CHECK_LAUNCH("k_target_fused");
     return MPG_OK;
 }

@@ -39,6 +39,14 @@ static inline hipStream_t mpg_stream(mpg_stream_t s) { return reinterpret_cast<h
 struct Philox4 {
     uint32_t v[4];
 };
+// word k (0..3) of a draw by selects.  NEVER index v[] with a run-time value in device code: the compiler moves the four
+// words to LDS, addresses them by the flattened thread id, and reads the workgroup size for that from the dispatch packet
+// - which lives in HOST memory.  That one scalar load cost the lanes that draw the minibatch 7 to 30 us per launch
+// (round 2; tools/kernel_resources.py --dispatch-ptr lists kernels that read the packet).
+__host__ __device__ static inline uint32_t philox_word(const Philox4& p, int k) {
+    const uint32_t lo = (k & 1) ? p.v[1] : p.v[0], hi = (k & 1) ? p.v[3] : p.v[2];
+    return (k & 2) ? hi : lo;
+}
 
 __host__ __device__ static inline Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                                         uint32_t k0, uint32_t k1) {

@@ -70,7 +70,7 @@ __global__ void k_uniform_idx(int n_storage, int n, uint32_t k0, uint32_t k1, ui
     if (i >= n) return;
     const Philox4 p = philox4x32_10((uint32_t)(i >> 2), c1, c2, 0x1d5u, k0, k1);
     // random.randint(0, len-1), buffer.py:70-71: multiply-shift maps a 32-bit draw to [0, n_storage)
-    idx[i] = (int)(((uint64_t)p.v[i & 3] * (uint64_t)n_storage) >> 32);
+    idx[i] = (int)(((uint64_t)philox_word(p, i & 3) * (uint64_t)n_storage) >> 32);
 }
 
 // ReplayBuffer.sample (buffer.py:70-78): index draw + gather in one launch (same Philox stream as k_uniform_idx)
@@ -80,7 +80,7 @@ __global__ void k_sample_gather(int n_storage, int n, uint32_t k0, uint32_t k1, 
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const Philox4 p = philox4x32_10((uint32_t)(i >> 2), c1, c2, 0x1d5u, k0, k1);
-    const long s = (long)(((uint64_t)p.v[i & 3] * (uint64_t)n_storage) >> 32);
+    const long s = (long)(((uint64_t)philox_word(p, i & 3) * (uint64_t)n_storage) >> 32);
     idx[i] = (int)s;
     gather_row(r, s, i, od, ad, o_obs, o_act, o_rew, o_obs2, o_done);
 }

@@ -84,6 +84,11 @@ extern "C" int mpg_step_begin(mpg_train_ctx_t* c, int iteration, mpg_stream_t s)
     const float* policy = c->params + l.off[l.n_nets - 1];
     const float* policy_t = c->targets + l.off[l.n_nets - 1];
     // ---- worker.sample + replay_buffer.add_batch (optimizer.py:332-337, worker.py:91-119) ----
+    // MPG-v2 draws its minibatch right after the add: the last env launch gathers it in spare workgroups (the random ring
+    // reads overlap the env's sub-steps) except the rows drawn from the slots that launch is writing
+    const bool draws_now = c->learner_version == 2 && c->learner_counter % c->num_batch_reuse == 0;
+    bool pre_gathered = false;
+    int fresh_start = 0;
     if (iteration % c->sampling_interval == 0) {
         for (int it = 0; it < c->sample_iters; ++it) {
             TRY(mpg_policy_action(&c->cfg, policy, c->num_agent, c->w_obs, c->explore_sigma, c->worker_seed, c->noise_ctr++,
@@ -91,9 +96,26 @@ extern "C" int mpg_step_begin(mpg_train_ctx_t* c, int iteration, mpg_stream_t s)
             MPG_REQUIRE(c->num_agent <= c->ring_capacity, "mpg_step_begin: ring smaller than one sample");
             // env.step -> ring slot (next + i) % capacity -> env.reset of the done agents, one launch
             mpg_prof_begin(c->cfg.prof, 2, mpg_stream(s));
-            TRY(mpg_env_step_store_reset(kind, c->num_agent, od, c->env_state, c->w_act, c->ring_capacity, c->ring_next, c->ring_obs,
-                                         c->ring_act, c->ring_rew, c->ring_obs2, c->ring_done, c->env_seed, c->env_ctr++, c->w_obs,
-                                         c->w_done, s));
+#ifdef MPG_AB_NO_PREDRAW
+            if (false) {
+#else
+            if (draws_now && it == c->sample_iters - 1 && kind == MPG_ENV_PATH_TRACKING && od == 6) {
+#endif
+                mpg_replay_draw_t pd = {};
+                pd.n_storage = std::min(c->ring_size + c->num_agent, c->ring_capacity);
+                pd.seed = c->replay_seed; pd.ctr = c->replay_times + 1;
+                pd.idx_out = c->idx; pd.done_out = c->b_done;
+                TRY(mpg_env_step_store_reset_draw(kind, c->num_agent, od, c->env_state, c->w_act, c->ring_capacity, c->ring_next,
+                                                  c->ring_obs, c->ring_act, c->ring_rew, c->ring_obs2, c->ring_done, c->env_seed,
+                                                  c->env_ctr++, c->w_obs, c->w_done, &pd, c->batch, c->b_obs, c->b_act, c->b_rew,
+                                                  c->b_obs2, s));
+                pre_gathered = true;
+                fresh_start = c->ring_next;
+            } else {
+                TRY(mpg_env_step_store_reset(kind, c->num_agent, od, c->env_state, c->w_act, c->ring_capacity, c->ring_next,
+                                             c->ring_obs, c->ring_act, c->ring_rew, c->ring_obs2, c->ring_done, c->env_seed,
+                                             c->env_ctr++, c->w_obs, c->w_done, s));
+            }
             mpg_prof_end(c->cfg.prof, 2, mpg_stream(s));
             c->ring_next = (c->ring_next + c->num_agent) % c->ring_capacity;
             c->ring_size = std::min(c->ring_size + c->num_agent, c->ring_capacity);
@@ -102,7 +124,7 @@ extern "C" int mpg_step_begin(mpg_train_ctx_t* c, int iteration, mpg_stream_t s)
     // ---- replay_buffer.replay (optimizer.py:340-341; buffer.py:70-91) ----
     MPG_REQUIRE(c->ring_size > 0, "mpg_step_begin: empty replay ring");
     c->replay_times++;
-    mpg_replay_draw_t draw;
+    mpg_replay_draw_t draw = {};
     bool draw_in_gradients = false;
     if (c->learner_counter % c->num_batch_reuse == 0) {       // get_batch_data, mpg_learner.py:402-403
         if (c->learner_version == 2) {
@@ -110,6 +132,8 @@ extern "C" int mpg_step_begin(mpg_train_ctx_t* c, int iteration, mpg_stream_t s)
             draw.n_storage = c->ring_size; draw.seed = c->replay_seed; draw.ctr = c->replay_times;
             draw.ring_obs = c->ring_obs; draw.ring_act = c->ring_act; draw.ring_rew = c->ring_rew; draw.ring_obs2 = c->ring_obs2;
             draw.ring_done = c->ring_done; draw.idx_out = c->idx; draw.done_out = c->b_done;
+            draw.pre_gathered = pre_gathered ? 1 : 0; draw.capacity = c->ring_capacity; draw.fresh_start = fresh_start;
+            draw.fresh_count = pre_gathered ? c->num_agent : 0;
             draw_in_gradients = true;
         } else {   // MPGLearner.sample + compute_n_step_target, mpg_learner.py:109-124,146-169
             TRY(mpg_replay_sample_uniform(c->ring_size, c->batch, c->replay_seed, c->replay_times, od, ad, c->ring_obs, c->ring_act,

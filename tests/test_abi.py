@@ -52,3 +52,17 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith('.py'):
                 src = open(os.path.join(dp, f)).read()
                 assert 'import oracle' not in src and 'from oracle' not in src, f
+
+
+def test_no_kernel_reads_the_dispatch_or_queue_packet():
+    """The AQL dispatch packet and the queue descriptor live in host memory; a kernel whose descriptor enables their
+    pointer reads them with scalar loads that cost microseconds (round 2: `p.v[i & 3]` on a Philox draw made the compiler
+    move the four words to LDS and fetch the workgroup size from the packet - 7 to 30 us on the lanes that draw the
+    minibatch).  Cross-compiles every translation unit and inspects the kernel descriptors (no GPU needed)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location('dispatch_ptr_check', os.path.join(os.path.dirname(__file__), '..', 'tools',
+                                                                                    'dispatch_ptr_check.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.offenders() == []
