@@ -143,6 +143,22 @@ __global__ void __launch_bounds__(1024) k_clip(const Segs sg, float* __restrict_
     for (; i < n; i += 1024) g[i] *= sc;
 }
 
+// Adam (Keras form, bias correction folded into lr_t; policy.py:123-156) and the Polyak mix (policy.py:158-171) for one
+// element.  Contraction is off inside: k_adam_polyak and k_clip_adam_polyak must round identically whatever else surrounds
+// the call (the native step driver is tested against the method-by-method path to 1e-6 over many iterations), and one
+// rounding per written operation is also what the reference's float32 tensors do.
+__device__ __forceinline__ void adam_update(float g, float lr_t, float& mj, float& vj, float& wj) {
+#pragma clang fp contract(off)
+    const float b1 = 0.9f, b2 = 0.999f, eps = 1e-7f;
+    mj += (g - mj) * (1.f - b1);
+    vj += (g * g - vj) * (1.f - b2);
+    wj -= lr_t * mj / (sqrtf(vj) + eps);
+}
+__device__ __forceinline__ float polyak_mix(float tau, float wj, float tj) {
+#pragma clang fp contract(off)
+    return tau * wj + (1.f - tau) * tj;
+}
+
 __global__ void k_adam_polyak(const Segs sg, float* __restrict__ w, float* __restrict__ m, float* __restrict__ v,
                               float* __restrict__ target, const float* __restrict__ grad, float tau,
                               const int* __restrict__ skip, int n_skip) {
@@ -150,17 +166,13 @@ __global__ void k_adam_polyak(const Segs sg, float* __restrict__ w, float* __res
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= sg.n[k]) return;
     const int j = sg.off[k] + i;
-    const float b1 = 0.9f, b2 = 0.999f, eps = 1e-7f;
     float wj = w[j];
     if (sg.do_adam[k]) {
         bool bad = false;                                     // optimizer.py:357-361: if ANY gradient is non-finite,
         if (skip)                                             // the whole list is replaced by zeros
             for (int q = 0; q < n_skip; ++q) bad |= skip[q] != 0;
-        const float g = bad ? 0.f : grad[j];
         float mj = m[j], vj = v[j];
-        mj += (g - mj) * (1.f - b1);
-        vj += (g * g - vj) * (1.f - b2);
-        wj -= sg.lr_t[k] * mj / (sqrtf(vj) + eps);
+        adam_update(bad ? 0.f : grad[j], sg.lr_t[k], mj, vj, wj);
         m[j] = mj; v[j] = vj; w[j] = wj;
     }
     // weight cache: the element's two packed copies are rewritten by the thread that owns it
@@ -172,7 +184,7 @@ __global__ void k_adam_polyak(const Segs sg, float* __restrict__ w, float* __res
         pack_store(sg.cache_w + (size_t)(2 * k + 1) * HH, col, row, wj);       // backward image: k = col, n = row
     }
     if (sg.do_polyak[k] && target) {
-        const float tj = tau * wj + (1.f - tau) * target[j];                     // policy.py:158-171
+        const float tj = polyak_mix(tau, wj, target[j]);
         target[j] = tj;
         if (in_w2 && sg.cache_t) {
             const int row = e >> 8, col = e & 255;
@@ -191,6 +203,15 @@ __global__ void __launch_bounds__(256) k_clip_adam_polyak(const Segs sg, float* 
     __shared__ float s_norm[MAXSEG];
     const int k = blockIdx.y;
     const int wave = threadIdx.x >> 6;
+    // this thread's element first: its five loads travel together with the partials' (one memory round trip, not two)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = i < sg.n[k];
+    const int j = sg.off[k] + (live ? i : 0);
+    const bool adam = sg.do_adam[k] != 0, polyak = sg.do_polyak[k] && target;
+    const float g_in = live ? grad[j] : 0.f;
+    float wj = live ? w[j] : 0.f;
+    float mj = (live && adam) ? m[j] : 0.f, vj = (live && adam) ? v[j] : 0.f;
+    const float t_in = (live && polyak) ? target[j] : 0.f;
     for (int q = wave; q < sg.n_seg; q += 4) {
         const float nrm = sqrtf(seg_sumsq(part, q));
         if ((threadIdx.x & 63) == 0) s_norm[q] = nrm;
@@ -203,19 +224,11 @@ __global__ void __launch_bounds__(256) k_clip_adam_polyak(const Segs sg, float* 
         norms[k] = nrm;
         if (nonfinite) nonfinite[k] = isfinite(nrm) ? 0 : 1;
     }
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= sg.n[k]) return;
-    const int j = sg.off[k] + i;
-    const float gc = grad[j] * (clip * fminf(1.f / nrm, 1.f / clip));
+    if (!live) return;
+    const float gc = g_in * (clip * fminf(1.f / nrm, 1.f / clip));
     grad[j] = gc;
-    const float b1 = 0.9f, b2 = 0.999f, eps = 1e-7f;
-    float wj = w[j];
-    if (sg.do_adam[k]) {
-        const float g = bad ? 0.f : gc;
-        float mj = m[j], vj = v[j];
-        mj += (g - mj) * (1.f - b1);
-        vj += (g * g - vj) * (1.f - b2);
-        wj -= sg.lr_t[k] * mj / (sqrtf(vj) + eps);
+    if (adam) {
+        adam_update(bad ? 0.f : gc, sg.lr_t[k], mj, vj, wj);
         m[j] = mj; v[j] = vj; w[j] = wj;
     }
     const int e = sg.w2_off[k] >= 0 ? i - sg.w2_off[k] : -1;
@@ -225,8 +238,8 @@ __global__ void __launch_bounds__(256) k_clip_adam_polyak(const Segs sg, float* 
         pack_store(sg.cache_w + (size_t)(2 * k) * HH, row, col, wj);
         pack_store(sg.cache_w + (size_t)(2 * k + 1) * HH, col, row, wj);
     }
-    if (sg.do_polyak[k] && target) {
-        const float tj = tau * wj + (1.f - tau) * target[j];
+    if (polyak) {
+        const float tj = polyak_mix(tau, wj, t_in);
         target[j] = tj;
         if (in_w2 && sg.cache_t) {
             const int row = e >> 8, col = e & 255;
