@@ -74,6 +74,17 @@ __device__ __forceinline__ PathRef path_ref(float x) {
     return r;
 }
 
+// x / 200.f, correctly rounded, in three instructions instead of the ~12 of an IEEE division: q = RN(x * RN(1/200)), the
+// exact remainder by one fma, one correction fma (Markstein).  Checked against the division on every float32 of 30 binades
+// (2^-17 .. 2^12, 2.5e8 values, no mismatch; outside the denormal range the mantissa behaviour does not depend on the
+// binade).  Three of the five divisions of a sub-step are by 200.
+__device__ __forceinline__ float div200(float x) {
+    const float c = 0.005f;                    // RN(1/200)
+    const float q = x * c;
+    const float r = fmaf(-q, 200.f, x);
+    return fmaf(r, c, q);
+}
+
 __device__ __forceinline__ float wrap_pi(float a) {        // :168-169 / :176-177
     if (a > PI_F) a = a - TWO_PI_F;
     if (a <= -PI_F) a = a + TWO_PI_F;
@@ -224,11 +235,11 @@ __device__ __forceinline__ StepOut step_agent(Agent& ag, const float2 an) {
         float nr = ((((-I_z) * r) * vx - K1 * vy) + (K5 * steer) * vx) / (K6 - I_z * vx);
         nvx = fminf(fmaxf(nvx, 1.f), 35.f);     // :153
         // world frame, :156-160: phi first, then y and x with the OLD v_x, v_y but the NEW phi (view aliasing)
-        phi = phi + r / 200.f;
+        phi = phi + div200(r);
         float sp, cp;
         sincos_bounded(phi, sp, cp);
-        y = y + (vx * sp + vy * cp) / 200.f;
-        x = x + (vx * cp - vy * sp) / 200.f;
+        y = y + div200(vx * sp + vy * cp);
+        x = x + div200(vx * cp - vy * sp);
         vx = nvx; vy = nvy; r = nr;             // :161
         x_u = x; phi_u = phi;                   // :163-165 read x and phi before their wraps
         phi = wrap_pi(phi);                     // :168-169

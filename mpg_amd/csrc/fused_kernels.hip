@@ -27,17 +27,6 @@ __device__ __forceinline__ void load_w2(const float* pack, const float* W2, bool
 #define MPG_LOAD2(SMALL, IMAGE) do { MPG_UNPAREN SMALL; MPG_UNPAREN IMAGE; } while (0)
 #endif
 
-#ifdef MPG_TIMELINE   // diagnostic build only (tools/timeline.sh): s_memtime of every wave at marked points of workgroup 0 / 100
-#define MPG_TL_MARKS 24
-#define MPG_TL_DECL __shared__ unsigned long long s_tl[NWAVE][MPG_TL_MARKS];
-#define MPG_TL(k) do { __builtin_amdgcn_sched_barrier(0); if ((threadIdx.x & 63) == 0) s_tl[threadIdx.x >> 6][k] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
-#define MPG_TL_DUMP(dbg) do { __syncthreads(); if (dbg && (blockIdx.x == 0 || blockIdx.x == 100) && threadIdx.x < NWAVE * MPG_TL_MARKS) \
-    dbg[(blockIdx.x ? 1 : 0) * NWAVE * MPG_TL_MARKS + threadIdx.x] = s_tl[threadIdx.x / MPG_TL_MARKS][threadIdx.x % MPG_TL_MARKS]; } while (0)
-#else
-#define MPG_TL_DECL
-#define MPG_TL(k)
-#define MPG_TL_DUMP(dbg)
-#endif
 
 constexpr int SMEM_FLOATS = 2 * A_IMG + GROUP * XS + NWAVE * GROUP * MAXOUT + GROUP * MAXOUT + NWAVE * GROUP * XS + 4 * GROUP;
 struct Smem {
@@ -468,6 +457,7 @@ struct WgradMulti {
     WgradArgs a[3];
     int type[3];               // 0: template pair A, 1: template pair B
     int chunk_off[4];          // blockIdx.y ranges of the jobs
+    unsigned long long* dbg;   // MPG_TIMELINE builds only
 };
 
 template <int IA, int OA, int IB, int OB>
@@ -479,8 +469,16 @@ __global__ void __launch_bounds__(NTHREAD, 4) k_wgrad_multi(const WgradMulti m) 
     int j = 0;
     while (j + 1 < m.n_jobs && gchunk >= m.chunk_off[j + 1]) ++j;
     const int chunk = gchunk - m.chunk_off[j];
+    MPG_TL_DECL
+    MPG_TL(0);
     if (m.type[j] == 0) wgrad_body<IA, OA>(m.a[j], sl, chunk, sRed);
     else wgrad_body<IB, OB>(m.a[j], sl, chunk, sRed);
+    MPG_TL(7);
+#ifdef MPG_TIMELINE
+    __syncthreads();
+    if (m.dbg && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1) && threadIdx.x < NWAVE * MPG_TL_MARKS)
+        m.dbg[(blockIdx.x ? 1 : 0) * NWAVE * MPG_TL_MARKS + threadIdx.x] = s_tl[threadIdx.x / MPG_TL_MARKS][threadIdx.x % MPG_TL_MARKS];
+#endif
 }
 
 struct ReduceMulti {
@@ -712,10 +710,31 @@ int launch_wgrad_multi(const mpg_cfg_t* cfg, const WgradJob* jobs, int n_jobs, c
     }
     m.chunk_off[n_jobs] = off;
     for (int j = n_jobs; j < 3; ++j) { m.type[j] = 0; m.chunk_off[j + 1] = off; rm.slabs[j] = nullptr; rm.nslab[j] = rm.n[j] = 0; rm.out[j] = nullptr; }
+    m.dbg = nullptr;
+#ifdef MPG_TIMELINE
+    static unsigned long long* s_dbg = nullptr;
+    static int s_calls = 0;
+    if (!s_dbg) (void)hipMalloc(&s_dbg, 2 * NWAVE * MPG_TL_MARKS * sizeof(unsigned long long));
+    m.dbg = s_dbg;
+#endif
     mpg_prof_begin(mpg_prof_of(cfg), 5, s);
     if (!pendulum) hipLaunchKernelGGL((k_wgrad_multi<8, 1, 6, 2>), dim3(8 * off), dim3(NTHREAD), 0, s, m);
     else hipLaunchKernelGGL((k_wgrad_multi<5, 1, 4, 1>), dim3(8 * off), dim3(NTHREAD), 0, s, m);
     mpg_prof_end(mpg_prof_of(cfg), 5, s);
+#ifdef MPG_TIMELINE
+    if (++s_calls % 100 == 0) {
+        static unsigned long long h[2 * NWAVE * MPG_TL_MARKS];
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(h, s_dbg, sizeof(h), hipMemcpyDeviceToHost);
+        for (int b = 0; b < 2; ++b)
+            for (int w = 0; w < NWAVE; w += 7) {
+                fprintf(stderr, "timeline wgrad %s wave%d:", b ? "last-wg(policy)" : "wg0(Q1)", w);
+                const unsigned long long* t = h + (b * NWAVE + w) * MPG_TL_MARKS;
+                for (int k = 1; k < 8; ++k) fprintf(stderr, " %d:%lld", k, (long long)(t[k] - t[0]));
+                fprintf(stderr, "\n");
+            }
+    }
+#endif
     MPG_CHECK_LAUNCH("k_wgrad_multi");
     rm.n_sums = n_sums;
     for (int k = 0; k < 8; ++k) {

@@ -106,6 +106,19 @@ struct Lane {
 // is needed.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+#ifdef MPG_TIMELINE   // diagnostic build only (tools/timeline.sh): s_memtime of every wave at marked points of workgroup 0 / 100
+#define MPG_TL_MARKS 24
+__shared__ unsigned long long s_tl[8][MPG_TL_MARKS];
+#define MPG_TL_DECL
+#define MPG_TL(k) do { __builtin_amdgcn_sched_barrier(0); if ((threadIdx.x & 63) == 0) s_tl[threadIdx.x >> 6][k] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define MPG_TL_DUMP(dbg) do { __syncthreads(); if (dbg && (blockIdx.x == 0 || blockIdx.x == 100) && threadIdx.x < NWAVE * MPG_TL_MARKS) \
+    dbg[(blockIdx.x ? 1 : 0) * NWAVE * MPG_TL_MARKS + threadIdx.x] = s_tl[threadIdx.x / MPG_TL_MARKS][threadIdx.x % MPG_TL_MARKS]; } while (0)
+#else
+#define MPG_TL_DECL
+#define MPG_TL(k)
+#define MPG_TL_DUMP(dbg)
+#endif
+
 #ifdef MPG_STAMP   // diagnostic build only: per-wave cycle accounting of the step phases (tools/stamp.sh)
 __shared__ unsigned long long g_st_acc[NWAVE][10];
 __shared__ unsigned long long g_st_prev[NWAVE];

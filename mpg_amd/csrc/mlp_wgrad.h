@@ -63,17 +63,26 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int sl, con
     // global addressing for 4 rows x (IN + OU) scalars per lane would cost ~100 registers and one workgroup of residency)
     float* stage = sRed + L.wave * (GROUP * 12);
     auto thin_accumulate = [&](long g, const Thin& t) {
+        // Every lane fills three slots of the staging corner.  Which array a slot comes from (x0 scaled, x1, dz3, or a
+        // zero pad) is settled by SELECTING the address, and the loads themselves are unconditional: as three nested
+        // branches each slot cost up to three dependent memory round trips (the wait sat inside the branch), ~2 us per
+        // row group on the critic jobs, which were then the longest workgroups of the launch.
+        float v[3], sc[3];
+        bool on[3];
 #pragma unroll
-        for (int e = L.lane; e < GROUP * 12; e += 64) {
-            const int row = e / 12, i = e % 12;
+        for (int u = 0; u < 3; ++u) {
+            const int e = L.lane + 64 * u, row = e / 12, i = e % 12;
             const long gr = g * GROUP + row;
-            float v = 0.f;
-            if (gr < a.rows) {
-                if (i < IN) v = x_value<IN>(a.x, gr, i);
-                else if (i >= 8 && i - 8 < OU) v = a.dz3[gr * OU + (i - 8)];
-            }
-            stage[e] = v;
+            const bool from_x0 = i < IN && i < a.x.d0, from_x1 = i < IN && !from_x0, from_d3 = i >= 8 && i - 8 < OU;
+            on[u] = gr < a.rows && (from_x0 || from_x1 || from_d3);
+            const float* p = a.dz3;                                      // any valid address for the slots that stay zero
+            if (on[u]) p = from_x0 ? a.x.x0 + gr * a.x.ld0 + i : (from_x1 ? a.x.x1 + gr * a.x.ld1 + (i - a.x.d0) : a.dz3 + gr * OU + (i - 8));
+            v[u] = *p;
+            sc[u] = a.x.scale[i & 7];
+            if (!from_x0) sc[u] = 1.f;
         }
+#pragma unroll
+        for (int u = 0; u < 3; ++u) stage[L.lane + 64 * u] = on[u] ? v[u] * sc[u] : 0.f;
         __builtin_amdgcn_wave_barrier();      // same wave writes and reads: LDS is in order within a wave
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -145,6 +154,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int sl, con
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     f32x2* sB2 = reinterpret_cast<f32x2*>(sRed);          // 8-byte slots: (((pair*2 + tile)*2 + part)*64 + lane)*2 + (group & 1)
     a_load(g0);
+    MPG_TL(1);
 #ifdef MPG_AB_WG_NOMFMA
     for (long tile = g0; tile < g0; tile += NWAVE) {
 #else
@@ -258,7 +268,9 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int sl, con
         }
     }
 #endif
+    MPG_TL(2);
     __syncthreads();                                      // the staging corners of the thin part alias the B tile
+    MPG_TL(3);
     // thin pieces after the matrix loop (their registers are then free): the chunk's groups are dealt round-robin to
     // the 8 waves; the load latency is covered by the other resident waves
     if (has_thin) {
@@ -268,6 +280,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int sl, con
             thin_accumulate(tg, tcur);
         }
     }
+    MPG_TL(4);
     // ---- this workgroup's part of the chunk slab ----
     float* slab = a.slabs + (size_t)chunk * net_size(a.in_dim, a.out_dim);
     float* sW1 = slab;
@@ -283,8 +296,10 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int sl, con
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 sW2[(16 * (2 * L.wave + u) + 4 * L.rg + j) * H + 32 * sl + 16 * t + L.c] = acc[u][t][j];
+    MPG_TL(5);
     // thin pieces: sum over the 8 waves and the 4 row quads through LDS in a fixed order
     __syncthreads();   // the staging corners used above alias this scratch
+    MPG_TL(6);
     {
         float* dst = sRed + (L.wave * NQ) * 64 + L.lane;
         int q = 0;
@@ -354,7 +369,16 @@ inline float wgrad_dz_scale(float inv_b) {
     return s;
 }
 
-constexpr int WGRAD_MAX_CHUNKS = 32;      // chunk slabs per network (16 and 64 measure the same, tools/ab_wgrad.sh history)
+// Chunking of a network's weight-gradient job: every chunk is 8 workgroups (one per 32-column slice) that leave one slab of
+// partial sums for the reduction.  16 chunks per network: the bench step's three jobs are then 384 workgroups, all resident at
+// once (512 slots), and 13 MB of slabs.  Measured on the bench step (tools/ab_repeat.sh, k_wgrad_multi / whole step):
+// 32 per network 28 us / 0.264 ms (768 workgroups: a second, mostly empty round; 26 MB of slabs), 16: 24.4 / 0.2555,
+// 8 + 8 + 48 by job size: 28.5 / 0.258, 8 per network: 29 / 0.259.  The launch as a whole moves ~430 MB of stash through
+// the Infinity Cache in that time; short workgroups mostly wait in the same queues as the long ones.
+#ifndef MPG_WGRAD_MAX_CHUNKS
+#define MPG_WGRAD_MAX_CHUNKS 16
+#endif
+constexpr int WGRAD_MAX_CHUNKS = MPG_WGRAD_MAX_CHUNKS;
 inline int wgrad_groups_per_chunk(long ngroups) {
     long gp = (ngroups + WGRAD_MAX_CHUNKS - 1) / WGRAD_MAX_CHUNKS;
     return (int)(gp < 1 ? 1 : gp);
