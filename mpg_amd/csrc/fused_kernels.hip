@@ -145,22 +145,24 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_target_fused(const TargetArgs a)
     MPG_TL(3);
     lds_barrier();
     MPG_TL(4);
-#pragma unroll
-    for (int g2 = 0; g2 < G2; ++g2) {   // a' = pi_target(s~')  (+ clip(sigma*eps, +-c), td3.py:74-76)
-        const Net& net = pnet;
-        forward_group<OBS, ACT>(sXg[g2], m.sA, m.sPart, L, w2, pr, h1, h2);
-        if (tid < GROUP * ACT) {
-            const int row = tid / ACT, k = tid % ACT;
-            const long gr = (g0 + g2) * GROUP + row;
-            const float z = out_preact(m.sPart, net.b3[k], row, k);
-            float act = a.out_tanh ? a.out_scale * tanhf(z) : z;
-            if (a.smooth_eps && gr < a.rows) act += fminf(fmaxf(a.sigma * a.smooth_eps[gr * ACT + k], -a.clipc), a.clipc);
-            sXg[g2][row * XS + OBS + k] = act;
-        }
-        MPG_TL(5 + 2 * g2);
-        lds_barrier();
-        MPG_TL(6 + 2 * g2);
+    float h1b[2][4], h2b[2][4];
+    // G2 == 2: both row groups go through every network as a pair (forward_group2: one pair of barriers for two groups)
+    if constexpr (G2 == 2) {   // a' = pi_target(s~')  (+ clip(sigma*eps, +-c), td3.py:74-76)
+        forward_group2<OBS, ACT>(sXg[0], sXg[1], m.sA, m.sA1, m.sPart, m.sPartX, L, w2, pr, h1, h2, h1b, h2b);
+    } else {
+        forward_group<OBS, ACT>(sXg[0], m.sA, m.sPart, L, w2, pr, h1, h2);
     }
+    if (tid < G2 * GROUP * ACT) {
+        const int g2 = tid / (GROUP * ACT), row = (tid / ACT) % GROUP, k = tid % ACT;
+        const long gr = (g0 + g2) * GROUP + row;
+        const float z = out_preact(g2 == 0 ? m.sPart : m.sPartX, pnet.b3[k], row, k);
+        float act = a.out_tanh ? a.out_scale * tanhf(z) : z;
+        if (a.smooth_eps && gr < a.rows) act += fminf(fmaxf(a.sigma * a.smooth_eps[gr * ACT + k], -a.clipc), a.clipc);
+        sXg[g2][row * XS + OBS + k] = act;
+    }
+    MPG_TL(5);
+    lds_barrier();
+    MPG_TL(6);
 #pragma unroll
     for (int qi = 0; qi < 2; ++qi) {
         const float* qp = qi == 0 ? a.q1 : a.q2;
@@ -169,14 +171,18 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_target_fused(const TargetArgs a)
         SmallRegs<QIN, 1> r;
         MPG_LOAD2((load_small<QIN, 1>(net, L, r)), (load_w2<PK>(qi == 0 ? a.pk_q1 : a.pk_q2, net.W2, false, L, w2)));
         MPG_TL(10 + 6 * qi);
-#pragma unroll
-        for (int g2 = 0; g2 < G2; ++g2) {
-            forward_group<QIN, 1>(sXg[g2], m.sA, m.sPart, L, w2, r, h1, h2);
-            if (tid < GROUP) sQg[g2][qi * GROUP + tid] = out_preact(m.sPart, net.b3[0], tid, 0);
-            MPG_TL(11 + 6 * qi + 2 * g2);
-            lds_barrier();
-            MPG_TL(12 + 6 * qi + 2 * g2);
+        if constexpr (G2 == 2) {
+            forward_group2<QIN, 1>(sXg[0], sXg[1], m.sA, m.sA1, m.sPart, m.sPartX, L, w2, r, h1, h2, h1b, h2b);
+        } else {
+            forward_group<QIN, 1>(sXg[0], m.sA, m.sPart, L, w2, r, h1, h2);
         }
+        if (tid < G2 * GROUP) {
+            const int g2 = tid / GROUP, row = tid % GROUP;
+            sQg[g2][qi * GROUP + row] = out_preact(g2 == 0 ? m.sPart : m.sPartX, net.b3[0], row, 0);
+        }
+        MPG_TL(11 + 6 * qi);
+        lds_barrier();
+        MPG_TL(12 + 6 * qi);
     }
     MPG_TL(22);
     if (tid < G2 * GROUP) {
@@ -234,8 +240,10 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_qloss_fused(const QlossArgs a) {
         m.sD3[d3_index(tid, 0)] = e * a.inv_b;
         m.sQ[tid] = e * e;
     }
+    MPG_TL(4);
     load_w2<PK>(a.pkb[qi], net.W2, true, L, w2);     // same registers, backward image
     lds_barrier();
+    MPG_TL(5);
     if (tid == 0) {
         float s2 = 0.f;
         for (int i = 0; i < GROUP; ++i) s2 += m.sQ[i];
@@ -364,6 +372,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_qslice_fused2(const QsliceArgs a
 struct CriticArgs {
     QlossArgs ql;
     QsliceArgs qs;
+    unsigned long long* dbg;   // MPG_TIMELINE builds only
 };
 
 template <int QIN, bool PK>
@@ -381,6 +390,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_critic_fused(const CriticArgs ca
     const int qi = blockIdx.y;
     const long ngroups = gridDim.x;                    // == q.R / GROUP == a.rows / GROUP
     const bool slices = qi == 0;
+    MPG_TL(0);
     const Net net = make_net(a.q[qi], QIN, 1);
     const CriticStash st = a.st[qi];
     load_x_group<QIN>(a.x, a.rows, g, m.sX);
@@ -390,11 +400,14 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_critic_fused(const CriticArgs ca
         sX2[tid] = i < QIN ? q.xq[gr * QIN + i] : 0.f;
     }
     lds_barrier();
+    MPG_TL(1);
     float w2[128], h1[3][2][4], h2[3][2][4], dz1[2][4], dz2[2][4];
     SmallRegs<QIN, 1> r;
     MPG_LOAD2((load_small<QIN, 1>(net, L, r)), (load_w2<PK>(a.pkf[qi], net.W2, false, L, w2)));
+    MPG_TL(2);
     // ---- forward: replay batch group ----
     forward_group<QIN, 1>(m.sX, m.sA, m.sPart, L, w2, r, h1[0], h2[0]);
+    MPG_TL(3);
     stash_store(st.h1, g, L, h1[0]);
     stash_store(st.h2, g, L, h2[0]);
     if (tid < GROUP) {   // err = Q(s~,a) - y; dL/dq = err / B_global   (mpg_learner.py:331-336)
@@ -420,8 +433,10 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_critic_fused(const CriticArgs ca
             }
         }
     }
+    MPG_TL(4);
     load_w2<PK>(a.pkb[qi], net.W2, true, L, w2);     // same registers, backward image
     lds_barrier();
+    MPG_TL(5);
     if (tid == 0) {
         float s2 = 0.f;
         for (int i = 0; i < GROUP; ++i) s2 += m.sQ[i];
@@ -438,6 +453,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_critic_fused(const CriticArgs ca
     backward_group<QIN, 1, false>(m.sD3, m.sA, m.sA1, m.sPartX, L, w2, r, h1[0], h2[0], dz1, dz2);
     stash_store(st.dz1, g, L, dz1);
     stash_store(st.dz2, g, L, dz2);
+    MPG_TL(6);
     if (slices) {
 #pragma unroll
         for (int sl = 0; sl < 2; ++sl) {
@@ -449,6 +465,12 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_critic_fused(const CriticArgs ca
             }
         }
     }
+    MPG_TL(7);
+#ifdef MPG_TIMELINE
+    __syncthreads();
+    if (ca.dbg && blockIdx.x == 7 && threadIdx.x < NWAVE * MPG_TL_MARKS)
+        ca.dbg[blockIdx.y * NWAVE * MPG_TL_MARKS + threadIdx.x] = s_tl[threadIdx.x / MPG_TL_MARKS][threadIdx.x % MPG_TL_MARKS];
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -673,11 +695,32 @@ int launch_critic_fused(const mpg_cfg_t* cfg, const float* const* q_params, int 
     q.R = rows; q.n_sel = 2; q.xq = xq; q.gk = gk; q.ret_part = ret_part; q.gxq = gxq;
     for (int k = 0; k < 4; ++k) { q.gpow[k] = k < 2 ? gpow[k] : 0.f; q.coef[k] = k < 2 ? coef[k] : 0.f; }
     const int ngroups = rows / GROUP;
+    c.dbg = nullptr;
+#ifdef MPG_TIMELINE
+    static unsigned long long* s_dbg = nullptr;
+    static int s_calls = 0;
+    if (!s_dbg) (void)hipMalloc(&s_dbg, 2 * NWAVE * MPG_TL_MARKS * sizeof(unsigned long long));
+    c.dbg = s_dbg;
+#endif
     mpg_prof_begin(mpg_prof_of(cfg), 7, s);
     if (qin == 8) { if (a.pkf[0] && a.pkb[0] && (n_q < 2 || (a.pkf[1] && a.pkb[1]))) hipLaunchKernelGGL((k_critic_fused<8, true>), dim3(ngroups, n_q), dim3(NTHREAD), 0, s, c); else hipLaunchKernelGGL((k_critic_fused<8, false>), dim3(ngroups, n_q), dim3(NTHREAD), 0, s, c); }
     else if (qin == 5) { if (a.pkf[0] && a.pkb[0] && (n_q < 2 || (a.pkf[1] && a.pkb[1]))) hipLaunchKernelGGL((k_critic_fused<5, true>), dim3(ngroups, n_q), dim3(NTHREAD), 0, s, c); else hipLaunchKernelGGL((k_critic_fused<5, false>), dim3(ngroups, n_q), dim3(NTHREAD), 0, s, c); }
     else { mpg_set_error("launch_critic_fused: unsupported dims"); return MPG_EINVAL; }
     mpg_prof_end(mpg_prof_of(cfg), 7, s);
+#ifdef MPG_TIMELINE
+    if (++s_calls % 100 == 0) {
+        static unsigned long long h[2 * NWAVE * MPG_TL_MARKS];
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(h, s_dbg, sizeof(h), hipMemcpyDeviceToHost);
+        for (int b = 0; b < 2; ++b)
+            for (int w = 0; w < NWAVE; w += 7) {
+                fprintf(stderr, "timeline critic Q%d wg7 wave%d:", b + 1, w);
+                const unsigned long long* t = h + (b * NWAVE + w) * MPG_TL_MARKS;
+                for (int k = 1; k < 8; ++k) fprintf(stderr, " %d:%lld", k, (long long)(t[k] - t[0]));
+                fprintf(stderr, "\n");
+            }
+    }
+#endif
     MPG_CHECK_LAUNCH("k_critic_fused");
     return MPG_OK;
 }

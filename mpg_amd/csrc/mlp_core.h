@@ -486,6 +486,64 @@ __device__ __forceinline__ void forward_group(const float* sX, float* sA, float*
     }
 }
 
+// Two row groups through ONE pair of barriers: layer 1 of both, barrier, the matrix block of both (the same register image,
+// back to back on the matrix pipe), both epilogues, barrier.  A kernel that applies one image to several groups spends most
+// of a group's ~4.9k cycles in barrier waits and LDS round trips, not in the 768 cycles of its matrix block; paired, the
+// second group rides in the first one's latencies.  Same arithmetic per group as forward_group (bit-identical results).
+template <int IN, int OU>
+__device__ __forceinline__ void forward_group2(const float* sXa, const float* sXb, float* sAa, float* sAb, float* sPartA,
+                                               float* sPartB, const Lane& L, const float (&w2)[128], const SmallRegs<IN, OU>& r,
+                                               float (&h1a)[2][4], float (&h2a)[2][4], float (&h1b)[2][4], float (&h2b)[2][4]) {
+    auto layer1 = [&](const float* sX, float* sA, float (&h1)[2][4]) {
+        f32x4 z0 = {r.b1[0], r.b1[0], r.b1[0], r.b1[0]}, z1 = {r.b1[1], r.b1[1], r.b1[1], r.b1[1]};
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const float xa = sX[L.c * XS + 4 * q + L.rg];
+            z0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, r.w1p[q][0], z0, 0, 0, 0);
+            z1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, r.w1p[q][1], z1, 0, 0, 0);
+        }
+        elu8(z0, z1, h1);
+        store_c_to_a(sA, L, h1);
+    };
+    auto output = [&](float* sPart, const float (&h2)[2][4]) {
+        float p[OU][4];
+#pragma unroll
+        for (int o = 0; o < OU; ++o)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) p[o][j] = fmaf(h2[1][j], r.w3[1][o], h2[0][j] * r.w3[0][o]);
+#define MPG_DPP_STAGE(MODS)                                     \
+        _Pragma("unroll") for (int o = 0; o < OU; ++o)           \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)            \
+            asm volatile("v_add_f32_dpp %0, %1, %1 " MODS " row_mask:0xf bank_mask:0xf" : "=v"(p[o][j]) : "v"(p[o][j]));
+        if constexpr (OU == 2)
+            asm volatile("s_nop 1" : "+v"(p[0][0]), "+v"(p[0][1]), "+v"(p[0][2]), "+v"(p[0][3]), "+v"(p[OU - 1][0]),
+                         "+v"(p[OU - 1][1]), "+v"(p[OU - 1][2]), "+v"(p[OU - 1][3]));
+        else
+            asm volatile("s_nop 1" : "+v"(p[0][0]), "+v"(p[0][1]), "+v"(p[0][2]), "+v"(p[0][3]));
+        MPG_DPP_STAGE("quad_perm:[1,0,3,2]") MPG_DPP_STAGE("quad_perm:[2,3,0,1]")
+        MPG_DPP_STAGE("row_half_mirror") MPG_DPP_STAGE("row_mirror")
+#undef MPG_DPP_STAGE
+        if (L.c == 0) {
+#pragma unroll
+            for (int o = 0; o < OU; ++o)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sPart[(L.wave * GROUP + L.row(j)) * MAXOUT + o] = p[o][j];
+        }
+    };
+    layer1(sXa, sAa, h1a);
+    layer1(sXb, sAb, h1b);
+    lds_barrier();
+    f32x4 a0 = {r.b2[0], r.b2[0], r.b2[0], r.b2[0]}, a1 = {r.b2[1], r.b2[1], r.b2[1], r.b2[1]};
+    f32x4 b0 = a0, b1 = a1;
+    mfma_16x256x32(sAa, L, w2, a0, a1);
+    mfma_16x256x32(sAb, L, w2, b0, b1);
+    elu8(a0, a1, h2a);
+    elu8(b0, b1, h2b);
+    output(sPartA, h2a);
+    output(sPartB, h2b);
+    lds_barrier();
+}
+
 // sum of the 8 per-wave partials + bias for (row, o)
 __device__ __forceinline__ float out_preact(const float* sPart, float bias, int row, int o) {
     float z = bias;
