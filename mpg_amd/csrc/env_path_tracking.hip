@@ -14,6 +14,13 @@
 
 namespace {
 
+#ifdef MPG_TIMELINE   // diagnostic build only (tools/timeline.sh)
+__device__ unsigned long long g_env_tl[2][16];
+#define ENV_TL(k) do { __builtin_amdgcn_sched_barrier(0); if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 200)) g_env_tl[blockIdx.x ? 1 : 0][k] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define ENV_TL(k)
+#endif
+
 constexpr float PI_F = 3.14159265358979323846f;          // float32(np.pi)
 constexpr float TWO_PI_F = (float)(2.0 * 3.14159265358979323846);   // float32(2*np.pi)
 constexpr float PERIOD = 1200.f;                          // path_tracking_env.py:205
@@ -246,11 +253,13 @@ __device__ __forceinline__ StepOut step_agent(Agent& ag, const float2 an) {
         if (x > PERIOD) x = x - PERIOD;         // :171
         if (x <= 0.f) x = x + PERIOD;           // :172
     }
+    ENV_TL(5);
     {
         PathRef p = path_ref(x_u);              // :163-164
         dphi = wrap_pi(phi_u - p.phi);          // :165, :176-177
         dy = y - p.y;                           // :166
     }
+    ENV_TL(6);
 
     // `others` of the last sub-step (:100-101,135-138), judge_done :474-487
     const float alpha_f = atanf((vy_pre + A_ * r_pre) / vx_pre) - steer;
@@ -297,6 +306,109 @@ __global__ void __launch_bounds__(64) k_step(int n, float* __restrict__ st, cons
 // OffPolicyWorker.sample's inner body after the policy (worker.py:108-112) in one launch: env.step, the transition
 // (obs, action, RAW reward, obs', done) written straight into the replay ring slot (next_idx + i) % capacity
 // (buffer.py:46-55), then env.reset() for the agents that are done (path_tracking_env.py:445).
+// The same step with FOUR lanes per agent (lanes 4a .. 4a+3 of one wave, q = lane & 3; k_step_store_reset).  The sub-steps'
+// serial part is the planar dynamics (v_x, v_y, r) and the heading; the sincos of each heading and the world-frame
+// increments are not on that chain and delta_y / delta_phi only matter after the last sub-step.  So: (A) every lane runs the
+// short serial chain and the 20 (heading, v_x, v_y) triples go to LDS, (B) lane q evaluates the increments of sub-steps
+// q, q+4, .. (5 of the 20 sincos each), (C) every lane adds the increments in order.  Same float32 operations on the same
+// operands in the same order per variable as step_agent: bit-identical results, ~2450 instead of ~4300 instructions per wave,
+// and 256 waves instead of 64 for 4096 agents.  sc: this agent's 100 floats of LDS, [5][20].
+__device__ __forceinline__ StepOut step_agent_quad(Agent& ag, const float2 an, const int q, float* sc) {
+    StepOut out;
+    float vx = ag.vx, vy = ag.vy, r = ag.r, y = ag.y, phi = ag.phi, x = ag.x, dy = ag.dy, dphi = ag.dphi;
+    // step(): scale and clip the action, path_tracking_env.py:457-459
+    const float ACT_HI0 = (float)(1.2 * 3.14159265358979323846 / 9.0), ACT_HI1 = 3.f;
+    float steer = ((an.x * 1.2f) * PI_F) / 9.f;
+    float a_x = an.y * 3.f;
+    steer = fminf(fmaxf(steer, -ACT_HI0), ACT_HI0);
+    a_x = fminf(fmaxf(a_x, -ACT_HI1), ACT_HI1);
+
+    // compute_rewards on the PRE-step veh_state, :181-199
+    {
+        float t = vx - 20.f;
+        float devi_v = -(t * t), devi_y = -(dy * dy), devi_phi = -(dphi * dphi), p_yaw = -(r * r),
+              p_steer = -(steer * steer), p_ax = -(a_x * a_x);
+        out.reward = 0.01f * devi_v + 0.04f * devi_y + 0.1f * devi_phi + 0.02f * p_yaw + 5.f * p_steer + 0.05f * p_ax;
+    }
+
+    // f_xu pieces that depend on the action only, :95-101,135-136
+    const float F_zf = B_ * MASS * G_ / (A_ + B_), F_zr = A_ * MASS * G_ / (A_ + B_);
+    const float F_xf = a_x < 0.f ? MASS * a_x / 2.f : 0.f;
+    const float F_xr = a_x < 0.f ? MASS * a_x / 2.f : MASS * a_x;
+    const float miu_f = sqrtf((MIU * F_zf) * (MIU * F_zf) - F_xf * F_xf) / F_zf;
+    const float miu_r = sqrtf((MIU * F_zr) * (MIU * F_zr) - F_xr * F_xr) / F_zr;
+
+    const float tau = 0.005f;                  // 1/base_freq as a python float, cast on contact (:141)
+    const float K1 = tau * (A_ * C_f - B_ * C_r);
+    const float K2 = tau * C_f, K3 = tau * MASS, K4 = tau * (C_f + C_r);
+    const float K5 = (tau * A_) * C_f;
+    const float K6 = tau * ((A_ * A_) * C_f + (B_ * B_) * C_r);
+
+    float vx_pre = vx, vy_pre = vy, r_pre = r;  // state entering the LAST sub-step (for `others`)
+    float phi_u = phi;
+    ENV_TL(2);
+#pragma unroll 1
+    for (int s = 0; s < 20; ++s) {              // (A) simulation(), :144-179: dynamics and heading
+        vx_pre = vx; vy_pre = vy; r_pre = r;
+        float nvx = vx + tau * (a_x + vy * r);
+        float nvy = (((MASS * vy) * vx + K1 * r) - (K2 * steer) * vx - (K3 * (vx * vx)) * r) / (MASS * vx - K4);
+        float nr = ((((-I_z) * r) * vx - K1 * vy) + (K5 * steer) * vx) / (K6 - I_z * vx);
+        nvx = fminf(fmaxf(nvx, 1.f), 35.f);     // :153
+        phi = phi + div200(r);                  // :156, the OLD yaw rate
+        if ((s & 3) == q) { sc[s] = phi; sc[20 + s] = vx; sc[40 + s] = vy; }   // new heading, OLD velocities (:157-160)
+        phi_u = phi;
+        vx = nvx; vy = nvy; r = nr;             // :161
+        phi = wrap_pi(phi);                     // :168-169
+    }
+    __builtin_amdgcn_wave_barrier();            // the four lanes of an agent sit in one wave: LDS is in order within it
+    ENV_TL(3);
+#pragma unroll 1
+    for (int s = q; s < 20; s += 4) {           // (B) this lane's five sub-steps
+        float sp, cp;
+        sincos_bounded(sc[s], sp, cp);
+        const float ovx = sc[20 + s], ovy = sc[40 + s];
+        sc[60 + s] = div200(ovx * sp + ovy * cp);
+        sc[80 + s] = div200(ovx * cp - ovy * sp);
+    }
+    __builtin_amdgcn_wave_barrier();
+    ENV_TL(4);
+    float x_u = x;
+#pragma unroll 1
+    for (int s4 = 0; s4 < 20; s4 += 4) {        // (C) positions, in order; four increments per LDS round trip
+        const float4 iy = *reinterpret_cast<const float4*>(sc + 60 + s4), ix = *reinterpret_cast<const float4*>(sc + 80 + s4);
+        const float ay[4] = {iy.x, iy.y, iy.z, iy.w}, ax[4] = {ix.x, ix.y, ix.z, ix.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            y = y + ay[u];
+            x = x + ax[u];
+            x_u = x;                            // :163-164 read x before the wrap
+            if (x > PERIOD) x = x - PERIOD;     // :171
+            if (x <= 0.f) x = x + PERIOD;       // :172
+        }
+    }
+    ENV_TL(5);
+    {
+        PathRef p = path_ref(x_u);              // :163-164
+        dphi = wrap_pi(phi_u - p.phi);          // :165, :176-177
+        dy = y - p.y;                           // :166
+    }
+    ENV_TL(6);
+
+    // `others` of the last sub-step (:100-101,135-138), judge_done :474-487
+    const float alpha_f = atanf((vy_pre + A_ * r_pre) / vx_pre) - steer;
+    const float alpha_r = atanf((vy_pre - B_ * r_pre) / vx_pre);
+    const float afb = 3.f * miu_f * F_zf / C_f, arb = 3.f * miu_r * F_zr / C_r;
+    const float rb = miu_r * G_ / fabsf(vx_pre);
+    const bool geo = (fabsf(dy) > 3.f) | (fabsf(dphi) > PI_F / 4.f) | (vx < 2.f);
+    const bool lit = geo | (alpha_f < -afb) | (alpha_f > afb) | (alpha_r < -arb) | (alpha_r > arb) | (r < -rb) |
+                     (r > rb);
+    out.done = lit;
+    out.done_intended = geo | (fabsf(alpha_f) > fabsf(afb)) | (fabsf(alpha_r) > fabsf(arb)) | (fabsf(r) > rb);
+
+    ag.vx = vx; ag.vy = vy; ag.r = r; ag.y = y; ag.phi = phi; ag.x = x; ag.dy = dy; ag.dphi = dphi;
+    return out;
+}
+
 struct RingPtrs {
     float *obs, *act, *rew, *obs2;
     uint8_t* done;
@@ -340,21 +452,30 @@ __global__ void __launch_bounds__(64) k_step_store_reset(int n, float* __restric
         if (gr < pd.rows) predraw_row(pd, ring, capacity, next_idx, n, gr);
         return;
     }
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ __attribute__((aligned(16))) float s_quad[16 * 100];
+    ENV_TL(0);
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, i = t >> 2, q = t & 3;
     if (i >= n) return;
     Agent ag = load_agent(st, n, i);
     const float2 an = reinterpret_cast<const float2*>(action)[i];
     const size_t slot = (size_t)((next_idx + i) % capacity);
-    write_obs(ring.obs, (int)slot, od, ag);                     // obs before the step
-    reinterpret_cast<float2*>(ring.act)[slot] = an;
-    const StepOut o = step_agent(ag, an);
-    write_obs(ring.obs2, (int)slot, od, ag);
-    ring.rew[slot] = o.reward;
-    ring.done[slot] = o.done ? 1 : 0;
-    if (done_out) done_out[i] = o.done ? 1 : 0;
+    if (q == 0) {
+        write_obs(ring.obs, (int)slot, od, ag);                 // obs before the step
+        reinterpret_cast<float2*>(ring.act)[slot] = an;
+    }
+    ENV_TL(1);
+    const StepOut o = step_agent_quad(ag, an, q, s_quad + (threadIdx.x >> 2) * 100);
+    ENV_TL(7);
+    if (q == 1) {
+        write_obs(ring.obs2, (int)slot, od, ag);
+        ring.rew[slot] = o.reward;
+        ring.done[slot] = o.done ? 1 : 0;
+        if (done_out) done_out[i] = o.done ? 1 : 0;
+    }
     if (o.done) reset_agent(ag, i, k0, k1, c1, c2);
-    store_agent(st, n, i, ag);
-    write_obs(obs_out, i, od, ag);
+    if (q == 2) store_agent(st, n, i, ag);
+    if (q == 3) write_obs(obs_out, i, od, ag);
+    ENV_TL(8);
 }
 
 inline bool pt_obs_dim_ok(int od) { return od >= 6 && od <= 6 + MPG_ENV_MAX_FUTURE; }
@@ -409,11 +530,24 @@ int step_store_reset_impl(int env_kind, int n, int obs_dim, float* state, const 
     MPG_REQUIRE(pt_obs_dim_ok(obs_dim), "mpg_env_step_store_reset: obs_dim");
     RingPtrs ring{ring_obs, ring_act, ring_rew, ring_obs2, ring_done};
     PreDraw pd = pd_in;
-    pd.env_blocks = (n + 63) / 64;
+    pd.env_blocks = (4 * n + 63) / 64;            // four lanes per agent
     const int blocks = pd.env_blocks + (pd.rows + 63) / 64;
     hipLaunchKernelGGL(k_step_store_reset, dim3(blocks), dim3(64), 0, mpg_stream(stream), n, state, action, ring,
                        capacity, next_idx, (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)ctr, (uint32_t)(ctr >> 32), obs_out,
                        done_out, obs_dim, pd);
+#ifdef MPG_TIMELINE
+    static int s_calls = 0;
+    if (++s_calls % 100 == 0) {
+        unsigned long long h[2][16];
+        (void)hipStreamSynchronize(mpg_stream(stream));
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_env_tl), sizeof(h));
+        for (int b = 0; b < 2; ++b) {
+            fprintf(stderr, "timeline env wg%d:", b ? 200 : 0);
+            for (int k = 1; k < 9; ++k) fprintf(stderr, " %d:%lld", k, (long long)(h[b][k] - h[b][0]));
+            fprintf(stderr, "\n");
+        }
+    }
+#endif
     MPG_CHECK_LAUNCH("mpg_env_step_store_reset");
     return MPG_OK;
 }
