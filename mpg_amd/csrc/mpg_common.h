@@ -6,7 +6,8 @@
 
 #include "../../include/mpg_hip.h"
 
-#define MPG_ABI_VERSION 3   // 3: caller-owned handles (mpg_wcache_t, mpg_prof_t) instead of process-wide state
+#define MPG_ABI_VERSION 4   // 3: caller-owned handles (mpg_wcache_t, mpg_prof_t) instead of process-wide state
+                            // 4: mpg_replay_draw_t gained the pre-gathered window, mpg_env_step_store_reset_draw
 
 void mpg_set_error(const char* fmt, ...);
 
