@@ -135,6 +135,74 @@ def test_fused_step_store_reset_equals_separate_calls():
     assert torch.equal(obs_a, obs_b) and torch.equal(env_a._state, env_b._state) and bool(done_b.all())
 
 
+def test_pre_gathered_draw_equals_the_draw_inside_the_gradient_launch():
+    """mpg_env_step_store_reset_draw + mpg_mpg_gradients(draw.pre_gathered = 1) == mpg_env_step_store_reset +
+    mpg_mpg_gradients(draw): same ring, same minibatch (indices, five columns), same targets and gradients, bit for bit -
+    with a full ring whose fresh window wraps around the end, so that some drawn rows fall into the slots the env launch
+    is writing (those are left to the gradient launch)."""
+    import ctypes
+    import mpg_amd._lib as L
+    from mpg_amd import ops
+    from mpg_amd.envs import PathTrackingEnv
+    from tests.golden_inputs import mlp_weights_flat
+
+    class Draw(ctypes.Structure):               # mpg_replay_draw_t, include/mpg_hip.h
+        _fields_ = [('n_storage', ctypes.c_int), ('seed', ctypes.c_uint64), ('ctr', ctypes.c_uint64),
+                    ('ring_obs', ctypes.c_void_p), ('ring_act', ctypes.c_void_p), ('ring_rew', ctypes.c_void_p),
+                    ('ring_obs2', ctypes.c_void_p), ('ring_done', ctypes.c_void_p), ('idx_out', ctypes.c_void_p),
+                    ('done_out', ctypes.c_void_p), ('pre_gathered', ctypes.c_int), ('capacity', ctypes.c_int),
+                    ('fresh_start', ctypes.c_int), ('fresh_count', ctypes.c_int)]
+
+    def dev(x):
+        return torch.as_tensor(np.ascontiguousarray(x), dtype=torch.float32).cuda()
+
+    n, cap, nxt, B = 64, 1000, 970, 512               # 970 + 64 wraps; ~6 % of the draws land in the fresh window
+    rng = np.random.Generator(np.random.PCG64(11))
+    params = dev(np.concatenate([mlp_weights_flat(rng, 8, 1), mlp_weights_flat(rng, 8, 1), mlp_weights_flat(rng, 6, 4)]))
+    targets = (params * 0.97).contiguous()
+    act = dev(rng.uniform(-1.2, 1.2, (n, 2)))
+    ring0 = [dev(rng.standard_normal((cap, 6)) * np.array([3, 1, .5, 1, .5, 300])), dev(rng.uniform(-1, 1, (cap, 2))),
+             dev(rng.standard_normal(cap)), dev(rng.standard_normal((cap, 6)) * np.array([3, 1, .5, 1, .5, 300])),
+             torch.as_tensor(rng.integers(0, 2, cap).astype(np.uint8)).cuda()]
+    cfg = ops.make_cfg()
+    nb = L.lib().mpg_mpg_gradients_workspace_bytes(ctypes.byref(cfg), L.c_int(B), L.c_int(1), L.c_int(25), L.c_int(2), L.c_int(2))
+    sel, w = (ctypes.c_int * 2)(0, 25), (ctypes.c_float * 2)(0.3, 0.7)
+
+    def run(pre):
+        env = PathTrackingEnv(num_agent=n, seed=5)
+        env.reset()
+        ring = [t.clone() for t in ring0]
+        out = dict(obs=torch.zeros(B, 6).cuda(), act=torch.zeros(B, 2).cuda(), rew=torch.zeros(B).cuda(), obs2=torch.zeros(B, 6).cuda(),
+                   idx=torch.zeros(B, dtype=torch.int32).cuda(), done=torch.zeros(B).cuda(), y=torch.zeros(B).cuda(),
+                   grad=torch.zeros(params.numel()).cuda(), stats=torch.zeros(16).cuda(), wobs=torch.empty(n, 6).cuda())
+        d = Draw(cap, 77, 5, *[t.data_ptr() for t in ring], out['idx'].data_ptr(), out['done'].data_ptr(), 0, 0, 0, 0)
+        env_args = [L.c_int(0), L.c_int(n), L.c_int(6), L.ptr(env._state), L.ptr(act), L.c_int(cap), L.c_int(nxt),
+                    *[L.ptr(t) for t in ring], L.c_u64(env.seed), L.c_u64(env._ctr), L.ptr(out['wobs']), L.ptr(None)]
+        if pre:
+            L.call('mpg_env_step_store_reset_draw', *env_args, ctypes.byref(d), L.c_int(B), L.ptr(out['obs']), L.ptr(out['act']),
+                   L.ptr(out['rew']), L.ptr(out['obs2']), L.stream())
+            d.pre_gathered, d.capacity, d.fresh_start, d.fresh_count = 1, cap, nxt, n
+        else:
+            L.call('mpg_env_step_store_reset', *env_args, L.stream())
+        ws = torch.empty(nb + 256, dtype=torch.uint8, device='cuda')
+        L.call('mpg_mpg_gradients', ctypes.byref(cfg), L.c_int(2), L.ptr(params), L.ptr(targets), L.c_int(B), L.ptr(out['obs']),
+               L.ptr(out['act']), L.ptr(out['rew']), L.ptr(out['obs2']), L.ptr(None), L.c_int(1), L.c_int(25), sel, L.c_int(2), w,
+               L.ptr(None), L.c_u64(3), L.c_u64(1), L.c_float(1.0 / B), L.ptr(out['grad']), L.ptr(out['stats']), L.ptr(out['y']),
+               L.ptr(None), ctypes.byref(d), L.ptr(ws), L.c_size_t(ws.numel()), L.stream())
+        torch.cuda.synchronize()
+        return out, ring
+    a, ring_a = run(False)
+    b, ring_b = run(True)
+    for x, y in zip(ring_a, ring_b):
+        assert torch.equal(x, y)
+    idx = a['idx'].long()
+    fresh = ((idx - nxt) % cap) < n
+    assert 5 < int(fresh.sum()) < 100                 # the window is exercised
+    assert torch.equal(a['obs'], ring_a[0][idx]) and torch.equal(a['obs2'], ring_a[3][idx])     # and it is the post-add ring
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+
+
 def test_future_data_observations_vs_reference_run(golden):
     """num_future_data = 3 (path_tracking_env.py:385-402): six base entries + three look-ahead delta-y terms, against the
     reference's own env on the same start states and actions; and the reset() branch against the oracle's statement of
