@@ -210,8 +210,9 @@ __global__ void k_reduce_slabs(const float* __restrict__ slabs, int nslab, int n
 
 size_t wgrad_workspace_floats(int rows, int in_dim, int out_dim) {
     const long ngroups = (rows + GROUP - 1) / GROUP;
-    const int gp = wgrad_groups_per_chunk(ngroups);
-    const long nch = (ngroups + gp - 1) / gp;
+    // the single-job launch cuts finer than the multi-job one: room for whichever is used
+    const int gp = wgrad_groups_per_chunk(ngroups, true), gpm = wgrad_groups_per_chunk(ngroups, false);
+    const long nch = std::max((ngroups + gp - 1) / gp, (ngroups + gpm - 1) / gpm);
     return (size_t)nch * net_size(in_dim, out_dim);
 }
 
@@ -223,7 +224,7 @@ int launch_wgrad(const mpg_cfg_t* cfg, int in_dim, int out_dim, int ou, int rows
     a.h1 = h1; a.h2 = h2; a.dz1 = dz1; a.dz2 = dz2; a.dz3 = dz3; a.slabs = ws;
     a.dz_scale = wgrad_dz_scale(inv_b);
     const long ngroups = (rows + GROUP - 1) / GROUP;
-    a.groups_per_chunk = wgrad_groups_per_chunk(ngroups);
+    a.groups_per_chunk = wgrad_groups_per_chunk(ngroups, true);
     const int nch = (int)((ngroups + a.groups_per_chunk - 1) / a.groups_per_chunk);
     mpg_prof_begin(mpg_prof_of(cfg), 5, s);
 #define CALL(I, O) hipLaunchKernelGGL((k_wgrad<I, O>), dim3(8 * nch), dim3(NTHREAD), 0, s, a)

@@ -375,12 +375,19 @@ inline float wgrad_dz_scale(float inv_b) {
 // 32 per network 28 us / 0.264 ms (768 workgroups: a second, mostly empty round; 26 MB of slabs), 16: 24.4 / 0.2555,
 // 8 + 8 + 48 by job size: 28.5 / 0.258, 8 per network: 29 / 0.259.  The launch as a whole moves ~430 MB of stash through
 // the Infinity Cache in that time; short workgroups mostly wait in the same queues as the long ones.
+// A launch that carries ONE network's job (NADP, TD3, the fine-grained entry points) wants more, shorter chunks: 64 (512
+// workgroups) - C3 NADP B = 8192: 1.06 ms per gradient step with 16, 0.87 with 32, 0.84 with 64; C4 TD3 B = 65 536: 1.40 /
+// 1.25 / 1.245 (tools/bench_configs.py).
 #ifndef MPG_WGRAD_MAX_CHUNKS
 #define MPG_WGRAD_MAX_CHUNKS 16
 #endif
-constexpr int WGRAD_MAX_CHUNKS = MPG_WGRAD_MAX_CHUNKS;
-inline int wgrad_groups_per_chunk(long ngroups) {
-    long gp = (ngroups + WGRAD_MAX_CHUNKS - 1) / WGRAD_MAX_CHUNKS;
+#ifndef MPG_WGRAD_MAX_CHUNKS_SINGLE
+#define MPG_WGRAD_MAX_CHUNKS_SINGLE 64
+#endif
+constexpr int WGRAD_MAX_CHUNKS = MPG_WGRAD_MAX_CHUNKS, WGRAD_MAX_CHUNKS_SINGLE = MPG_WGRAD_MAX_CHUNKS_SINGLE;
+inline int wgrad_groups_per_chunk(long ngroups, bool single_job = false) {
+    const long mc = single_job ? WGRAD_MAX_CHUNKS_SINGLE : WGRAD_MAX_CHUNKS;
+    long gp = (ngroups + mc - 1) / mc;
     return (int)(gp < 1 ? 1 : gp);
 }
 
