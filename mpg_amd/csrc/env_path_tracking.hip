@@ -118,7 +118,7 @@ __device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& z0, fl
     float u1 = u01(a), u2 = u01(b);
     float rad = sqrtf(-2.f * logf(u1));
     float s, c;
-    sincosf(TWO_PI_F * u2, &s, &c);
+    sincos_bounded(TWO_PI_F * u2, s, c);                  // argument in [0, 2 pi)
     z0 = rad * c;
     z1 = rad * s;
 }
@@ -184,7 +184,9 @@ __device__ __forceinline__ void reset_agent(Agent& ag, int i, uint32_t k0, uint3
     PathRef p = path_ref(x);
     float y = dy + p.y;                                // compute_y :222-224
     float phi = wrap_pi(dphi + p.phi);                 // compute_phi :230-235
-    ag.vx = vx; ag.vy = vx * tanf(beta);               // :436
+    float sb, cb;                                       // beta = 0.15 * N(0, 1): far inside the bounded range
+    sincos_bounded(beta, sb, cb);
+    ag.vx = vx; ag.vy = vx * (sb / cb);                // :436, tan(beta)
     ag.r = r; ag.y = y; ag.phi = phi; ag.x = x;
     ag.dy = y - p.y;                                   // :450
     ag.dphi = phi - p.phi;                             // :449
