@@ -393,17 +393,27 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_critic_fused(const CriticArgs ca
     MPG_TL(0);
     const Net net = make_net(a.q[qi], QIN, 1);
     const CriticStash st = a.st[qi];
-    load_x_group<QIN>(a.x, a.rows, g, m.sX);
+    // The group's inputs are REQUESTED first, then the small pieces and the 256 KB image, and only then are the inputs
+    // consumed (LDS + barrier): the vector-memory counter retires in order, so this is the order in which the input round
+    // trip (2 us in the first workgroup of a CU, cold) overlaps the image request instead of preceding it.
+    float xv = 0.f, xv2 = 0.f;
+    if (tid < GROUP * XS) {
+        const int row = tid / XS, i = tid % XS;
+        const long gr = g * GROUP + row;
+        if (gr < a.rows && i < QIN) xv = i < a.x.d0 ? a.x.x0[gr * a.x.ld0 + i] * a.x.scale[i] : a.x.x1[gr * a.x.ld1 + (i - a.x.d0)];
+    }
     if (slices && tid < 2 * GROUP * XS) {
         const int sl = tid / (GROUP * XS), row = (tid / XS) % GROUP, i = tid % XS;
         const long gr = (sl * ngroups + g) * GROUP + row;
-        sX2[tid] = i < QIN ? q.xq[gr * QIN + i] : 0.f;
+        xv2 = i < QIN ? q.xq[gr * QIN + i] : 0.f;
     }
-    lds_barrier();
-    MPG_TL(1);
     float w2[128], h1[3][2][4], h2[3][2][4], dz1[2][4], dz2[2][4];
     SmallRegs<QIN, 1> r;
     MPG_LOAD2((load_small<QIN, 1>(net, L, r)), (load_w2<PK>(a.pkf[qi], net.W2, false, L, w2)));
+    if (tid < GROUP * XS) m.sX[tid] = xv;
+    if (slices && tid < 2 * GROUP * XS) sX2[tid] = xv2;
+    lds_barrier();
+    MPG_TL(1);
     MPG_TL(2);
     // ---- forward: replay batch group ----
     forward_group<QIN, 1>(m.sX, m.sA, m.sPart, L, w2, r, h1[0], h2[0]);

@@ -30,11 +30,24 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_forward(const FwdArgs a) {
     const Net net = make_net(a.params, a.in_dim, a.out_dim);
     float w2[128];
     SmallRegs<IN, OU> r;
-    if constexpr (PK) load_w2_packed(a.pack, L, w2); else load_w2_fwd(net.W2, L, w2);
-    load_small<IN, OU>(net, L, r);
     const long ngroups = (a.rows + GROUP - 1) / GROUP;
+    // the first group's inputs are requested BEFORE the small pieces and the 256 KB image and consumed after them: loads
+    // retire in order, so layer 1 and its barrier then run while the image is still streaming in
+    auto x_value = [&](long g) {
+        float v = 0.f;
+        if (threadIdx.x < GROUP * XS) {
+            const int row = threadIdx.x / XS, i = threadIdx.x % XS;
+            const long gr = g * GROUP + row;
+            if (gr < a.rows && i < IN) v = i < a.x.d0 ? a.x.x0[gr * a.x.ld0 + i] * a.x.scale[i] : a.x.x1[gr * a.x.ld1 + (i - a.x.d0)];
+        }
+        return v;
+    };
+    float xv = x_value(blockIdx.x);
+    load_small<IN, OU>(net, L, r);
+    if constexpr (PK) load_w2_packed(a.pack, L, w2); else load_w2_fwd(net.W2, L, w2);
     for (long g = blockIdx.x; g < ngroups; g += gridDim.x) {
-        load_x_group<IN>(a.x, a.rows, g, sX);
+        if (g != (long)blockIdx.x) xv = x_value(g);
+        if (threadIdx.x < GROUP * XS) sX[threadIdx.x] = xv;
         lds_barrier();
         float h1[2][4], h2[2][4];
         forward_group<IN, OU>(sX, sA, sPart, L, w2, r, h1, h2);
