@@ -27,7 +27,7 @@ EXTRA = {'env_path_tracking.hip': ['-ffp-contract=off'],
          'env_cart_pole.hip': ['-ffp-contract=off'],
          # the two rollout sweeps are separate translation units so that each gets the scheduling options that suit it
          # (MPG_FWD_CFLAGS / MPG_BWD_CFLAGS override them in experiments, tools/ab_sweeps.sh)
-         'rollout_fwd.hip': os.environ.get('MPG_FWD_CFLAGS', '').split(),
+         'rollout_fwd.hip': os.environ.get('MPG_FWD_CFLAGS', '-mllvm -amdgpu-sched-strategy=max-memory-clause').split(),
          # reverse sweep: the max-memory-clause scheduler strategy measures 1.7 us faster than the default (tools/ab_sweeps.sh)
          'rollout_bwd.hip': os.environ.get('MPG_BWD_CFLAGS', '-mllvm -amdgpu-sched-strategy=max-memory-clause').split()}
 
