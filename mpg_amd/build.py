@@ -26,9 +26,10 @@ EXTRA = {'env_path_tracking.hip': ['-ffp-contract=off'],
          # same reason of a different kind: the step and the fused step+store+reset kernel must round identically
          'env_cart_pole.hip': ['-ffp-contract=off'],
          # the two rollout sweeps are separate translation units so that each gets the scheduling options that suit it
-         # (MPG_FWD_CFLAGS / MPG_BWD_CFLAGS override them in experiments, tools/ab_sweeps.sh)
+         # (MPG_FWD_CFLAGS / MPG_BWD_CFLAGS override them in experiments: tools/ab.sh "FWD=... BWD=...")
+         # forward sweep: max-memory-clause measures 64.5 us against 68.4 with the default strategy
          'rollout_fwd.hip': os.environ.get('MPG_FWD_CFLAGS', '-mllvm -amdgpu-sched-strategy=max-memory-clause').split(),
-         # reverse sweep: the max-memory-clause scheduler strategy measures 1.7 us faster than the default (tools/ab_sweeps.sh)
+         # reverse sweep: the same strategy measures 1.7 us faster than the default
          'rollout_bwd.hip': os.environ.get('MPG_BWD_CFLAGS', '-mllvm -amdgpu-sched-strategy=max-memory-clause').split()}
 
 
