@@ -48,9 +48,9 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int sl, con
     const f32x4* H2 = reinterpret_cast<const f32x4*>(a.h2);
     const f32x4* DZ1 = reinterpret_cast<const f32x4*>(a.dz1);
     const f32x4* DZ2 = reinterpret_cast<const f32x4*>(a.dz2);
-    // ---- thin pieces (dW1, db1, db2, dW3, db3): the chunk's groups are dealt round-robin to the 8 waves.  The loads
-    //      of a wave's first thin group are issued before the MFMA loop and consumed after it, so their latency is
-    //      hidden; later groups (long chunks, e.g. NADP's 26*B rows) are prefetched one ahead. ----
+    // ---- thin pieces (dW1, db1, db2, dW3, db3): the chunk's groups are dealt round-robin to the 8 waves and handled
+    //      after the matrix loop (requesting a wave's first group ahead of the loop costs 27 registers across it: 35 spills
+    //      at the 128-register cap) ----
     struct Thin {
         f32x4 d10, d11, d20, d21, h20, h21;
     };
