@@ -68,6 +68,28 @@ def test_policy_action_and_clipped_double_q_target_vs_golden(golden):
     np.testing.assert_allclose(a, a_ref, rtol=0, atol=2e-6)
 
 
+def test_target_kernel_two_groups_per_workgroup_equals_one():
+    """From 256 row groups on, k_target_fused sends two groups through every network per workgroup (forward_group2).  A row's
+    target does not depend on its neighbours: 4107 rows (257 groups, ragged last one, odd count) in one call equal the same
+    rows in two calls of 128 + 129 groups, which take the one-group path - bit for bit, with and without the smoothing noise."""
+    from mpg_amd import ops
+    rng = np.random.Generator(np.random.PCG64(21))
+    cfg = ops.make_cfg()
+    pol, q1, q2 = dev(rand_net(rng, 6, 4)), dev(rand_net(rng, 8, 1)), dev(rand_net(rng, 8, 1))
+    n = 4107
+    obs2 = dev(rng.standard_normal((n, 6)) * np.array([3, 1, .5, 1, .5, 300]))
+    rew = dev(rng.standard_normal(n))
+    eps = dev(rng.standard_normal((n, 2)))
+    for sm in (None, eps):
+        cut = 2048
+        whole = ops.q_targets(cfg, pol, q1, q2, rew, obs2, smooth_eps=sm).clone()
+        a = ops.q_targets(cfg, pol, q1, q2, rew[:cut].contiguous(), obs2[:cut].contiguous(),
+                          smooth_eps=None if sm is None else sm[:cut].contiguous()).clone()
+        b = ops.q_targets(cfg, pol, q1, q2, rew[cut:].contiguous(), obs2[cut:].contiguous(),
+                          smooth_eps=None if sm is None else sm[cut:].contiguous()).clone()
+        assert torch.equal(whole, torch.cat([a, b]))
+
+
 def test_td3_smoothed_target_vs_golden(golden):
     from mpg_amd import ops
     g = golden('td3_H256_B64.npz')
