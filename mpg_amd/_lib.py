@@ -17,11 +17,23 @@ class MpgError(RuntimeError):
     pass
 
 
+def _header_text():
+    src = open(HEADER).read()
+    return re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+
+
 def declared_symbols():
     """Every function name include/mpg_hip.h declares (used by the ABI export test)."""
-    src = open(HEADER).read()
-    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
-    return sorted(set(re.findall(r'\b(mpg_[a-z0-9_]+)\s*\(', src)))
+    return sorted(set(re.findall(r'\b(mpg_[a-z0-9_]+)\s*\(', _header_text())))
+
+
+def declared_return_types():
+    """{function name: C return type as written in include/mpg_hip.h} - the restype of every symbol is taken from
+    the declaration itself, not from a naming convention."""
+    out = {}
+    for m in re.finditer(r'^\s*((?:const\s+)?[A-Za-z_][A-Za-z0-9_]*\s*\*?)\s*(mpg_[a-z0-9_]+)\s*\(', _header_text(), flags=re.M):
+        out[m.group(2)] = re.sub(r'\s+', ' ', m.group(1)).strip()
+    return out
 
 
 def lib():
@@ -31,15 +43,11 @@ def lib():
             raise MpgError('%s is missing - run `python -m mpg_amd.build` (hipcc, gfx950). '
                            'mpg_amd has no CPU fallback.' % LIB_PATH)
         _lib = ctypes.CDLL(LIB_PATH)
-        _lib.mpg_last_error.restype = ctypes.c_char_p
+        ctype = {'size_t': ctypes.c_size_t, 'int': ctypes.c_int, 'const char*': ctypes.c_char_p, 'const char *': ctypes.c_char_p}
+        rtypes = declared_return_types()
         for name in declared_symbols():
             fn = getattr(_lib, name)            # AttributeError here = header/library out of sync
-            if name.endswith('_workspace_bytes'):
-                fn.restype = ctypes.c_size_t
-            elif name == 'mpg_prof_slot_name':
-                fn.restype = ctypes.c_char_p
-            elif name != 'mpg_last_error':
-                fn.restype = ctypes.c_int
+            fn.restype = ctype[rtypes[name]]    # KeyError here = a return type this binding does not know
     return _lib
 
 

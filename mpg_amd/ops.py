@@ -59,11 +59,20 @@ class Profiler(object):
 
     def __init__(self, max_samples=4096):
         self.h = ctypes.c_void_p(0)
+        self._attached = []          # every cfg that carries this handle: cleared in close(), so none is left dangling
         L.call('mpg_prof_create', L.c_int(max_samples), ctypes.byref(self.h))
 
     def attach(self, *cfgs):
         for c in cfgs:
             c.prof = self.h.value
+            if not any(c is a for a in self._attached):
+                self._attached.append(c)
+
+    def detach(self, *cfgs):
+        for c in cfgs:
+            if c.prof == self.h.value:
+                c.prof = None
+            self._attached = [a for a in self._attached if a is not c]
 
     def start(self, every):
         L.call('mpg_prof_start', self.h, L.c_int(every))
@@ -79,6 +88,10 @@ class Profiler(object):
 
     def close(self):
         if self.h:
+            for c in self._attached:      # a cfg must never outlive the events it points at
+                if c.prof == self.h.value:
+                    c.prof = None
+            self._attached = []
             L.lib().mpg_prof_destroy(self.h)
             self.h = ctypes.c_void_p(0)
 

@@ -44,11 +44,17 @@ class SingleProcessOffPolicyOptimizer(object):
 
     def set_profiler(self, prof):
         """attach an ops.Profiler (or None) to every cfg this optimizer launches with"""
-        h = prof.h.value if prof is not None else None
-        self.worker.policy_with_value.cfg.prof = h
-        self.learner.policy_with_value.cfg.prof = h
+        cfgs = [self.worker.policy_with_value.cfg, self.learner.policy_with_value.cfg]
         if self._fused is not None:
-            self._fused.c.cfg.prof = h
+            cfgs.append(self._fused.c.cfg)
+        old = getattr(self, '_prof', None)
+        if old is not None:
+            old.detach(*cfgs)
+        for c in cfgs:
+            c.prof = None
+        self._prof = prof            # the optimizer keeps the timer alive for as long as its cfgs point at it
+        if prof is not None:
+            prof.attach(*cfgs)
 
     def get_stats(self):
         self.stats.update(dict(num_sampled_steps=self.num_sampled_steps, iteration=self.iteration))
