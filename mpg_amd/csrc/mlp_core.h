@@ -88,29 +88,6 @@ __host__ __device__ inline Net make_net(const float* p, int in_dim, int out_dim)
     return n;
 }
 
-// ---- which hidden unit a (wave, tile, lane column) slot of the engine owns --------------------------------------
-// Slot (w, t, c): the output column that lane column c of tile t of wave w produces.  The unit it stands for is
-//     unit = 32 kb + 8 kg + 4 t + (c & 3),   kb = 2 (w & 3) + ((c >> 2) & 1),   kg = 2 (w >> 2) + (c >> 3)
-// i.e. the four lane columns 4a .. 4a+3 of BOTH tiles are the eight consecutive units of one 16-byte chunk (kb, kg) of the
-// split-fp16 LDS image (h_index).  Two engines share this labelling and therefore the same packed weight images:
-//   * the row-quad engine below ("C layout": a lane holds 4 rows x 1 unit per tile) - adjacent lane columns are adjacent
-//     units, so a pair of lanes still packs (k even, k odd) words; its 32 lanes of a store instruction now touch 16
-//     banks (2-way, free) exactly as before;
-//   * the row-per-lane engine of mlp_ct.h ("CT layout", the MFMA with its operands swapped: a lane holds 1 row x the 8
-//     units of one chunk) - its image store is ONE 16-byte write per lane and image, no cross-lane exchange.
-// Contraction indices (the k of every product) stay the natural unit index everywhere.
-__host__ __device__ inline int unit_of(int w, int t, int c) {
-    const int a = c >> 2;
-    return 32 * (2 * (w & 3) + (a & 1)) + 8 * (2 * (w >> 2) + (a >> 1)) + 4 * t + (c & 3);
-}
-// inverse: unit n -> wave, tile, lane column
-__host__ __device__ inline void slot_of(int n, int& w, int& t, int& c) {
-    const int kb = n >> 5, kg = (n >> 3) & 3;
-    t = (n >> 2) & 1;
-    w = (kb >> 1) + 4 * (kg >> 1);
-    c = 4 * ((kb & 1) + 2 * (kg & 1)) + (n & 3);
-}
-
 struct Lane {
     int lane, wave, c, rg;     // c = lane & 15 (column in tile), rg = lane >> 4 (row quad)
     __device__ Lane() {
@@ -119,7 +96,7 @@ struct Lane {
         c = lane & 15;
         rg = lane >> 4;
     }
-    __device__ int col(int t) const { return unit_of(wave, t, c); }
+    __device__ int col(int t) const { return 32 * wave + 16 * t + c; }
     __device__ int row(int j) const { return 4 * rg + j; }
 };
 
@@ -233,7 +210,7 @@ __device__ __forceinline__ void store_c_to_a(float* sA, const Lane& L, const flo
         float p[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) p[j] = dpp_mov<0xB1>(v[t][j]);               // partner lane (c ^ 1)
-        const int k = L.col(t) & ~1;                                              // lane columns c, c^1 are units k, k+1
+        const int k = 32 * L.wave + 16 * t + (L.c & ~1);
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const float x = odd ? p[2 + u] : v[t][u], y = odd ? v[t][2 + u] : p[u];   // (k even, k odd) of row row0 + u
@@ -391,17 +368,10 @@ __device__ __forceinline__ void mfma_16x256x32(const float* sA, const Lane& L, c
 #endif
 
 // ---- small per-lane stationary pieces -----------------------------------------------------------------
-// The 32 units of wave w enumerated as 8 k-steps x 4 (the contraction of the small dx product over the wave's own columns):
-// k-step q, k-quarter rg -> unit.  Steps 0..3 and 4..7 are 16 consecutive units each (the wave's two kb blocks), so the
-// float32 A image (a_index) serves four steps with one 16-byte read.
-__host__ __device__ inline int wave_unit(int w, int q, int rg) {
-    return 32 * (2 * (w & 3) + (q >> 2)) + 8 * (2 * (w >> 2) + ((q >> 1) & 1)) + 4 * (q & 1) + rg;
-}
-
 template <int IN, int OU>
 struct SmallRegs {
     float w1p[2][2];   // layer-1 MFMA B operand: W1[4q + rg][col(t)] (0 beyond IN), index [q][t]
-    float w1t[8];      // dx MFMA B operand: W1[c][wave_unit(w, q, rg)] (0 for c >= IN), q = 0..7
+    float w1t[8];      // dx MFMA B operand: W1[c][32w + 4q + rg] (0 for c >= IN), q = 0..7
     float b1[2], b2[2];
     float w3[2][OU];   // W3[col(t)][o]
 };
@@ -410,7 +380,7 @@ template <int IN, int OU>
 __device__ __forceinline__ void load_small(const Net& n, const Lane& L, SmallRegs<IN, OU>& r) {
     static_assert(IN <= 8, "layer-1 MFMA covers K <= 8");
 #pragma unroll
-    for (int q = 0; q < 8; ++q) r.w1t[q] = L.c < IN ? n.W1[L.c * H + wave_unit(L.wave, q, L.rg)] : 0.f;
+    for (int q = 0; q < 8; ++q) r.w1t[q] = L.c < IN ? n.W1[L.c * H + 32 * L.wave + 4 * q + L.rg] : 0.f;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int col = L.col(t);
@@ -680,9 +650,8 @@ __device__ __forceinline__ void backward_rest(const float* sD3, float* sA, float
         store_c_to_a_f32(sA1, L, dz1);
         __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): this wave reads back only what it wrote itself
         __builtin_amdgcn_wave_barrier();
-        // wave_unit(w, q, rg) >> 2 = 8 kb + 2 kg + (q & 1): steps 0..3 sit at float offset 16 (w & 3) + 4 (w >> 2), steps 4..7 eight further
-        const float* base = sA1 + L.c * LDA + L.rg * KS + 16 * (L.wave & 3) + 4 * (L.wave >> 2);
-        const f32x4 a0 = *reinterpret_cast<const f32x4*>(base), a1 = *reinterpret_cast<const f32x4*>(base + 8);
+        const float* base = sA1 + L.c * LDA + L.rg * KS + 8 * L.wave;
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(base), a1 = *reinterpret_cast<const f32x4*>(base + 4);
         f32x4 dx = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int q = 0; q < 4; ++q) dx = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[q], r.w1t[q], dx, 0, 0, 0);

@@ -295,7 +295,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int sl, con
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                sW2[unit_of(L.wave, u, 4 * L.rg + j) * H + unit_of(sl, t, L.c)] = acc[u][t][j];   // stash positions -> units (mlp_core.h)
+                sW2[(16 * (2 * L.wave + u) + 4 * L.rg + j) * H + 32 * sl + 16 * t + L.c] = acc[u][t][j];
     MPG_TL(5);
     // thin pieces: sum over the 8 waves and the 4 row quads through LDS in a fixed order
     __syncthreads();   // the staging corners used above alias this scratch
@@ -324,7 +324,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int sl, con
             for (int rg = 0; rg < 4; ++rg) sum += sRed[(w * NQ + q) * 64 + rg * 16 + c];
         constexpr int PER_T = IN + 2 + OU;
         if (q < 2 * PER_T) {
-            const int t = q / PER_T, r = q % PER_T, col = unit_of(sl, t, c);
+            const int t = q / PER_T, r = q % PER_T, col = 32 * sl + 16 * t + c;
             if (r < IN) sW1[r * H + col] = sum;
             else if (r == IN) sb1[col] = sum;
             else if (r == IN + 1) sb2[col] = sum;
@@ -338,7 +338,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int sl, con
     }
     // unused output columns of W3 / b3 (the log-std half of the policy head, SURVEY B-5) have zero gradient
     for (int item = tid; item < 32 * (a.out_dim - OU); item += NTHREAD) {
-        const int e = item / (a.out_dim - OU), col = unit_of(sl, e >> 4, e & 15), o = OU + item % (a.out_dim - OU);
+        const int col = 32 * sl + item / (a.out_dim - OU), o = OU + item % (a.out_dim - OU);
         sW3[col * a.out_dim + o] = 0.f;
     }
     if (sl == 0 && tid < a.out_dim - OU) sb3[OU + tid] = 0.f;

@@ -25,9 +25,7 @@ constexpr int HH = MPG_HIDDEN * MPG_HIDDEN;
 // Packed images of the split engine (mlp_core.h / weight_cache.hip): the fp16 hi and lo halves of W2[row][col] * W_SCALE,
 // where contraction index k owns the lane group and register, output index n the lane column.  Writes both halves.
 __device__ __forceinline__ void pack_store(float* __restrict__ image, int k, int n, float w) {
-    int wave, t, c;
-    mlp::slot_of(n, wave, t, c);
-    const int kb = k >> 5, rg = (k >> 3) & 3, r = (k >> 1) & 3, e = k & 1;
+    const int wave = n >> 5, t = (n >> 4) & 1, c = n & 15, kb = k >> 5, rg = (k >> 3) & 3, r = (k >> 1) & 3, e = k & 1;
     const int word = (((wave * 32 + (kb * 2 + t) * 2) * 64 + rg * 16 + c) << 2) + r;      // hi word; the lo word is 256 further
     const float ws = w * mlp::W_SCALE;
     const _Float16 hi = (_Float16)ws;
@@ -39,9 +37,7 @@ __device__ __forceinline__ void pack_store(float* __restrict__ image, int k, int
 #else
 // position of W2[row][col] in the packed image where `col`-like index n owns the lane and `row`-like index k the step
 __device__ __forceinline__ int pack_index(int k, int n) {
-    int wave, t, c;
-    mlp::slot_of(n, wave, t, c);
-    const int q = k >> 2, rg = k & 3;
+    const int wave = n >> 5, t = (n >> 4) & 1, c = n & 15, q = k >> 2, rg = k & 3;
     return ((((wave * 16 + (q >> 2)) * 2 + t) * 64 + rg * 16 + c) << 2) + (q & 3);
 }
 __device__ __forceinline__ void pack_store(float* __restrict__ image, int k, int n, float w) { image[pack_index(k, n)] = w; }

@@ -27,10 +27,10 @@ __global__ void k_pack(const PackArgs a) {
     float* out = a.cache + ((size_t)net * 2 + dir) * (mlp::H * mlp::H);
 #ifdef MPG_SPLIT
     // word ((wave*32 + v)*64 + lane)*4 + r, v = (kb*2 + t)*2 + part: the packed pair (k0, k0 + 1), k0 = 32 kb + 8 (lane>>4) + 2 r,
-    // of output unit n = unit_of(wave, t, lane&15) (mlp_core.h); part 0 = hi halves, 1 = lo halves of W * W_SCALE (mlp_core.h)
+    // of output column n = 32 wave + 16 t + (lane&15); part 0 = hi halves, 1 = lo halves of W * W_SCALE (mlp_core.h)
     const int r = idx & 3, lane = (idx >> 2) & 63, v = (idx >> 8) & 31, wave = idx >> 13;
     const int part = v & 1, t = (v >> 1) & 1, kb = v >> 2;
-    const int k0 = 32 * kb + 8 * (lane >> 4) + 2 * r, n = mlp::unit_of(wave, t, lane & 15);
+    const int k0 = 32 * kb + 8 * (lane >> 4) + 2 * r, n = 32 * wave + 16 * t + (lane & 15);
     const float w0 = (dir == 0 ? W2[k0 * mlp::H + n] : W2[n * mlp::H + k0]) * mlp::W_SCALE;
     const float w1 = (dir == 0 ? W2[(k0 + 1) * mlp::H + n] : W2[n * mlp::H + k0 + 1]) * mlp::W_SCALE;
     float hi, lo;
@@ -40,7 +40,7 @@ __global__ void k_pack(const PackArgs a) {
     const int e = idx & 3, lane = (idx >> 2) & 63, t = (idx >> 8) & 1, q4 = (idx >> 9) & 15, wave = idx >> 13;
     const int c = lane & 15, rg = lane >> 4;
     const int k = 4 * (4 * q4 + e) + rg;                         // contraction index of the MFMA step
-    const int n = mlp::unit_of(wave, t, c);                      // output unit owned by the lane
+    const int n = 32 * wave + 16 * t + c;                        // output column owned by the lane
     out[idx] = dir == 0 ? W2[k * mlp::H + n] : W2[n * mlp::H + k];
 #endif
 }
