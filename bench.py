@@ -267,6 +267,7 @@ def main():
     per_step = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(a.steps))
     finite = bool(torch.isfinite(worker.policy_with_value.params).all().item())
     assert finite and int(worker.policy_with_value.nonfinite.sum().item()) == 0, 'non-finite parameters after the timed region'
+    worker.policy_with_value.check_status()          # raises if the split-fp16 engine left its numerical envelope anywhere
 
     if rank != 0:
         return
@@ -277,6 +278,13 @@ def main():
     if os.path.exists(tpath):
         with open(tpath) as fh:
             traffic = json.load(fh).get('bytes_per_launch', {})
+    # the same command on the exact-fp32 engine (-DMPG_F32_MFMA: v_mfma_f32_16x16x4_f32, no fp16 operands anywhere), measured
+    # once per round through gpurun by tools/profile.sh and committed under profiles/ - reported beside the split-fp16 number
+    exact = {}
+    epath = os.path.join(ROOT, 'profiles', 'exact_fp32_bench.json')
+    if os.path.exists(epath):
+        with open(epath) as fh:
+            exact = json.load(fh)
 
     def roof(kernel, nbytes, flop, ms, n):
         """Both roofs of a rollout sweep.  With the split-fp16 engine the sweeps sit closer to the HBM roof (the activation
@@ -289,7 +297,8 @@ def main():
         executed = (flop + 2 * HIDDEN_FLOP_PER_STATE) * B_PER_GPU / sec / 1e12      # hidden layer counted 3x
         algorithmic = flop * B_PER_GPU / sec / 1e12
         return {'kernel': kernel, 'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                'frac': gbs / HBM_PEAK_GBS, 'traffic': tr, 'avg_ms': ms, 'launches': n,
+                'frac': gbs / HBM_PEAK_GBS, 'frac_hbm': gbs / HBM_PEAK_GBS, 'frac_f16_mfma': executed / F16_MFMA_PEAK_TFLOPS,
+                'traffic': tr, 'avg_ms': ms, 'launches': n,
                 'timed_with': 'HIP events on the launch stream around every %d-th launch of the timed region' % PROF_EVERY,
                 'algorithmic_bytes_per_launch': nbytes * B_PER_GPU,
                 'traffic_gbs': (tr / sec / 1e9) if tr else None,
@@ -311,7 +320,10 @@ def main():
         'gc': 'gc.collect()+gc.freeze() before the burn-in, gc.disable() inside the timed region',
         'step_ms_median': per_step[len(per_step) // 2], 'step_ms_min': per_step[0], 'step_ms_max': per_step[-1],
         'step_ms_from': 'second pass of the same %d steps, one HIP event per step (not part of value)' % a.steps,
-        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32-via-split-f16', 'data': 'synthetic',
+        'schema': 3,     # 3: roofline.frac = HBM view (round 1: fp32-MFMA view), frac_hbm / frac_f16_mfma under stable keys, exact_fp32_*
+        'exact_fp32_ms_per_step': exact.get('ms_per_step'),
+        'exact_fp32_from': exact.get('from'),
         'dtype_note': 'float32 data and accumulation; the 256x256 hidden-layer products run as fp16 hi/lo split operands on the f16 matrix pipe (3 MFMAs per fp32-equivalent step, more accurate than the fp32 fma chain on a single layer; csrc/mlp_core.h)',
         'config': {'workload': 'PathTrackingEnv, MPG-v2 learner, n=25, M=1, 4096 vectorised envs + replay batch 4096 per '
                                'GPU; step = worker.sample(4096 env-steps) + add_batch + replay + compute_gradient + '

@@ -72,10 +72,34 @@ typedef struct {
     float* packed;        /* device: mpg_weight_cache_floats(n_nets) floats */
     int n_nets;           /* <= 8 */
     int in_dim[8], out_dim[8];
+    int* status;          /* device, nullable: MPG_STATUS_* bits are OR-ed into it (see "Numerical envelope" below) */
 } mpg_wcache_t;
 size_t mpg_weight_cache_floats(int n_nets);
 /* (re)builds both images of every network of `wc` from wc->params: one launch on `stream`. */
 int mpg_weight_cache_pack(const mpg_wcache_t* wc, mpg_stream_t stream);
+
+/* Numerical envelope of the hidden-layer engine and how leaving it is reported.  The 256 x 256 hidden-layer products run
+ * on the f16 matrix pipe with every float32 operand split into two fp16 halves (hi + lo: 22-23 significant bits, exact
+ * products, float32 accumulation; csrc/mlp_core.h).  Operands are pre-scaled by powers of two; what that leaves as the
+ * supported range is
+ *     |first hidden activation| < 4094           (enters the image as x * 16; fp16 ends at 65504)
+ *     |any network parameter|   < 1023.5         (hidden kernels enter as W * 64; the bound also keeps the reverse layer's
+ *                                                 row-scaled operands, <= 16 * out * |W3|, in range)
+ * Gradients entering the reverse layer and the weight-gradient product are scaled by data-dependent powers of two (per row
+ * / per chunk of rows) and have no envelope of their own.  Outside the range a result would silently be wrong (an fp16
+ * infinity turns a whole row into NaN, which the ELU's median instruction then drops), so the library reports it: every
+ * forward pass tracks the largest first-layer pre-activation it saw, every (re)pack of an image checks the parameters, and a
+ * violation sets a bit in the caller's device-side status word (mpg_cfg_t.status / mpg_wcache_t.status; nullable = not
+ * reported).  A parameter beyond the bound enters the image clamped to +-65504 / 64.  The word is sticky: the caller reads
+ * and clears it (mpg_amd.PolicyWithQs.check_status raises on it); `-DMPG_F32_MFMA` builds the exact-fp32 engine, which has
+ * no envelope.  Reference counterpart: none (TensorFlow computes in float32 throughout). */
+enum {
+    MPG_STATUS_ACTIVATION_RANGE = 1, /* a first-hidden-layer activation reached 4094: that row's outputs are invalid */
+    MPG_STATUS_PARAMETER_RANGE = 2,  /* a parameter reached 1023.5: clamped in the packed image */
+    MPG_STATUS_NAN = 4               /* a NaN went into or came out of a network forward pass (mpg_policy_action and the other
+                                        cfg-carrying forward entry points) - worker.py:95-107 `judge_is_nan` on the processed
+                                        observations and on the actions, evaluated on the device */
+};
 
 /* Optional per-kernel timing with HIP events recorded on the launch stream.  mpg_prof_create allocates every event
  * up front (2 * MPG_PROF_SLOTS * max_samples of them), so that nothing is created inside a timed region;
@@ -156,6 +180,7 @@ typedef struct {
     const mpg_wcache_t* wcache[2]; /* packed images of up to two parameter vectors (e.g. networks, targets) that calls
                                       made with this cfg may receive pointers into */
     mpg_prof_t* prof;           /* kernel timer that the calls made with this cfg report to */
+    int* status;                /* device, nullable: MPG_STATUS_* bits are OR-ed into it by the forward passes made with this cfg */
 } mpg_cfg_t;
 
 /* MLPNet.call  - model.py:39-43:  y[rows][out_used] = act(ELU(ELU(x W1 + b1) W2 + b2) W3 + b3)[:, :out_used].

@@ -61,6 +61,7 @@ struct TargetArgs {
     const uint8_t* r_done;
     int* o_idx;
     float *o_obs, *o_act, *o_rew, *o_obs2, *o_done;
+    int* status;               // nullable: MPG_STATUS_* word of the caller
     unsigned long long* dbg;   // MPG_TIMELINE builds only
 };
 
@@ -115,6 +116,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_target_fused(const TargetArgs a)
         }
     }
     float w2[128], h1[2][4], h2[2][4];
+    float zmax = 0.f;                          // largest first-layer activation seen by this lane (the engine's envelope, mlp_core.h)
     const Net pnet = make_net(a.pol, OBS, 2 * ACT);
     SmallRegs<OBS, ACT> pr;
     MPG_TL(1);
@@ -148,9 +150,9 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_target_fused(const TargetArgs a)
     float h1b[2][4], h2b[2][4];
     // G2 == 2: both row groups go through every network as a pair (forward_group2: one pair of barriers for two groups)
     if constexpr (G2 == 2) {   // a' = pi_target(s~')  (+ clip(sigma*eps, +-c), td3.py:74-76)
-        forward_group2<OBS, ACT>(sXg[0], sXg[1], m.sA, m.sA1, m.sPart, m.sPartX, L, w2, pr, h1, h2, h1b, h2b);
+        forward_group2<OBS, ACT>(sXg[0], sXg[1], m.sA, m.sA1, m.sPart, m.sPartX, L, w2, pr, h1, h2, h1b, h2b, &zmax);
     } else {
-        forward_group<OBS, ACT>(sXg[0], m.sA, m.sPart, L, w2, pr, h1, h2);
+        forward_group<OBS, ACT>(sXg[0], m.sA, m.sPart, L, w2, pr, h1, h2, nullptr, 0, nullptr, &zmax);
     }
     if (tid < G2 * GROUP * ACT) {
         const int g2 = tid / (GROUP * ACT), row = (tid / ACT) % GROUP, k = tid % ACT;
@@ -172,9 +174,9 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_target_fused(const TargetArgs a)
         MPG_LOAD2((load_small<QIN, 1>(net, L, r)), (load_w2<PK>(qi == 0 ? a.pk_q1 : a.pk_q2, net.W2, false, L, w2)));
         MPG_TL(10 + 6 * qi);
         if constexpr (G2 == 2) {
-            forward_group2<QIN, 1>(sXg[0], sXg[1], m.sA, m.sA1, m.sPart, m.sPartX, L, w2, r, h1, h2, h1b, h2b);
+            forward_group2<QIN, 1>(sXg[0], sXg[1], m.sA, m.sA1, m.sPart, m.sPartX, L, w2, r, h1, h2, h1b, h2b, &zmax);
         } else {
-            forward_group<QIN, 1>(sXg[0], m.sA, m.sPart, L, w2, r, h1, h2);
+            forward_group<QIN, 1>(sXg[0], m.sA, m.sPart, L, w2, r, h1, h2, nullptr, 0, nullptr, &zmax);
         }
         if (tid < G2 * GROUP) {
             const int g2 = tid / GROUP, row = tid % GROUP;
@@ -193,6 +195,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_target_fused(const TargetArgs a)
             a.y[gr] = (sRew[tid] + a.rshift) * a.rscale + a.gamma * q;      // mpg_learner.py:132-133
         }
     }
+    report_activation_range(a.status, zmax);
     MPG_TL(23);
     MPG_TL_DUMP(a.dbg);
 }
@@ -208,6 +211,7 @@ struct QlossArgs {
     CriticStash st[2];
     float* loss_part;          // [n_q][ngroups]
     float* td;
+    int* status;               // nullable: MPG_STATUS_* word of the caller
 };
 
 template <int QIN, bool PK>
@@ -224,9 +228,11 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_qloss_fused(const QlossArgs a) {
     load_x_group<QIN>(a.x, a.rows, g, m.sX);
     lds_barrier();
     float w2[128], h1[2][4], h2[2][4], dz1[2][4], dz2[2][4];
+    float zmax = 0.f;
     SmallRegs<QIN, 1> r;
     MPG_LOAD2((load_small<QIN, 1>(net, L, r)), (load_w2<PK>(a.pkf[qi], net.W2, false, L, w2)));
-    forward_group<QIN, 1>(m.sX, m.sA, m.sPart, L, w2, r, h1, h2);
+    forward_group<QIN, 1>(m.sX, m.sA, m.sPart, L, w2, r, h1, h2, nullptr, 0, nullptr, &zmax);
+    report_activation_range(a.status, zmax);
     stash_store(st.h1, g, L, h1);
     stash_store(st.h2, g, L, h2);
     if (tid < GROUP) {   // err = Q(s~,a) - y; dL/dq = err / B_global   (mpg_learner.py:331-336)
@@ -263,6 +269,7 @@ struct QsliceArgs {
     float gpow[4], coef[4];
     float* ret_part;           // [ngroups_total][2]: sum and sum of squares of G + gpow*q over the group's rows
     float* gxq;
+    int* status;               // nullable: MPG_STATUS_* word of the caller
 };
 
 template <int QIN, bool PK>
@@ -281,9 +288,11 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_qslice_fused(const QsliceArgs a)
     }
     lds_barrier();
     float w2[128], h1[2][4], h2[2][4], dz1[2][4], dz2[2][4];
+    float zmax = 0.f;
     SmallRegs<QIN, 1> r;
     MPG_LOAD2((load_small<QIN, 1>(net, L, r)), (load_w2<PK>(a.pkf, net.W2, false, L, w2)));
-    forward_group<QIN, 1>(m.sX, m.sA, m.sPart, L, w2, r, h1, h2);
+    forward_group<QIN, 1>(m.sX, m.sA, m.sPart, L, w2, r, h1, h2, nullptr, 0, nullptr, &zmax);
+    report_activation_range(a.status, zmax);
     if (tid < GROUP) {
         const long gr = g * GROUP + tid;
         float ret = 0.f, d = 0.f;
@@ -334,17 +343,19 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_qslice_fused2(const QsliceArgs a
     }
     lds_barrier();
     float w2[128], h1[2][2][4], h2[2][2][4], dz1[2][4], dz2[2][4];
+    float zmax = 0.f;
     SmallRegs<QIN, 1> r;
     MPG_LOAD2((load_small<QIN, 1>(net, L, r)), (load_w2<PK>(a.pkf, net.W2, false, L, w2)));
 #pragma unroll
     for (int sl = 0; sl < 2; ++sl) {
-        forward_group<QIN, 1>(sX2 + sl * GROUP * XS, m.sA, m.sPart, L, w2, r, h1[sl], h2[sl]);
+        forward_group<QIN, 1>(sX2 + sl * GROUP * XS, m.sA, m.sPart, L, w2, r, h1[sl], h2[sl], nullptr, 0, nullptr, &zmax);
         if (tid < GROUP) {
             const long gr = (sl * gpers + gb) * GROUP + tid;
             sQ2[sl * GROUP + tid] = a.gk[gr] + a.gpow[sl] * out_preact(m.sPart, net.b3[0], tid, 0);   // mpg_learner.py:266
             sD32[sl * GROUP * MAXOUT + d3_index(tid, 0)] = a.coef[sl];
         }
     }
+    report_activation_range(a.status, zmax);
     load_w2<PK>(a.pkb, net.W2, true, L, w2);
     lds_barrier();
     if (tid < 2) {
@@ -408,6 +419,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_critic_fused(const CriticArgs ca
         xv2 = i < QIN ? q.xq[gr * QIN + i] : 0.f;
     }
     float w2[128], h1[3][2][4], h2[3][2][4], dz1[2][4], dz2[2][4];
+    float zmax = 0.f;
     SmallRegs<QIN, 1> r;
     MPG_LOAD2((load_small<QIN, 1>(net, L, r)), (load_w2<PK>(a.pkf[qi], net.W2, false, L, w2)));
     if (tid < GROUP * XS) m.sX[tid] = xv;
@@ -416,7 +428,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_critic_fused(const CriticArgs ca
     MPG_TL(1);
     MPG_TL(2);
     // ---- forward: replay batch group ----
-    forward_group<QIN, 1>(m.sX, m.sA, m.sPart, L, w2, r, h1[0], h2[0]);
+    forward_group<QIN, 1>(m.sX, m.sA, m.sPart, L, w2, r, h1[0], h2[0], nullptr, 0, nullptr, &zmax);
     MPG_TL(3);
     stash_store(st.h1, g, L, h1[0]);
     stash_store(st.h2, g, L, h2[0]);
@@ -435,7 +447,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_critic_fused(const CriticArgs ca
     if (slices) {
 #pragma unroll
         for (int sl = 0; sl < 2; ++sl) {
-            forward_group<QIN, 1>(sX2 + sl * GROUP * XS, m.sA, m.sPart, L, w2, r, h1[1 + sl], h2[1 + sl]);
+            forward_group<QIN, 1>(sX2 + sl * GROUP * XS, m.sA, m.sPart, L, w2, r, h1[1 + sl], h2[1 + sl], nullptr, 0, nullptr, &zmax);
             if (tid < GROUP) {
                 const long gr = (sl * ngroups + g) * GROUP + tid;
                 sQ2[sl * GROUP + tid] = q.gk[gr] + q.gpow[sl] * out_preact(m.sPart, net.b3[0], tid, 0);   // mpg_learner.py:266
@@ -444,6 +456,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_critic_fused(const CriticArgs ca
         }
     }
     MPG_TL(4);
+    report_activation_range(a.status, zmax);
     load_w2<PK>(a.pkb[qi], net.W2, true, L, w2);     // same registers, backward image
     lds_barrier();
     MPG_TL(5);
@@ -588,7 +601,7 @@ int launch_target_fused(const mpg_cfg_t* cfg, const float* policy_t, const float
         a.r_done = draw->ring_done; a.o_idx = draw->idx_out; a.o_done = draw->done_out;
         a.o_obs = draw_out->obs; a.o_act = draw_out->act; a.o_rew = draw_out->rew; a.o_obs2 = draw_out->obs2;
     }
-    a.pol = policy_t; a.q1 = q1t; a.q2 = q2t;
+    a.pol = policy_t; a.q1 = q1t; a.q2 = q2t; a.status = mpg_status_of(cfg);
     a.pk_pol = weight_cache_lookup(cfg, make_net(policy_t, od, 2 * ad).W2, 0);
     a.pk_q1 = weight_cache_lookup(cfg, make_net(q1t, od + ad, 1).W2, 0);
     a.pk_q2 = q2t ? weight_cache_lookup(cfg, make_net(q2t, od + ad, 1).W2, 0) : nullptr;
@@ -657,6 +670,7 @@ int launch_qloss_fused(const mpg_cfg_t* cfg, const float* const* q_params, int n
         if (k < n_q) a.st[k] = st[k];
     }
     a.rows = rows; a.x = xspec(obs, od, act, ad, cfg->obs_scale, od); a.y = y; a.inv_b = inv_b; a.loss_part = loss_part; a.td = td;
+    a.status = mpg_status_of(cfg);
     const int ngroups = (rows + GROUP - 1) / GROUP;
     if (qin == 8) { if (a.pkf[0] && a.pkb[0] && (n_q < 2 || (a.pkf[1] && a.pkb[1]))) hipLaunchKernelGGL((k_qloss_fused<8, true>), dim3(ngroups, n_q), dim3(NTHREAD), 0, s, a); else hipLaunchKernelGGL((k_qloss_fused<8, false>), dim3(ngroups, n_q), dim3(NTHREAD), 0, s, a); }
     else if (qin == 5) { if (a.pkf[0] && a.pkb[0] && (n_q < 2 || (a.pkf[1] && a.pkb[1]))) hipLaunchKernelGGL((k_qloss_fused<5, true>), dim3(ngroups, n_q), dim3(NTHREAD), 0, s, a); else hipLaunchKernelGGL((k_qloss_fused<5, false>), dim3(ngroups, n_q), dim3(NTHREAD), 0, s, a); }
@@ -672,7 +686,7 @@ int launch_qslice_fused(const mpg_cfg_t* cfg, const float* q_params, int qin, in
     a.q = q_params;
     a.pkf = weight_cache_lookup(cfg, make_net(q_params, qin, 1).W2, 0);
     a.pkb = weight_cache_lookup(cfg, make_net(q_params, qin, 1).W2, 1);
-    a.R = R; a.n_sel = n_sel; a.xq = xq; a.gk = gk; a.ret_part = ret_part; a.gxq = gxq;
+    a.R = R; a.n_sel = n_sel; a.xq = xq; a.gk = gk; a.ret_part = ret_part; a.gxq = gxq; a.status = mpg_status_of(cfg);
     for (int k = 0; k < 4; ++k) { a.gpow[k] = k < n_sel ? gpow[k] : 0.f; a.coef[k] = k < n_sel ? coef[k] : 0.f; }
     const int ngroups = n_sel * (R / GROUP);
     if (n_sel == 2) {
@@ -700,9 +714,10 @@ int launch_critic_fused(const mpg_cfg_t* cfg, const float* const* q_params, int 
         if (k < n_q) a.st[k] = st[k];
     }
     a.rows = rows; a.x = xspec(obs, od, act, ad, cfg->obs_scale, od); a.y = y; a.inv_b = inv_b; a.loss_part = loss_part; a.td = nullptr;
+    a.status = mpg_status_of(cfg);
     QsliceArgs& q = c.qs;
     q.q = q_params[0]; q.pkf = a.pkf[0]; q.pkb = a.pkb[0];
-    q.R = rows; q.n_sel = 2; q.xq = xq; q.gk = gk; q.ret_part = ret_part; q.gxq = gxq;
+    q.R = rows; q.n_sel = 2; q.xq = xq; q.gk = gk; q.ret_part = ret_part; q.gxq = gxq; q.status = a.status;
     for (int k = 0; k < 4; ++k) { q.gpow[k] = k < 2 ? gpow[k] : 0.f; q.coef[k] = k < 2 ? coef[k] : 0.f; }
     const int ngroups = rows / GROUP;
     c.dbg = nullptr;
@@ -747,7 +762,6 @@ int launch_wgrad_multi(const mpg_cfg_t* cfg, const WgradJob* jobs, int n_jobs, c
         WgradArgs& a = m.a[j];
         a.in_dim = jb.in_dim; a.out_dim = jb.out_dim; a.rows = jb.rows; a.x = jb.x;
         a.h1 = jb.h1; a.h2 = jb.h2; a.dz1 = jb.dz1; a.dz2 = jb.dz2; a.dz3 = jb.dz3; a.slabs = jb.slabs;
-        a.dz_scale = wgrad_dz_scale(jb.inv_b);
         const long ngroups = (jb.rows + GROUP - 1) / GROUP;
         a.groups_per_chunk = wgrad_groups_per_chunk(ngroups);
         const int nch = (int)((ngroups + a.groups_per_chunk - 1) / a.groups_per_chunk);

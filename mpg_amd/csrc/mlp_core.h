@@ -57,6 +57,22 @@ constexpr int ROW_H = 72, PLANE_H = GROUP * ROW_H, IMG_H = 4 * PLANE_H;      // 
 __device__ __forceinline__ int h_index(int row, int k) { return ((k >> 3) & 3) * PLANE_H + row * ROW_H + 8 * (k >> 5) + (k & 7); }
 constexpr float W_SCALE = 64.f;          // stationary weights are stored as W * 64
 constexpr float A_SCALE = 16.f;          // activations enter the LDS images as x * 16
+// Envelope of the split engine (include/mpg_hip.h, "Numerical envelope"): a first-layer activation at or beyond H_LIMIT would
+// enter the image as an fp16 infinity.  Every forward pass folds its first-layer pre-activations into a running maximum (four
+// v_max3 per row group: for z > 0 the ELU is the identity, and it never goes below -1) and the kernel reports once, at its end.
+constexpr float H_LIMIT = 65504.f / A_SCALE;      // 4094
+constexpr float P_LIMIT = 65504.f / W_SCALE;      // 1023.5
+__device__ __forceinline__ float max8(const float (&a)[4], const float (&b)[4], float m) {
+    m = __builtin_fmaxf(__builtin_fmaxf(a[0], a[1]), m);     // the compiler fuses each pair into one v_max3_f32
+    m = __builtin_fmaxf(__builtin_fmaxf(a[2], a[3]), m);
+    m = __builtin_fmaxf(__builtin_fmaxf(b[0], b[1]), m);
+    m = __builtin_fmaxf(__builtin_fmaxf(b[2], b[3]), m);
+    return m;
+}
+// one lane of the wave ORs the bit: the word is sticky, the caller reads and clears it
+__device__ __forceinline__ void report_activation_range(int* status, float zmax) {
+    if (status && !(zmax < H_LIMIT)) atomicOr(status, MPG_STATUS_ACTIVATION_RANGE);
+}
 
 // (w0, w1) -> the two packed fp16 words: hi pair and lo pair (element 0 in the low half)
 __device__ __forceinline__ void split_pack2(float w0, float w1, float& hi_word, float& lo_word) {
@@ -65,6 +81,10 @@ __device__ __forceinline__ void split_pack2(float w0, float w1, float& hi_word, 
     hi_word = __builtin_bit_cast(float, hi);
     lo_word = __builtin_bit_cast(float, lo);
 }
+
+// stationary weights: W * W_SCALE, clamped to the fp16 range (a parameter beyond the envelope is reported where the images
+// are packed - weight_cache.hip, optim_kernels.hip; this strided path only keeps it finite)
+__device__ __forceinline__ float w_scaled(float w) { return fminf(fmaxf(w * W_SCALE, -65504.f), 65504.f); }
 
 struct Net {
     const float *W1, *b1, *W2, *b2, *W3, *b3;
@@ -239,7 +259,7 @@ __device__ __forceinline__ void load_w2_fwd(const float* __restrict__ W2, const 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int k0 = 32 * kb + 8 * L.rg + 2 * r;
-                split_pack2(W2[k0 * H + L.col(t)] * W_SCALE, W2[(k0 + 1) * H + L.col(t)] * W_SCALE,
+                split_pack2(w_scaled(W2[k0 * H + L.col(t)]), w_scaled(W2[(k0 + 1) * H + L.col(t)]),
                             w[4 * ((kb * 2 + t) * 2) + r], w[4 * ((kb * 2 + t) * 2 + 1) + r]);
                 if (r == 3) __builtin_amdgcn_sched_barrier(0);      // 8 loads in flight, not 256: this is the slow (uncached) path
             }
@@ -253,7 +273,7 @@ __device__ __forceinline__ void load_w2_bwd(const float* __restrict__ W2, const 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int k0 = 32 * kb + 8 * L.rg + 2 * r;
-                split_pack2(W2[L.col(t) * H + k0] * W_SCALE, W2[L.col(t) * H + k0 + 1] * W_SCALE,
+                split_pack2(w_scaled(W2[L.col(t) * H + k0]), w_scaled(W2[L.col(t) * H + k0 + 1]),
                             w[4 * ((kb * 2 + t) * 2) + r], w[4 * ((kb * 2 + t) * 2 + 1) + r]);
                 if (r == 3) __builtin_amdgcn_sched_barrier(0);
             }
@@ -417,7 +437,7 @@ template <int IN, int OU, bool FINAL_BARRIER = true>
 __device__ __forceinline__ void forward_group(const float* sX, float* sA, float* sPart, const Lane& L,
                                               const float (&w2)[128], const SmallRegs<IN, OU>& r,
                                               float (&h1)[2][4], float (&h2)[2][4], float* h1_stash = nullptr,
-                                              long stash_group = 0, const float* xa_regs = nullptr) {
+                                              long stash_group = 0, const float* xa_regs = nullptr, float* zmax = nullptr) {
     {   // layer 1 on the matrix pipe too: K = IN <= 8 zero-padded = 2 k-steps (sX rows are zero beyond IN).
         // xa_regs (optional, 2 floats): this lane's A operand x[row l&15][4q + (l>>4)] already in registers (no LDS round trip)
         f32x4 z0 = {r.b1[0], r.b1[0], r.b1[0], r.b1[0]}, z1 = {r.b1[1], r.b1[1], r.b1[1], r.b1[1]};
@@ -428,6 +448,7 @@ __device__ __forceinline__ void forward_group(const float* sX, float* sA, float*
             z1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, r.w1p[q][1], z1, 0, 0, 0);
         }
         elu8(z0, z1, h1);
+        if (zmax) *zmax = max8(h1[0], h1[1], *zmax);
     }
     store_c_to_a(sA, L, h1);
     // h1 is final here: its stash goes out now and drains under the MFMA block instead of queueing behind the h2
@@ -493,7 +514,8 @@ __device__ __forceinline__ void forward_group(const float* sX, float* sA, float*
 template <int IN, int OU>
 __device__ __forceinline__ void forward_group2(const float* sXa, const float* sXb, float* sAa, float* sAb, float* sPartA,
                                                float* sPartB, const Lane& L, const float (&w2)[128], const SmallRegs<IN, OU>& r,
-                                               float (&h1a)[2][4], float (&h2a)[2][4], float (&h1b)[2][4], float (&h2b)[2][4]) {
+                                               float (&h1a)[2][4], float (&h2a)[2][4], float (&h1b)[2][4], float (&h2b)[2][4],
+                                               float* zmax = nullptr) {
     auto layer1 = [&](const float* sX, float* sA, float (&h1)[2][4]) {
         f32x4 z0 = {r.b1[0], r.b1[0], r.b1[0], r.b1[0]}, z1 = {r.b1[1], r.b1[1], r.b1[1], r.b1[1]};
 #pragma unroll
@@ -503,6 +525,7 @@ __device__ __forceinline__ void forward_group2(const float* sXa, const float* sX
             z1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, r.w1p[q][1], z1, 0, 0, 0);
         }
         elu8(z0, z1, h1);
+        if (zmax) *zmax = max8(h1[0], h1[1], *zmax);
         store_c_to_a(sA, L, h1);
     };
     auto output = [&](float* sPart, const float (&h2)[2][4]) {

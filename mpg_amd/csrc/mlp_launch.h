@@ -63,8 +63,8 @@ int launch_backward(const mpg_cfg_t* cfg, const float* params, int in_dim, int o
 // Weight gradient of one network over `rows` rows from stashes; result (net_size floats, fully reduced over rows,
 // accumulate == 0: overwritten) in grad.  ws must hold wgrad_workspace_floats(rows, in_dim, out_dim) floats.
 size_t wgrad_workspace_floats(int rows, int in_dim, int out_dim);
-// inv_b: the scale the upstream gradients carry (1/B_global, / M for tiled rollouts) - only its order of magnitude is used,
-// to centre the fp16 split operands (wgrad_dz_scale)
+// inv_b: the scale the upstream gradients carry (1/B_global, / M for tiled rollouts); informational - the fp16 split operands are
+// centred per chunk from the data itself (mlp_wgrad.h)
 int launch_wgrad(const mpg_cfg_t* cfg, int in_dim, int out_dim, int ou, int rows, const XSpec& x, const float* h1, const float* h2,
                  const float* dz1, const float* dz2, const float* dz3, float inv_b, float* grad, float* ws, hipStream_t s);
 

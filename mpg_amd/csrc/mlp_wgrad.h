@@ -8,7 +8,6 @@ namespace mlp {
 
 struct WgradArgs {
     int in_dim, out_dim, rows, groups_per_chunk;
-    float dz_scale;         // split engine: power of two that brings dz2 to O(1) (wgrad_dz_scale)
     XSpec x;
     const float *h1, *h2, *dz1, *dz2, *dz3;
     float* slabs;
@@ -117,6 +116,30 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int sl, con
         }
         __builtin_amdgcn_wave_barrier();
     };
+#ifdef MPG_SPLIT
+    // Scale of the DZ2 operand of the split-fp16 product: a power of two taken from the chunk's own data, 2^(4 - e) with e the
+    // exponent of max |dL/dz3| over the chunk's rows (|dz2| <= out * max|dz3| * max|W3|, so the scaled operand stays below
+    // 32 * max|W3| < 65504 inside the parameter envelope).  A fixed scale of ~B (the 1/B of the loss mean) left per-sample
+    // gradients of 1e-3 .. 1e-4 - small TD errors, late-training policy gradients - with 3 .. 0 bits in their fp16 lo halves.
+    // The accumulators are scaled back per workgroup, so chunks are free to differ.
+    float dz_scale;
+    {
+        float mx = 0.f;
+        const long r0 = g0 * GROUP * OU, r1 = ((g1 * GROUP < (long)a.rows) ? g1 * GROUP : (long)a.rows) * OU;
+        for (long i = r0 + tid; i < r1; i += NTHREAD) mx = fmaxf(mx, fabsf(a.dz3[i]));
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        if (L.lane == 0) sRed[L.wave] = mx;
+        __syncthreads();
+        float m = sRed[0];
+#pragma unroll
+        for (int w = 1; w < NWAVE; ++w) m = fmaxf(m, sRed[w]);
+        __syncthreads();                                   // sRed is the B tile / the staging corners from here on
+        int e = __builtin_amdgcn_frexp_expf(m);            // 0 for m == 0
+        e = e < -100 ? -100 : (e > 100 ? 100 : e);
+        dz_scale = ldexpf(A_SCALE, -e);
+    }
+#endif
     long tg = g0 + L.wave;
 #ifdef MPG_AB_WG_NOTHIN
     const bool has_thin = false;
@@ -132,7 +155,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int sl, con
     // Split-fp16 form (mlp_core.h): the contraction index is the batch row, 32 rows = TWO row groups per
     // v_mfma_f32_16x16x32_f16: lane (c, rg) supplies rows 4rg..4rg+3 of both groups of a pair - exactly the two float4 it
     // loads from the G16 stash - as hi/lo halves; three MFMAs (hi*hi, hi*lo, lo*hi) per tile pair.  H1 enters as x*16, DZ2 as
-    // dz * dz_scale (a power of two from the launcher, ~1/inv_b: dz carries the 1/B of the mean), undone at the end.
+    // dz * dz_scale (the chunk's data-dependent power of two, above), undone at the end.
     auto split8 = [](const f32x4& u, const f32x4& v, float sc, f16x8& hi, f16x8& lo) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -174,7 +197,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int sl, con
             _Float16 h[4], l[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float x = b[j] * a.dz_scale;
+                const float x = b[j] * dz_scale;
                 h[j] = (_Float16)x;
                 l[j] = (_Float16)(x - (float)h[j]);
             }
@@ -216,7 +239,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int sl, con
         }
     }
     {
-        const float un = 1.f / (A_SCALE * a.dz_scale);
+        const float un = 1.f / (A_SCALE * dz_scale);
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -359,14 +382,6 @@ __device__ __forceinline__ void wgrad_map(int b, int nch, int& chunk, int& sl) {
         chunk = b >> 3;
         sl = b & 7;
     }
-}
-
-// dz carries the 1/B_global of the loss mean (and the 1/M of the tile mean): the power of two next to its inverse brings the
-// fp16 split operands of the weight-gradient product to O(1)
-inline float wgrad_dz_scale(float inv_b) {
-    float s = 1.f;
-    while (s * inv_b < 1.f && s < 1073741824.f) s *= 2.f;
-    return s;
 }
 
 // Chunking of a network's weight-gradient job: every chunk is 8 workgroups (one per 32-column slice) that leave one slab of

@@ -6,8 +6,9 @@
 
 #include "../../include/mpg_hip.h"
 
-#define MPG_ABI_VERSION 4   // 3: caller-owned handles (mpg_wcache_t, mpg_prof_t) instead of process-wide state
+#define MPG_ABI_VERSION 5   // 3: caller-owned handles (mpg_wcache_t, mpg_prof_t) instead of process-wide state
                             // 4: mpg_replay_draw_t gained the pre-gathered window, mpg_env_step_store_reset_draw
+                            // 5: status words (mpg_cfg_t.status, mpg_wcache_t.status), step entry points for TD3 / NADP
 
 void mpg_set_error(const char* fmt, ...);
 
@@ -33,6 +34,7 @@ void mpg_set_error(const char* fmt, ...);
 void mpg_prof_begin(mpg_prof_t* p, int slot, hipStream_t s);
 void mpg_prof_end(mpg_prof_t* p, int slot, hipStream_t s);
 inline mpg_prof_t* mpg_prof_of(const mpg_cfg_t* cfg) { return cfg ? cfg->prof : nullptr; }
+inline int* mpg_status_of(const mpg_cfg_t* cfg) { return cfg ? cfg->status : nullptr; }
 
 static inline hipStream_t mpg_stream(mpg_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 

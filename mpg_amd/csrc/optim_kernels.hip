@@ -18,6 +18,7 @@ struct Segs {
     int do_adam[MAXSEG], do_polyak[MAXSEG];
     int w2_off[MAXSEG];              // offset of W2 inside the segment's network, -1 when no weight cache is bound
     float *cache_w, *cache_t;        // packed register images of the bound buffers (nullable)
+    int *status_w, *status_t;        // their owners' MPG_STATUS_* words (nullable)
 };
 
 constexpr int HH = MPG_HIDDEN * MPG_HIDDEN;
@@ -27,7 +28,9 @@ constexpr int HH = MPG_HIDDEN * MPG_HIDDEN;
 __device__ __forceinline__ void pack_store(float* __restrict__ image, int k, int n, float w) {
     const int wave = n >> 5, t = (n >> 4) & 1, c = n & 15, kb = k >> 5, rg = (k >> 3) & 3, r = (k >> 1) & 3, e = k & 1;
     const int word = (((wave * 32 + (kb * 2 + t) * 2) * 64 + rg * 16 + c) << 2) + r;      // hi word; the lo word is 256 further
-    const float ws = w * mlp::W_SCALE;
+    // a parameter beyond the engine's envelope (|w| >= 1023.5, include/mpg_hip.h) enters the image clamped, never as an fp16
+    // infinity; the caller of pack_store reports it (range_check)
+    const float ws = fminf(fmaxf(w * mlp::W_SCALE, -65504.f), 65504.f);
     const _Float16 hi = (_Float16)ws;
     const _Float16 lo = (_Float16)(ws - (float)hi);
     _Float16* p = reinterpret_cast<_Float16*>(image);
@@ -42,6 +45,11 @@ __device__ __forceinline__ int pack_index(int k, int n) {
 }
 __device__ __forceinline__ void pack_store(float* __restrict__ image, int k, int n, float w) { image[pack_index(k, n)] = w; }
 #endif
+
+// every parameter the update writes is checked against the envelope of the split engine (one compare in a memory-bound kernel)
+__device__ __forceinline__ void range_check(int* status, float w) {
+    if (status && !(fabsf(w) < mlp::P_LIMIT)) atomicOr(status, MPG_STATUS_PARAMETER_RANGE);
+}
 
 // Parallel form of the clip.  (1) per-network partial sums of squares, one per 256-element block, MPG_CLIP_PARTS slots
 // per network (`k_sq_blocks`; the fused gradient kernel's final slab reduction writes the SAME partials for free, see
@@ -174,6 +182,7 @@ __global__ void k_adam_polyak(const Segs sg, float* __restrict__ w, float* __res
         float mj = m[j], vj = v[j];
         adam_update(bad ? 0.f : grad[j], sg.lr_t[k], mj, vj, wj);
         m[j] = mj; v[j] = vj; w[j] = wj;
+        range_check(sg.status_w, wj);
     }
     // weight cache: the element's two packed copies are rewritten by the thread that owns it
     const int e = sg.w2_off[k] >= 0 ? i - sg.w2_off[k] : -1;
@@ -186,6 +195,7 @@ __global__ void k_adam_polyak(const Segs sg, float* __restrict__ w, float* __res
     if (sg.do_polyak[k] && target) {
         const float tj = polyak_mix(tau, wj, target[j]);
         target[j] = tj;
+        range_check(sg.status_t, tj);
         if (in_w2 && sg.cache_t) {
             const int row = e >> 8, col = e & 255;
             pack_store(sg.cache_t + (size_t)(2 * k) * HH, row, col, tj);
@@ -230,6 +240,7 @@ __global__ void __launch_bounds__(256) k_clip_adam_polyak(const Segs sg, float* 
     if (adam) {
         adam_update(bad ? 0.f : gc, sg.lr_t[k], mj, vj, wj);
         m[j] = mj; v[j] = vj; w[j] = wj;
+        range_check(sg.status_w, wj);
     }
     const int e = sg.w2_off[k] >= 0 ? i - sg.w2_off[k] : -1;
     const bool in_w2 = e >= 0 && e < HH;
@@ -241,6 +252,7 @@ __global__ void __launch_bounds__(256) k_clip_adam_polyak(const Segs sg, float* 
     if (polyak) {
         const float tj = polyak_mix(tau, wj, t_in);
         target[j] = tj;
+        range_check(sg.status_t, tj);
         if (in_w2 && sg.cache_t) {
             const int row = e >> 8, col = e & 255;
             pack_store(sg.cache_t + (size_t)(2 * k) * HH, row, col, tj);
@@ -262,6 +274,7 @@ int fill(Segs& sg, int n_seg, const int* seg_sizes) {
         sg.w2_off[k] = -1;
     }
     sg.cache_w = sg.cache_t = nullptr;
+    sg.status_w = sg.status_t = nullptr;
     return off;
 }
 
@@ -307,8 +320,8 @@ int fill_adam(Segs& sg, int n_seg, const int* seg_sizes, const float* w, const f
         return true;
     };
     const mpg_wcache_t* ref = usable(wc_w, w) ? wc_w : (usable(wc_t, target) ? wc_t : nullptr);
-    if (usable(wc_w, w)) sg.cache_w = wc_w->packed;
-    if (usable(wc_t, target)) sg.cache_t = wc_t->packed;
+    if (usable(wc_w, w)) { sg.cache_w = wc_w->packed; sg.status_w = wc_w->status; }
+    if (usable(wc_t, target)) { sg.cache_t = wc_t->packed; sg.status_t = wc_t->status; }
     if (ref)
         for (int k = 0; k < n_seg; ++k) sg.w2_off[k] = mlp::wcache_w2_offset(ref, k) - sg.off[k];
     return 0;

@@ -208,6 +208,7 @@ struct RollArgs {
     float* XQ;                          // [n_sel][R][OBS+ACT] critic inputs (scaled obs | action) at the selected slices
     float* GK;                          // [n_sel][R] discounted reward sums G_k
     const float* pack;                  // nullable: packed forward image of the policy's W2
+    int* status;                        // nullable: MPG_STATUS_* word of the caller
     float* dbg;                         // diagnostic builds only
 };
 
@@ -235,6 +236,7 @@ inline void fill_roll(RollArgs& a, const mpg_cfg_t* cfg, const float* policy, in
     a.out_tanh = (cfg->policy_out_act == MPG_ACT_TANH || ranged) ? 1 : 0;
     a.out_scale = ranged ? cfg->action_range : 1.f;
     a.pack = weight_cache_lookup(cfg, make_net(policy, cfg->obs_dim, 2 * cfg->act_dim).W2, 0);
+    a.status = mpg_status_of(cfg);
 }
 
 inline int grid_for(long ngroups) { return (int)(ngroups < 256 ? ngroups : 256); }

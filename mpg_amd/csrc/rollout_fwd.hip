@@ -30,6 +30,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_fwd(const RollArgs a) {
     for (int k = 0; k < ACT; ++k) b3r[k] = net.b3[k];
     const long R = (long)a.rows * a.M;
     const long ngroups = (R + GROUP - 1) / GROUP;
+    float zmax = 0.f;                          // largest first-layer activation seen by this lane (the engine's envelope, mlp_core.h)
 #ifdef MPG_STAMP
     if ((tid & 63) == 0) {
         for (int k = 0; k < 10; ++k) g_st_acc[tid >> 6][k] = 0;
@@ -105,7 +106,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_fwd(const RollArgs a) {
             lds_barrier();
             MPG_STAMP_AT(0);
             float h1[2][4], h2[2][4];
-            forward_group<OBS, ACT, false>(sX, sA, sPart, L, w2, r, h1, h2, a.H1, (long)t * ngroups + g);
+            forward_group<OBS, ACT, false>(sX, sA, sPart, L, w2, r, h1, h2, a.H1, (long)t * ngroups + g, nullptr, &zmax);
             if (a.H1) stash_store(a.H2, (long)t * ngroups + g, L, h2);
             // book lanes, before B2: fetch what the chain lanes left in sTraj (they overwrite it right after B2) and prepare
             // the action-independent half of this step's model step - the only part of their work the chain waits for
@@ -186,6 +187,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_fwd(const RollArgs a) {
             for (int k = 0; k < 8; ++k) a.dbg[((long)blockIdx.x * NWAVE + (tid >> 6)) * 8 + k] = (float)g_st_acc[tid >> 6][k];
 #endif
     }
+    report_activation_range(a.status, zmax);
 }
 
 }  // namespace

@@ -17,6 +17,7 @@ struct PackArgs {
     float* cache;
     int n_nets;
     int w2_off[8];
+    int* status;      // nullable: MPG_STATUS_PARAMETER_RANGE is OR-ed into it
 };
 
 // one thread per (net, direction, packed 32-bit word)
@@ -31,8 +32,10 @@ __global__ void k_pack(const PackArgs a) {
     const int r = idx & 3, lane = (idx >> 2) & 63, v = (idx >> 8) & 31, wave = idx >> 13;
     const int part = v & 1, t = (v >> 1) & 1, kb = v >> 2;
     const int k0 = 32 * kb + 8 * (lane >> 4) + 2 * r, n = 32 * wave + 16 * t + (lane & 15);
-    const float w0 = (dir == 0 ? W2[k0 * mlp::H + n] : W2[n * mlp::H + k0]) * mlp::W_SCALE;
-    const float w1 = (dir == 0 ? W2[(k0 + 1) * mlp::H + n] : W2[n * mlp::H + k0 + 1]) * mlp::W_SCALE;
+    // a hidden-kernel entry beyond the envelope (|w| >= 1023.5, include/mpg_hip.h) enters clamped and is reported
+    const float r0 = dir == 0 ? W2[k0 * mlp::H + n] : W2[n * mlp::H + k0], r1 = dir == 0 ? W2[(k0 + 1) * mlp::H + n] : W2[n * mlp::H + k0 + 1];
+    if (a.status && (!(fabsf(r0) < mlp::P_LIMIT) || !(fabsf(r1) < mlp::P_LIMIT))) atomicOr(a.status, MPG_STATUS_PARAMETER_RANGE);
+    const float w0 = fminf(fmaxf(r0 * mlp::W_SCALE, -65504.f), 65504.f), w1 = fminf(fmaxf(r1 * mlp::W_SCALE, -65504.f), 65504.f);
     float hi, lo;
     mlp::split_pack2(w0, w1, hi, lo);
     out[idx] = part == 0 ? hi : lo;
@@ -82,7 +85,7 @@ extern "C" size_t mpg_weight_cache_floats(int n_nets) { return n_nets > 0 ? (siz
 extern "C" int mpg_weight_cache_pack(const mpg_wcache_t* wc, mpg_stream_t stream) {
     MPG_REQUIRE(wc_ok(wc), "mpg_weight_cache_pack: incomplete descriptor");
     PackArgs a;
-    a.base = wc->params; a.cache = wc->packed; a.n_nets = wc->n_nets;
+    a.base = wc->params; a.cache = wc->packed; a.n_nets = wc->n_nets; a.status = wc->status;
     for (int k = 0; k < 8; ++k) a.w2_off[k] = k < wc->n_nets ? mlp::wcache_w2_offset(wc, k) : 0;
     hipLaunchKernelGGL(k_pack, dim3(mlp::H * mlp::H / 256, 2 * wc->n_nets), dim3(256), 0, mpg_stream(stream), a);
     MPG_CHECK_LAUNCH("k_pack");

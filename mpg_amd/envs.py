@@ -92,3 +92,13 @@ class InvertedPendulumContiEnv(_DeviceVecEnv):
 
     def __init__(self, num_agent=1, device='cuda', seed=0, **kwargs):
         super().__init__(num_agent, device, seed)
+
+
+def make_env(env_id, num_agent=1, num_future_data=0, device='cuda', seed=0):
+    """gym.make(env_id, ...) of the reference's worker / evaluator (worker.py:40-44, evaluator.py:33-36) for the two
+    environments of the hot path."""
+    if env_id == 'PathTracking-v0':
+        return PathTrackingEnv(num_future_data=num_future_data, num_agent=num_agent, device=device, seed=seed)
+    if env_id == 'InvertedPendulumConti-v0':
+        return InvertedPendulumContiEnv(num_agent=num_agent, device=device, seed=seed)
+    raise ValueError('no device environment for %r (PathTracking-v0, InvertedPendulumConti-v0)' % (env_id,))

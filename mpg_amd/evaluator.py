@@ -5,18 +5,18 @@ ploter.py:85)."""
 import torch
 
 from . import ops
-from .envs import PathTrackingEnv
+from .envs import make_env
 
 
 class Evaluator(object):
     def __init__(self, policy_cls, env_id, args, device='cuda'):
-        assert env_id == 'PathTracking-v0'
+        self.env_id = env_id
         self.args = args
         self.device = torch.device(device)
         self.num_eval_agent = int(getattr(args, 'num_eval_agent', 5))
         self.fixed_steps = int(getattr(args, 'fixed_steps', 200))
-        self.env = PathTrackingEnv(num_agent=self.num_eval_agent, num_future_data=args.num_future_data, device=device,
-                                   seed=int(getattr(args, 'seed', 0)) + 424242)
+        self.env = make_env(env_id, num_agent=self.num_eval_agent, num_future_data=getattr(args, 'num_future_data', 0), device=device,
+                            seed=int(getattr(args, 'seed', 0)) + 424242)
         self.policy_with_value = policy_cls(**vars(args), device=device)
         self.iteration = 0
         self.stats = {}
@@ -52,11 +52,18 @@ class Evaluator(object):
         # the reference accumulates in numpy: np.mean / python sum() promote to float64 (evaluator.py:141-142,172-178)
         obs, act, rew = torch.stack(obs_l).double(), torch.stack(act_l).double(), torch.stack(rew_l).double()   # [T, N, .]
         rms = lambda x: torch.sqrt(torch.mean(torch.square(x), 0))
-        per_episode = dict(                                # metrics_for_an_episode, evaluator.py:160-184
-            episode_return=rew.sum(0), episode_len=torch.full_like(rew[0], float(self.fixed_steps)),
-            delta_y_mse=rms(obs[:, :, 3]), delta_phi_mse=rms(obs[:, :, 4]), delta_v_mse=rms(obs[:, :, 0]),
-            stationary_rew_mean=rew[20:].mean(0), steer_mse=rms(act[:, :, 0] * (1.2 * 3.141592653589793 / 9)),
-            acc_mse=rms(act[:, :, 1] * 3.))
+        per_episode = dict(episode_return=rew.sum(0), episode_len=torch.full_like(rew[0], float(self.fixed_steps)))
+        if self.env_id == 'PathTracking-v0':               # metrics_for_an_episode, evaluator.py:160-184
+            per_episode.update(
+                delta_y_mse=rms(obs[:, :, 3]), delta_phi_mse=rms(obs[:, :, 4]), delta_v_mse=rms(obs[:, :, 0]),
+                stationary_rew_mean=rew[20:].mean(0), steer_mse=rms(act[:, :, 0] * (1.2 * 3.141592653589793 / 9)),
+                acc_mse=rms(act[:, :, 1] * 3.))
+        else:                                              # InvertedPendulumConti-v0, evaluator.py:185-211
+            for j, nm in enumerate(('x', 'theta', 'xdot', 'thetadot')):
+                per_episode[nm + '_mean'] = obs[:, :, j].mean(0)
+                per_episode[nm + '_var'] = obs[:, :, j].var(0, unbiased=False)
+                per_episode[nm + '_mse'] = rms(obs[:, :, j])
+                per_episode[nm + '_mse_25'] = rms(obs[:25, :, j])
         mean = {k: float(v.mean().item()) for k, v in per_episode.items()}
         return per_episode, mean
 

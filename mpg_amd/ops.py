@@ -6,13 +6,14 @@ import torch
 from . import _lib as L
 
 ACT_LINEAR, ACT_TANH = 0, 1
+STATUS_ACTIVATION_RANGE, STATUS_PARAMETER_RANGE, STATUS_NAN = 1, 2, 4      # MPG_STATUS_* (include/mpg_hip.h, "Numerical envelope")
 HIDDEN = 256
 
 
 class WCacheStruct(ctypes.Structure):
     """mpg_wcache_t: caller-owned descriptor of the packed W2 images of one flat parameter vector"""
     _fields_ = [('params', ctypes.c_void_p), ('packed', ctypes.c_void_p), ('n_nets', ctypes.c_int),
-                ('in_dim', ctypes.c_int * 8), ('out_dim', ctypes.c_int * 8)]
+                ('in_dim', ctypes.c_int * 8), ('out_dim', ctypes.c_int * 8), ('status', ctypes.c_void_p)]
 
 
 class CfgStruct(ctypes.Structure):
@@ -21,19 +22,21 @@ class CfgStruct(ctypes.Structure):
                 ('action_range', ctypes.c_float), ('obs_scale', ctypes.c_float * 8),
                 ('rew_scale', ctypes.c_float), ('rew_shift', ctypes.c_float), ('gamma', ctypes.c_float),
                 ('env_kind', ctypes.c_int),
-                ('wcache', ctypes.POINTER(WCacheStruct) * 2), ('prof', ctypes.c_void_p)]
+                ('wcache', ctypes.POINTER(WCacheStruct) * 2), ('prof', ctypes.c_void_p), ('status', ctypes.c_void_p)]
 
 
 class WeightCache(object):
     """Owns the packed images of one flat [net0 | net1 | ...] tensor (mpg_wcache_t + the device array).  Keep the object
     alive for as long as a cfg points at it; call pack() after writing `params` by anything but the Adam entry points."""
 
-    def __init__(self, params, dims):
+    def __init__(self, params, dims, status=None):
         k = len(dims)
         self.params = params
+        self.status = status           # int32[1] device tensor the (re)packing reports MPG_STATUS_* bits into (keeps it alive)
         self.packed = torch.empty(L.lib().mpg_weight_cache_floats(L.c_int(k)), dtype=torch.float32, device=params.device)
         self.desc = WCacheStruct()
         self.desc.params, self.desc.packed, self.desc.n_nets = params.data_ptr(), self.packed.data_ptr(), k
+        self.desc.status = status.data_ptr() if status is not None else None
         for i, (ind, outd) in enumerate(dims):
             self.desc.in_dim[i], self.desc.out_dim[i] = ind, outd
         self.pack()

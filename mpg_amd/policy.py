@@ -71,15 +71,40 @@ class PolicyWithQs(object):
         self.schedules = {n: (tuple(policy_lr_schedule) if n == 'policy' else tuple(value_lr_schedule)) for n in self.names}
         self.opt_steps = {n: 0 for n in self.names}
         self.nonfinite = torch.zeros(len(self.names), dtype=torch.int32, device=self.device)
+        # sticky MPG_STATUS_* word (include/mpg_hip.h, "Numerical envelope"): every forward pass made with self.cfg and every
+        # (re)pack of the weight images ORs into it; check_status() reads, clears and raises
+        self.status = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.cfg.status = self.status.data_ptr()
         self._bind_weight_cache()
 
     # ---- weight cache (packed register images of the hidden kernels; caller-owned, see include/mpg_hip.h) ----
     def _bind_weight_cache(self):
         dims = [self.dims[n] for n in self.names]
-        self.wc_params = ops.WeightCache(self.params, dims)
-        self.wc_targets = ops.WeightCache(self.targets, dims)
+        self.wc_params = ops.WeightCache(self.params, dims, status=self.status)
+        self.wc_targets = ops.WeightCache(self.targets, dims, status=self.status)
         self.cfg.wcache[0] = self.wc_params.pointer
         self.cfg.wcache[1] = self.wc_targets.pointer
+
+    def check_status(self, clear=True):
+        """Host read of the status word (synchronises).  Raises MpgError if the split-fp16 engine left its envelope since
+        the last check: the results computed in between are not to be trusted (the analogue of the reference's
+        `judge_is_nan` stop, optimizer.py:357-361, for a failure TensorFlow's float32 graph cannot have)."""
+        bits = int(self.status.item())
+        if clear and bits:
+            self.status.zero_()
+        if bits:
+            what = []
+            if bits & ops.STATUS_ACTIVATION_RANGE:
+                what.append('a first-hidden-layer activation reached 4094 (fp16 image overflow: that row is invalid)')
+            if bits & ops.STATUS_PARAMETER_RANGE:
+                what.append('a network parameter reached 1023.5 (clamped in the packed image)')
+            if bits & ops.STATUS_NAN:
+                what.append('NaN in an observation or action (worker.py:95-107 judge_is_nan)')
+            if bits & ~ops.STATUS_NAN:
+                raise L.MpgError('hidden-layer engine left its numerical envelope: ' + '; '.join(what) +
+                                 ' - rebuild with MPG_EXTRA_CFLAGS=-DMPG_F32_MFMA for the exact-fp32 engine')
+            raise L.MpgError('; '.join(what))
+        return 0
 
     def refresh_weight_cache(self):
         """call after writing params/targets by anything other than apply_gradients"""

@@ -3,7 +3,7 @@ the optimizer state (`apply_gradients`).  `sample()` keeps the reference's loop 
 env.step -> env.reset, worker.py:91-119) but every stage is one HIP launch over all `num_agent` agents."""
 import torch
 
-from .envs import PathTrackingEnv
+from .envs import make_env
 from . import ops
 
 
@@ -13,9 +13,10 @@ class OffPolicyWorker(object):
         self.args = args
         self.device = torch.device(device)
         self.num_agent = int(args.num_agent)
-        assert env_id == 'PathTracking-v0', 'only PathTracking has a real vectorised env on the hot path'
         seed = int(getattr(args, 'seed', 0)) * 1000003 + int(worker_id)
-        self.env = PathTrackingEnv(num_agent=self.num_agent, num_future_data=args.num_future_data, device=device, seed=seed)
+        # PathTracking-v0, or InvertedPendulumConti-v0 (the reference wraps the single MuJoCo env in DummyVecEnv with
+        # num_agent 1, train_script4mujoco.py:328; here `num_agent` pendulums step in one launch)
+        self.env = make_env(env_id, num_agent=self.num_agent, num_future_data=getattr(args, 'num_future_data', 0), device=device, seed=seed)
         self.policy_with_value = policy_cls(**vars(args), device=device)
         self.batch_size = int(args.batch_size)
         self.obs = self.env.reset()
@@ -24,6 +25,7 @@ class OffPolicyWorker(object):
         self.iteration = 0
         self.num_sample = 0
         self.sample_times = 0
+        self.nan_check_interval = int(getattr(args, 'nan_check_interval', 100))
         self._noise_ctr = 0
         self.stats = {}
 
@@ -66,10 +68,15 @@ class OffPolicyWorker(object):
             obs_tp1, reward, done, _ = self.env.step(action)          # fresh tensors every call (never aliased later)
             for lst, x in zip(out, (obs, action, reward, obs_tp1, done)):
                 lst.append(x)
-            self.obs = self.env.reset()          # done is always 1: every agent is re-drawn
+            self.obs = self.env.reset()          # PathTracking: done is always 1, every agent is re-drawn; the pendulum
+                                                 # re-draws the agents that fell (inverted_pendulum_conti.py:17-18)
         batch = tuple(x[0] for x in out) if iters == 1 else tuple(torch.cat(x, 0) for x in out)
         self.num_sample += batch[0].shape[0]
         self.sample_times += 1
+        # judge_is_nan (worker.py:95-107) runs inside the policy kernel: a NaN observation or action sets MPG_STATUS_NAN in the
+        # policy's status word; it is read (one host synchronisation) every `nan_check_interval` calls, not per step
+        if self.sample_times % self.nan_check_interval == 0:
+            self.policy_with_value.check_status()
         return batch
 
     def sample_with_count(self):

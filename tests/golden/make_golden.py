@@ -396,13 +396,32 @@ sys.path.insert(0, os.path.join(ROOT, 'tests'))
 from golden_inputs import BENCH_CASES, bench_case_inputs      # noqa: E402  (seeded inputs shared with the GPU tests)
 
 
-def fx_bench_case(name):
+def trained_nets():
+    """The ONLINE networks of a 20 000-iteration MPG-v2 run of the HIP path at the reference's default learning rates
+    (tools/train_export.py on the GPU box; evaluation return -4365 -> -5), as Keras-shaped lists."""
+    z = np.load(os.path.join(HERE, 'trained_weights.npz'))
+    dims = {'policy': (6, 4), 'Q1': (8, 1), 'Q2': (8, 1)}
+    nets = {}
+    for k, (din, dout) in dims.items():
+        f, o, ws = z['w_' + k], 0, []
+        for shp in [(din, 256), (256,), (256, 256), (256,), (256, dout), (dout,)]:
+            n = int(np.prod(shp))
+            ws.append(f[o:o + n].reshape(shp).astype(np.float32))
+            o += n
+        assert o == f.size
+        nets[k] = ws
+    return nets
+
+
+def fx_bench_case(name, trained=False):
     """C2 / C3 / C4 at their full batch sizes.  Inputs are pure functions of the seed (tests/golden_inputs.py), so the
     fixture carries only what the reference computed: the clipped gradient list (float32, complete), every 8th element
-    of the float64 run (yard-stick), every 8th target, and the scalar statistics."""
+    of the float64 run (yard-stick), every 8th target, and the scalar statistics.
+    trained: the C2 case on TRAINED networks (trained_nets) instead of freshly initialised ones - the split-fp16 engine's
+    accuracy on the weights it actually meets (fixture trained_c2_mpg_v2_B4096.npz)."""
     d = bench_case_inputs(name)
     kind, B, H = d['kind'], d['B'], 256
-    nets = dict(d['nets'])
+    nets = trained_nets() if trained else dict(d['nets'])
     add_targets(nets)
     out = dict(target_scale=TARGET_SCALE)
     if kind == 'MPG-v2':
@@ -449,7 +468,7 @@ def fx_bench_case(name):
                 out[p + 'all_losses' + tag] = np.asarray(st['all_losses'])
     tf.set_ref_dtype(torch.float32)
     tf.set_noise_source(None)
-    np.savez_compressed(os.path.join(HERE, 'bench_%s.npz' % name), **out)
+    np.savez_compressed(os.path.join(HERE, ('trained_%s.npz' if trained else 'bench_%s.npz') % name), **out)
 
 
 def fx_replay_buffer(seed=40):
@@ -591,6 +610,7 @@ def fx_q_estimation(H=256, B=64, seed=70):
 ROUND2 = {'replay_buffer': fx_replay_buffer, 'evaluator': fx_evaluator, 'env_future': fx_env_future,
           'q_estimation': fx_q_estimation}
 ROUND2.update({n: (lambda n=n: fx_bench_case(n)) for n in BENCH_CASES})
+ROUND2['trained_c2'] = lambda: fx_bench_case('c2_mpg_v2_B4096', trained=True)      # round 3
 
 
 def main():

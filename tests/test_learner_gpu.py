@@ -172,6 +172,44 @@ def test_bench_size_cases_vs_reference(golden, name):
         assert int(pw.nonfinite.sum().item()) == 0
 
 
+def test_trained_networks_vs_reference(golden):
+    """The bench workload's gradient (MPG-v2, B = 4096, iterations 100 and 9000) on TRAINED networks: the online weights after
+    20 000 iterations of the HIP path at the reference's default learning rates (tools/train_export.py: evaluation return
+    -4365 -> -5; tests/golden/trained_weights.npz), every output computed by the unmodified reference from them
+    (make_golden.py --only trained_c2).  Same rule as for the freshly initialised nets of every other fixture: <= 1e-4 rel-L2
+    and within 4x the reference's own float32 error of its float64 run.  Trained hidden kernels (max |W2| 0.4) and
+    activations (max |h1| 4.2) sit three orders of magnitude inside the split-fp16 engine's envelope (1023.5 / 4094), and
+    the status word stays clear."""
+    from mpg_amd.config import default_args
+    from mpg_amd.learners import MPGLearner
+    from mpg_amd.policy import PolicyWithQs
+    from tests.golden_inputs import bench_case_inputs
+    g = golden('trained_c2_mpg_v2_B4096.npz')
+    tw = golden('trained_weights.npz')
+    d = bench_case_inputs('c2_mpg_v2_B4096')
+    B = d['B']
+    batch = [dev(x) for x in d['batch']]
+    learner = MPGLearner(PolicyWithQs, default_args('MPG-v2', replay_batch_size=B, num_batch_reuse=1))
+    pw = learner.policy_with_value
+    w = np.concatenate([tw['w_' + n] for n in pw.names]).astype(np.float32)
+    pw.set_flat(w, (w * np.float32(g['target_scale'])).astype(np.float32))
+    worst = 0.0
+    for it in (100, 9000):
+        learner.counter = 0
+        grads = learner.compute_gradient(batch, None, None, it, eps=dev(d['eps']))
+        got = torch.cat([x.reshape(-1) for x in grads]).cpu().numpy()
+        p = 'it%d_' % it
+        worst = max(worst, Y.check_gradients(got, g[p + 'grads'], g[p + 'grads_f64'], [(n,) + tuple(pw.dims[n]) for n in pw.names],
+                                             where='trained nets, it %d' % it))
+        Y.check_values(learner.batch_data['batch_targets'].cpu().numpy()[::8], g[p + 'targets_sub'], g[p + 'targets_sub_f64'],
+                       what='trained nets, targets')
+        st = learner.get_stats()
+        for k in ('value_mean', 'policy_total_loss', 'policy_gradient_norm', 'q_loss1', 'q_gradient_norm1', 'q_loss2', 'q_gradient_norm2'):
+            np.testing.assert_allclose(st[k], g[p + k], rtol=5e-5, atol=1e-6, err_msg=k)
+    assert int(pw.nonfinite.sum().item()) == 0 and pw.check_status() == 0
+    print('trained nets: worst error / allowance = %.2f' % worst)
+
+
 @pytest.mark.parametrize('name,reps', [('c2_mpg_v2_B4096', 3000), ('c3_nadp_B8192', 600), ('c4_td3_B65536', 200)])
 def test_repeated_launches_are_bit_identical(name, reps):
     """The same gradient computation launched `reps` times must return the same bits every time.  This is the check that

@@ -304,6 +304,22 @@ def test_bench_size_cases(golden, name):
             np.testing.assert_allclose(st[k], g['it0_' + k], rtol=1e-4, atol=1e-7, err_msg=k)
 
 
+def test_trained_networks_case(golden):
+    """Round 3: the C2 case on TRAINED networks (tests/golden/trained_weights.npz: 20 000 iterations of the HIP path; outputs by
+    the unmodified reference, make_golden.py --only trained_c2) - the oracle restates the reference there as well."""
+    g = golden('trained_c2_mpg_v2_B4096.npz')
+    tw = golden('trained_weights.npz')
+    d = bench_case_inputs('c2_mpg_v2_B4096')
+    cfg = O.Cfg()
+    nets = O.Nets(cfg, {k: tw['w_' + k] for k in ('Q1', 'Q2', 'policy')}, target_scale=g['target_scale'])
+    grads, st = O.mpg_compute_gradient(cfg, nets, d['batch'], d['eps'], 100, 'MPG-v2')
+    Y.check_gradients(np.concatenate([x.ravel() for x in grads]), g['it100_grads'], g['it100_grads_f64'],
+                      [('Q1', 8, 1), ('Q2', 8, 1), ('policy', 6, 4)], where='trained nets it100')
+    Y.check_values(st['targets'][::8], g['it100_targets_sub'], g['it100_targets_sub_f64'], what='targets')
+    for k in ('value_mean', 'policy_total_loss', 'policy_gradient_norm', 'q_loss1', 'q_gradient_norm1'):
+        np.testing.assert_allclose(st[k], g['it100_' + k], rtol=5e-5, atol=1e-7, err_msg=k)
+
+
 def test_replay_buffer_vs_reference(golden):
     """The reference's own ReplayBuffer (buffer.py imports as-is): ring wrap, storage content, _encode_sample column order
     and dtypes, replay()'s gate and counter - all exact."""

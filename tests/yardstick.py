@@ -2,7 +2,8 @@
 
     a float32 implementation is accepted when its error against the float64 run of the REFERENCE graph is at most
     4 x the error of the reference's own float32 run against that same float64 run (plus a small floor for arrays
-    the reference happens to hit exactly), AND it is within 1e-4 relative L2 of the reference's float32 result.
+    the reference happens to hit exactly), AND that error is at most 1e-4 relative L2 (also checked against the reference's
+    float32 result, allowing for that result's own distance from the float64 run).
 
 The fixtures carry the reference's float32 result completely and, for the 256-unit nets, every 8th element of the flat
 float64 gradient vector (tests/golden/make_golden.py: sub64); the yard-stick is evaluated on that subsample."""
@@ -45,13 +46,20 @@ def check_gradients(got, ref32, ref64_sub, nets, where='', bar=1e-4, factor=4.0)
             assert np.linalg.norm(got[o:o + n]) == 0, (where, name, shp, 'reference gradient is exactly zero')
             continue
         e = rel_l2(got[o:o + n], r)
-        assert e <= bar, (where, name, shp, 'rel-L2 vs reference float32', e)
         first = (o + 7) // 8 * 8                    # flat indices that are multiples of 8 inside [o, o + n)
         idx = np.arange(first, o + n, 8)
         if idx.size < 8:
+            assert e <= bar, (where, name, shp, 'rel-L2 vs reference float32', e)
             continue                                # too few yard-stick samples in this array (biases of width <= 4)
         r64 = ref64_sub[idx // 8]
         e_ref, e_got = rel_l2(ref32[idx], r64), rel_l2(got[idx], r64)
+        # the 1e-4 bar is a bar on the ERROR ("error vs fp64 oracle ... <= 1e-4 rel-L2"): measured against the
+        # float64 run where the fixture samples it, and against the reference's float32 result with that result's own
+        # distance from the float64 run allowed for (triangle inequality).  It matters for near-zero gradients: on trained
+        # networks the model-free-weighted policy gradient has norm 1e-3 and the REFERENCE's float32 run is 1.1e-4 off its
+        # float64 run (trained_c2 fixture, iteration 9000; this engine: 5e-5)
+        assert e_got <= bar, (where, name, shp, 'rel-L2 vs reference float64', e_got)
+        assert e <= bar + e_ref, (where, name, shp, 'rel-L2 vs reference float32', e, 'reference float32 vs float64', e_ref)
         allow = factor * e_ref + FLOOR
         assert e_got <= allow, (where, name, shp, 'vs float64: got %.3e, reference float32 %.3e' % (e_got, e_ref))
         worst = max(worst, e_got / allow)

@@ -16,6 +16,13 @@ bash tools/pmc.sh $TAG/pmc > $OUT/pmc.log 2>&1
 cp $OUT/pmc/pmc_summary.csv $OUT/pmc/pmc_traffic.json $OUT/ 2>/dev/null
 for i in 1 2 3; do python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_driver_form_$i.json 2>/dev/null; done
 python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
+# 4. the exact-fp32 engine (-DMPG_F32_MFMA) on the driver's command -> exact_fp32_bench.json (copy to profiles/: bench.py reports it)
+MPG_EXTRA_CFLAGS="-DMPG_F32_MFMA" python3 -m mpg_amd.build > $OUT/build_exact.log 2>&1 && \
+  python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read())
+print(json.dumps({'ms_per_step': d['ms_per_step'], 'step_ms_median': d['step_ms_median'], 'from': 'bash tools/profile.sh $TAG: -DMPG_F32_MFMA build, python3 bench.py --gpus 1 --steps 20 --warmup 5, ' + d['device']['name'], 'rollout_kernels_ms': [d['roofline']['avg_ms'], d['roofline_other_rollout_kernel']['avg_ms']]}))" > $OUT/exact_fp32_bench.json
+python3 -m mpg_amd.build > $OUT/build_default.log 2>&1
 rm -rf $OUT/trace/*/*.db $OUT/pmc/pass*/*/*.db 2>/dev/null
 head -12 $OUT/kernel_stats.csv | cut -c1-150
 cat $OUT/pmc_traffic.json | head -20
