@@ -181,7 +181,7 @@ def launch_ranks(a):
     (torch.distributed.run, one process per GPU), then leaves with their exit code."""
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(a.gpus), '--master-addr',
            '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__), '--gpus', str(a.gpus), '--steps',
-           str(a.steps), '--warmup', str(a.warmup)] + (['--no-cpu-baseline'] if a.no_cpu_baseline else [])
+           str(a.steps), '--warmup', str(a.warmup), '--config', a.config] + (['--no-cpu-baseline'] if a.no_cpu_baseline else [])
     env = dict(os.environ)
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     env.setdefault('OMP_NUM_THREADS', '1')
@@ -199,15 +199,235 @@ def _device_info():
     return info
 
 
+# ---- side configurations C3 / C4 (BASELINE.json configs[2], configs[3]) ---------------------------------------------------
+# Algorithmic work per unit, SURVEY.md section 8d: NADP step 14.8 Mflop per start state (pi 4->256->256->2, Q 5->256->256->1,
+# 55 MLP evaluations forward + as many reverse), TD3 step 2.17 Mflop per replay row, PER 212 B per sampled index at
+# B = 65 536 / N = 2^19.  The hidden-layer products run 3x on the f16 matrix pipe (split operands), so the matrix view prices
+# 3x the hidden-layer part against the f16 dense peak - the pipe actually used.
+SIDE = {
+    'c3': dict(B=8192, alg='NADP', flop_per_row=14.8e6, hidden_flop_per_row=110 * 2 * 256 * 256,
+               metric='grad-steps/sec, InvertedPendulumConti model NADP n=25 batch=8192',
+               workload='InvertedPendulumConti (inverted_pendulum_model.py), NADP learner, n=25, replay batch 8192 per GPU; step = '
+                        'compute_gradient (Q-target rollout + Q loss/grad + policy rollout with all-step parameter gradients) + '
+                        '(all-reduce) + apply_gradients'),
+    'c4': dict(B=65536, alg='TD3', flop_per_row=2.17e6, hidden_flop_per_row=16 * 2 * 256 * 256,
+               metric='replay-rows/sec + grad-steps/sec, PathTrackingEnv TD3 + prioritized replay batch=65536',
+               workload='PathTrackingEnv, TD3 learner, prioritized replay (segment trees, capacity 2^19, 500k transitions), replay '
+                        'batch 65536 per GPU; step = replay (proportional sampling + gather) + compute_gradient + update_priorities + '
+                        '(all-reduce) + apply_gradients'),
+}
+
+
+def _cpu_side_worker(budget_s, seed, q, config):
+    """one single-threaded actor running the oracle's gradient step of the side configuration on a REDUCED batch (the unit is
+    rows / s, so the sample scales): NADP 512 rows, TD3 4096 rows"""
+    import numpy as np
+    import torch
+    torch.set_num_threads(1)
+    from oracle import mpg_oracle as O
+    from tests.golden_inputs import mlp_weights_flat, reset_law_obs
+    rng = np.random.Generator(np.random.PCG64(seed))
+    n_done, t0 = 0, time.perf_counter()
+    if config == 'c3':
+        rows = 512
+        cfg = O.Cfg(env='InvertedPendulumConti-v0', select=[25], delay_update=1)
+        flat = {'policy': mlp_weights_flat(rng, 4, 2), 'Q1': mlp_weights_flat(rng, 5, 1)}
+        obs = (rng.standard_normal((rows, 4)) * np.array([0.5, 0.1, 0.5, 0.5])).astype(np.float32)
+        act = rng.uniform(-3, 3, (rows, 1)).astype(np.float32)
+    else:
+        rows = 4096
+        cfg = O.Cfg()
+        flat = {'policy': mlp_weights_flat(rng, 6, 4), 'Q1': mlp_weights_flat(rng, 8, 1), 'Q2': mlp_weights_flat(rng, 8, 1)}
+        batch = [reset_law_obs(rng, rows), rng.uniform(-1, 1, (rows, 2)).astype(np.float32), rng.uniform(-30, 0, rows).astype(np.float32),
+                 reset_law_obs(rng, rows), np.ones(rows, np.float32)]
+    while True:
+        nets = O.Nets(cfg, flat, target_scale=1.0)
+        if config == 'c3':
+            O.nadp_compute_gradient(cfg, nets, [obs, act], rng.standard_normal((25, rows)).astype(np.float32),
+                                    rng.standard_normal((25, rows)).astype(np.float32))
+        else:
+            O.td3_compute_gradient(cfg, nets, batch, rng.standard_normal((rows, 2)).astype(np.float32))
+        n_done += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n_done >= 500:
+            break
+    q.put((n_done * rows, el))
+
+
+def cpu_side_baseline(config, budget_s=10.0, max_procs=256):
+    import multiprocessing as mp
+    try:
+        host = len(os.sched_getaffinity(0))
+    except AttributeError:
+        host = os.cpu_count() or 1
+    try:
+        import psutil
+        mem_cap = max(1, int(psutil.virtual_memory().available * 0.5 / 1.5e9))
+    except Exception:
+        mem_cap = 8
+    procs = max(1, min(host, max_procs, mem_cap))
+    for k in ('OMP_NUM_THREADS', 'MKL_NUM_THREADS', 'OPENBLAS_NUM_THREADS', 'NUMEXPR_NUM_THREADS'):
+        os.environ[k] = '1'
+    os.environ['HIP_VISIBLE_DEVICES'] = ''
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_cpu_side_worker, args=(budget_s, 2000 + i, q, config)) for i in range(procs)]
+    for p in ps:
+        p.start()
+    res = []
+    for _ in ps:
+        try:
+            res.append(q.get(timeout=budget_s * 6 + 120))
+        except Exception:
+            break
+    for p in ps:
+        p.join(timeout=10)
+        if p.is_alive():
+            p.kill()
+    rows_per_s = sum(n / el for n, el in res)
+    return {'value': rows_per_s, 'unit': 'rows/s', 'cores': len(res), 'kind': 'port', 'host_cores': host, 'cpu_model': _cpu_model(),
+            'sample': '%d single-threaded processes side by side, each %.0f s of the oracle\'s %s gradient step on %d-row batches '
+                      '(rows/s scales with the batch); process count = min(host cores %d, %d, free-memory cap %d)'
+                      % (len(res), budget_s, SIDE[config]['alg'], 512 if config == 'c3' else 4096, host, max_procs, mem_cap)}
+
+
+def side_config(a):
+    import numpy as np
+    import torch
+    from mpg_amd import dist as D
+    from mpg_amd import ops
+    from mpg_amd.config import default_args
+    from mpg_amd.optimizer import quiesce_gc
+    from mpg_amd.policy import PolicyWithQs
+    rank, world, local = D.init_from_env()
+    assert world == a.gpus and torch.cuda.is_available()
+    ndev = torch.cuda.device_count()
+    local = local % ndev
+    dev = torch.device('cuda', local)
+    torch.cuda.set_device(dev)
+    c = SIDE[a.config]
+    B = c['B']
+    rng = np.random.Generator(np.random.PCG64(rank))
+    if a.config == 'c3':
+        from mpg_amd.learners import NADPLearner
+        learner = NADPLearner(PolicyWithQs, default_args('NADP', replay_batch_size=B), device=dev)
+        obs = torch.as_tensor((rng.standard_normal((B, 4)) * np.array([0.5, 0.1, 0.5, 0.5])).astype(np.float32)).to(dev)
+        act = torch.as_tensor(rng.uniform(-3, 3, (B, 1)).astype(np.float32)).to(dev)
+        batch = [obs, act, torch.zeros(B, device=dev), obs, torch.zeros(B, device=dev)]
+        rb = None
+    else:
+        from mpg_amd.buffer import PrioritizedReplayBuffer
+        from mpg_amd.learners import TD3Learner
+        from tests.golden_inputs import reset_law_obs
+        N = 500000
+        args = default_args('TD3', replay_batch_size=B, buffer_type='priority', replay_starts=N)
+        learner = TD3Learner(PolicyWithQs, args, device=dev)
+        rb = PrioritizedReplayBuffer(args, rank, device=dev)
+        for _ in range(N // 50000):
+            rb.add_batch((torch.as_tensor(reset_law_obs(rng, 50000)).to(dev), torch.as_tensor(rng.uniform(-1, 1, (50000, 2)), dtype=torch.float32).to(dev),
+                          torch.as_tensor(rng.standard_normal(50000), dtype=torch.float32).to(dev),
+                          torch.as_tensor(reset_law_obs(rng, 50000)).to(dev), torch.ones(50000, dtype=torch.uint8, device=dev)))
+    pw = learner.policy_with_value
+    pw.sync_from_rank0()
+    prof = ops.Profiler(max_samples=4096)
+    prof.attach(pw.cfg)
+    it = [0]
+
+    def step():
+        if rb is None:
+            learner.compute_gradient(batch, None, None, it[0])
+        else:
+            smp = rb.replay()
+            learner.compute_gradient(smp[:5], rb, smp[-1], it[0])
+            info = learner.get_info_for_buffer()
+            info['rb'].update_priorities(info['indexes'], info['td_error'])
+        pw.apply_gradients(it[0], learner.flat_grad)
+        it[0] += 1
+    quiesce_gc()
+    for _ in range(max(a.warmup, 5)):
+        step()
+    D.barrier()
+    torch.cuda.synchronize()
+    gc.disable()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    D.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    gc.enable()
+    dt = D.max_over_ranks(dt)
+    # kernel groups: a second, short pass with EVERY launch of the library's timer slots bracketed by HIP events (the records
+    # cost ~4-5 us each, which is why this pass is not the timed one)
+    nprof = min(a.steps, 10)
+    prof.start(1)
+    for _ in range(nprof):
+        step()
+    torch.cuda.synchronize()
+    slots = {}
+    for k in range(8):
+        ms, n = prof.read(k)
+        if n:
+            slots[ctypes_name(k)] = {'avg_ms': ms, 'launches_per_step': n / nprof, 'ms_per_step': ms * n / nprof}
+    prof.stop()
+    t_per = None
+    if rb is not None:      # the sampling + gather alone, timed with device events on the launch stream
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            rb.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        t_per = e0.elapsed_time(e1) / 20
+    assert bool(torch.isfinite(pw.params).all().item()) and int(pw.nonfinite.sum().item()) == 0
+    pw.check_status()
+    if rank != 0:
+        return
+    ms = 1e3 * dt / a.steps
+    dom = max(slots, key=lambda k: slots[k]['ms_per_step']) if slots else None
+    executed = (c['flop_per_row'] + 2 * c['hidden_flop_per_row']) * B / (ms * 1e-3) / 1e12
+    out = {
+        'metric': c['metric'], 'value': world * B * a.steps / dt, 'unit': 'rows/s', 'grad_steps_per_sec': a.steps / dt,
+        'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'f32-via-split-f16', 'data': 'synthetic', 'schema': 3,
+        'config': {'workload': c['workload'], 'global_batch': world * B, 'parallelism': 'dp%d' % world, 'dist_backend': D.backend()},
+        'device': _device_info(),
+        # whole-step matrix view (the step is a chain of weight-stationary launches, all on the f16 pipe): executed flop =
+        # algorithmic flop with the hidden-layer part counted 3x
+        'roofline': {'bound': 'mfma', 'kernel': 'whole gradient step (%s dominates: %.3f ms of it)' % (dom, slots[dom]['ms_per_step']) if dom else 'whole gradient step',
+                     'achieved': executed, 'peak': F16_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': executed / F16_MFMA_PEAK_TFLOPS,
+                     'frac_f16_mfma': executed / F16_MFMA_PEAK_TFLOPS, 'traffic': None,
+                     'algorithmic_tflops': c['flop_per_row'] * B / (ms * 1e-3) / 1e12,
+                     'timed_with': 'wall clock over the timed region (kernel groups by HIP events on the launch stream below)'},
+        'kernel_groups_ms_per_step': slots,
+    }
+    if t_per is not None:
+        out['per'] = {'sample_gather_ms': t_per, 'algorithmic_bytes_per_index': 212, 'achieved_GBs': 212 * B / (t_per * 1e-3) / 1e9,
+                      'peak_GBs': HBM_PEAK_GBS, 'frac_hbm': 212 * B / (t_per * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    if world == 1 and not a.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_side_baseline(a.config)
+    print(json.dumps(out), flush=True)
+
+
+def ctypes_name(slot):
+    from mpg_amd import _lib as L
+    return L.lib().mpg_prof_slot_name(slot).decode()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--config', default='c2', choices=['c2', 'c3', 'c4'],
+                    help='c2 (default): the BASELINE metric - PathTracking MPG n=25 batch 4096; c3: NADP on the pendulum model, batch '
+                         '8192; c4: TD3 + prioritized replay, batch 65536 (BASELINE.json configs[2], [3]: side lines, same JSON shape)')
     a = ap.parse_args()
     if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(launch_ranks(a))
+    if a.config != 'c2':
+        return side_config(a)
 
     import torch
     from mpg_amd import dist as D

@@ -163,6 +163,12 @@ int mpg_env_step_store_reset(int env_kind, int n, int obs_dim, float* state, con
                              float* ring_obs, float* ring_act, float* ring_rew, float* ring_obs2, uint8_t* ring_done,
                              uint64_t seed, uint64_t ctr, float* obs_out, uint8_t* done_out, mpg_stream_t stream);
 
+/* out[i] = ((slots[0][i] + slots[1][i]) + slots[2][i]) + ...  - the local sum of the one-shot all-reduce (SURVEY.md 8 f4;
+ * mpg_amd/dist.py OneShotAllReduce): every rank of a node holds the ranks' gradient buffers in `n_slots` staging slots of
+ * `n` floats and adds them in rank order, so that all replicas compute the same association.  Replaces the arithmetic of
+ * the gradient exchange, optimizer.py:60-94 (there: one learner's gradients applied at a time). */
+int mpg_sum_slots(const float* slots, int n_slots, int n, float* out, mpg_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Networks (K3), critic targets, losses and gradients (K5, K6)
  * ---------------------------------------------------------------------------------------------- */

@@ -236,8 +236,12 @@ __device__ __forceinline__ void store_c_to_a(float* sA, const Lane& L, const flo
             const float x = odd ? p[2 + u] : v[t][u], y = odd ? v[t][2 + u] : p[u];   // (k even, k odd) of row row0 + u
             float hi, lo;
             split_pack2(x * A_SCALE, y * A_SCALE, hi, lo);
+#ifdef MPG_AB_NO_IMGWRITE   // ablation build (tools/lds_conflicts.sh): the image stores are dropped, their operands kept alive
+            asm volatile("" :: "v"(hi), "v"(lo));
+#else
             *reinterpret_cast<float*>(sH + h_index(row0 + u, k)) = hi;
             *reinterpret_cast<float*>(sH + IMG_H + h_index(row0 + u, k)) = lo;
+#endif
         }
     }
 }

@@ -21,24 +21,28 @@ struct FwdArgs {
     int* status;         // nullable: MPG_STATUS_* word of the caller
 };
 
-template <int IN, int OU, bool PK>
+// G2 = 2: a workgroup takes its row groups in PAIRS through one pair of barriers (forward_group2): with many groups per
+// workgroup (TD3 at B = 65 536: 16) a group's pass is ~4.9k cycles of which the matrix block is 0.8k; the second group of a
+// pair rides in the first one's barrier waits and LDS round trips.  Same arithmetic per group (bit-identical results).
+template <int IN, int OU, bool PK, int G2>
 __global__ void __launch_bounds__(NTHREAD, 2) k_forward(const FwdArgs a) {
-    __shared__ __attribute__((aligned(16))) float smem[A_IMG + GROUP * XS + NWAVE * GROUP * MAXOUT];
+    __shared__ __attribute__((aligned(16))) float smem[G2 * (A_IMG + GROUP * XS + NWAVE * GROUP * MAXOUT)];
     float* sA = smem;
-    float* sX = sA + A_IMG;
-    float* sPart = sX + GROUP * XS;
+    float* sX = sA + G2 * A_IMG;
+    float* sPart = sX + G2 * GROUP * XS;
     const Lane L;
     const Net net = make_net(a.params, a.in_dim, a.out_dim);
     float w2[128];
     SmallRegs<IN, OU> r;
     const long ngroups = (a.rows + GROUP - 1) / GROUP;
-    // the first group's inputs are requested BEFORE the small pieces and the 256 KB image and consumed after them: loads
+    const long nunits = (ngroups + G2 - 1) / G2;                // units of G2 consecutive groups
+    // the first unit's inputs are requested BEFORE the small pieces and the 256 KB image and consumed after them: loads
     // retire in order, so layer 1 and its barrier then run while the image is still streaming in
-    auto x_value = [&](long g) {
+    auto x_value = [&](long u) {
         float v = 0.f;
-        if (threadIdx.x < GROUP * XS) {
-            const int row = threadIdx.x / XS, i = threadIdx.x % XS;
-            const long gr = g * GROUP + row;
+        if (threadIdx.x < G2 * GROUP * XS) {
+            const int g2 = threadIdx.x / (GROUP * XS), e = threadIdx.x % (GROUP * XS), row = e / XS, i = e % XS;
+            const long gr = (u * G2 + g2) * GROUP + row;
             if (gr < a.rows && i < IN) v = i < a.x.d0 ? a.x.x0[gr * a.x.ld0 + i] * a.x.scale[i] : a.x.x1[gr * a.x.ld1 + (i - a.x.d0)];
         }
         return v;
@@ -48,21 +52,31 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_forward(const FwdArgs a) {
     bool saw_nan = false;                       // worker.py:95-107 judge_is_nan, on the device: inputs and outputs of the pass
     load_small<IN, OU>(net, L, r);
     if constexpr (PK) load_w2_packed(a.pack, L, w2); else load_w2_fwd(net.W2, L, w2);
-    for (long g = blockIdx.x; g < ngroups; g += gridDim.x) {
-        if (g != (long)blockIdx.x) xv = x_value(g);
+    for (long u = blockIdx.x; u < nunits; u += gridDim.x) {
+        if (u != (long)blockIdx.x) xv = x_value(u);
         saw_nan |= xv != xv;
-        if (threadIdx.x < GROUP * XS) sX[threadIdx.x] = xv;
+        if (threadIdx.x < G2 * GROUP * XS) sX[threadIdx.x] = xv;
         lds_barrier();
-        float h1[2][4], h2[2][4];
-        forward_group<IN, OU>(sX, sA, sPart, L, w2, r, h1, h2, nullptr, 0, nullptr, &zmax);
-        if (a.h1) stash_store(a.h1, g, L, h1);
-        if (a.h2) stash_store(a.h2, g, L, h2);
+        float h1[G2][2][4], h2[G2][2][4];
+        if constexpr (G2 == 2)
+            forward_group2<IN, OU>(sX, sX + GROUP * XS, sA, sA + A_IMG, sPart, sPart + NWAVE * GROUP * MAXOUT, L, w2, r, h1[0], h2[0], h1[1],
+                                   h2[1], &zmax);
+        else
+            forward_group<IN, OU>(sX, sA, sPart, L, w2, r, h1[0], h2[0], nullptr, 0, nullptr, &zmax);
+#pragma unroll
+        for (int g2 = 0; g2 < G2; ++g2) {
+            const long g = u * G2 + g2;
+            if (g < ngroups) {
+                if (a.h1) stash_store(a.h1, g, L, h1[g2]);
+                if (a.h2) stash_store(a.h2, g, L, h2[g2]);
+            }
+        }
         const int tid = threadIdx.x;
-        if (tid < GROUP * OU) {
-            const int row = tid / OU, o = tid % OU;
-            const long gr = g * GROUP + row;
+        if (tid < G2 * GROUP * OU) {
+            const int g2 = tid / (GROUP * OU), row = (tid / OU) % GROUP, o = tid % OU;
+            const long gr = (u * G2 + g2) * GROUP + row;
             if (gr < a.rows) {
-                float z = out_preact(sPart, net.b3[o], row, o);
+                float z = out_preact(sPart + g2 * NWAVE * GROUP * MAXOUT, net.b3[o], row, o);
                 float y = a.out_tanh ? a.out_scale * tanhf(z) : z;
                 if (a.sigma > 0.f) {   // OffPolicyWorker.sample: action += N(0, sigma), worker.py:97-98
                     Philox4 p = philox4x32_10((uint32_t)gr, a.c1, a.c2, 0x5eedu + (uint32_t)o, a.k0, a.k1);
@@ -73,6 +87,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_forward(const FwdArgs a) {
                 a.y[gr * a.ldy + o] = y;
             }
         }
+        // (sX / sPart of the next unit are ordered behind these reads by the barrier at the top of the loop)
     }
     report_activation_range(a.status, zmax);
     if (a.status && saw_nan) atomicOr(a.status, MPG_STATUS_NAN);
@@ -103,9 +118,17 @@ int launch_forward(const mpg_cfg_t* cfg, const float* params, int in_dim, int ou
     a.status = mpg_status_of(cfg);
     const long ngroups = (rows + GROUP - 1) / GROUP;
     mpg_prof_begin(mpg_prof_of(cfg), 3, s);
-#define CALL(I, O)                                                                                          \
-    if (a.pack) hipLaunchKernelGGL((k_forward<I, O, true>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, a);  \
-    else hipLaunchKernelGGL((k_forward<I, O, false>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, a)
+    // pairs of groups per pass once a workgroup has at least two groups to take
+#ifndef MPG_FORWARD_G2_MIN_GROUPS
+#define MPG_FORWARD_G2_MIN_GROUPS 512
+#endif
+    const bool two = ngroups >= MPG_FORWARD_G2_MIN_GROUPS;
+    const int grid = grid_for(two ? (ngroups + 1) / 2 : ngroups);
+#define CALL(I, O)                                                                                                  \
+    if (a.pack && two) hipLaunchKernelGGL((k_forward<I, O, true, 2>), dim3(grid), dim3(NTHREAD), 0, s, a);           \
+    else if (a.pack) hipLaunchKernelGGL((k_forward<I, O, true, 1>), dim3(grid), dim3(NTHREAD), 0, s, a);             \
+    else if (two) hipLaunchKernelGGL((k_forward<I, O, false, 2>), dim3(grid), dim3(NTHREAD), 0, s, a);               \
+    else hipLaunchKernelGGL((k_forward<I, O, false, 1>), dim3(grid), dim3(NTHREAD), 0, s, a)
     MPG_DISPATCH_NET(in_dim, ou, CALL)
 #undef CALL
     mpg_prof_end(mpg_prof_of(cfg), 3, s);

@@ -82,6 +82,9 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int sl, con
         }
 #pragma unroll
         for (int u = 0; u < 3; ++u) stage[L.lane + 64 * u] = on[u] ? v[u] * sc[u] : 0.f;
+#ifdef MPG_AB_PKFMA_WAIT   // hypothesis test (tools/pk_anomaly.sh): the staged values are fully written before anything reads them
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
         __builtin_amdgcn_wave_barrier();      // same wave writes and reads: LDS is in order within a wave
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -96,15 +99,40 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int sl, con
             // lost nondeterministically: first the (row 13, even i) terms of dW1 in ~85 % of launches, after dW1 was
             // unpacked the t = 1 half of dW3 in ~5 % (found by the repeated-launch determinism
             // check, not reproduced in isolation by tools/proto/pk_hazard.hip; a build without packed fp32 is clean).
+#ifdef MPG_AB_PKFMA
+            // ablation build (tools/pk_anomaly.sh): the form the compiler is free to pack (v_pk_fma_f32 / v_pk_add_f32 with
+            // op_sel) - the one that lost products in round 2
+#define MPG_FMAC(acc, a_, b_) acc = fmaf(a_, b_, acc)
+#define MPG_ADD(acc, a_) acc += a_
+#else
 #define MPG_FMAC(acc, a_, b_) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(acc) : "v"(a_), "v"(b_))
 #define MPG_ADD(acc, a_) asm volatile("v_add_f32 %0, %0, %1" : "+v"(acc) : "v"(a_))
+#endif
             MPG_ADD(gb1[0], t.d10[j]); MPG_ADD(gb1[1], t.d11[j]);
             MPG_ADD(gb2[0], t.d20[j]); MPG_ADD(gb2[1], t.d21[j]);
+#ifdef MPG_AB_PKFMA
+            {   // explicitly packed: (gW1[t][i], gW1[t][i + 1]) += (x[i], x[i + 1]) * d1t[j] - v_pk_fma_f32 with an op_sel splat
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+                for (int i = 0; i + 1 < IN; i += 2) {
+                    const f32x2 xx = {x[i], x[i + 1]};
+                    f32x2 a0 = {gW1[0][i], gW1[0][i + 1]}, a1 = {gW1[1][i], gW1[1][i + 1]};
+                    a0 = __builtin_elementwise_fma(xx, f32x2{t.d10[j], t.d10[j]}, a0);
+                    a1 = __builtin_elementwise_fma(xx, f32x2{t.d11[j], t.d11[j]}, a1);
+                    gW1[0][i] = a0[0]; gW1[0][i + 1] = a0[1]; gW1[1][i] = a1[0]; gW1[1][i + 1] = a1[1];
+                }
+                if (IN & 1) {
+                    MPG_FMAC(gW1[0][IN - 1], x[IN - 1], t.d10[j]);
+                    MPG_FMAC(gW1[1][IN - 1], x[IN - 1], t.d11[j]);
+                }
+            }
+#else
 #pragma unroll
             for (int i = 0; i < IN; ++i) {
                 MPG_FMAC(gW1[0][i], x[i], t.d10[j]);
                 MPG_FMAC(gW1[1][i], x[i], t.d11[j]);
             }
+#endif
 #pragma unroll
             for (int o = 0; o < OU; ++o) {
                 MPG_FMAC(gW3[0][o], t.h20[j], d3[o]);

@@ -365,3 +365,20 @@ extern "C" int mpg_clip_adam_polyak(float* w, float* m, float* v, float* target,
     MPG_CHECK_LAUNCH("k_clip_adam_polyak");
     return MPG_OK;
 }
+
+namespace {
+__global__ void k_sum_slots(const float* __restrict__ slots, int n_slots, int n, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = slots[i];
+    for (int r = 1; r < n_slots; ++r) s += slots[(size_t)r * n + i];       // rank order: the same association on every replica
+    out[i] = s;
+}
+}  // namespace
+
+extern "C" int mpg_sum_slots(const float* slots, int n_slots, int n, float* out, mpg_stream_t stream) {
+    MPG_REQUIRE(slots && out && n_slots > 0 && n > 0, "mpg_sum_slots: bad argument");
+    hipLaunchKernelGGL(k_sum_slots, dim3((n + 255) / 256), dim3(256), 0, mpg_stream(stream), slots, n_slots, n, out);
+    MPG_CHECK_LAUNCH("k_sum_slots");
+    return MPG_OK;
+}

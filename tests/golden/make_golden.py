@@ -267,6 +267,8 @@ def fx_mpg(version, H, B, seed):
             st = learner.get_stats()
             p = 'it%d_' % it
             out[p + 'grads' + tag] = flat(grads) if tag == '' else sub64(flat(grads), H)
+            if trained and tag == '_f64':      # output-layer biases are too short for the every-8th subsample: keep them whole
+                out[p + 'grads_small_f64'] = np.concatenate([np.asarray(x, np.float64).ravel() for x in grads if np.asarray(x).size < 8])
             out[p + 'targets' + tag] = np.asarray(learner.batch_data['batch_targets'])
             for key in ('value_mean', 'policy_total_loss', 'policy_gradient_norm', 'q_loss1',
                         'q_gradient_norm1', 'q_loss2', 'q_gradient_norm2'):
@@ -459,6 +461,8 @@ def fx_bench_case(name, trained=False):
             st = learner.get_stats()
             p = 'it%d_' % it
             out[p + 'grads' + tag] = flat(grads) if tag == '' else sub64(flat(grads), H)
+            if trained and tag == '_f64':      # output-layer biases are too short for the every-8th subsample: keep them whole
+                out[p + 'grads_small_f64'] = np.concatenate([np.asarray(x, np.float64).ravel() for x in grads if np.asarray(x).size < 8])
             if 'batch_targets' in learner.batch_data:
                 out[p + 'targets_sub' + tag] = np.asarray(learner.batch_data['batch_targets'])[::8].astype(np.float32)
             for key in keys:

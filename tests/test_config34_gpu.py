@@ -207,3 +207,60 @@ def test_prioritized_replay_at_config4_sizes():
     w = s[5]
     assert w.max().item() <= 1.0 + 1e-6 and w.min().item() > 0
     np.testing.assert_array_equal(s[0].cpu().numpy(), batch[0][s[-1].long()].cpu().numpy())
+
+
+def test_config3_end_to_end_worker_ring_nadp_adam():
+    """Config 3 end to end on the device (SURVEY.md section 8 f3): OffPolicyWorker on the analytic cart-pole (64 pendulums per launch;
+    the reference steps ONE MuJoCo pendulum behind DummyVecEnv, train_script4mujoco.py:328, with explore_sigma None) -> replay
+    ring -> NADPLearner on the pendulum MODEL -> clip / Adam / Polyak, in SingleProcessOffPolicyOptimizer's order, plus the
+    Evaluator's pendulum metrics (evaluator.py:185-211).  Learning check: 100-step evaluation episodes (done ignored, like the
+    reference's evaluator) start at about -900 with the initial policy (the pole falls and swings) and must come within -60
+    at one of the first checkpoints - the pole is then held near upright (theta rms < 0.1).  NOT claimed: the reference's
+    plotted base score of -2 (ploter.py:85) - the real environment here is an analytic cart-pole whose parity with MuJoCo is
+    unpinned, NADP's bootstrapped target is unclipped (nadp.py:87-126), and longer runs of this pair drift (value_mean grows
+    positive although every reward is <= 0; tools: scratch run recorded in DESIGN.md section 7)."""
+    from mpg_amd.buffer import ReplayBuffer
+    from mpg_amd.config import default_args
+    from mpg_amd.evaluator import Evaluator
+    from mpg_amd.learners import NADPLearner
+    from mpg_amd.optimizer import SingleProcessOffPolicyOptimizer
+    from mpg_amd.policy import PolicyWithQs
+    from mpg_amd.worker import OffPolicyWorker
+    args = default_args('NADP', num_agent=64, batch_size=512, replay_batch_size=512, replay_starts=3000, num_eval_agent=16,
+                        fixed_steps=100)
+    assert args.env_id == 'InvertedPendulumConti-v0' and args.explore_sigma is None
+    worker = OffPolicyWorker(PolicyWithQs, args.env_id, args, 0)
+    learner = NADPLearner(PolicyWithQs, args)
+    rb = ReplayBuffer(args, 0)
+    opt = SingleProcessOffPolicyOptimizer(worker, learner, rb, None, args, sampling_interval=10)
+    assert opt._fused is None                                  # the method-by-method path (the native driver is MPG's)
+    ev = Evaluator(PolicyWithQs, args.env_id, args)
+    ev.share_policy(worker.policy_with_value)
+    m0 = ev.run_evaluation(0)
+    assert set(('x_mean', 'theta_var', 'xdot_mse', 'thetadot_mse_25')) <= set(m0)
+    best, best_theta = m0['episode_return'], m0['theta_mse']
+    for it in range(500, 2001, 500):
+        for _ in range(500):
+            opt.step()
+        m = ev.run_evaluation(it)
+        if m['episode_return'] > best:
+            best, best_theta = m['episode_return'], m['theta_mse']
+    assert len(rb) >= 3000 and rb.obs.shape[1] == 4 and rb.act.shape[1] == 1
+    assert m0['episode_return'] < -300 and best > -60 and best_theta < 0.1, (m0['episode_return'], best, best_theta)
+    assert worker.policy_with_value.check_status() == 0 and int(worker.policy_with_value.nonfinite.sum().item()) == 0
+
+
+def test_worker_nan_is_reported_from_the_device():
+    """worker.py:95-107 `judge_is_nan`: a NaN in an observation (or produced by the policy) sets MPG_STATUS_NAN inside the policy
+    kernel; OffPolicyWorker.sample reads the word every `nan_check_interval` calls and raises."""
+    from mpg_amd._lib import MpgError
+    from mpg_amd.config import default_args
+    from mpg_amd.policy import PolicyWithQs
+    from mpg_amd.worker import OffPolicyWorker
+    args = default_args('MPG-v2', num_agent=64, batch_size=64, nan_check_interval=1)
+    worker = OffPolicyWorker(PolicyWithQs, args.env_id, args, 0)
+    worker.sample()                                            # clean
+    worker.obs = worker.obs.clone()
+    worker.obs[5, 2] = float('nan')
+    with pytest.raises(MpgError, match='judge_is_nan'):
+        worker.sample()

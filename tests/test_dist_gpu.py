@@ -25,10 +25,12 @@ def _free_port():
 
 
 def _init(rank, world, port):
-    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    """MPG_DIST_BACKEND (inherited from the test that spawned this process): 'gloo' or 'oneshot' (the IPC one-shot exchange)"""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                      HSA_ENABLE_IPC_MODE_LEGACY='0')
     from mpg_amd import dist as D
-    D.init_from_env(backend='gloo')
     torch.cuda.set_device(0)
+    D.init_from_env(backend=os.environ.get('MPG_DIST_BACKEND', 'gloo'))
     return D
 
 
@@ -71,8 +73,16 @@ def _run(fn, world=2):
     return sorted(out, key=lambda t: t[0])
 
 
+@pytest.fixture(params=['gloo', 'oneshot'])
+def exchange(request, monkeypatch):
+    """the two exchanges of the gradient buffer that a 1-GPU box can run with two ranks: gloo's all-reduce, and the one-shot
+    all-reduce over IPC-mapped staging slots (mpg_amd/dist.py OneShotAllReduce) - spawned workers inherit the variable"""
+    monkeypatch.setenv('MPG_DIST_BACKEND', request.param)
+    return request.param
+
+
 @pytest.mark.timeout(300)
-def test_two_rank_gradient_equals_reference_gradient_on_the_full_batch():
+def test_two_rank_gradient_equals_reference_gradient_on_the_full_batch(exchange):
     out = _run(_golden_worker)
     g = np.load(os.path.join(GOLDEN, 'mpg_v2_H256_B64.npz'))
     ref = g['it100_grads']
@@ -114,12 +124,41 @@ def _driver_worker(rank, world, port, q):
 
 
 @pytest.mark.timeout(300)
-def test_native_step_driver_keeps_two_replicas_bit_identical():
+def test_native_step_driver_keeps_two_replicas_bit_identical(exchange):
     """Different env / replay / noise streams per rank, ONE all-reduce per step, replicated clip + Adam + Polyak:
     parameters, targets and Adam moments stay bit-identical across ranks without any weight broadcast."""
     out = _run(_driver_worker)
     assert np.array_equal(out[0][1], out[1][1]) and np.isfinite(out[0][1]).all()
     assert not np.array_equal(out[0][2], out[1][2])               # the ranks really saw different data
+
+
+def _oneshot_sum_worker(rank, world, port, q):
+    D = _init(rank, world, port)
+    n = 205318 + 16                                      # the MPG-v2 gradient buffer
+    g = torch.Generator(device='cpu').manual_seed(100 + rank)
+    mine = (torch.randn(n, generator=g) * torch.logspace(-6, 2, n)).float()
+    flat = mine.cuda()
+    outs = []
+    for k in range(3):                                    # both staging parities and a re-use
+        buf = flat * float(k + 1)
+        D.all_reduce_sum_(buf)
+        outs.append(buf.cpu().numpy())
+    torch.cuda.synchronize()
+    D.barrier()
+    q.put((rank, mine.numpy(), outs))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_oneshot_all_reduce_is_the_in_rank_order_sum_bit_for_bit(monkeypatch):
+    """OneShotAllReduce on its own: three exchanges of a 205 334-float buffer with entries over eight orders of magnitude.
+    Every rank must hold exactly fl(x_0 + x_1) - the rank-order float32 sum - each time."""
+    monkeypatch.setenv('MPG_DIST_BACKEND', 'oneshot')
+    out = _run(_oneshot_sum_worker)
+    x0, x1 = out[0][1], out[1][1]
+    for k in range(3):
+        ref = (x0 * np.float32(k + 1)) + (x1 * np.float32(k + 1))       # float32 arithmetic, rank order
+        assert np.array_equal(out[0][2][k], ref) and np.array_equal(out[1][2][k], ref), k
 
 
 def _rccl_worker(rank, world, port, q):

@@ -200,7 +200,7 @@ def test_trained_networks_vs_reference(golden):
         got = torch.cat([x.reshape(-1) for x in grads]).cpu().numpy()
         p = 'it%d_' % it
         worst = max(worst, Y.check_gradients(got, g[p + 'grads'], g[p + 'grads_f64'], [(n,) + tuple(pw.dims[n]) for n in pw.names],
-                                             where='trained nets, it %d' % it))
+                                             where='trained nets, it %d' % it, small64=g[p + 'grads_small_f64']))
         Y.check_values(learner.batch_data['batch_targets'].cpu().numpy()[::8], g[p + 'targets_sub'], g[p + 'targets_sub_f64'],
                        what='trained nets, targets')
         st = learner.get_stats()

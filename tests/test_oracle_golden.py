@@ -314,7 +314,7 @@ def test_trained_networks_case(golden):
     nets = O.Nets(cfg, {k: tw['w_' + k] for k in ('Q1', 'Q2', 'policy')}, target_scale=g['target_scale'])
     grads, st = O.mpg_compute_gradient(cfg, nets, d['batch'], d['eps'], 100, 'MPG-v2')
     Y.check_gradients(np.concatenate([x.ravel() for x in grads]), g['it100_grads'], g['it100_grads_f64'],
-                      [('Q1', 8, 1), ('Q2', 8, 1), ('policy', 6, 4)], where='trained nets it100')
+                      [('Q1', 8, 1), ('Q2', 8, 1), ('policy', 6, 4)], where='trained nets it100', small64=g['it100_grads_small_f64'])
     Y.check_values(st['targets'][::8], g['it100_targets_sub'], g['it100_targets_sub_f64'], what='targets')
     for k in ('value_mean', 'policy_total_loss', 'policy_gradient_norm', 'q_loss1', 'q_gradient_norm1'):
         np.testing.assert_allclose(st[k], g['it100_' + k], rtol=5e-5, atol=1e-7, err_msg=k)
