@@ -29,4 +29,8 @@ def default_args(alg='MPG-v2', env_id=None, **overrides):
         policy_smoothing_sigma=0.2, policy_smoothing_clip=0.5,
         max_iter=100000, seed=0, init_seed=0)
     d.update(overrides)
+    if not pend and d['num_future_data'] and 'obs_dim' not in overrides:       # train_script.py:146-147, 794-811
+        d['obs_dim'] = 6 + d['num_future_data']
+        if 'obs_scale' not in overrides:
+            d['obs_scale'] = d['obs_scale'] + [1.] * d['num_future_data']
     return argparse.Namespace(**d)

@@ -24,7 +24,14 @@ constexpr int GROUP = 16;      // rows per row group
 constexpr int A_IMG = 4608;    // floats reserved per LDS A image region: >= GROUP*LDA (float32 image) and = 2 split-fp16 images
 constexpr int LDA = 280;       // row stride (floats) of the float32 LDS A image
 constexpr int KS = 68;         // stride between the 4 k-phases of a row; (LDA, KS) = (280, 68): b128 reads conflict-free, b32 writes 2-way (free)
-constexpr int XS = 8;          // row stride of the small LDS input block
+constexpr int XS = 8;          // row stride of the small LDS input block for networks with up to 8 inputs
+// Networks with 9 .. 16 inputs (observations with look-ahead terms, path_tracking_env.py:385-402: obs_dim = 6 + num_future_data;
+// SURVEY f3) run the same engine with a 16-wide input block: template parameter IN = 16 stands for "up to 16, the actual width
+// is Net::in_dim", layer 1 is four k-steps of the fp32 MFMA instead of two, the dx partials are 16 wide.
+template <int IN>
+__host__ __device__ constexpr int xs_of() { return IN <= 8 ? 8 : 16; }
+template <int IN>
+__host__ __device__ constexpr int l1_steps() { return IN <= 8 ? 2 : 4; }
 constexpr int MAXOUT = 2;      // outputs ever *used* (policy mean: act_dim <= 2; critic: 1)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -394,22 +401,23 @@ __device__ __forceinline__ void mfma_16x256x32(const float* sA, const Lane& L, c
 // ---- small per-lane stationary pieces -----------------------------------------------------------------
 template <int IN, int OU>
 struct SmallRegs {
-    float w1p[2][2];   // layer-1 MFMA B operand: W1[4q + rg][col(t)] (0 beyond IN), index [q][t]
-    float w1t[8];      // dx MFMA B operand: W1[c][32w + 4q + rg] (0 for c >= IN), q = 0..7
+    float w1p[l1_steps<IN>()][2];   // layer-1 MFMA B operand: W1[4q + rg][col(t)] (0 beyond in_dim), index [q][t]
+    float w1t[8];      // dx MFMA B operand: W1[c][32w + 4q + rg] (0 for c >= in_dim), q = 0..7
     float b1[2], b2[2];
     float w3[2][OU];   // W3[col(t)][o]
 };
 
 template <int IN, int OU>
 __device__ __forceinline__ void load_small(const Net& n, const Lane& L, SmallRegs<IN, OU>& r) {
-    static_assert(IN <= 8, "layer-1 MFMA covers K <= 8");
+    static_assert(IN <= 16, "layer-1 MFMA covers K <= 16");
+    // masks by the network's actual width (== IN for the exact instantiations, <= 16 for the wide one)
 #pragma unroll
-    for (int q = 0; q < 8; ++q) r.w1t[q] = L.c < IN ? n.W1[L.c * H + 32 * L.wave + 4 * q + L.rg] : 0.f;
+    for (int q = 0; q < 8; ++q) r.w1t[q] = L.c < n.in_dim ? n.W1[L.c * H + 32 * L.wave + 4 * q + L.rg] : 0.f;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int col = L.col(t);
 #pragma unroll
-        for (int q = 0; q < 2; ++q) r.w1p[q][t] = (4 * q + L.rg) < IN ? n.W1[(4 * q + L.rg) * H + col] : 0.f;
+        for (int q = 0; q < l1_steps<IN>(); ++q) r.w1p[q][t] = (4 * q + L.rg) < n.in_dim ? n.W1[(4 * q + L.rg) * H + col] : 0.f;
         r.b1[t] = n.b1[col];
         r.b2[t] = n.b2[col];
 #pragma unroll
@@ -442,12 +450,12 @@ __device__ __forceinline__ void forward_group(const float* sX, float* sA, float*
                                               const float (&w2)[128], const SmallRegs<IN, OU>& r,
                                               float (&h1)[2][4], float (&h2)[2][4], float* h1_stash = nullptr,
                                               long stash_group = 0, const float* xa_regs = nullptr, float* zmax = nullptr) {
-    {   // layer 1 on the matrix pipe too: K = IN <= 8 zero-padded = 2 k-steps (sX rows are zero beyond IN).
-        // xa_regs (optional, 2 floats): this lane's A operand x[row l&15][4q + (l>>4)] already in registers (no LDS round trip)
+    {   // layer 1 on the matrix pipe too: K = in_dim zero-padded to 8 (2 k-steps) or 16 (4) - sX rows are zero beyond in_dim.
+        // xa_regs (optional): this lane's A operand x[row l&15][4q + (l>>4)] already in registers (no LDS round trip)
         f32x4 z0 = {r.b1[0], r.b1[0], r.b1[0], r.b1[0]}, z1 = {r.b1[1], r.b1[1], r.b1[1], r.b1[1]};
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const float xa = xa_regs ? xa_regs[q] : sX[L.c * XS + 4 * q + L.rg];
+        for (int q = 0; q < l1_steps<IN>(); ++q) {
+            const float xa = xa_regs ? xa_regs[q] : sX[L.c * xs_of<IN>() + 4 * q + L.rg];
             z0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, r.w1p[q][0], z0, 0, 0, 0);
             z1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, r.w1p[q][1], z1, 0, 0, 0);
         }
@@ -523,8 +531,8 @@ __device__ __forceinline__ void forward_group2(const float* sXa, const float* sX
     auto layer1 = [&](const float* sX, float* sA, float (&h1)[2][4]) {
         f32x4 z0 = {r.b1[0], r.b1[0], r.b1[0], r.b1[0]}, z1 = {r.b1[1], r.b1[1], r.b1[1], r.b1[1]};
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const float xa = sX[L.c * XS + 4 * q + L.rg];
+        for (int q = 0; q < l1_steps<IN>(); ++q) {
+            const float xa = sX[L.c * xs_of<IN>() + 4 * q + L.rg];
             z0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, r.w1p[q][0], z0, 0, 0, 0);
             z1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, r.w1p[q][1], z1, 0, 0, 0);
         }
@@ -684,9 +692,9 @@ __device__ __forceinline__ void backward_rest(const float* sD3, float* sA, float
         for (int q = 0; q < 4; ++q) dx = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[q], r.w1t[q], dx, 0, 0, 0);
 #pragma unroll
         for (int q = 0; q < 4; ++q) dx = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[q], r.w1t[4 + q], dx, 0, 0, 0);
-        if (L.c < IN) {
+        if (L.c < xs_of<IN>()) {        // columns beyond in_dim carry zero weights: they are written as zeros
 #pragma unroll
-            for (int j = 0; j < 4; ++j) sPartX[(L.wave * GROUP + L.row(j)) * XS + L.c] = dx[j];
+            for (int j = 0; j < 4; ++j) sPartX[(L.wave * GROUP + L.row(j)) * xs_of<IN>() + L.c] = dx[j];
         }
     }
     MPG_STAMP_AT(4);
@@ -708,30 +716,34 @@ __device__ __forceinline__ void backward_group(const float* sD3, float* sA, floa
 
 // all XS partial sums of one row: ds_read_b128 pairs in two batches of four waves (32 VGPRs in flight; all sixteen
 // reads at once cost 64 VGPRs at a point where the reverse sweep has none to spare)
-__device__ __forceinline__ void dx_reduce_row(const float* sPartX, int row, float (&out)[XS]) {
+template <int XSW = XS>
+__device__ __forceinline__ void dx_reduce_row(const float* sPartX, int row, float (&out)[XSW]) {
 #pragma unroll
-    for (int i = 0; i < XS; ++i) out[i] = 0.f;
+    for (int i = 0; i < XSW; ++i) out[i] = 0.f;
 #pragma unroll
-    for (int b = 0; b < NWAVE; b += 4) {
-        f32x4 lo[4], hi[4];
+    for (int half = 0; half < XSW / 8; ++half)
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const f32x4* p = reinterpret_cast<const f32x4*>(sPartX + ((b + w) * GROUP + row) * XS);
-            lo[w] = p[0];
-            hi[w] = p[1];
+        for (int b = 0; b < NWAVE; b += 4) {
+            f32x4 lo[4], hi[4];
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const f32x4* p = reinterpret_cast<const f32x4*>(sPartX + ((b + w) * GROUP + row) * XSW + 8 * half);
+                lo[w] = p[0];
+                hi[w] = p[1];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                out[8 * half + i] += (lo[0][i] + lo[1][i]) + (lo[2][i] + lo[3][i]);
+                out[8 * half + 4 + i] += (hi[0][i] + hi[1][i]) + (hi[2][i] + hi[3][i]);
+            }
         }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            out[i] += (lo[0][i] + lo[1][i]) + (lo[2][i] + lo[3][i]);
-            out[4 + i] += (hi[0][i] + hi[1][i]) + (hi[2][i] + hi[3][i]);
-        }
-    }
 }
 
+template <int XSW = XS>
 __device__ __forceinline__ float dx_reduce(const float* sPartX, int row, int i) {
     float z = 0.f;
 #pragma unroll
-    for (int w = 0; w < NWAVE; ++w) z += sPartX[(w * GROUP + row) * XS + i];
+    for (int w = 0; w < NWAVE; ++w) z += sPartX[(w * GROUP + row) * XSW + i];
     return z;
 }
 

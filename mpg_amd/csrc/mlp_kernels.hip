@@ -26,10 +26,11 @@ struct FwdArgs {
 // pair rides in the first one's barrier waits and LDS round trips.  Same arithmetic per group (bit-identical results).
 template <int IN, int OU, bool PK, int G2>
 __global__ void __launch_bounds__(NTHREAD, 2) k_forward(const FwdArgs a) {
-    __shared__ __attribute__((aligned(16))) float smem[G2 * (A_IMG + GROUP * XS + NWAVE * GROUP * MAXOUT)];
+    constexpr int XSW = xs_of<IN>();
+    __shared__ __attribute__((aligned(16))) float smem[G2 * (A_IMG + GROUP * XSW + NWAVE * GROUP * MAXOUT)];
     float* sA = smem;
     float* sX = sA + G2 * A_IMG;
-    float* sPart = sX + G2 * GROUP * XS;
+    float* sPart = sX + G2 * GROUP * XSW;
     const Lane L;
     const Net net = make_net(a.params, a.in_dim, a.out_dim);
     float w2[128];
@@ -40,10 +41,10 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_forward(const FwdArgs a) {
     // retire in order, so layer 1 and its barrier then run while the image is still streaming in
     auto x_value = [&](long u) {
         float v = 0.f;
-        if (threadIdx.x < G2 * GROUP * XS) {
-            const int g2 = threadIdx.x / (GROUP * XS), e = threadIdx.x % (GROUP * XS), row = e / XS, i = e % XS;
+        if (threadIdx.x < G2 * GROUP * XSW) {
+            const int g2 = threadIdx.x / (GROUP * XSW), e = threadIdx.x % (GROUP * XSW), row = e / XSW, i = e % XSW;
             const long gr = (u * G2 + g2) * GROUP + row;
-            if (gr < a.rows && i < IN) v = i < a.x.d0 ? a.x.x0[gr * a.x.ld0 + i] * a.x.scale[i] : a.x.x1[gr * a.x.ld1 + (i - a.x.d0)];
+            if (gr < a.rows && i < a.in_dim) v = i < a.x.d0 ? a.x.x0[gr * a.x.ld0 + i] * a.x.scale[i] : a.x.x1[gr * a.x.ld1 + (i - a.x.d0)];
         }
         return v;
     };
@@ -55,11 +56,11 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_forward(const FwdArgs a) {
     for (long u = blockIdx.x; u < nunits; u += gridDim.x) {
         if (u != (long)blockIdx.x) xv = x_value(u);
         saw_nan |= xv != xv;
-        if (threadIdx.x < G2 * GROUP * XS) sX[threadIdx.x] = xv;
+        if (threadIdx.x < G2 * GROUP * XSW) sX[threadIdx.x] = xv;
         lds_barrier();
         float h1[G2][2][4], h2[G2][2][4];
         if constexpr (G2 == 2)
-            forward_group2<IN, OU>(sX, sX + GROUP * XS, sA, sA + A_IMG, sPart, sPart + NWAVE * GROUP * MAXOUT, L, w2, r, h1[0], h2[0], h1[1],
+            forward_group2<IN, OU>(sX, sX + GROUP * XSW, sA, sA + A_IMG, sPart, sPart + NWAVE * GROUP * MAXOUT, L, w2, r, h1[0], h2[0], h1[1],
                                    h2[1], &zmax);
         else
             forward_group<IN, OU>(sX, sA, sPart, L, w2, r, h1[0], h2[0], nullptr, 0, nullptr, &zmax);
@@ -99,6 +100,10 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_forward(const FwdArgs a) {
     else if ((in_dim) == 4 && (ou) == 1) { CALL(4, 1); }                      \
     else if ((in_dim) == 5 && (ou) == 1) { CALL(5, 1); }                      \
     else if ((in_dim) == 6 && (ou) == 1) { CALL(6, 1); }                      \
+    else if ((in_dim) > 8 && (in_dim) <= 16 && (ou) == 2) { CALL(16, 2); }    \
+    else if ((in_dim) > 8 && (in_dim) <= 16 && (ou) == 1) { CALL(16, 1); }    \
+    else if ((in_dim) == 7 && (ou) == 2) { CALL(16, 2); }                     \
+    else if ((in_dim) == 8 && (ou) == 2) { CALL(16, 2); }                     \
     else {                                                                    \
         mpg_set_error("unsupported network shape in=%d used-out=%d", (in_dim), (ou)); \
         return MPG_EINVAL;                                                    \
@@ -155,7 +160,8 @@ struct BwdArgs {
 
 template <int IN, int OU, bool WANT_DX, bool PK>
 __global__ void __launch_bounds__(NTHREAD, 2) k_backward(const BwdArgs a) {
-    __shared__ __attribute__((aligned(16))) float smem[2 * A_IMG + GROUP * MAXOUT + NWAVE * GROUP * XS];
+    constexpr int XSW = xs_of<IN>();
+    __shared__ __attribute__((aligned(16))) float smem[2 * A_IMG + GROUP * MAXOUT + NWAVE * GROUP * XSW];
     float* sA = smem;
     float* sA1 = sA + A_IMG;
     float* sD3 = sA1 + A_IMG;
@@ -191,10 +197,10 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_backward(const BwdArgs a) {
         if (a.dz1) stash_store(a.dz1, g, L, dz1);
         if (a.dz2) stash_store(a.dz2, g, L, dz2);
         if (WANT_DX) {
-            if (tid < GROUP * IN) {
-                const int row = tid / IN, i = tid % IN;
+            if (tid < GROUP * a.in_dim) {
+                const int row = tid / a.in_dim, i = tid % a.in_dim;
                 const long gr = g * GROUP + row;
-                if (gr < a.rows) a.dx[gr * a.lddx + i] = dx_reduce(sPartX, row, i);
+                if (gr < a.rows) a.dx[gr * a.lddx + i] = dx_reduce<XSW>(sPartX, row, i);
             }
             lds_barrier();   // sPartX / sD3 are rewritten by the next group
         }
@@ -237,7 +243,7 @@ int launch_backward(const mpg_cfg_t* cfg, const float* params, int in_dim, int o
 // by 8 workgroups; k_reduce_slabs sums the <= 32 chunk slabs in a fixed order (deterministic, no float atomics).
 // -------------------------------------------------------------------------------------------------------
 template <int IN, int OU>
-__global__ void __launch_bounds__(NTHREAD, 4) k_wgrad(const WgradArgs a) {
+__global__ void __launch_bounds__(NTHREAD, IN <= 8 ? 4 : 2) k_wgrad(const WgradArgs a) {      // (16-wide: 80 KB of LDS, one workgroup per CU anyway)
     __shared__ __attribute__((aligned(16))) float sRed[NWAVE * wgrad_nq<IN, OU>() * 64];
     int chunk, sl;
     wgrad_map(blockIdx.x, gridDim.x >> 3, chunk, sl);

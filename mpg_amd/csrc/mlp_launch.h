@@ -9,27 +9,28 @@ struct XSpec {              // network input = [x0 (d0 columns, column i < n_sca
     int d0, ld0;            // ld = row stride in floats
     const float* x1;
     int d1, ld1;
-    float scale[8];
+    float scale[16];
     int n_scaled;
 };
 
 inline XSpec xspec(const float* x0, int d0, const float* x1, int d1, const float* scale, int n_scaled) {
     XSpec s;
     s.x0 = x0; s.d0 = d0; s.ld0 = d0; s.x1 = x1; s.d1 = d1; s.ld1 = d1; s.n_scaled = n_scaled;
-    for (int i = 0; i < 8; ++i) s.scale[i] = (scale && i < n_scaled) ? scale[i] : 1.f;
+    for (int i = 0; i < 16; ++i) s.scale[i] = (scale && i < n_scaled) ? scale[i] : 1.f;
     return s;
 }
 
 #ifdef __HIPCC__
-// loads one row group of the network input into sX [16][XS] (zero padded)
+// loads one row group of the network input into sX [16][xs_of<IN>()] (zero padded; width = d0 + d1 columns)
 template <int IN>
 __device__ __forceinline__ void load_x_group(const XSpec& x, int rows, long g, float* sX) {
+    constexpr int XSW = xs_of<IN>();
     const int tid = threadIdx.x;
-    if (tid < GROUP * XS) {
-        const int row = tid / XS, i = tid % XS;
+    if (tid < GROUP * XSW) {
+        const int row = tid / XSW, i = tid % XSW;
         const long gr = g * GROUP + row;
         float v = 0.f;
-        if (gr < rows && i < IN) {
+        if (gr < rows && i < x.d0 + x.d1) {
             if (i < x.d0)
                 v = x.x0[gr * x.ld0 + i] * x.scale[i];
             else

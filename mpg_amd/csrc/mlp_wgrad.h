@@ -60,40 +60,42 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int sl, con
     };
     // the per-row inputs (x, dz3) of the group are staged through a wave-private corner of the LDS scratch (64-bit
     // global addressing for 4 rows x (IN + OU) scalars per lane would cost ~100 registers and one workgroup of residency)
-    float* stage = sRed + L.wave * (GROUP * 12);
+    // a staged row: [x (8 or 16 floats) | dz3 (OU) | pad] - 12 floats for networks with up to 8 inputs, 20 for the 16-wide ones
+    constexpr int XW = xs_of<IN>(), RS = XW + 4, NSLOT = GROUP * RS / 64;
+    float* stage = sRed + L.wave * (GROUP * RS);
     auto thin_accumulate = [&](long g, const Thin& t) {
         // Every lane fills three slots of the staging corner.  Which array a slot comes from (x0 scaled, x1, dz3, or a
         // zero pad) is settled by SELECTING the address, and the loads themselves are unconditional: as three nested
         // branches each slot cost up to three dependent memory round trips (the wait sat inside the branch), ~2 us per
         // row group on the critic jobs, which were then the longest workgroups of the launch.
-        float v[3], sc[3];
-        bool on[3];
+        float v[NSLOT], sc[NSLOT];
+        bool on[NSLOT];
 #pragma unroll
-        for (int u = 0; u < 3; ++u) {
-            const int e = L.lane + 64 * u, row = e / 12, i = e % 12;
+        for (int u = 0; u < NSLOT; ++u) {
+            const int e = L.lane + 64 * u, row = e / RS, i = e % RS;
             const long gr = g * GROUP + row;
-            const bool from_x0 = i < IN && i < a.x.d0, from_x1 = i < IN && !from_x0, from_d3 = i >= 8 && i - 8 < OU;
+            const bool from_x0 = i < a.in_dim && i < a.x.d0, from_x1 = i < a.in_dim && !from_x0, from_d3 = i >= XW && i - XW < OU;
             on[u] = gr < a.rows && (from_x0 || from_x1 || from_d3);
             const float* p = a.dz3;                                      // any valid address for the slots that stay zero
-            if (on[u]) p = from_x0 ? a.x.x0 + gr * a.x.ld0 + i : (from_x1 ? a.x.x1 + gr * a.x.ld1 + (i - a.x.d0) : a.dz3 + gr * OU + (i - 8));
+            if (on[u]) p = from_x0 ? a.x.x0 + gr * a.x.ld0 + i : (from_x1 ? a.x.x1 + gr * a.x.ld1 + (i - a.x.d0) : a.dz3 + gr * OU + (i - XW));
             v[u] = *p;
-            sc[u] = a.x.scale[i & 7];
+            sc[u] = a.x.scale[i & 15];
             if (!from_x0) sc[u] = 1.f;
         }
 #pragma unroll
-        for (int u = 0; u < 3; ++u) stage[L.lane + 64 * u] = on[u] ? v[u] * sc[u] : 0.f;
+        for (int u = 0; u < NSLOT; ++u) stage[L.lane + 64 * u] = on[u] ? v[u] * sc[u] : 0.f;
 #ifdef MPG_AB_PKFMA_WAIT   // hypothesis test (tools/pk_anomaly.sh): the staged values are fully written before anything reads them
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
         __builtin_amdgcn_wave_barrier();      // same wave writes and reads: LDS is in order within a wave
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float* rowp = stage + L.row(j) * 12;
+            const float* rowp = stage + L.row(j) * RS;
             float d3[OU], x[IN];
 #pragma unroll
             for (int i = 0; i < IN; ++i) x[i] = rowp[i];
 #pragma unroll
-            for (int o = 0; o < OU; ++o) d3[o] = rowp[8 + o];
+            for (int o = 0; o < OU; ++o) d3[o] = rowp[XW + o];
             // Every multiply-add of this block is ONE hand-written single-precision instruction.  Left to the compiler
             // they become packed v_pk_fma_f32 / v_pk_add_f32 (op_sel forms), and in k_wgrad_multi single products were then
             // lost nondeterministically: first the (row 13, even i) terms of dW1 in ~85 % of launches, after dW1 was
@@ -376,7 +378,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int sl, con
         constexpr int PER_T = IN + 2 + OU;
         if (q < 2 * PER_T) {
             const int t = q / PER_T, r = q % PER_T, col = 32 * sl + 16 * t + c;
-            if (r < IN) sW1[r * H + col] = sum;
+            if (r < IN) { if (r < a.in_dim) sW1[r * H + col] = sum; }       // (the 16-wide instantiation: rows beyond in_dim do not exist)
             else if (r == IN) sb1[col] = sum;
             else if (r == IN + 1) sb2[col] = sum;
             else sW3[col * a.out_dim + (r - IN - 2)] = sum;

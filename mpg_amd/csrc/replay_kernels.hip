@@ -28,13 +28,14 @@ __global__ void k_add(int capacity, int next_idx, int n, int od, int ad, const f
 
 // one transition: every load is issued before the first store (written as dependent load/store pairs the 15 random
 // reads of a row serialise on HBM latency: 11 us for 4096 rows instead of 3)
-constexpr int MAXOD = 8, MAXAD = 2;
-__device__ __forceinline__ void gather_row(const Ring& r, long s, long i, int od, int ad, float* __restrict__ o_obs,
+constexpr int MAXOD = 16, MAXAD = 2;       // 16: PathTracking observations with look-ahead entries (6 + num_future_data <= 14)
+template <int WOD>
+__device__ __forceinline__ void gather_row_w(const Ring& r, long s, long i, int od, int ad, float* __restrict__ o_obs,
                                            float* __restrict__ o_act, float* __restrict__ o_rew,
                                            float* __restrict__ o_obs2, float* __restrict__ o_done) {
-    float vo[MAXOD], vo2[MAXOD], va[MAXAD];
+    float vo[WOD], vo2[WOD], va[MAXAD];
 #pragma unroll
-    for (int k = 0; k < MAXOD; ++k) {
+    for (int k = 0; k < WOD; ++k) {
         vo[k] = k < od ? r.obs[s * od + k] : 0.f;
         vo2[k] = k < od ? r.obs2[s * od + k] : 0.f;
     }
@@ -43,7 +44,7 @@ __device__ __forceinline__ void gather_row(const Ring& r, long s, long i, int od
     const float rew = r.rew[s];
     const uint8_t dn = r.done[s];
 #pragma unroll
-    for (int k = 0; k < MAXOD; ++k)
+    for (int k = 0; k < WOD; ++k)
         if (k < od) {
             o_obs[i * od + k] = vo[k];
             o_obs2[i * od + k] = vo2[k];
@@ -53,6 +54,12 @@ __device__ __forceinline__ void gather_row(const Ring& r, long s, long i, int od
         if (k < ad) o_act[i * ad + k] = va[k];
     o_rew[i] = rew;
     if (o_done) o_done[i] = (float)dn;                     // learners cast dones to float32 (mpg_learner.py:71)
+}
+__device__ __forceinline__ void gather_row(const Ring& r, long s, long i, int od, int ad, float* __restrict__ o_obs,
+                                           float* __restrict__ o_act, float* __restrict__ o_rew,
+                                           float* __restrict__ o_obs2, float* __restrict__ o_done) {
+    if (od <= 8) gather_row_w<8>(r, s, i, od, ad, o_obs, o_act, o_rew, o_obs2, o_done);      // (uniform branch)
+    else gather_row_w<16>(r, s, i, od, ad, o_obs, o_act, o_rew, o_obs2, o_done);
 }
 
 __global__ void k_gather(int n, const int* __restrict__ idx, int od, int ad, Ring r, float* __restrict__ o_obs,
@@ -105,7 +112,7 @@ extern "C" int mpg_replay_gather(int n, const int* idx, int obs_dim, int act_dim
                                  float* o_rew, float* o_obs2, float* o_done, mpg_stream_t stream) {
     MPG_REQUIRE(n > 0 && idx && obs && act && rew && obs2 && done && o_obs && o_act && o_rew && o_obs2,
                 "mpg_replay_gather: bad argument");
-    MPG_REQUIRE(obs_dim >= 1 && obs_dim <= MAXOD && act_dim >= 1 && act_dim <= MAXAD, "mpg_replay_gather: obs_dim <= 8, act_dim <= 2");
+    MPG_REQUIRE(obs_dim >= 1 && obs_dim <= MAXOD && act_dim >= 1 && act_dim <= MAXAD, "mpg_replay_gather: obs_dim <= 16, act_dim <= 2");
     Ring r{const_cast<float*>(obs), const_cast<float*>(act), const_cast<float*>(rew), const_cast<float*>(obs2),
            const_cast<uint8_t*>(done)};
     hipLaunchKernelGGL(k_gather, dim3((n + 255) / 256), dim3(256), 0, mpg_stream(stream), n, idx, obs_dim, act_dim, r,
@@ -128,7 +135,7 @@ extern "C" int mpg_replay_sample_uniform(int n_storage, int n, uint64_t seed, ui
                                          float* o_done, mpg_stream_t stream) {
     MPG_REQUIRE(n_storage > 0 && n > 0 && obs && act && rew && obs2 && done && idx && o_obs && o_act && o_rew && o_obs2,
                 "mpg_replay_sample_uniform: bad argument");
-    MPG_REQUIRE(obs_dim >= 1 && obs_dim <= MAXOD && act_dim >= 1 && act_dim <= MAXAD, "mpg_replay_sample_uniform: obs_dim <= 8, act_dim <= 2");
+    MPG_REQUIRE(obs_dim >= 1 && obs_dim <= MAXOD && act_dim >= 1 && act_dim <= MAXAD, "mpg_replay_sample_uniform: obs_dim <= 16, act_dim <= 2");
     Ring r{const_cast<float*>(obs), const_cast<float*>(act), const_cast<float*>(rew), const_cast<float*>(obs2),
            const_cast<uint8_t*>(done)};
     hipLaunchKernelGGL(k_sample_gather, dim3((n + 255) / 256), dim3(256), 0, mpg_stream(stream), n_storage, n, (uint32_t)seed,

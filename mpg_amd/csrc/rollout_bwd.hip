@@ -4,10 +4,14 @@
 namespace rollout {
 namespace {
 
-template <class ENV, bool PK>
+// WIDE: observations with look-ahead entries (see the forward sweep): the adjoint of a MODEL observation's look-ahead entries
+// folds into the adjoint of entry ENV::FUT_SRC, which they copy; the start observation's are inputs.
+template <class ENV, bool PK, bool WIDE = false>
 __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_bwd(const RollBwdArgs a) {
-    constexpr int OBS = ENV::OBS, ACT = ENV::ACT, QIN = OBS + ACT;
-    __shared__ __attribute__((aligned(16))) float smem[2 * A_IMG + GROUP * MAXOUT + NWAVE * GROUP * XS];
+    constexpr int OBS = ENV::OBS, ACT = ENV::ACT;
+    constexpr int NIN = WIDE ? 16 : OBS, XSW = xs_of<NIN>();
+    const int nf = WIDE ? a.obs_dim - OBS : 0, OD = OBS + nf, QIN = OD + ACT;
+    __shared__ __attribute__((aligned(16))) float smem[2 * A_IMG + GROUP * MAXOUT + NWAVE * GROUP * XSW];
     float* sA = smem;
     float* sA1 = sA + A_IMG;
     float* sD3 = sA1 + A_IMG;
@@ -17,11 +21,11 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_bwd(const RollBwdArgs a)
     __shared__ __attribute__((aligned(16))) float sCarry[GROUP * 16];
     const Lane L;
     const int tid = threadIdx.x;
-    const Net net = make_net(a.policy, OBS, 2 * ACT);
+    const Net net = make_net(a.policy, OD, 2 * ACT);
     float w2t[128];
-    SmallRegs<OBS, ACT> r;
+    SmallRegs<NIN, ACT> r;
     if constexpr (PK) load_w2_packed(a.pack, L, w2t); else load_w2_bwd(net.W2, L, w2t);
-    load_small<OBS, ACT>(net, L, r);
+    load_small<NIN, ACT>(net, L, r);
     const long R = (long)a.rows * a.M;
     const long ngroups = (R + GROUP - 1) / GROUP;
 #ifdef MPG_STAMP
@@ -76,8 +80,15 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_bwd(const RollBwdArgs a)
                             const float* gx = a.GXQ + ((long)ks * R + tr) * QIN;
 #pragma unroll
                             for (int i = 0; i < OBS; ++i) lam[i] += gx[i] * a.obs_scale[i];
+                            if constexpr (WIDE) {
+                                if (t > 0) {
 #pragma unroll
-                            for (int k = 0; k < ACT; ++k) ga[k] += gx[OBS + k];
+                                    for (int k = 0; k < 8; ++k)
+                                        if (k < nf) lam[ENV::FUT_SRC] += gx[OBS + k] * a.obs_scale[OBS + k];
+                                }
+                            }
+#pragma unroll
+                            for (int k = 0; k < ACT; ++k) ga[k] += gx[OD + k];
                         }
                 }
 #pragma unroll
@@ -95,7 +106,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_bwd(const RollBwdArgs a)
             float dz1[2][4], dz2[2][4];
             lds_barrier();
             MPG_STAMP_AT(0);
-            backward_dz2<OBS, ACT>(sD3, sA, L, r, h2_cur, dz2);
+            backward_dz2<NIN, ACT>(sD3, sA, L, r, h2_cur, dz2);
             // all global loads of the step are issued HERE, behind the dz2 phase: h1 is consumed after the MFMA block,
             // the record and h2 stash of step t-1 in the next iteration (software pipeline)
             stash_load(a.H1, (long)t * ngroups + g, L, h1);
@@ -109,9 +120,9 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_bwd(const RollBwdArgs a)
                 stash_load(a.H2, (long)(t - 1) * ngroups + g, L, h2_pre);
             }
             if (t > 0)
-                backward_rest<OBS, ACT, true>(sD3, sA, sA1, sPartX, L, w2t, r, h1, dz1);
+                backward_rest<NIN, ACT, true>(sD3, sA, sA1, sPartX, L, w2t, r, h1, dz1);
             else
-                backward_rest<OBS, ACT, false>(sD3, sA, sA1, sPartX, L, w2t, r, h1, dz1);
+                backward_rest<NIN, ACT, false>(sD3, sA, sA1, sPartX, L, w2t, r, h1, dz1);
             if (a.DZ1 && (a.stash_all || t == 0)) {
                 const long sg = (long)(a.stash_all ? t : 0) * ngroups + g;
                 stash_store(a.DZ1, sg, L, dz1);
@@ -119,10 +130,15 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_bwd(const RollBwdArgs a)
             }
             if (own) {
                 if (t > 0) {
-                    float dxr[XS];
-                    dx_reduce_row(sPartX, tid, dxr);
+                    float dxr[XSW];
+                    dx_reduce_row<XSW>(sPartX, tid, dxr);
 #pragma unroll
                     for (int i = 0; i < OBS; ++i) lam[i] += dxr[i] * a.obs_scale[i];
+                    if constexpr (WIDE) {       // t > 0 here: the observation of this step came out of the model
+#pragma unroll
+                        for (int k = 0; k < 8; ++k)
+                            if (k < nf) lam[ENV::FUT_SRC] += dxr[OBS + k] * a.obs_scale[OBS + k];
+                    }
                 }
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
@@ -158,7 +174,9 @@ int launch_rollout_bwd(const RollBwdArgs& ba_in, int env_kind, long ngroups, int
     ba.dbg = s_dbg_b;
 #endif
     mpg_prof_begin(prof, 1, s);
-    if (env_kind == MPG_ENV_PATH_TRACKING)
+    if (env_kind == MPG_ENV_PATH_TRACKING && ba.obs_dim > PathTracking::OBS)
+        { if (ba.pack) hipLaunchKernelGGL((k_rollout_bwd<PathTracking, true, true>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, ba); else hipLaunchKernelGGL((k_rollout_bwd<PathTracking, false, true>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, ba); }
+    else if (env_kind == MPG_ENV_PATH_TRACKING)
         { if (ba.pack) hipLaunchKernelGGL((k_rollout_bwd<PathTracking, true>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, ba); else hipLaunchKernelGGL((k_rollout_bwd<PathTracking, false>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, ba); }
     else
         { if (ba.pack) hipLaunchKernelGGL((k_rollout_bwd<Pendulum, true>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, ba); else hipLaunchKernelGGL((k_rollout_bwd<Pendulum, false>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, ba); }

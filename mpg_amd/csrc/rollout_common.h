@@ -41,6 +41,8 @@ __device__ __forceinline__ float fast_tanh(float z) {                       // 1
 struct PathTracking {
     static constexpr int OBS = 6, ACT = 2;
     static constexpr int NPRE = 9;
+    static constexpr int FUT_SRC = 3;     // PathTrackingModel._get_obs (path_tracking_env.py:262-268): every look-ahead entry of a MODEL
+                                          // observation is a copy of delta_y (entry 3); only the start observation carries real ones
     // vehicle parameters, path_tracking_env.py:60-68; tau = 1/10 (:248)
     static constexpr float C_f = -128915.5f, C_r = -85943.6f, A = 1.06f, B = 1.85f, MASS = 1412.f, I_z = 1536.7f;
     static constexpr float TAU = 0.1f;
@@ -126,6 +128,7 @@ struct PathTracking {
 struct Pendulum {
     static constexpr int OBS = 4, ACT = 1;
     static constexpr int NPRE = 6;
+    static constexpr int FUT_SRC = 0;     // (no look-ahead entries)
     // inverted_pendulum_model.py:18-26,38-44: m = 9.42, m1 = 4.89, m2 = 0, l1 = 0.6
     static constexpr float D1c = 9.42f + 4.89f, D2c = 0.5f * 4.89f * 0.6f, D4c = (1.f / 3.f) * 4.89f * 0.6f * 0.6f;
     static constexpr float F1c = 0.5f * 4.89f * 0.6f * 9.81f, TAU = 0.04f;
@@ -194,7 +197,8 @@ struct Pendulum {
 struct RollArgs {
     const float* policy;
     int rows, M, n;                     // R = rows * M trajectories, horizon n
-    float obs_scale[8];
+    int obs_dim;                        // ENV::OBS + number of look-ahead entries (PathTracking: 6 .. 14)
+    float obs_scale[16];
     float rew_scale, rew_shift, gamma;
     int out_tanh;
     float out_scale;
@@ -215,7 +219,8 @@ struct RollArgs {
 struct RollBwdArgs {
     const float* policy;
     int rows, M, n;
-    float obs_scale[8];
+    int obs_dim;
+    float obs_scale[16];
     int out_tanh;
     float out_scale;
     const float *H1, *H2, *SA;
@@ -230,7 +235,8 @@ struct RollBwdArgs {
 
 inline void fill_roll(RollArgs& a, const mpg_cfg_t* cfg, const float* policy, int rows, int M, int n) {
     a.policy = policy; a.rows = rows; a.M = M; a.n = n;
-    for (int i = 0; i < 8; ++i) a.obs_scale[i] = i < cfg->obs_dim ? cfg->obs_scale[i] : 1.f;
+    a.obs_dim = cfg->obs_dim;
+    for (int i = 0; i < 16; ++i) a.obs_scale[i] = i < cfg->obs_dim ? cfg->obs_scale[i] : 1.f;
     a.rew_scale = cfg->rew_scale; a.rew_shift = cfg->rew_shift; a.gamma = cfg->gamma;
     const bool ranged = cfg->action_range > 0.f;
     a.out_tanh = (cfg->policy_out_act == MPG_ACT_TANH || ranged) ? 1 : 0;

@@ -4,13 +4,18 @@
 namespace rollout {
 namespace {
 
-template <class ENV, bool PK>
+// WIDE: observations with look-ahead entries (obs_dim = ENV::OBS + nf, nf <= 8): the networks run the 16-wide form of
+// the engine (mlp_core.h), the six base entries evolve with the model and the look-ahead entries of every MODEL observation are
+// copies of entry ENV::FUT_SRC (path_tracking_env.py:262-268), the start observation's come from the batch.
+template <class ENV, bool PK, bool WIDE = false>
 __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_fwd(const RollArgs a) {
-    constexpr int OBS = ENV::OBS, ACT = ENV::ACT, QIN = OBS + ACT;
-    __shared__ __attribute__((aligned(16))) float smem[A_IMG + GROUP * XS + NWAVE * GROUP * MAXOUT + MAXN * GROUP];
+    constexpr int OBS = ENV::OBS, ACT = ENV::ACT;
+    constexpr int NIN = WIDE ? 16 : OBS, XSW = xs_of<NIN>();
+    const int nf = WIDE ? a.obs_dim - OBS : 0, OD = OBS + nf, QIN = OD + ACT;
+    __shared__ __attribute__((aligned(16))) float smem[A_IMG + GROUP * XSW + NWAVE * GROUP * MAXOUT + MAXN * GROUP];
     float* sA = smem;
     float* sX = sA + A_IMG;
-    float* sPart = sX + GROUP * XS;
+    float* sPart = sX + GROUP * XSW;
     float* sEps = sPart + NWAVE * GROUP * MAXOUT;
     __shared__ float sGp[MAXN];
     constexpr int TRAJ_STRIDE = 12, PRE_STRIDE = 12;              // floats per trajectory: (obs[8] | act[2] | rew | -), ENV::pre's values
@@ -20,11 +25,11 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_fwd(const RollArgs a) {
     const Lane L;
     const int tid = threadIdx.x;
     if (tid <= a.n) sGp[tid] = powf(a.gamma, (float)tid);     // tf.pow(gamma, ri) in float32, mpg_learner.py:245
-    const Net net = make_net(a.policy, OBS, 2 * ACT);
+    const Net net = make_net(a.policy, OD, 2 * ACT);
     float w2[128];
-    SmallRegs<OBS, ACT> r;
+    SmallRegs<NIN, ACT> r;
     if constexpr (PK) load_w2_packed(a.pack, L, w2); else load_w2_fwd(net.W2, L, w2);
-    load_small<OBS, ACT>(net, L, r);
+    load_small<NIN, ACT>(net, L, r);
     float b3r[2] = {0.f, 0.f};                         // output bias in registers: no global load on the serial chain
 #pragma unroll
     for (int k = 0; k < ACT; ++k) b3r[k] = net.b3[k];
@@ -53,10 +58,15 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_fwd(const RollArgs a) {
         float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};        // book lanes: the model state (as observation)
         float G = 0.f;                                                  // book lanes: discounted reward sum so far
         float act_first[2] = {0.f, 0.f};
+        float f0[WIDE ? 8 : 1] = {};                                    // look-ahead entries of the start observation
         if (live) {
-            const float* src = a.obs0 + (tr % a.rows) * OBS;
+            const float* src = a.obs0 + (tr % a.rows) * OD;
 #pragma unroll
             for (int i = 0; i < OBS; ++i) o[i] = src[i];
+            if constexpr (WIDE) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) f0[k] = k < nf ? src[OBS + k] : 0.f;
+            }
             if (a.act0) {
 #pragma unroll
                 for (int k = 0; k < ACT; ++k) act_first[k] = a.act0[(tr % a.rows) * ACT + k];
@@ -91,22 +101,29 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_fwd(const RollArgs a) {
 #pragma unroll
                 for (int ks = 0; ks < MAXSEL; ++ks)
                     if (ks < a.n_sel && a.sel[ks] == tb) {
-                        float* xq = a.XQ + ((long)ks * R + tr) * QIN + OBS;
+                        float* xq = a.XQ + ((long)ks * R + tr) * QIN + OD;
 #pragma unroll
                         for (int k = 0; k < ACT; ++k) xq[k] = act[k];
                     }
             }
             if (tb < a.n) G += sGp[tb] * ((rew + a.rew_shift) * a.rew_scale);                 // mpg_learner.py:245
         };
-        if (chain) {
+        // the network input of the next evaluation: scaled base entries, then the look-ahead entries (first: the batch's own)
+        auto publish = [&](const float (&ob)[8], bool first) {
 #pragma unroll
-            for (int i = 0; i < XS; ++i) sX[tid * XS + i] = i < OBS ? o[i] * a.obs_scale[i] : 0.f;
-        }
+            for (int i = 0; i < XSW; ++i) {
+                float v = 0.f;
+                if (i < OBS) v = ob[i] * a.obs_scale[i];
+                else if (WIDE && i - OBS < nf) v = (first ? f0[(i - OBS) & 7] : ob[ENV::FUT_SRC]) * a.obs_scale[i];
+                sX[tid * XSW + i] = v;
+            }
+        };
+        if (chain) publish(o, true);
         for (int t = 0; t <= a.n; ++t) {
             lds_barrier();
             MPG_STAMP_AT(0);
             float h1[2][4], h2[2][4];
-            forward_group<OBS, ACT, false>(sX, sA, sPart, L, w2, r, h1, h2, a.H1, (long)t * ngroups + g, nullptr, &zmax);
+            forward_group<NIN, ACT, false>(sX, sA, sPart, L, w2, r, h1, h2, a.H1, (long)t * ngroups + g, nullptr, &zmax);
             if (a.H1) stash_store(a.H2, (long)t * ngroups + g, L, h2);
             // book lanes, before B2: fetch what the chain lanes left in sTraj (they overwrite it right after B2) and prepare
             // the action-independent half of this step's model step - the only part of their work the chain waits for
@@ -146,8 +163,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_fwd(const RollArgs a) {
 #pragma unroll
                     for (int i = 0; i < ENV::NPRE; ++i) pre[i] = sPre[tid * PRE_STRIDE + i];
                     ENV::finish(pre, act, on, rew);
-#pragma unroll
-                    for (int i = 0; i < XS; ++i) sX[tid * XS + i] = i < OBS ? on[i] * a.obs_scale[i] : 0.f;
+                    publish(on, false);
                 }
                 f32x4* tp = reinterpret_cast<f32x4*>(sTraj + tid * TRAJ_STRIDE);
                 tp[0] = f32x4{on[0], on[1], on[2], on[3]};
@@ -169,6 +185,11 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_fwd(const RollArgs a) {
                             float* xq = a.XQ + ((long)ks * R + tr) * QIN;
 #pragma unroll
                             for (int i = 0; i < OBS; ++i) xq[i] = o[i] * a.obs_scale[i];
+                            if constexpr (WIDE) {
+#pragma unroll
+                                for (int k = 0; k < 8; ++k)
+                                    if (k < nf) xq[OBS + k] = (t == 0 ? f0[k] : o[ENV::FUT_SRC]) * a.obs_scale[OBS + k];
+                            }
                             a.GK[(long)ks * R + tr] = G;
                         }
                 }
@@ -202,7 +223,9 @@ int launch_rollout_fwd(const RollArgs& fa_in, int env_kind, long ngroups, int n,
     fa.dbg = s_dbg;
 #endif
     mpg_prof_begin(prof, 0, s);
-    if (env_kind == MPG_ENV_PATH_TRACKING)
+    if (env_kind == MPG_ENV_PATH_TRACKING && fa.obs_dim > PathTracking::OBS)
+        { if (fa.pack) hipLaunchKernelGGL((k_rollout_fwd<PathTracking, true, true>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, fa); else hipLaunchKernelGGL((k_rollout_fwd<PathTracking, false, true>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, fa); }
+    else if (env_kind == MPG_ENV_PATH_TRACKING)
         { if (fa.pack) hipLaunchKernelGGL((k_rollout_fwd<PathTracking, true>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, fa); else hipLaunchKernelGGL((k_rollout_fwd<PathTracking, false>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, fa); }
     else
         { if (fa.pack) hipLaunchKernelGGL((k_rollout_fwd<Pendulum, true>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, fa); else hipLaunchKernelGGL((k_rollout_fwd<Pendulum, false>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, fa); }

@@ -110,7 +110,7 @@ struct Carver {
 inline size_t pad256(size_t nfloat) { return ((nfloat * sizeof(float) + 255) & ~size_t(255)) + 256; }
 
 inline bool cfg_ok(const mpg_cfg_t* c) {
-    return c && ((c->obs_dim == 6 && c->act_dim == 2 && c->env_kind == MPG_ENV_PATH_TRACKING) ||
+    return c && ((c->obs_dim >= 6 && c->obs_dim <= 14 && c->act_dim == 2 && c->env_kind == MPG_ENV_PATH_TRACKING) ||
                  (c->obs_dim == 4 && c->act_dim == 1 && c->env_kind == MPG_ENV_INVERTED_PENDULUM)) &&
            !(c->policy_out_act == MPG_ACT_TANH && c->action_range > 0.f);   // see learner_api.hip:cfg_ok
 }
@@ -188,7 +188,8 @@ int run_rollout_bwd(const mpg_cfg_t* cfg, const float* policy_params, int rows, 
     // ---- reverse sweep ----
     RollBwdArgs ba;
     ba.policy = policy_params; ba.rows = rows; ba.M = M; ba.n = n;
-    for (int i = 0; i < 8; ++i) ba.obs_scale[i] = fa.obs_scale[i];
+    ba.obs_dim = fa.obs_dim;
+    for (int i = 0; i < 16; ++i) ba.obs_scale[i] = fa.obs_scale[i];
     ba.out_tanh = fa.out_tanh; ba.out_scale = fa.out_scale;
     ba.H1 = H1; ba.H2 = H2; ba.SA = SA; ba.n_sel = n_select;
     for (int k = 0; k < MAXSEL; ++k) ba.sel[k] = fa.sel[k];
@@ -261,8 +262,14 @@ extern "C" int mpg_rollout_pg(const mpg_cfg_t* cfg, const float* policy_params, 
 
     // ---- policy weight gradient from the stashes (step 0 only, or every step for NADP) ----
     const int T = all_steps_param_grad ? n + 1 : 1;
+    // the first layer's input of every stashed step: the (obs | action) records hold the six base entries; with look-ahead entries
+    // (obs_dim > 6) only step 0 is ever differentiated through the parameters here and its input is the caller's batch itself
     XSpec xs = xspec(SA, od, nullptr, 0, cfg->obs_scale, od);
     xs.ld0 = SAW;
+    if (od > 6) {
+        MPG_REQUIRE(!all_steps_param_grad && M == 1, "mpg_rollout_pg: look-ahead observations need M == 1 and the step-0 parameter gradient");
+        xs = xspec(obs0, od, nullptr, 0, cfg->obs_scale, od);
+    }
     return launch_wgrad(cfg, od, 2 * ad, ad, (int)(T * R), xs, H1, H2, DZ1, DZ2, DZ3, inv_b_global / (float)M, grad, slabs, s);
 }
 
@@ -427,7 +434,7 @@ extern "C" int mpg_mpg_gradients(const mpg_cfg_t* cfg, int n_q, const float* par
     float* gq[2] = {grad, grad + q_size};
     float* gp = grad + (size_t)n_q * q_size;
     const MgLayout l = mg_layout(cfg, rows, M, n, n_select, n_q);
-    const bool fused = rows % GROUP == 0 && M == 1;
+    const bool fused = rows % GROUP == 0 && M == 1 && (od == 6 || od == 4);      // the fused kernels are built for the base widths
     if (draw && (!fused || y_in)) {      // the draw cannot ride in the target launch: do it as its own launch
         MPG_REQUIRE(rew && obs_tp1, "mpg_mpg_gradients: a replay draw needs the rew / obs_tp1 output buffers");
         int rc = mpg_replay_sample_uniform(draw->n_storage, rows, draw->seed, draw->ctr, cfg->obs_dim, cfg->act_dim, draw->ring_obs,

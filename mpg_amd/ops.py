@@ -19,7 +19,7 @@ class WCacheStruct(ctypes.Structure):
 class CfgStruct(ctypes.Structure):
     """mpg_cfg_t"""
     _fields_ = [('obs_dim', ctypes.c_int), ('act_dim', ctypes.c_int), ('policy_out_act', ctypes.c_int),
-                ('action_range', ctypes.c_float), ('obs_scale', ctypes.c_float * 8),
+                ('action_range', ctypes.c_float), ('obs_scale', ctypes.c_float * 16),
                 ('rew_scale', ctypes.c_float), ('rew_shift', ctypes.c_float), ('gamma', ctypes.c_float),
                 ('env_kind', ctypes.c_int),
                 ('wcache', ctypes.POINTER(WCacheStruct) * 2), ('prof', ctypes.c_void_p), ('status', ctypes.c_void_p)]
@@ -106,11 +106,13 @@ class Profiler(object):
 
 
 def make_cfg(env_id='PathTracking-v0', obs_scale=None, rew_scale=None, rew_shift=0.0, gamma=0.98,
-             policy_out_activation=None, action_range=None):
-    """Defaults are the reference's (train_script.py:202-306 / train_script4mujoco.py:296-411)."""
+             policy_out_activation=None, action_range=None, obs_dim=None):
+    """Defaults are the reference's (train_script.py:202-306 / train_script4mujoco.py:296-411).  obs_dim: 6 + num_future_data
+    for PathTracking (train_script.py:794-811), up to 14."""
     pt = env_id == 'PathTracking-v0'
     c = CfgStruct()
-    c.obs_dim, c.act_dim = (6, 2) if pt else (4, 1)
+    c.obs_dim, c.act_dim = (int(obs_dim) if (pt and obs_dim) else 6, 2) if pt else (4, 1)
+    assert not pt or 6 <= c.obs_dim <= 14, 'PathTracking: obs_dim = 6 + num_future_data, num_future_data <= 8 through the networks'
     if policy_out_activation is None:
         policy_out_activation = 'tanh' if pt else 'linear'
     c.policy_out_act = ACT_TANH if policy_out_activation == 'tanh' else ACT_LINEAR
@@ -118,7 +120,7 @@ def make_cfg(env_id='PathTracking-v0', obs_scale=None, rew_scale=None, rew_shift
         action_range = 0.0 if pt else 3.0
     c.action_range = float(action_range or 0.0)
     sc = obs_scale if obs_scale is not None else ([1., 1., 2., 1., 2.4, 1 / 1200] if pt else [0.001, 1 / 3, 0.1, 0.5])
-    for i in range(8):
+    for i in range(16):
         c.obs_scale[i] = float(sc[i]) if i < len(sc) else 1.0
     c.rew_scale = float(rew_scale if rew_scale is not None else (0.01 if pt else 1.0))
     c.rew_shift = float(rew_shift)
@@ -170,7 +172,7 @@ def _f32(t):
 def mlp_forward(params, in_dim, out_dim, out_used, out_act, x, in_scale=None, n_scaled=0, wcache=None):
     rows = x.shape[0]
     y = torch.empty(rows, out_used, dtype=torch.float32, device=x.device)
-    sc = (ctypes.c_float * 8)(*([float(v) for v in in_scale] + [1.0] * (8 - len(in_scale)))) if in_scale is not None else None
+    sc = (ctypes.c_float * 16)(*([float(v) for v in in_scale] + [1.0] * (16 - len(in_scale)))) if in_scale is not None else None
     L.call('mpg_mlp_forward', L.ptr(_f32(params)), L.c_int(in_dim), L.c_int(out_dim), L.c_int(out_used),
            L.c_int(out_act), L.c_int(rows), L.ptr(_f32(x)), sc, L.c_int(n_scaled), L.ptr(y), _wc(wcache), L.stream())
     return y

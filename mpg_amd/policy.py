@@ -54,7 +54,7 @@ class PolicyWithQs(object):
         self.device = torch.device(device)
         self.double_Q, self.tau, self.delay_update = bool(double_Q), float(tau), int(delay_update)
         self.cfg = ops.make_cfg(env_id, obs_scale=obs_scale, rew_scale=rew_scale, rew_shift=rew_shift, gamma=gamma,
-                                policy_out_activation=policy_out_activation, action_range=action_range)
+                                policy_out_activation=policy_out_activation, action_range=action_range, obs_dim=obs_dim)
         self.obs_dim, self.act_dim = obs_dim, act_dim
         self.names = ['Q1', 'Q2', 'policy'] if self.double_Q else ['Q1', 'policy']      # policy.py:72-86
         self.dims = {'Q1': (obs_dim + act_dim, 1), 'Q2': (obs_dim + act_dim, 1), 'policy': (obs_dim, 2 * act_dim)}

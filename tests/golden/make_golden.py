@@ -16,6 +16,7 @@ same float32-rounded inputs - the error yard-stick of SURVEY.md §8c):
   model_rollout_ref.npz  PathTrackingModel.rollout_out x 25 with a fixed action sequence + noise (a6)
   pendulum_model_ref.npz InvertedPendulumModel.rollout_out x 25 (a7)
   mpg_{v1,v2}_H{H}_B{B}.npz   MPGLearner.compute_gradient (a11-a17) at iterations 100 and 9000
+  mpg_v2_H256_B64_K3.npz      the same with num_future_data = 3 (obs_dim 9, first layers 9 / 11 wide)
   nadp_H{H}_B{B}.npz     NADPLearner.compute_gradient on the pendulum model (a18)
   td3_H{H}_B{B}.npz      TD3Learner.compute_gradient with recorded smoothing noise (a19)
   segment_tree_ref.npz   SumSegmentTree / MinSegmentTree primitives (a22)
@@ -228,27 +229,36 @@ def fx_pendulum_model(N=64, T=25, seed=2):
     np.savez_compressed(os.path.join(HERE, 'pendulum_model_ref.npz'), **out)
 
 
-def make_replay_batch_pt(rng, B):
-    """(obs, act, RAW reward, obs', done) produced by the reference env itself (worker.py:108-111)."""
+def make_replay_batch_pt(rng, B, K=0):
+    """(obs, act, RAW reward, obs', done) produced by the reference env itself (worker.py:108-111).  K look-ahead entries
+    (num_future_data): one extra env step first, so that obs as well as obs' carry look-ahead entries the env computed."""
     from envs_and_models.path_tracking_env import PathTrackingEnv
-    env = PathTrackingEnv(num_agent=B, num_future_data=0)
+    env = PathTrackingEnv(num_agent=B, num_future_data=K)
     obs = reset_law_obs(rng, B)
     act = np.clip(rng.uniform(-1, 1, (B, 2)) + 0.1 * rng.standard_normal((B, 2)), -1.2, 1.2).astype(np.float32)
-    env.reset(init_obs=obs.copy())
+    if K:
+        act0 = rng.uniform(-0.3, 0.3, (B, 2)).astype(np.float32)
+        env.reset(init_obs=np.concatenate([obs, np.zeros((B, K), np.float32)], 1))
+        obs = env.step(act0)[0].astype(np.float32)
+    else:
+        env.reset(init_obs=obs.copy())
     obs2, rew, done, _ = env.step(act)
     return [obs, act, rew.astype(np.float32), obs2.astype(np.float32), done.astype(np.float32)]
 
 
-def fx_mpg(version, H, B, seed):
+def fx_mpg(version, H, B, seed, K=0):
+    """K: num_future_data (train_script.py:90,146-147 - obs_dim 6 + K, obs_scale padded with ones); fixture ..._K{K}.npz"""
     from learners.mpg_learner import MPGLearner
     from policy import PolicyWithQs
     rng = np.random.Generator(np.random.PCG64(seed))
     args = mpg_args(version, B, H)
-    nets = {'policy': mlp_weights(rng, 6, H, 4), 'Q1': mlp_weights(rng, 8, H, 1)}
+    if K:
+        args.num_future_data, args.obs_dim, args.obs_scale = K, 6 + K, OBS_SCALE_PT + [1.] * K
+    nets = {'policy': mlp_weights(rng, 6 + K, H, 4), 'Q1': mlp_weights(rng, 8 + K, H, 1)}
     if version == 'MPG-v2':
-        nets['Q2'] = mlp_weights(rng, 8, H, 1)
+        nets['Q2'] = mlp_weights(rng, 8 + K, H, 1)
     add_targets(nets)
-    batch = make_replay_batch_pt(rng, B)
+    batch = make_replay_batch_pt(rng, B, K)
     eps = rng.standard_normal((25, B)).astype(np.float32)
     out = dict(batch_obs=batch[0], batch_actions=batch[1], batch_rewards=batch[2], batch_obs_tp1=batch[3],
                batch_dones=batch[4], eps=eps, iterations=np.array([100, 9000]))
@@ -267,8 +277,6 @@ def fx_mpg(version, H, B, seed):
             st = learner.get_stats()
             p = 'it%d_' % it
             out[p + 'grads' + tag] = flat(grads) if tag == '' else sub64(flat(grads), H)
-            if trained and tag == '_f64':      # output-layer biases are too short for the every-8th subsample: keep them whole
-                out[p + 'grads_small_f64'] = np.concatenate([np.asarray(x, np.float64).ravel() for x in grads if np.asarray(x).size < 8])
             out[p + 'targets' + tag] = np.asarray(learner.batch_data['batch_targets'])
             for key in ('value_mean', 'policy_total_loss', 'policy_gradient_norm', 'q_loss1',
                         'q_gradient_norm1', 'q_loss2', 'q_gradient_norm2'):
@@ -289,7 +297,7 @@ def fx_mpg(version, H, B, seed):
             out['td_error'] = np.asarray(learner.compute_td_error())
     tf.set_ref_dtype(torch.float32)
     tf.set_noise_source(None)
-    np.savez_compressed(os.path.join(HERE, 'mpg_%s_H%d_B%d.npz' % (version[-2:], H, B)), **out)
+    np.savez_compressed(os.path.join(HERE, 'mpg_%s_H%d_B%d%s.npz' % (version[-2:], H, B, '_K%d' % K if K else '')), **out)
 
 
 def fx_nadp(H, B, seed):
@@ -615,6 +623,7 @@ ROUND2 = {'replay_buffer': fx_replay_buffer, 'evaluator': fx_evaluator, 'env_fut
           'q_estimation': fx_q_estimation}
 ROUND2.update({n: (lambda n=n: fx_bench_case(n)) for n in BENCH_CASES})
 ROUND2['trained_c2'] = lambda: fx_bench_case('c2_mpg_v2_B4096', trained=True)      # round 3
+ROUND2['mpg_future'] = lambda: fx_mpg('MPG-v2', 256, 64, seed=12, K=3)               # round 3: num_future_data = 3
 
 
 def main():

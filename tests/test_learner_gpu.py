@@ -20,11 +20,11 @@ def dev(x):
     return torch.as_tensor(np.ascontiguousarray(x), dtype=torch.float32).to(DEV)
 
 
-def _learner(g, version, B=64):
+def _learner(g, version, B=64, K=0):
     from mpg_amd.config import default_args
     from mpg_amd.learners import MPGLearner
     from mpg_amd.policy import PolicyWithQs
-    args = default_args('MPG-' + version, replay_batch_size=B, num_batch_reuse=1)
+    args = default_args('MPG-' + version, replay_batch_size=B, num_batch_reuse=1, num_future_data=K)
     learner = MPGLearner(PolicyWithQs, args)
     pw = learner.policy_with_value
     flat = np.concatenate([g['w_' + n] for n in pw.names])
@@ -32,13 +32,16 @@ def _learner(g, version, B=64):
     return learner
 
 
-@pytest.mark.parametrize('version', ['v2', 'v1'])
-def test_compute_gradient_vs_reference_golden(golden, version):
+@pytest.mark.parametrize('version,K', [('v2', 0), ('v1', 0), ('v2', 3)])
+def test_compute_gradient_vs_reference_golden(golden, version, K):
     """The full list the reference's MPGLearner.compute_gradient returns (clipped q1, (q2), policy gradients) and its
-    stats, on the same minibatch, weights and model noise.  <= 1e-4 relative L2 per array."""
-    g = golden('mpg_%s_H256_B64.npz' % version)
-    learner = _learner(g, version)
+    stats, on the same minibatch, weights and model noise.  <= 1e-4 relative L2 per array.
+    K = num_future_data (train_script.py:90,146-147): observations with K look-ahead entries, first layers 6+K / 8+K
+    wide - the 16-column instantiations of the network kernels and of the two rollout sweeps."""
+    g = golden('mpg_%s_H256_B64%s.npz' % (version, '_K%d' % K if K else ''))
+    learner = _learner(g, version, K=K)
     pw = learner.policy_with_value
+    assert pw.obs_dim == 6 + K and pw.cfg.obs_dim == 6 + K
     batch = [dev(g[k]) for k in ('batch_obs', 'batch_actions', 'batch_rewards', 'batch_obs_tp1', 'batch_dones')]
     for it in (100, 9000):
         learner.counter = 0
@@ -298,6 +301,60 @@ def test_single_process_training_loop_runs_and_learns_the_critic(alg):
     assert (pw.targets - t0).abs().max().item() > 0
     assert np.mean(losses[-5:]) < np.mean(losses[:5])
     assert int(pw.nonfinite.sum().item()) == 0
+
+
+@pytest.mark.parametrize('fused', [False, True])
+def test_training_loop_with_look_ahead_observations(fused):
+    """num_future_data = 3 through worker, replay ring, learner and optimizer (train_script.py:90,146-147; worker.py:38;
+    mpg_learner.py:35,48): observations are 9 wide, the first layers 9 / 11 wide.  The loop runs, stays finite, learns the
+    critic; the gradient of the last minibatch equals the oracle's on the same minibatch, weights and model noise."""
+    from mpg_amd.buffer import ReplayBuffer
+    from mpg_amd.config import default_args
+    from mpg_amd.learners import MPGLearner
+    from mpg_amd.optimizer import SingleProcessOffPolicyOptimizer
+    from mpg_amd.policy import PolicyWithQs
+    from mpg_amd.worker import OffPolicyWorker
+    K = 3
+    args = default_args('MPG-v2', num_agent=64, batch_size=512, replay_batch_size=256, replay_starts=1024, max_buffer_size=8192,
+                        value_lr_schedule=[1e-3, 100000, 1e-4], num_future_data=K)
+    assert args.obs_dim == 9 and len(args.obs_scale) == 9
+    worker = OffPolicyWorker(PolicyWithQs, args.env_id, args, 0)
+    learner = MPGLearner(PolicyWithQs, args)
+    rb = ReplayBuffer(args, 0)
+    opt = SingleProcessOffPolicyOptimizer(worker, learner, rb, None, args, fused=fused)
+    assert (opt._fused is not None) == fused
+    pw = worker.policy_with_value
+    assert rb.obs.shape[1] == 9 and pw.dims['policy'] == (9, 4) and pw.dims['Q1'] == (11, 1)
+    # the look-ahead entries in the ring are the env's (path_tracking_env.py:385-402), not copies of delta_y
+    o = rb.obs[:len(rb)].cpu().numpy()
+    assert np.abs(o[:, 6:] - o[:, 3:4]).max() > 1e-3
+    losses = []
+    for i in range(30):
+        opt.step()
+        losses.append(learner.get_stats()['q_loss1'])
+    assert all(np.isfinite(losses)) and torch.isfinite(pw.params).all()
+    assert pw.opt_steps['Q1'] == 30 and pw.opt_steps['policy'] == 15
+    assert np.mean(losses[-5:]) < np.mean(losses[:5])
+    pw.check_status()
+    # one more gradient on a fresh minibatch with recorded noise, against the oracle
+    batch = [b.clone() for b in rb.sample(256)[:5]]
+    eps = torch.randn(25, 256, device=DEV)
+    learner.counter = 0
+    grads = learner.compute_gradient(batch, None, None, 500, eps=eps)
+    got = torch.cat([x.reshape(-1) for x in grads]).cpu().numpy()
+    cfg = O.Cfg(obs_dim=9, obs_scale=list(O.OBS_SCALE_PT) + [1.] * K)
+    flat, tflat = pw.params.cpu().numpy(), pw.targets.cpu().numpy()
+    off = np.cumsum([0] + list(pw.sizes))
+    w = {n: flat[off[i]:off[i + 1]] for i, n in enumerate(pw.names)}
+    wt = {n: tflat[off[i]:off[i + 1]] for i, n in enumerate(pw.names)}
+    nb = [b.cpu().numpy() for b in batch]
+    ref = {}
+    for dt in (torch.float32, torch.float64):
+        nets = O.Nets(cfg, w, flat_targets=wt, dtype=dt)
+        g, _ = O.mpg_compute_gradient(cfg, nets, nb, eps.cpu().numpy(), 500, 'MPG-v2')
+        ref[dt] = np.concatenate([np.asarray(x, np.float64).ravel() for x in g])
+    Y.check_gradients(got, ref[torch.float32].astype(np.float32), ref[torch.float64][::8], [(n,) + tuple(pw.dims[n]) for n in pw.names],
+                      where='look-ahead K=3 (%s)' % ('native step driver' if fused else 'method by method'))
 
 
 @pytest.mark.parametrize('alg', ['MPG-v2', 'MPG-v1'])

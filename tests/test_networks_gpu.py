@@ -45,6 +45,13 @@ def test_mlp_forward_vs_oracle(rows, shape):
     assert np.abs(y - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize('rows', [1, 17, 4099])
+@pytest.mark.parametrize('shape', [(7, 4, 2, 1), (9, 4, 2, 1), (14, 4, 2, 1), (9, 1, 1, 0), (11, 1, 1, 0), (16, 1, 1, 0)])
+def test_mlp_forward_wide_first_layer_vs_oracle(rows, shape):
+    """first layers 7 .. 16 wide (observations with look-ahead entries, num_future_data <= 8): the 16-column instantiations"""
+    test_mlp_forward_vs_oracle(rows, shape)
+
+
 def _cfg_nets(g, names, env='PathTracking-v0'):
     from mpg_amd import ops
     cfg = ops.make_cfg(env)
@@ -147,18 +154,20 @@ def test_q_loss_grad_vs_golden(golden, fixture, loss_keys):
             o += n
 
 
-@pytest.mark.parametrize('rows', [1, 17, 300, 4096])
-def test_q_loss_grad_vs_oracle_autograd_ragged(rows):
+@pytest.mark.parametrize('rows,K', [(1, 0), (17, 0), (300, 0), (4096, 0), (17, 1), (300, 3), (4096, 8)])
+def test_q_loss_grad_vs_oracle_autograd_ragged(rows, K):
+    """K look-ahead entries (num_future_data): critic input 8 + K wide"""
     from mpg_amd import ops
     rng = np.random.Generator(np.random.PCG64(rows))
-    cfg = ops.make_cfg()
-    flat = rand_net(rng, 8, 1)
-    obs = (rng.standard_normal((rows, 6)) * np.array([3, 1, .5, 1, .5, 300])).astype(np.float32)
+    scale = list(O.OBS_SCALE_PT) + [1.] * K
+    cfg = ops.make_cfg(obs_dim=6 + K, obs_scale=scale)
+    flat = rand_net(rng, 8 + K, 1)
+    obs = (rng.standard_normal((rows, 6 + K)) * np.array([3, 1, .5, 1, .5, 300] + [1.] * K)).astype(np.float32)
     act = rng.uniform(-1, 1, (rows, 2)).astype(np.float32)
     y = rng.standard_normal(rows).astype(np.float32)
     loss, grad, td = ops.q_loss_grad(cfg, dev(flat), dev(obs), dev(act), dev(y), want_td=True)
-    ocfg = O.Cfg()
-    ws = O.unflatten(flat, 8, 256, 1, dtype=torch.float64, requires_grad=True)
+    ocfg = O.Cfg(obs_dim=6 + K, obs_scale=scale)
+    ws = O.unflatten(flat, 8 + K, 256, 1, dtype=torch.float64, requires_grad=True)
     po = O.process_obses(ocfg, torch.as_tensor(obs).double())
     q = O.mlp(ws, torch.cat([po, torch.as_tensor(act).double()], 1), 'linear')[:, 0]
     l = 0.5 * torch.mean((q - torch.as_tensor(y).double()) ** 2)
@@ -168,7 +177,8 @@ def test_q_loss_grad_vs_oracle_autograd_ragged(rows):
     np.testing.assert_allclose(td.cpu().numpy(), (q.detach().numpy() - y), rtol=0, atol=3e-5)
     got = grad.cpu().numpy()
     o = 0
-    for shp in O.mlp_shapes(8, 256, 1):
+    assert got.size == ref.size
+    for shp in O.mlp_shapes(8 + K, 256, 1):
         n = int(np.prod(shp))
         assert rel_l2(got[o:o + n], ref[o:o + n]) <= 2e-5, (rows, shp, rel_l2(got[o:o + n], ref[o:o + n]))
         o += n

@@ -102,11 +102,11 @@ def _check_grads(got_flat, g, key, cfg, names, H):
             assert e_got <= 4 * e_ref + 1e-6, (key, nm, e_got, e_ref)
 
 
-@pytest.mark.parametrize('version', ['v2', 'v1'])
-@pytest.mark.parametrize('H', [32, 256])
-def test_mpg_compute_gradient(golden, version, H):
-    g = golden('mpg_%s_H%d_B64.npz' % (version, H))
-    cfg = O.Cfg(H=H)
+@pytest.mark.parametrize('version,H,K', [('v2', 32, 0), ('v1', 32, 0), ('v2', 256, 0), ('v1', 256, 0), ('v2', 256, 3)])
+def test_mpg_compute_gradient(golden, version, H, K):
+    """K = num_future_data (train_script.py:90,146-147): observations carry K look-ahead entries, first layers 6+K / 8+K wide"""
+    g = golden('mpg_%s_H%d_B64%s.npz' % (version, H, '_K%d' % K if K else ''))
+    cfg = O.Cfg(H=H, obs_dim=6 + K, obs_scale=list(O.OBS_SCALE_PT) + [1.] * K)
     names = ['Q1', 'Q2', 'policy'] if version == 'v2' else ['Q1', 'policy']
     batch = [g['batch_obs'], g['batch_actions'], g['batch_rewards'], g['batch_obs_tp1'], g['batch_dones']]
     for it in (100, 9000):
