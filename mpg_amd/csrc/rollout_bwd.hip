@@ -109,7 +109,17 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_bwd(const RollBwdArgs a)
             backward_dz2<NIN, ACT>(sD3, sA, L, r, h2_cur, dz2);
             // all global loads of the step are issued HERE, behind the dz2 phase: h1 is consumed after the MFMA block,
             // the record and h2 stash of step t-1 in the next iteration (software pipeline)
+#ifdef MPG_AB_NO_H1
+            if (t == 0) stash_load(a.H1, (long)t * ngroups + g, L, h1);
+            else {
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) h1[tt][j] = h2_cur[tt][j];
+            }
+#else
             stash_load(a.H1, (long)t * ngroups + g, L, h1);
+#endif
             if (t > 0) {
                 if (live) {
                     const f32x4* rp = reinterpret_cast<const f32x4*>(a.SA + ((long)(t - 1) * R + tr) * SAW);

@@ -123,7 +123,11 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_fwd(const RollArgs a) {
             lds_barrier();
             MPG_STAMP_AT(0);
             float h1[2][4], h2[2][4];
+            #ifdef MPG_AB_NO_H1
+            forward_group<NIN, ACT, false>(sX, sA, sPart, L, w2, r, h1, h2, t == 0 ? a.H1 : nullptr, (long)t * ngroups + g, nullptr, &zmax);
+#else
             forward_group<NIN, ACT, false>(sX, sA, sPart, L, w2, r, h1, h2, a.H1, (long)t * ngroups + g, nullptr, &zmax);
+#endif
             if (a.H1) stash_store(a.H2, (long)t * ngroups + g, L, h2);
             // book lanes, before B2: fetch what the chain lanes left in sTraj (they overwrite it right after B2) and prepare
             // the action-independent half of this step's model step - the only part of their work the chain waits for

@@ -82,7 +82,8 @@ def c3():
     t = timed(step, 100, 10)
     flop = 14.8e6 * B
     print(json.dumps(dict(what='C3 NADP pendulum model B=8192 (compute_gradient + apply_gradients)', ms_per_grad_step=t * 1e3,
-                          grad_steps_per_s=1 / t, algorithmic_gflop=flop / 1e9, tflops=flop / t / 1e12, frac_fp32_mfma_peak=flop / t / 157.3e12)))
+                          grad_steps_per_s=1 / t, algorithmic_gflop=flop / 1e9, algorithmic_tflops=flop / t / 1e12, executed_f16_tflops=3 * flop / t / 1e12,
+                          frac_f16_mfma_peak=3 * flop / t / 2500e12)))
 
 
 def c4():
@@ -116,7 +117,8 @@ def c4():
     flop = 2.17e6 * B
     print(json.dumps(dict(what='C4 TD3 + prioritized replay B=65536, 500k transitions (replay + compute_gradient + update_priorities + apply_gradients)',
                           ms_per_grad_step=t * 1e3, grad_steps_per_s=1 / t, replay_rows_per_s=B / t, per_sample_gather_ms=t_per * 1e3,
-                          algorithmic_gflop=flop / 1e9, tflops=flop / t / 1e12, frac_fp32_mfma_peak=flop / t / 157.3e12)))
+                          algorithmic_gflop=flop / 1e9, algorithmic_tflops=flop / t / 1e12, executed_f16_tflops=3 * flop / t / 1e12,
+                          frac_f16_mfma_peak=3 * flop / t / 2500e12)))
 
 
 if __name__ == '__main__':
