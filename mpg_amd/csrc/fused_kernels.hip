@@ -501,7 +501,8 @@ struct WgradMulti {
     int n_jobs;
     WgradArgs a[3];
     int type[3];               // 0: template pair A, 1: template pair B
-    int chunk_off[4];          // blockIdx.y ranges of the jobs
+    int chunk_off[4];          // chunk ranges of the jobs
+    int chunk0;                // first chunk this launch covers (a launch may cover a suffix of the jobs)
     unsigned long long* dbg;   // MPG_TIMELINE builds only
 };
 
@@ -511,6 +512,7 @@ __global__ void __launch_bounds__(NTHREAD, 4) k_wgrad_multi(const WgradMulti m) 
     __shared__ __attribute__((aligned(16))) float sRed[NWAVE * (NQA > NQB ? NQA : NQB) * 64];
     int gchunk, sl;
     wgrad_map(blockIdx.x, gridDim.x >> 3, gchunk, sl);
+    gchunk += m.chunk0;
     int j = 0;
     while (j + 1 < m.n_jobs && gchunk >= m.chunk_off[j + 1]) ++j;
     const int chunk = gchunk - m.chunk_off[j];
@@ -750,8 +752,11 @@ int launch_critic_fused(const mpg_cfg_t* cfg, const float* const* q_params, int 
     return MPG_OK;
 }
 
-int launch_wgrad_multi(const mpg_cfg_t* cfg, const WgradJob* jobs, int n_jobs, const SumJob* sums, int n_sums, float* sq_part, hipStream_t s) {
-    MPG_REQUIRE(jobs && n_jobs >= 1 && n_jobs <= 3 && n_sums >= 0 && n_sums <= 8, "launch_wgrad_multi: bad argument");
+// phases: 1 = the chunk products of jobs[first_job .. n_jobs) only, 2 = the slab reduction (+ sums) of jobs[0 .. n_jobs) only,
+// 3 = both (one weight-gradient launch over all jobs, then the reduction)
+int launch_wgrad_multi(const mpg_cfg_t* cfg, const WgradJob* jobs, int n_jobs, const SumJob* sums, int n_sums, float* sq_part, hipStream_t s,
+                       int phases, int first_job) {
+    MPG_REQUIRE(jobs && n_jobs >= 1 && n_jobs <= 3 && n_sums >= 0 && n_sums <= 8 && first_job >= 0 && first_job < n_jobs, "launch_wgrad_multi: bad argument");
     WgradMulti m;
     ReduceMulti rm;
     m.n_jobs = rm.n_jobs = n_jobs;
@@ -776,6 +781,7 @@ int launch_wgrad_multi(const mpg_cfg_t* cfg, const WgradJob* jobs, int n_jobs, c
         if (rm.n[j] > maxn) maxn = rm.n[j];
     }
     m.chunk_off[n_jobs] = off;
+    const int chunk0 = m.chunk_off[first_job];          // the launch covers the chunks of jobs[first_job ..) only
     for (int j = n_jobs; j < 3; ++j) { m.type[j] = 0; m.chunk_off[j + 1] = off; rm.slabs[j] = nullptr; rm.nslab[j] = rm.n[j] = 0; rm.out[j] = nullptr; }
     m.dbg = nullptr;
 #ifdef MPG_TIMELINE
@@ -784,10 +790,13 @@ int launch_wgrad_multi(const mpg_cfg_t* cfg, const WgradJob* jobs, int n_jobs, c
     if (!s_dbg) (void)hipMalloc(&s_dbg, 2 * NWAVE * MPG_TL_MARKS * sizeof(unsigned long long));
     m.dbg = s_dbg;
 #endif
+    m.chunk0 = chunk0;
+    if (phases & 1) {
     mpg_prof_begin(mpg_prof_of(cfg), 5, s);
-    if (!pendulum) hipLaunchKernelGGL((k_wgrad_multi<8, 1, 6, 2>), dim3(8 * off), dim3(NTHREAD), 0, s, m);
-    else hipLaunchKernelGGL((k_wgrad_multi<5, 1, 4, 1>), dim3(8 * off), dim3(NTHREAD), 0, s, m);
+    if (!pendulum) hipLaunchKernelGGL((k_wgrad_multi<8, 1, 6, 2>), dim3(8 * (off - chunk0)), dim3(NTHREAD), 0, s, m);
+    else hipLaunchKernelGGL((k_wgrad_multi<5, 1, 4, 1>), dim3(8 * (off - chunk0)), dim3(NTHREAD), 0, s, m);
     mpg_prof_end(mpg_prof_of(cfg), 5, s);
+    }
 #ifdef MPG_TIMELINE
     if (++s_calls % 100 == 0) {
         static unsigned long long h[2 * NWAVE * MPG_TL_MARKS];
@@ -803,6 +812,7 @@ int launch_wgrad_multi(const mpg_cfg_t* cfg, const WgradJob* jobs, int n_jobs, c
     }
 #endif
     MPG_CHECK_LAUNCH("k_wgrad_multi");
+    if (!(phases & 2)) return MPG_OK;
     rm.n_sums = n_sums;
     for (int k = 0; k < 8; ++k) {
         if (k < n_sums) rm.sums[k] = sums[k];

@@ -114,7 +114,8 @@ struct SumJob {
     int n, stride;         // sums src[0], src[stride], ... (n terms)
     float* dst;
 };
-int launch_wgrad_multi(const mpg_cfg_t* cfg, const WgradJob* jobs, int n_jobs, const SumJob* sums, int n_sums, float* sq_part, hipStream_t s);
+int launch_wgrad_multi(const mpg_cfg_t* cfg, const WgradJob* jobs, int n_jobs, const SumJob* sums, int n_sums, float* sq_part, hipStream_t s,
+                       int phases = 3, int first_job = 0);
 // critic losses + critic at the two selected slices in one launch (launch_qloss_fused + launch_qslice_fused with n_sel == 2)
 int launch_critic_fused(const mpg_cfg_t* cfg, const float* const* q_params, int n_q, int rows, const float* obs,
                         const float* act, const float* y, float inv_b, const CriticStash* st, float* loss_part, const float* xq,

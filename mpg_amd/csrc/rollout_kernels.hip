@@ -508,10 +508,7 @@ extern "C" int mpg_mpg_gradients(const mpg_cfg_t* cfg, int n_q, const float* par
         rc = launch_qslice_fused(cfg, qp[0], qin, rows, n_select, XQ, GK, cf.gpow, cf.coef, ret_part, GXQ, s);
         if (rc) return rc;
     }
-    // 5. reverse sweep
-    rc = run_rollout_bwd(cfg, policy, rows, 1, n, select, n_select, cf.rho, H1, H2, SA, GXQ, 0, DZ1, DZ2, DZ3, s);
-    if (rc) return rc;
-    // 6./7. weight gradients of every network + all scalar statistics, two launches
+    // 6./7. weight gradients of every network + all scalar statistics
     WgradJob jobs[3];
     const XSpec xq = xspec(obs, od, act, ad, cfg->obs_scale, od);
     for (int k = 0; k < n_q; ++k) {
@@ -532,6 +529,21 @@ extern "C" int mpg_mpg_gradients(const mpg_cfg_t* cfg, int n_q, const float* par
     for (int k = 0; k < n_select && ns + 1 < 8; ++k) {
         sums[ns].src = ret_part + (size_t)k * ngroups * 2; sums[ns].n = ngroups; sums[ns].stride = 2; sums[ns].dst = stats + 2 + k; ++ns;
         sums[ns].src = ret_part + (size_t)k * ngroups * 2 + 1; sums[ns].n = ngroups; sums[ns].stride = 2; sums[ns].dst = stats + 2 + n_select + k; ++ns;
+    }
+    // MPG_WGRAD_EARLY=1 (experiment): the critics' chunk products right behind the critic launch, while their stashes are still in
+    // the caches, the policy's behind the reverse sweep, one reduction at the end (10 launches instead of 9)
+    static const int early = getenv("MPG_WGRAD_EARLY") ? atoi(getenv("MPG_WGRAD_EARLY")) : 0;
+    if (early) {
+        rc = launch_wgrad_multi(cfg, jobs, n_q, nullptr, 0, nullptr, s, 1, 0);
+        if (rc) return rc;
+    }
+    // 5. reverse sweep
+    rc = run_rollout_bwd(cfg, policy, rows, 1, n, select, n_select, cf.rho, H1, H2, SA, GXQ, 0, DZ1, DZ2, DZ3, s);
+    if (rc) return rc;
+    if (early) {
+        rc = launch_wgrad_multi(cfg, jobs, n_q + 1, nullptr, 0, nullptr, s, 1, n_q);
+        if (rc) return rc;
+        return launch_wgrad_multi(cfg, jobs, n_q + 1, sums, ns, sq_part, s, 2, 0);
     }
     return launch_wgrad_multi(cfg, jobs, n_q + 1, sums, ns, sq_part, s);
 }

@@ -66,3 +66,38 @@ def test_no_kernel_reads_the_dispatch_or_queue_packet():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.offenders() == []
+
+
+def test_no_dpp_instruction_reads_a_register_inside_its_hazard_window():
+    """A DPP instruction needs two wait states behind the VALU write of its DPP operand; the assembler does not check inline
+    asm, and the engine's output reduction is hand-written `v_add_f32_dpp` stages (mlp_core.h) that rely on their stage-major
+    order.  tools/dpp_hazard_check.py verifies the property on the ISA of every translation unit as the shipped flags compile
+    it; the checker itself is first shown to fire on a synthetic violation."""
+    import os
+    import sys
+    tools = os.path.join(os.path.dirname(__file__), '..', 'tools')
+    sys.path.insert(0, tools)
+    try:
+        import dpp_hazard_check as C
+    finally:
+        sys.path.remove(tools)
+    bad_asm = """
+_Zfoo:
+    v_fma_f32 v3, v1, v2, v3
+    v_add_f32_dpp v4, v3, v3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf
+"""
+    ok_asm = """
+_Zfoo:
+    v_fma_f32 v3, v1, v2, v3
+    s_nop 1
+    v_add_f32_dpp v4, v3, v3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf
+    v_fma_f32 v[8:11], v1, v2, v3
+    v_mov_b32_e32 v20, v21
+    v_mov_b32_dpp v5, v9 row_mirror row_mask:0xf bank_mask:0xf
+"""
+    b, n = C.violations(bad_asm)
+    assert n == 1 and len(b) == 1
+    b, n = C.violations(ok_asm)
+    assert n == 2 and len(b) == 1 and 'v_mov_b32_dpp' in b[0][2]          # one wait state is not enough, a range write counts
+    bad, n = C.check()
+    assert n > 1000 and bad == [], bad[:5]

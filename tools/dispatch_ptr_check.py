@@ -11,14 +11,15 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 from mpg_amd import build as B   # noqa: E402
+sys.path.insert(0, HERE)
+from dpp_hazard_check import asm_of   # noqa: E402
 
 
 def offenders(files=None):
     files = files or sorted(f for f in os.listdir(B.CSRC) if f.endswith('.hip'))
     bad = []
     for f in files:
-        flags = B.COMMON + B.EXTRA.get(f, []) + ['-x', 'hip', '--offload-device-only', '-S']
-        asm = subprocess.run([B.hipcc()] + flags + [os.path.join(B.CSRC, f), '-o', '-'], capture_output=True, text=True).stdout
+        asm = asm_of(f)          # (cached: tests/test_abi.py runs this check and the DPP hazard check on the same dumps)
         for m in re.finditer(r'\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel', asm, re.S):
             what = [k for k in ('dispatch_ptr', 'queue_ptr') if re.search(r'user_sgpr_%s 1' % k, m.group(2))]
             if what:
