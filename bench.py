@@ -437,8 +437,8 @@ def main():
     assert world == a.gpus, '--gpus %d but WORLD_SIZE=%d' % (a.gpus, world)
     assert torch.cuda.is_available(), 'bench.py needs a GPU: the product path has no CPU fallback'
     ndev = torch.cuda.device_count()
-    if local >= ndev:        # only in MPG_DIST_BACKEND=gloo dry runs with more ranks than GPUs
-        assert os.environ.get('MPG_DIST_BACKEND') == 'gloo', 'LOCAL_RANK %d but %d GPUs' % (local, ndev)
+    if local >= ndev:        # only in MPG_DIST_BACKEND=gloo / oneshot dry runs with more ranks than GPUs
+        assert os.environ.get('MPG_DIST_BACKEND') in ('gloo', 'oneshot'), 'LOCAL_RANK %d but %d GPUs' % (local, ndev)
         local = local % ndev
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)

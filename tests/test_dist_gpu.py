@@ -215,3 +215,30 @@ def test_rccl_all_reduce_between_step_begin_and_step_end():
     assert p.exitcode == 0
     assert np.isfinite(a).all() and np.array_equal(a, b) and np.array_equal(a, c)
     assert np.array_equal(na, nb) and np.array_equal(na, nc)
+
+
+@pytest.mark.parametrize('backend', ['gloo', 'oneshot'])
+def test_bench_in_the_drivers_multi_rank_form(backend):
+    """`bench.py` exactly as the driver launches it for N > 1 - `python -m torch.distributed.run --nnodes=1 --nproc-per-node 2
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus 2 --steps K --warmup W` - as a dry run on the one GPU of the test
+    box (MPG_DIST_BACKEND=gloo / oneshot: both ranks on device 0; RCCL itself refuses two ranks on one device).  Checks the
+    launch form, the rendezvous, the barrier-bracketed timed region, the max over ranks and the one JSON line of rank 0:
+    n_gpus 2, weak scaling, whole-job value = 2 x 4096 env-steps per step / time."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MPG_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '10', '--warmup', '3',
+           '--no-cpu-baseline']
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, out.stdout[-2000:]                 # rank 0 prints ONE line
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['steps'] == 10 and d['warmup'] == 3 and d['scaling'] == 'weak' and d['higher_is_better'] is True
+    assert d['config']['parallelism'] == 'dp2' and d['config']['global_batch'] == 2 * 4096
+    assert d['config']['dist_backend'].startswith(backend)
+    np.testing.assert_allclose(d['value'], 2 * 4096 / (d['ms_per_step'] * 1e-3), rtol=1e-6)
+    assert 'roofline' in d and d['vs_baseline'] is None
