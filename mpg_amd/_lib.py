@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(HERE, 'libmpg_hip.so')
 HEADER = os.path.join(HERE, '..', 'include', 'mpg_hip.h')
 
 _lib = None
+ABI_VERSION = 6      # the struct mirrors of ops.py (CfgStruct, WCacheStruct, ...) follow include/mpg_hip.h at this version
 
 
 class MpgError(RuntimeError):
@@ -48,6 +49,11 @@ def lib():
         for name in declared_symbols():
             fn = getattr(_lib, name)            # AttributeError here = header/library out of sync
             fn.restype = ctype[rtypes[name]]    # KeyError here = a return type this binding does not know
+        got = _lib.mpg_abi_version()
+        if got != ABI_VERSION:
+            _lib = None
+            raise MpgError('%s has ABI version %d, this binding mirrors version %d - rebuild with `python -m mpg_amd.build`'
+                           % (LIB_PATH, got, ABI_VERSION))
     return _lib
 
 
