@@ -1,0 +1,241 @@
+// Forward sweep of the fused n-step model rollout (see rollout_kernels.hip for the overview and the references).
+#include "rollout_common.h"
+
+namespace rollout {
+namespace {
+
+// WIDE: observations with look-ahead entries (obs_dim = ENV::OBS + nf, nf <= 8): the networks run the 16-wide form of
+// the engine (mlp_core.h), the six base entries evolve with the model and the look-ahead entries of every MODEL observation are
+// copies of entry ENV::FUT_SRC (path_tracking_env.py:262-268), the start observation's come from the batch.
+template <class ENV, bool PK, bool WIDE = false>
+__global__ void __launch_bounds__(NTHREAD, 2) k_rollout_fwd(const RollArgs a) {
+    constexpr int OBS = ENV::OBS, ACT = ENV::ACT;
+    constexpr int NIN = WIDE ? 16 : OBS, XSW = xs_of<NIN>();
+    const int nf = WIDE ? a.obs_dim - OBS : 0, OD = OBS + nf, QIN = OD + ACT;
+    __shared__ __attribute__((aligned(16))) float smem[A_IMG + NWAVE * GROUP * MAXOUT + MAXN * GROUP];
+    float* sA = smem;
+    float* sPart = sA + A_IMG;
+    float* sEps = sPart + NWAVE * GROUP * MAXOUT;
+    __shared__ float sGp[MAXN];
+    constexpr int PRE_STRIDE = 12;                                // floats per trajectory of ENV::pre's values
+    static_assert(ENV::NPRE <= PRE_STRIDE, "sPre row too short");
+    __shared__ __attribute__((aligned(16))) float sPre[GROUP * PRE_STRIDE];
+    const Lane L;
+    const int tid = threadIdx.x;
+    if (tid <= a.n) sGp[tid] = powf(a.gamma, (float)tid);     // tf.pow(gamma, ri) in float32, mpg_learner.py:245
+    const Net net = make_net(a.policy, OD, 2 * ACT);
+    float w2[128];
+    SmallRegs<NIN, ACT> r;
+    if constexpr (PK) load_w2_packed(a.pack, L, w2); else load_w2_fwd(net.W2, L, w2);
+    load_small<NIN, ACT>(net, L, r);
+    float b3r[2] = {0.f, 0.f};                         // output bias in registers: no global load on the serial chain
+#pragma unroll
+    for (int k = 0; k < ACT; ++k) b3r[k] = net.b3[k];
+    const long R = (long)a.rows * a.M;
+    const long ngroups = (R + GROUP - 1) / GROUP;
+    float zmax = 0.f;                          // largest first-layer activation seen by this lane (the engine's envelope, mlp_core.h)
+#ifdef MPG_STAMP
+    if ((tid & 63) == 0) {
+        for (int k = 0; k < 10; ++k) g_st_acc[tid >> 6][k] = 0;
+        g_st_prev[tid >> 6] = __builtin_amdgcn_s_memtime();
+    }
+#endif
+    for (long g = blockIdx.x; g < ngroups; g += gridDim.x) {
+        // EVERY lane carries the trajectory of row (lane & 15) of the group - the row whose layer-1 operand it feeds to the
+        // matrix pipe - and advances it itself: the serial part of a step (output activation, the action-dependent half of the
+        // model step, the next network input) is computed redundantly by all lanes instead of by 16 lanes of one wave that
+        // then publish the next input through LDS behind a third barrier.  Registers are allocated for all 512 lanes anyway;
+        // the step has two barriers (image, output partials) and no input block in LDS.
+        //   book lanes (first 16 lanes of wave 1): everything that is not serial - the action-independent half of the model
+        //   step (ENV::pre: sincos, reciprocals; handed to all lanes through sPre, ahead of the second barrier), the
+        //   discounted reward sum and all records for the reverse sweep and the critic.  Wave 1 is an older wave: it leaves
+        //   the matrix block early and would otherwise wait ~1300 cycles at the step's second barrier.
+        const bool booker = tid >= 64 && tid < 64 + GROUP;
+        const int row = tid & 15;
+        const long tr = g * GROUP + row;               // this lane's trajectory
+        const bool live = tr < R, blive = booker && live;
+        float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};        // the model state (as observation)
+        float G = 0.f;                                                  // book lanes: discounted reward sum so far
+        float act_first[2] = {0.f, 0.f};
+        float f0[WIDE ? 8 : 1] = {};                                    // look-ahead entries of the start observation
+        if (live) {
+            const float* src = a.obs0 + (tr % a.rows) * OD;
+#pragma unroll
+            for (int i = 0; i < OBS; ++i) o[i] = src[i];
+            if constexpr (WIDE) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) f0[k] = k < nf ? src[OBS + k] : 0.f;
+            }
+            if (a.act0) {
+#pragma unroll
+                for (int k = 0; k < ACT; ++k) act_first[k] = a.act0[(tr % a.rows) * ACT + k];
+            }
+        }
+        // the whole group's model noise goes to LDS up front (one value per thread), off the serial chain: either the
+        // caller's eps or Philox draws.  Visible to the book lanes after the first barrier of the step loop.
+        for (int idx = tid; idx < a.n * GROUP; idx += NTHREAD) {
+            const int t = idx / GROUP;
+            const long trj = g * GROUP + (idx % GROUP);
+            float z = 0.f;
+            if (a.eps) {
+                if (trj < R) z = a.eps[(long)t * R + trj];
+            } else {
+                const Philox4 p = philox4x32_10((uint32_t)trj, (uint32_t)t, a.nc0, a.nc1 ^ 0x6e6f6973u, a.nk0, a.nk1);
+                z = sqrtf(-2.f * logf(u01(p.v[0]))) * cosf(6.283185307179586f * u01(p.v[1]));
+            }
+            sEps[idx] = z;
+        }
+        // Per step: layer 1 from registers -> B1 -> layer-2 MFMA block -> output partials -> [book lanes: ENV::pre of this
+        // step] -> B2 -> [all lanes: tanh, ENV::finish, the next input; book lanes: the records of this step].
+        // record the action of step tb, its critic-input part and the discounted reward (book lanes, one step late)
+        auto book = [&](int tb, const float (&act)[2], float rew) {
+            if (blive) {
+                if (a.SA) {
+                    float* rec = a.SA + ((long)tb * R + tr) * SAW + OBS;
+#pragma unroll
+                    for (int k = 0; k < ACT; ++k) rec[k] = act[k];
+                }
+                // constant indices only: a dynamically indexed kernel-argument array is re-read from memory by a scalar load
+                // (+ wait) on every use - ~200 cycles each
+#pragma unroll
+                for (int ks = 0; ks < MAXSEL; ++ks)
+                    if (ks < a.n_sel && a.sel[ks] == tb) {
+                        float* xq = a.XQ + ((long)ks * R + tr) * QIN + OD;
+#pragma unroll
+                        for (int k = 0; k < ACT; ++k) xq[k] = act[k];
+                    }
+            }
+            if (tb < a.n) G += sGp[tb] * ((rew + a.rew_shift) * a.rew_scale);                 // mpg_learner.py:245
+        };
+        // this lane's layer-1 A operand x[row][4 q + (lane >> 4)] of the next evaluation: scaled base entries, then the
+        // look-ahead entries (first: the batch's own)
+        float xa[l1_steps<NIN>()];
+        auto make_xa = [&](const float (&ob)[8], bool first) {
+            float sx[4 * l1_steps<NIN>()];
+#pragma unroll
+            for (int i = 0; i < 4 * l1_steps<NIN>(); ++i) {
+                float v = 0.f;
+                if (i < OBS) v = ob[i] * a.obs_scale[i];
+                else if (WIDE && i - OBS < nf) v = (first ? f0[(i - OBS) & 7] : ob[ENV::FUT_SRC]) * a.obs_scale[i];
+                sx[i] = v;
+            }
+#pragma unroll
+            for (int q = 0; q < l1_steps<NIN>(); ++q)
+                xa[q] = L.rg == 0 ? sx[4 * q] : L.rg == 1 ? sx[4 * q + 1] : L.rg == 2 ? sx[4 * q + 2] : sx[4 * q + 3];
+        };
+        make_xa(o, true);
+        float pa[2] = {0.f, 0.f}, prew = 0.f;          // action and reward of the previous step (book lanes record them)
+        lds_barrier();                                  // sEps / sGp; the previous group's last reads of sPart / sPre
+        for (int t = 0; t <= a.n; ++t) {
+            MPG_STAMP_AT(0);
+            float h1[2][4], h2[2][4];
+            forward_group<NIN, ACT, false>(nullptr, sA, sPart, L, w2, r, h1, h2, a.H1, (long)t * ngroups + g, xa, &zmax);
+            if (a.H1) stash_store(a.H2, (long)t * ngroups + g, L, h2);
+            // book lanes, before B2: the action-independent half of this step's model step - the only part of their work
+            // the chain waits for
+            if (booker && t < a.n) {
+                float pre[ENV::NPRE];
+                ENV::pre(o, sEps[t * GROUP + row], pre);
+#pragma unroll
+                for (int i = 0; i < ENV::NPRE; ++i) sPre[row * PRE_STRIDE + i] = pre[i];
+            }
+            MPG_STAMP_AT(6);
+            lds_barrier();
+            MPG_STAMP_AT(5);
+            float act[2] = {0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < ACT; ++k) {
+                const float z = out_preact_tree(sPart, b3r[k], row, k);
+                act[k] = a.out_tanh ? a.out_scale * fast_tanh(z) : z;
+            }
+            if (t == 0 && a.act0) {
+#pragma unroll
+                for (int k = 0; k < ACT; ++k) act[k] = act_first[k];
+            }
+            float on[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, rew = 0.f;
+            if (t < a.n) {
+                float pre[ENV::NPRE];
+#pragma unroll
+                for (int i = 0; i < ENV::NPRE; ++i) pre[i] = sPre[row * PRE_STRIDE + i];
+                ENV::finish(pre, act, on, rew);
+                make_xa(on, false);
+            }
+            // book lanes: the records of this step (its state, and - one step late - the previous action and reward)
+            if (booker) {
+                if (t > 0) book(t - 1, pa, prew);
+                if (live) {
+                    if (a.SA) {
+                        float* rec = a.SA + ((long)t * R + tr) * SAW;
+#pragma unroll
+                        for (int i = 0; i < OBS; ++i) rec[i] = o[i];
+                    }
+#pragma unroll
+                    for (int ks = 0; ks < MAXSEL; ++ks)
+                        if (ks < a.n_sel && a.sel[ks] == t) {
+                            float* xq = a.XQ + ((long)ks * R + tr) * QIN;
+#pragma unroll
+                            for (int i = 0; i < OBS; ++i) xq[i] = o[i] * a.obs_scale[i];
+                            if constexpr (WIDE) {
+#pragma unroll
+                                for (int k = 0; k < 8; ++k)
+                                    if (k < nf) xq[OBS + k] = (t == 0 ? f0[k] : o[ENV::FUT_SRC]) * a.obs_scale[OBS + k];
+                            }
+                            a.GK[(long)ks * R + tr] = G;
+                        }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = on[i];
+            pa[0] = act[0]; pa[1] = act[1]; prew = rew;
+            MPG_STAMP_AT(7);
+        }
+        if (booker) book(a.n, pa, prew);
+#ifdef MPG_STAMP
+        if ((tid & 63) == 0 && a.dbg)
+            for (int k = 0; k < 8; ++k) a.dbg[((long)blockIdx.x * NWAVE + (tid >> 6)) * 8 + k] = (float)g_st_acc[tid >> 6][k];
+#endif
+    }
+    report_activation_range(a.status, zmax);
+}
+
+}  // namespace
+
+int launch_rollout_fwd(const RollArgs& fa_in, int env_kind, long ngroups, int n, hipStream_t s, mpg_prof_t* prof) {
+    RollArgs fa = fa_in;
+    fa.dbg = nullptr;
+#ifdef MPG_STAMP
+    static float* s_dbg = nullptr;
+    static int s_calls = 0;
+    if (!s_dbg) (void)hipMalloc(&s_dbg, 256 * 8 * 8 * sizeof(float));
+    fa.dbg = s_dbg;
+#endif
+    mpg_prof_begin(prof, 0, s);
+    if (env_kind == MPG_ENV_PATH_TRACKING && fa.obs_dim > PathTracking::OBS)
+        { if (fa.pack) hipLaunchKernelGGL((k_rollout_fwd<PathTracking, true, true>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, fa); else hipLaunchKernelGGL((k_rollout_fwd<PathTracking, false, true>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, fa); }
+    else if (env_kind == MPG_ENV_PATH_TRACKING)
+        { if (fa.pack) hipLaunchKernelGGL((k_rollout_fwd<PathTracking, true>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, fa); else hipLaunchKernelGGL((k_rollout_fwd<PathTracking, false>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, fa); }
+    else
+        { if (fa.pack) hipLaunchKernelGGL((k_rollout_fwd<Pendulum, true>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, fa); else hipLaunchKernelGGL((k_rollout_fwd<Pendulum, false>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, fa); }
+    mpg_prof_end(prof, 0, s);
+    MPG_CHECK_LAUNCH("k_rollout_fwd");
+#ifdef MPG_STAMP
+    if (++s_calls % 50 == 0) {
+        static float h[256 * 8 * 8];
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(h, s_dbg, sizeof(h), hipMemcpyDeviceToHost);
+        const int nwg = grid_for(ngroups);
+        for (int w = 0; w < 8; ++w) {
+            double acc[8] = {0};
+            for (int b = 0; b < nwg; ++b) for (int k = 0; k < 8; ++k) acc[k] += h[(b * 8 + w) * 8 + k];
+            fprintf(stderr, "[stamp fwd] wave %d cycles/step:", w);
+            double tot = 0;
+            for (int k = 0; k < 8; ++k) { fprintf(stderr, " p%d=%.0f", k, acc[k] / nwg / (n + 1)); tot += acc[k] / nwg / (n + 1); }
+            fprintf(stderr, " total=%.0f\n", tot);
+        }
+    }
+#endif
+    (void)n;
+    return MPG_OK;
+}
+
+}  // namespace rollout
