@@ -274,8 +274,9 @@ class NADPLearner(_LearnerBase):
                        n=self.n_pi, noise_seed=self.seed, noise_ctr=2 * self.counter + 1)
         out = self._finish(iteration, float(self.args.gradient_clip_norm))
         B = rows * world
-        self.stats.update(dict(q_loss=stats[0], policy_loss=-stats[3] / B, value_mean=stats[2] / B,
-                               q_gradient_norm=self.norms[0], policy_gradient_norm=self.norms[1]))
+        # evaluated only when get_stats() is called: no elementwise launches in the training loop
+        self._lazy_stats = lambda: dict(q_loss=stats[0], policy_loss=-stats[3] / B, value_mean=stats[2] / B,
+                                        q_gradient_norm=self.norms[0], policy_gradient_norm=self.norms[1])
         return out
 
 
@@ -301,8 +302,16 @@ class TD3Learner(_LearnerBase):
     def get_batch_data(self, batch_data, rb, indexes, smooth_eps=None):
         self._get_batch(batch_data)
         self.batch_data['batch_targets'] = self.compute_clipped_double_q_target(smooth_eps)
+        self._y1 = None
         if self.args.buffer_type != 'normal':
-            self.info_for_buffer.update(dict(td_error=self.compute_td_error(), rb=rb, indexes=indexes))
+            if self.num_batch_reuse == 1:
+                # the priorities' td error y1 - Q1(s, a) (td3.py:83-92) needs Q1 on the batch - which the critic-loss pass of
+                # compute_gradient evaluates anyway, on the same weights: keep y1 and finish there (one network pass less)
+                pw, b = self.policy_with_value, self.batch_data
+                self._y1 = ops.q_targets(self.cfg, pw.net('policy', True), pw.net('Q1', True), None, b['batch_rewards'], b['batch_obs_tp1'])
+                self.info_for_buffer.update(dict(td_error=None, rb=rb, indexes=indexes))
+            else:
+                self.info_for_buffer.update(dict(td_error=self.compute_td_error(), rb=rb, indexes=indexes))
 
     def compute_gradient(self, batch_data, rb, indexes, iteration, smooth_eps=None):
         """td3.py:150-188"""
@@ -315,14 +324,21 @@ class TD3Learner(_LearnerBase):
         inv_b = 1.0 / (rows * world)
         stats = self.flat[self.n_grad:]
         for i, nm in enumerate(('Q1', 'Q2')):
-            ops.q_loss_grad(self.cfg, pw.net(nm), b['batch_obs'], b['batch_actions'], b['batch_targets'], inv_b_global=inv_b,
-                            grad_out=self.grad(nm), loss_out=stats[i:i + 1])
+            pending = nm == 'Q1' and getattr(self, '_y1', None) is not None
+            td = ops.q_loss_grad(self.cfg, pw.net(nm), b['batch_obs'], b['batch_actions'], b['batch_targets'], inv_b_global=inv_b,
+                                 grad_out=self.grad(nm), loss_out=stats[i:i + 1], want_td=pending)[2]
+            if pending:        # td = Q1(s, a) - y  =>  y1 - Q1(s, a) = (y1 - y) - td
+                self.info_for_buffer['td_error'] = (self._y1 - b['batch_targets']) - td
+                self._y1 = None
         ops.td3_policy_grad(self.cfg, pw.net('policy'), pw.net('Q1'), pw.net('Q2'), b['batch_obs'], inv_b_global=inv_b,
                             grad_out=self.grad('policy'), stats_out=stats[2:4])
         out = self._finish(iteration, float(self.args.gradient_clip_norm))
         B = rows * world
-        mean = stats[2] / B
-        self.stats.update(dict(q_loss1=stats[0], q_loss2=stats[1], policy_loss=-mean, value_mean=mean,
-                               value_var=stats[3] / B - mean * mean, q_gradient_norm1=self.norms[0],
-                               q_gradient_norm2=self.norms[1], policy_gradient_norm=self.norms[2]))
+
+        def lazy():        # evaluated only when get_stats() is called: no elementwise launches in the training loop
+            mean = stats[2] / B
+            return dict(q_loss1=stats[0], q_loss2=stats[1], policy_loss=-mean, value_mean=mean,
+                        value_var=stats[3] / B - mean * mean, q_gradient_norm1=self.norms[0],
+                        q_gradient_norm2=self.norms[1], policy_gradient_norm=self.norms[2])
+        self._lazy_stats = lazy
         return out

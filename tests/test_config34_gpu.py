@@ -100,6 +100,26 @@ def test_td3_compute_gradient_vs_golden(golden):
     np.testing.assert_allclose(learner.compute_td_error().cpu().numpy(), g['td_error'], rtol=1e-4, atol=3e-6)
 
 
+def test_td3_priorities_td_error_finished_in_the_critic_pass(golden):
+    """With a prioritized buffer and num_batch_reuse = 1 the learner does not evaluate Q1(s, a) a second time for the
+    priorities' td error (td3.py:83-92, handed to the buffer at optimizer.py:351-353): it keeps y1 and finishes
+    y1 - Q1(s, a) from the critic-loss pass of compute_gradient.  Same numbers as the reference's own td_error."""
+    from mpg_amd.config import default_args
+    from mpg_amd.learners import TD3Learner
+    from mpg_amd.policy import PolicyWithQs
+    g = golden('td3_H256_B64.npz')
+    args = default_args('TD3', replay_batch_size=64, buffer_type='priority')
+    learner = TD3Learner(PolicyWithQs, args)
+    _load(learner, g)
+    batch = [dev(g[k]) for k in ('batch_obs', 'batch_actions', 'batch_rewards', 'batch_obs_tp1', 'batch_dones')]
+    idx = torch.arange(64, dtype=torch.int32, device=DEV)
+    learner.compute_gradient(batch, 'the buffer', idx, 0, smooth_eps=dev(g['smooth_eps']))
+    info = learner.get_info_for_buffer()
+    assert info['rb'] == 'the buffer' and info['indexes'] is idx
+    np.testing.assert_allclose(info['td_error'].cpu().numpy(), g['td_error'], rtol=1e-4, atol=3e-6)
+    np.testing.assert_allclose(info['td_error'].cpu().numpy(), learner.compute_td_error().cpu().numpy(), rtol=0, atol=2e-6)
+
+
 def test_td3_at_config4_batch_runs():
     from mpg_amd.config import default_args
     from mpg_amd.learners import TD3Learner
