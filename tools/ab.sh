@@ -3,6 +3,15 @@
 # Each variant is built with MPG_EXTRA_CFLAGS (fwd/bwd per-file flags can be given as FWD=... / BWD=... prefixes:
 # "FWD=-mllvm x BWD= -DFOO"), benched with the default workload, and its per-kernel averages are printed.  The baseline
 # ("") is run first and last.  Leaves the tree built with the shipped flags.
+# Ablation / variant macros the kernels understand (timing or diagnosis only - several give wrong numbers on purpose):
+#   -DMPG_F32_MFMA            exact-fp32 engine (v_mfma_f32_16x16x4_f32) instead of split-fp16        [correct results]
+#   -DMPG_AB_NOMFMA           hidden-layer matrix block reduced to one k-block          -DMPG_AB_NO_ELU8   element-wise ELU
+#   -DMPG_AB_NO_DPPASM        compiler-lowered DPP reduction instead of v_add_f32_dpp   -DMPG_AB_NO_IMGWRITE  LDS image stores dropped
+#   -DMPG_AB_NO_H1            forward sweep stashes h1 of step 0 only     -DMPG_AB_IMAGE_FIRST  image requested before the small pieces
+#   -DMPG_AB_NO_PREDRAW       the env launch does not pre-gather the minibatch window   -DMPG_AB_NODYN        (build.py) no dynamic LDS promotion flag
+#   -DMPG_AB_WG_NOMFMA / -DMPG_AB_WG_NOTHIN   weight gradients without the matrix loop / without the thin part
+#   -DMPG_AB_PKFMA [-DMPG_AB_PKFMA_WAIT]      the packed-FMA form of the thin block that loses products (tools/pk_anomaly.sh)
+#   -DMPG_STAMP / -DMPG_TIMELINE              per-phase cycle stamps (tools/stamp.sh, tools/timeline.sh)
 cd ${GRAFT_REPO_ROOT:-$(dirname "$0")/..}
 STEPS=${STEPS:-400}
 run() {
