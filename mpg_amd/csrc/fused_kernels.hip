@@ -62,6 +62,8 @@ struct TargetArgs {
     int* o_idx;
     float *o_obs, *o_act, *o_rew, *o_obs2, *o_done;
     int* status;               // nullable: MPG_STATUS_* word of the caller
+    float* qpart;              // nullable: SPLIT launch (gridDim.y == 2) - workgroup (p, h) evaluates the target policy and target
+                               // critic h only and leaves gamma-free Q values in qpart[h][rows]; the consumer takes the minimum
     unsigned long long* dbg;   // MPG_TIMELINE builds only
 };
 
@@ -78,6 +80,9 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_target_fused(const TargetArgs a)
     const Lane L;
     const int tid = threadIdx.x;
     const long g0 = (long)blockIdx.x * G2;
+    // split launch: two workgroups per pair of row groups, one per target critic (both evaluate the target policy: a third of
+    // the passes twice instead of half of the chip idle); only half 0 writes the drawn minibatch
+    const int half = a.qpart ? (int)blockIdx.y : -1;
     __shared__ float sRew[G2 * GROUP];
     MPG_TL_DECL
     MPG_TL(0);
@@ -124,7 +129,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_target_fused(const TargetArgs a)
     MPG_TL(2);
     if (a.draw) {
         if (tid < G2 * GROUP) {
-            if (gather) {
+            if (gather && half <= 0) {
                 const long gr = g0 * GROUP + tid;
                 if (a.o_idx) a.o_idx[gr] = (int)sr;
 #pragma unroll
@@ -169,6 +174,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_target_fused(const TargetArgs a)
     for (int qi = 0; qi < 2; ++qi) {
         const float* qp = qi == 0 ? a.q1 : a.q2;
         if (!qp) break;
+        if (half >= 0 && qi != half) continue;          // (workgroup-uniform)
         const Net net = make_net(qp, QIN, 1);
         SmallRegs<QIN, 1> r;
         MPG_LOAD2((load_small<QIN, 1>(net, L, r)), (load_w2<PK>(qi == 0 ? a.pk_q1 : a.pk_q2, net.W2, false, L, w2)));
@@ -191,8 +197,11 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_target_fused(const TargetArgs a)
         const int g2 = tid / GROUP, row = tid % GROUP;
         const long gr = (g0 + g2) * GROUP + row;
         if (gr < a.rows) {
-            const float q = a.q2 ? fminf(sQg[g2][row], sQg[g2][GROUP + row]) : sQg[g2][row];
-            a.y[gr] = (sRew[tid] + a.rshift) * a.rscale + a.gamma * q;      // mpg_learner.py:132-133
+            if (half >= 0) a.qpart[(long)half * a.rows + gr] = sQg[g2][half * GROUP + row];
+            else {
+                const float q = a.q2 ? fminf(sQg[g2][row], sQg[g2][GROUP + row]) : sQg[g2][row];
+                a.y[gr] = (sRew[tid] + a.rshift) * a.rscale + a.gamma * q;      // mpg_learner.py:132-133
+            }
         }
     }
     report_activation_range(a.status, zmax);
@@ -212,6 +221,12 @@ struct QlossArgs {
     float* loss_part;          // [n_q][ngroups]
     float* td;
     int* status;               // nullable: MPG_STATUS_* word of the caller
+    // k_critic_fused only, nullable: the target launch ran in its split form - y = (rew + shift) * scale + gamma * min(qpart[0],
+    // qpart[1]) is finished here (the same arithmetic as k_target_fused's) and written to y_out by the Q1 workgroups
+    const float* qpart;
+    const float* rew;
+    float rshift, rscale, gamma;
+    float* y_out;
 };
 
 template <int QIN, bool PK>
@@ -436,7 +451,12 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_critic_fused(const CriticArgs ca
         const long gr = g * GROUP + tid;
         float e = 0.f;
         if (gr < a.rows) {
-            e = out_preact(m.sPart, net.b3[0], tid, 0) - a.y[gr];
+            float yv;
+            if (a.qpart) {
+                yv = (a.rew[gr] + a.rshift) * a.rscale + a.gamma * fminf(a.qpart[gr], a.qpart[(long)a.rows + gr]);   // mpg_learner.py:132-133
+                if (qi == 0) a.y_out[gr] = yv;
+            } else yv = a.y[gr];
+            e = out_preact(m.sPart, net.b3[0], tid, 0) - yv;
             st.dz3[gr] = e * a.inv_b;
             if (a.td && qi == 0) a.td[gr] = e;
         }
@@ -581,9 +601,11 @@ inline void fill_scale(float (&dst)[8], const mpg_cfg_t* cfg) {
 
 int launch_target_fused(const mpg_cfg_t* cfg, const float* policy_t, const float* q1t, const float* q2t, int rows,
                         const float* rew, const float* obs_tp1, const float* smooth_eps, float sigma, float clipc, float* y,
-                        hipStream_t s, const mpg_replay_draw_t* draw, const DrawOut* draw_out) {
+                        hipStream_t s, const mpg_replay_draw_t* draw, const DrawOut* draw_out, float* qpart) {
     const int od = cfg->obs_dim, ad = cfg->act_dim;
+    MPG_REQUIRE(!qpart || q2t, "launch_target_fused: the split form needs both target critics");
     TargetArgs a;
+    a.qpart = qpart;
     a.draw = 0; a.n_storage = 0; a.dk0 = a.dk1 = a.dc1 = a.dc2 = 0;
     a.d_capacity = a.d_fresh_start = a.d_fresh_count = 0;
     a.r_obs = a.r_act = a.r_rew = a.r_obs2 = nullptr; a.r_done = nullptr; a.o_idx = nullptr;
@@ -628,7 +650,7 @@ int launch_target_fused(const mpg_cfg_t* cfg, const float* policy_t, const float
 #endif
     const bool pk = a.pk_pol && a.pk_q1 && (a.pk_q2 || !a.q2);
     const bool two = ngroups >= MPG_TARGET_G2_MIN_GROUPS;
-    const dim3 grid(two ? (ngroups + 1) / 2 : ngroups), block(NTHREAD);
+    const dim3 grid(two ? (ngroups + 1) / 2 : ngroups, qpart ? 2 : 1), block(NTHREAD);
 #define MPG_TARGET_LAUNCH(O_, A_) \
     do { \
         if (pk && two) hipLaunchKernelGGL((k_target_fused<O_, A_, true, 2>), grid, block, 0, s, a); \
@@ -672,6 +694,7 @@ int launch_qloss_fused(const mpg_cfg_t* cfg, const float* const* q_params, int n
         if (k < n_q) a.st[k] = st[k];
     }
     a.rows = rows; a.x = xspec(obs, od, act, ad, cfg->obs_scale, od); a.y = y; a.inv_b = inv_b; a.loss_part = loss_part; a.td = td;
+    a.qpart = a.rew = nullptr; a.y_out = nullptr; a.rshift = a.gamma = 0.f; a.rscale = 1.f;
     a.status = mpg_status_of(cfg);
     const int ngroups = (rows + GROUP - 1) / GROUP;
     if (qin == 8) { if (a.pkf[0] && a.pkb[0] && (n_q < 2 || (a.pkf[1] && a.pkb[1]))) hipLaunchKernelGGL((k_qloss_fused<8, true>), dim3(ngroups, n_q), dim3(NTHREAD), 0, s, a); else hipLaunchKernelGGL((k_qloss_fused<8, false>), dim3(ngroups, n_q), dim3(NTHREAD), 0, s, a); }
@@ -704,8 +727,10 @@ int launch_qslice_fused(const mpg_cfg_t* cfg, const float* q_params, int qin, in
 
 int launch_critic_fused(const mpg_cfg_t* cfg, const float* const* q_params, int n_q, int rows, const float* obs,
                         const float* act, const float* y, float inv_b, const CriticStash* st, float* loss_part, const float* xq,
-                        const float* gk, const float* gpow, const float* coef, float* ret_part, float* gxq, hipStream_t s) {
+                        const float* gk, const float* gpow, const float* coef, float* ret_part, float* gxq, hipStream_t s,
+                        const float* qpart, const float* rew, float* y_out) {
     MPG_REQUIRE((n_q == 1 || n_q == 2) && rows % GROUP == 0, "launch_critic_fused: n_q / rows");
+    MPG_REQUIRE(!qpart || (rew && y_out), "launch_critic_fused: the split target needs rew and y_out");
     const int od = cfg->obs_dim, ad = cfg->act_dim, qin = od + ad;
     CriticArgs c;
     QlossArgs& a = c.ql;
@@ -716,6 +741,7 @@ int launch_critic_fused(const mpg_cfg_t* cfg, const float* const* q_params, int 
         if (k < n_q) a.st[k] = st[k];
     }
     a.rows = rows; a.x = xspec(obs, od, act, ad, cfg->obs_scale, od); a.y = y; a.inv_b = inv_b; a.loss_part = loss_part; a.td = nullptr;
+    a.qpart = qpart; a.rew = rew; a.y_out = y_out; a.rshift = cfg->rew_shift; a.rscale = cfg->rew_scale; a.gamma = cfg->gamma;
     a.status = mpg_status_of(cfg);
     QsliceArgs& q = c.qs;
     q.q = q_params[0]; q.pkf = a.pkf[0]; q.pkb = a.pkb[0];

@@ -83,7 +83,8 @@ struct DrawOut {
 };
 int launch_target_fused(const mpg_cfg_t* cfg, const float* policy_t, const float* q1t, const float* q2t, int rows,
                         const float* rew, const float* obs_tp1, const float* smooth_eps, float sigma, float clipc, float* y,
-                        hipStream_t s, const mpg_replay_draw_t* draw = nullptr, const DrawOut* draw_out = nullptr);
+                        hipStream_t s, const mpg_replay_draw_t* draw = nullptr, const DrawOut* draw_out = nullptr,
+                        float* qpart = nullptr);
 
 struct CriticStash {       // G16 stashes + dz3 of one critic, kept for the weight-gradient launch
     float *h1, *h2, *dz1, *dz2, *dz3;
@@ -119,7 +120,8 @@ int launch_wgrad_multi(const mpg_cfg_t* cfg, const WgradJob* jobs, int n_jobs, c
 // critic losses + critic at the two selected slices in one launch (launch_qloss_fused + launch_qslice_fused with n_sel == 2)
 int launch_critic_fused(const mpg_cfg_t* cfg, const float* const* q_params, int n_q, int rows, const float* obs,
                         const float* act, const float* y, float inv_b, const CriticStash* st, float* loss_part, const float* xq,
-                        const float* gk, const float* gpow, const float* coef, float* ret_part, float* gxq, hipStream_t s);
+                        const float* gk, const float* gpow, const float* coef, float* ret_part, float* gxq, hipStream_t s,
+                        const float* qpart = nullptr, const float* rew = nullptr, float* y_out = nullptr);
 
 inline size_t stash_floats(int rows) { return (size_t)((rows + GROUP - 1) / GROUP) * GROUP * H; }
 

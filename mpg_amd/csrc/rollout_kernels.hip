@@ -391,7 +391,7 @@ MgLayout mg_layout(const mpg_cfg_t* cfg, int rows, int M, int n, int n_sel, int 
     l.slab_p = wgrad_workspace_floats((int)R, od, 2 * ad);
     l.fused_total = (size_t)n_q * (4 * pad256(l.stash) + pad256(l.dz3) + pad256(l.slab_q)) + pad256(l.loss_part) +
                     2 * pad256(l.h) + pad256(l.sa) + pad256(l.xq) + pad256(l.gk) + pad256(l.gxq) + pad256(l.ret_part) +
-                    2 * pad256(stash_floats(R)) + pad256(l.dz3p) + pad256(l.slab_p);
+                    2 * pad256(stash_floats(R)) + pad256(l.dz3p) + pad256(l.slab_p) + pad256(2 * (size_t)rows);   // (+ the split target's Q values)
     l.fallback0 = std::max(mpg_q_targets_workspace_bytes(cfg, rows), mpg_q_loss_grad_workspace_bytes(cfg, rows));
     l.fallback1 = mpg_rollout_pg_workspace_bytes(cfg, rows, M, n, n_sel, 0);
     return l;
@@ -478,11 +478,19 @@ extern "C" int mpg_mpg_gradients(const mpg_cfg_t* cfg, int n_q, const float* par
     float* ret_part = cv.take(l.ret_part);
     float* DZ1 = cv.take(stash_floats(rows)); float* DZ2 = cv.take(stash_floats(rows)); float* DZ3 = cv.take(l.dz3p);
     float* slab_p = cv.take(l.slab_p);
+    float* qpart = cv.take(2 * (size_t)rows);
 
+    // Split target (MPG_TARGET_SPLIT, default on): with both target critics and one pair of row groups per two CUs the target
+    // launch would leave half of the chip idle (256 groups = 128 workgroups of two); instead workgroup (p, h) runs the target
+    // policy and target critic h on pair p - 256 workgroups, two image loads and two passes each instead of three - and the
+    // critic launch finishes y = r~ + gamma * min(Q1t, Q2t) (same arithmetic, bit-identical y) and writes y_out.
+    static const int split_on = getenv("MPG_TARGET_SPLIT") ? atoi(getenv("MPG_TARGET_SPLIT")) : 1;
+    const bool split = split_on && !y_in && n_q == 2 && n_select == 2 && qt[1] && rows / GROUP >= 256;
     const float* y = y_in;
     if (!y) {   // 1. clipped double-Q (or single-Q) target, mpg_learner.py:126-134
         const DrawOut dout{obs, act, rew, obs_tp1};
-        int rc = launch_target_fused(cfg, policy_t, qt[0], qt[1], rows, rew, obs_tp1, nullptr, 0.f, 0.f, y_out, s, draw, &dout);
+        int rc = launch_target_fused(cfg, policy_t, qt[0], qt[1], rows, rew, obs_tp1, nullptr, 0.f, 0.f, y_out, s, draw, &dout,
+                                     split ? qpart : nullptr);
         if (rc) return rc;
         y = y_out;
     }
@@ -495,7 +503,7 @@ extern "C" int mpg_mpg_gradients(const mpg_cfg_t* cfg, int n_q, const float* par
         // 3.+4. critics (forward, error, input-side backward, mpg_learner.py:326-354) and the critic at the two selected
         //       slices (returns and input gradients) in one launch
         rc = launch_critic_fused(cfg, qp, n_q, rows, obs, act, y, inv_b_global, st, loss_part, XQ, GK, cf.gpow, cf.coef, ret_part,
-                                 GXQ, s);
+                                 GXQ, s, split ? qpart : nullptr, rew, y_out);
         if (rc) return rc;
     } else {
         // 2. critics: forward, error, input-side backward (mpg_learner.py:326-354)
