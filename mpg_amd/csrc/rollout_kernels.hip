@@ -480,12 +480,15 @@ extern "C" int mpg_mpg_gradients(const mpg_cfg_t* cfg, int n_q, const float* par
     float* slab_p = cv.take(l.slab_p);
     float* qpart = cv.take(2 * (size_t)rows);
 
-    // Split target (MPG_TARGET_SPLIT, default on): with both target critics and one pair of row groups per two CUs the target
+    // Split target: with both target critics and one pair of row groups per two CUs the target
     // launch would leave half of the chip idle (256 groups = 128 workgroups of two); instead workgroup (p, h) runs the target
     // policy and target critic h on pair p - 256 workgroups, two image loads and two passes each instead of three - and the
     // critic launch finishes y = r~ + gamma * min(Q1t, Q2t) (same arithmetic, bit-identical y) and writes y_out.
-    static const int split_on = getenv("MPG_TARGET_SPLIT") ? atoi(getenv("MPG_TARGET_SPLIT")) : 1;
-    const bool split = split_on && !y_in && n_q == 2 && n_select == 2 && qt[1] && rows / GROUP >= 256;
+#ifdef MPG_AB_TARGET_SINGLE          // A/B build (tools/ab_split.sh): the single target launch
+    const bool split = false;
+#else
+    const bool split = !y_in && n_q == 2 && n_select == 2 && qt[1] && rows / GROUP >= 256;
+#endif
     const float* y = y_in;
     if (!y) {   // 1. clipped double-Q (or single-Q) target, mpg_learner.py:126-134
         const DrawOut dout{obs, act, rew, obs_tp1};
@@ -538,9 +541,13 @@ extern "C" int mpg_mpg_gradients(const mpg_cfg_t* cfg, int n_q, const float* par
         sums[ns].src = ret_part + (size_t)k * ngroups * 2; sums[ns].n = ngroups; sums[ns].stride = 2; sums[ns].dst = stats + 2 + k; ++ns;
         sums[ns].src = ret_part + (size_t)k * ngroups * 2 + 1; sums[ns].n = ngroups; sums[ns].stride = 2; sums[ns].dst = stats + 2 + n_select + k; ++ns;
     }
-    // MPG_WGRAD_EARLY=1 (experiment): the critics' chunk products right behind the critic launch, while their stashes are still in
-    // the caches, the policy's behind the reverse sweep, one reduction at the end (10 launches instead of 9)
-    static const int early = getenv("MPG_WGRAD_EARLY") ? atoi(getenv("MPG_WGRAD_EARLY")) : 0;
+    // -DMPG_AB_WGRAD_EARLY (A/B build, tools/ab_early.sh; slower): the critics' chunk products right behind the critic
+    // launch, while their stashes are still in the caches, the policy's behind the reverse sweep, one reduction at the end
+#ifdef MPG_AB_WGRAD_EARLY
+    constexpr bool early = true;
+#else
+    constexpr bool early = false;
+#endif
     if (early) {
         rc = launch_wgrad_multi(cfg, jobs, n_q, nullptr, 0, nullptr, s, 1, 0);
         if (rc) return rc;
