@@ -101,3 +101,14 @@ _Zfoo:
     assert n == 2 and len(b) == 1 and 'v_mov_b32_dpp' in b[0][2]          # one wait state is not enough, a range write counts
     bad, n = C.check()
     assert n > 1000 and bad == [], bad[:5]
+
+
+def test_library_sources_read_no_environment_variables():
+    """DESIGN.md section 1, "No process-wide state": the library's behaviour is a function of its arguments - no getenv in the
+    product sources (A/B variants are compile-time macros, tools/ab.sh)."""
+    import os
+    import re
+    csrc = os.path.join(os.path.dirname(__file__), '..', 'mpg_amd', 'csrc')
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith(('.hip', '.h', '.cpp')):
+            assert not re.search(r'\bgetenv\s*\(', open(os.path.join(csrc, f)).read()), f
