@@ -208,7 +208,7 @@ class MPGLearner(_LearnerBase):
             out = self._finish(iteration, float(self.args.gradient_clip_norm))
             self._lazy_stats = self._mpg_lazy_stats(iteration)
             return out
-        # one native call: critic losses/gradients + model rollout + mixed policy gradient (7 launches); the targets
+        # one native call: critic losses/gradients + model rollout + mixed policy gradient (5 launches); the targets
         # were computed by get_batch_data (the reference caches them per batch, mpg_learner.py:402-403)
         ops.mpg_gradients(self.cfg, len(pw.names) - 1, pw.params, pw.targets, b['batch_obs'], b['batch_actions'],
                           b['batch_rewards'], b['batch_obs_tp1'], b['batch_targets'], select, ws, self.flat[:self.n_grad],
