@@ -127,6 +127,18 @@ struct Lane {
     __device__ int row(int j) const { return 4 * rg + j; }
 };
 
+// Static issue priority for the second-dispatched half of the workgroup.  The two waves of a SIMD (w and w + 4) share its
+// matrix pipe and vector issue, arbitrated by priority, then AGE: at equal priority the younger wave loses every
+// arbitration, leaves each matrix block last and is the one the step's barriers wait for.  One s_setprio for waves 4..7 at
+// kernel entry (never flipped) evens the pair out: reverse sweep 81.9 -> 80.6 us, forward sweep 65.3 -> 64.8 us
+// (tools/ab_scale.sh; levels 3 for the young half or 1 for the OLD half are slower; in the critic / target / network kernels
+// it made no difference or a negative one and is not used).  -DMPG_AB_NO_PRIO: A/B build without it.
+__device__ __forceinline__ void prefer_young_waves() {
+#ifndef MPG_AB_NO_PRIO
+    if (threadIdx.x >= 256) __builtin_amdgcn_s_setprio(1);
+#endif
+}
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding GLOBAL store
 // (s_waitcnt vmcnt(0)), which puts the HBM write latency of the activation stash on the serial chain of every
 // rollout step; nothing inside the engine kernels communicates through global memory, so LDS ordering is all that

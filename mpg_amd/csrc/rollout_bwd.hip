@@ -21,6 +21,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_bwd(const RollBwdArgs a)
     __shared__ __attribute__((aligned(16))) float sCarry[GROUP * 16];
     const Lane L;
     const int tid = threadIdx.x;
+    prefer_young_waves();
     const Net net = make_net(a.policy, OD, 2 * ACT);
     float w2t[128];
     SmallRegs<NIN, ACT> r;

@@ -24,6 +24,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_fwd(const RollArgs a) {
     __shared__ __attribute__((aligned(16))) float sPre[GROUP * PRE_STRIDE];
     const Lane L;
     const int tid = threadIdx.x;
+    prefer_young_waves();
     if (tid <= a.n) sGp[tid] = powf(a.gamma, (float)tid);     // tf.pow(gamma, ri) in float32, mpg_learner.py:245
     const Net net = make_net(a.policy, OD, 2 * ACT);
     float w2[128];
