@@ -19,9 +19,22 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_bwd(const RollBwdArgs a)
     // carry state of the 16 trajectory lanes between steps (adjoint of the next obs, record of the next step): kept in
     // LDS because registers are allocated for all 512 lanes while only 16 use them (the kernel sits at the 256 VGPR limit)
     __shared__ __attribute__((aligned(16))) float sCarry[GROUP * 16];
+    // dL/d(raw reward) per step from LDS: `a.rho[t]` with a run-time t is a scalar load from the kernel-argument segment plus a
+    // wait on the serial chain of EVERY step (and a loop over `a.sel[ks]` with a run-time ks is one per slice)
+    __shared__ float sRho[MAXN];
     const Lane L;
     const int tid = threadIdx.x;
     prefer_young_waves();
+    if (tid < MAXN) {
+        float rv = 0.f;
+#pragma unroll
+        for (int k = 0; k < MAXN; ++k) rv = tid == k ? a.rho[k] : rv;       // (constant indices: SGPR reads, no memory)
+        sRho[tid] = rv;
+    }
+    unsigned selmask = 0;                      // bit t: step t is a selected slice
+#pragma unroll
+    for (int ks = 0; ks < MAXSEL; ++ks)
+        if (ks < a.n_sel) selmask |= 1u << a.sel[ks];
     const Net net = make_net(a.policy, OD, 2 * ACT);
     float w2t[128];
     SmallRegs<NIN, ACT> r;
@@ -74,8 +87,15 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_bwd(const RollBwdArgs a)
                         float lam_next[8];
 #pragma unroll
                         for (int i = 0; i < 8; ++i) lam_next[i] = sCarry[tid * 16 + i];
+                        #ifdef MPG_AB_BWD_KERNARG
                         ENV::vjp(o, act, on, lam_next, a.rho[t], lam, ga);
+#else
+                        ENV::vjp(o, act, on, lam_next, sRho[t], lam, ga);
+#endif
                     }
+#ifndef MPG_AB_BWD_KERNARG
+                    if ((selmask >> t) & 1u)             // (two of the 26 steps: the slice search stays a plain loop)
+#endif
                     for (int ks = 0; ks < a.n_sel; ++ks)
                         if (a.sel[ks] == t) {
                             const float* gx = a.GXQ + ((long)ks * R + tr) * QIN;

@@ -14,6 +14,7 @@
 #   -DMPG_AB_TARGET_SINGLE                    the target kernel as one launch over all three networks (tools/ab_split.sh)
 #   -DMPG_AB_WGRAD_EARLY                      the critics' weight-gradient jobs ahead of the reverse sweep (tools/ab_early.sh)
 #   -DMPG_AB_NO_PRIO                           the sweeps without the static issue priority of waves 4..7
+#   -DMPG_AB_BWD_KERNARG                       reverse sweep with run-time indices into the kernel arguments (rho[t], sel[ks]) as before
 #   -DMPG_STAMP / -DMPG_TIMELINE              per-phase cycle stamps (tools/stamp.sh, tools/timeline.sh)
 cd ${GRAFT_REPO_ROOT:-$(dirname "$0")/..}
 STEPS=${STEPS:-400}
