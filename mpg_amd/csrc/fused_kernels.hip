@@ -123,6 +123,18 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_target_fused(const TargetArgs a)
     float w2[128], h1[2][4], h2[2][4];
     float zmax = 0.f;                          // largest first-layer activation seen by this lane (the engine's envelope, mlp_core.h)
     const Net pnet = make_net(a.pol, OBS, 2 * ACT);
+    // output biases and smoothing noise of the output threads, requested up front (at their point of use each is a memory
+    // round trip between two passes)
+    float pb3 = 0.f, qb3[2] = {0.f, 0.f}, sm_eps = 0.f;
+    if (tid < G2 * GROUP * ACT) {
+        pb3 = pnet.b3[tid % ACT];
+        const long gr0 = (g0 + tid / (GROUP * ACT)) * GROUP + (tid / ACT) % GROUP;
+        if (a.smooth_eps && gr0 < a.rows) sm_eps = a.smooth_eps[gr0 * ACT + tid % ACT];
+    }
+    if (tid < G2 * GROUP) {
+        qb3[0] = make_net(a.q1, OBS + ACT, 1).b3[0];
+        if (a.q2) qb3[1] = make_net(a.q2, OBS + ACT, 1).b3[0];
+    }
     SmallRegs<OBS, ACT> pr;
     MPG_TL(1);
     MPG_LOAD2((load_small<OBS, ACT>(pnet, L, pr)), (load_w2<PK>(a.pk_pol, pnet.W2, false, L, w2)));
@@ -162,9 +174,9 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_target_fused(const TargetArgs a)
     if (tid < G2 * GROUP * ACT) {
         const int g2 = tid / (GROUP * ACT), row = (tid / ACT) % GROUP, k = tid % ACT;
         const long gr = (g0 + g2) * GROUP + row;
-        const float z = out_preact(g2 == 0 ? m.sPart : m.sPartX, pnet.b3[k], row, k);
+        const float z = out_preact(g2 == 0 ? m.sPart : m.sPartX, pb3, row, k);
         float act = a.out_tanh ? a.out_scale * tanhf(z) : z;
-        if (a.smooth_eps && gr < a.rows) act += fminf(fmaxf(a.sigma * a.smooth_eps[gr * ACT + k], -a.clipc), a.clipc);
+        if (a.smooth_eps && gr < a.rows) act += fminf(fmaxf(a.sigma * sm_eps, -a.clipc), a.clipc);
         sXg[g2][row * XS + OBS + k] = act;
     }
     MPG_TL(5);
@@ -186,7 +198,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_target_fused(const TargetArgs a)
         }
         if (tid < G2 * GROUP) {
             const int g2 = tid / GROUP, row = tid % GROUP;
-            sQg[g2][qi * GROUP + row] = out_preact(g2 == 0 ? m.sPart : m.sPartX, net.b3[0], row, 0);
+            sQg[g2][qi * GROUP + row] = out_preact(g2 == 0 ? m.sPart : m.sPartX, qb3[qi], row, 0);
         }
         MPG_TL(11 + 6 * qi);
         lds_barrier();
@@ -433,6 +445,22 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_critic_fused(const CriticArgs ca
         const long gr = (sl * ngroups + g) * GROUP + row;
         xv2 = i < QIN ? q.xq[gr * QIN + i] : 0.f;
     }
+    // ... and so is everything the 16 output lanes will need behind the forward passes (the target's inputs, the slices'
+    // reward sums, the output bias): loaded where they are used they are a memory round trip in the middle of the kernel, and
+    // the wait in front of them (vmcnt counts stores too) also drains the stash stores issued just before
+    float t_y = 0.f, t_rew = 0.f, t_q1 = 0.f, t_q2 = 0.f, gk_in[2] = {0.f, 0.f};
+    const float b3v = net.b3[0];
+    if (tid < GROUP) {
+        const long gr = g * GROUP + tid;
+        if (gr < a.rows) {
+            if (a.qpart) { t_rew = a.rew[gr]; t_q1 = a.qpart[gr]; t_q2 = a.qpart[(long)a.rows + gr]; }
+            else t_y = a.y[gr];
+        }
+        if (slices) {
+#pragma unroll
+            for (int sl = 0; sl < 2; ++sl) gk_in[sl] = q.gk[(sl * ngroups + g) * GROUP + tid];
+        }
+    }
     float w2[128], h1[3][2][4], h2[3][2][4], dz1[2][4], dz2[2][4];
     float zmax = 0.f;
     SmallRegs<QIN, 1> r;
@@ -451,12 +479,12 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_critic_fused(const CriticArgs ca
         const long gr = g * GROUP + tid;
         float e = 0.f;
         if (gr < a.rows) {
-            float yv;
+            float yv = t_y;
             if (a.qpart) {
-                yv = (a.rew[gr] + a.rshift) * a.rscale + a.gamma * fminf(a.qpart[gr], a.qpart[(long)a.rows + gr]);   // mpg_learner.py:132-133
+                yv = (t_rew + a.rshift) * a.rscale + a.gamma * fminf(t_q1, t_q2);   // mpg_learner.py:132-133
                 if (qi == 0) a.y_out[gr] = yv;
-            } else yv = a.y[gr];
-            e = out_preact(m.sPart, net.b3[0], tid, 0) - yv;
+            }
+            e = out_preact(m.sPart, b3v, tid, 0) - yv;
             st.dz3[gr] = e * a.inv_b;
             if (a.td && qi == 0) a.td[gr] = e;
         }
@@ -469,8 +497,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_critic_fused(const CriticArgs ca
         for (int sl = 0; sl < 2; ++sl) {
             forward_group<QIN, 1>(sX2 + sl * GROUP * XS, m.sA, m.sPart, L, w2, r, h1[1 + sl], h2[1 + sl], nullptr, 0, nullptr, &zmax);
             if (tid < GROUP) {
-                const long gr = (sl * ngroups + g) * GROUP + tid;
-                sQ2[sl * GROUP + tid] = q.gk[gr] + q.gpow[sl] * out_preact(m.sPart, net.b3[0], tid, 0);   // mpg_learner.py:266
+                sQ2[sl * GROUP + tid] = gk_in[sl] + q.gpow[sl] * out_preact(m.sPart, b3v, tid, 0);   // mpg_learner.py:266
                 sD32[sl * GROUP * MAXOUT + d3_index(tid, 0)] = q.coef[sl];
             }
         }

@@ -49,6 +49,8 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_forward(const FwdArgs a) {
         return v;
     };
     float xv = x_value(blockIdx.x);
+    float b3v = 0.f;             // this output thread's bias, requested up front (at its point of use it is a memory round trip)
+    if (threadIdx.x < G2 * GROUP * OU) b3v = net.b3[threadIdx.x % OU];
     float zmax = 0.f;
     bool saw_nan = false;                       // worker.py:95-107 judge_is_nan, on the device: inputs and outputs of the pass
     load_small<IN, OU>(net, L, r);
@@ -77,7 +79,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_forward(const FwdArgs a) {
             const int g2 = tid / (GROUP * OU), row = (tid / OU) % GROUP, o = tid % OU;
             const long gr = (u * G2 + g2) * GROUP + row;
             if (gr < a.rows) {
-                float z = out_preact(sPart + g2 * NWAVE * GROUP * MAXOUT, net.b3[o], row, o);
+                float z = out_preact(sPart + g2 * NWAVE * GROUP * MAXOUT, b3v, row, o);
                 float y = a.out_tanh ? a.out_scale * tanhf(z) : z;
                 if (a.sigma > 0.f) {   // OffPolicyWorker.sample: action += N(0, sigma), worker.py:97-98
                     Philox4 p = philox4x32_10((uint32_t)gr, a.c1, a.c2, 0x5eedu + (uint32_t)o, a.k0, a.k1);
