@@ -116,7 +116,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_bwd(const RollBwdArgs a)
                 for (int k = 0; k < ACT; ++k) {
                     float d = ga[k];
                     if (a.out_tanh) {
-                        const float th = act[k] / a.out_scale;
+                        const float th = act[k] * a.inv_out_scale;
                         d *= a.out_scale * (1.f - th * th);
                     }
                     sD3[d3_index(tid, k)] = d;

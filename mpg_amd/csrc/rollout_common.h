@@ -222,7 +222,7 @@ struct RollBwdArgs {
     int obs_dim;
     float obs_scale[16];
     int out_tanh;
-    float out_scale;
+    float out_scale, inv_out_scale;     // (the reciprocal from the host: a division on the serial chain is ten instructions)
     const float *H1, *H2, *SA;
     int sel[MAXSEL], n_sel;
     const float* GXQ;                   // [n_sel][R][OBS+ACT] dL/d(critic input) at the selected slices

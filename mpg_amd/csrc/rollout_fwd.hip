@@ -61,7 +61,9 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_fwd(const RollArgs a) {
         float act_first[2] = {0.f, 0.f};
         float f0[WIDE ? 8 : 1] = {};                                    // look-ahead entries of the start observation
         if (live) {
-            const float* src = a.obs0 + (tr % a.rows) * OD;
+            // (M == 1: the trajectory IS the batch row - no 64-bit modulo, ~150 instructions, in front of the first loads)
+            const long brow = a.M == 1 ? tr : tr % a.rows;
+            const float* src = a.obs0 + brow * OD;
 #pragma unroll
             for (int i = 0; i < OBS; ++i) o[i] = src[i];
             if constexpr (WIDE) {
@@ -70,7 +72,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_fwd(const RollArgs a) {
             }
             if (a.act0) {
 #pragma unroll
-                for (int k = 0; k < ACT; ++k) act_first[k] = a.act0[(tr % a.rows) * ACT + k];
+                for (int k = 0; k < ACT; ++k) act_first[k] = a.act0[brow * ACT + k];
             }
         }
         // the whole group's model noise goes to LDS up front (one value per thread), off the serial chain: either the

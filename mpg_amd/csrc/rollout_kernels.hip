@@ -190,7 +190,7 @@ int run_rollout_bwd(const mpg_cfg_t* cfg, const float* policy_params, int rows, 
     ba.policy = policy_params; ba.rows = rows; ba.M = M; ba.n = n;
     ba.obs_dim = fa.obs_dim;
     for (int i = 0; i < 16; ++i) ba.obs_scale[i] = fa.obs_scale[i];
-    ba.out_tanh = fa.out_tanh; ba.out_scale = fa.out_scale;
+    ba.out_tanh = fa.out_tanh; ba.out_scale = fa.out_scale; ba.inv_out_scale = 1.f / fa.out_scale;
     ba.H1 = H1; ba.H2 = H2; ba.SA = SA; ba.n_sel = n_select;
     for (int k = 0; k < MAXSEL; ++k) ba.sel[k] = fa.sel[k];
     ba.GXQ = GXQ;
