@@ -29,8 +29,10 @@ EXTRA = {'env_path_tracking.hip': ['-ffp-contract=off'],
          # (MPG_FWD_CFLAGS / MPG_BWD_CFLAGS override them in experiments: tools/ab.sh "FWD=... BWD=...")
          # forward sweep: max-memory-clause measures 64.5 us against 68.4 with the default strategy
          'rollout_fwd.hip': os.environ.get('MPG_FWD_CFLAGS', '-mllvm -amdgpu-sched-strategy=max-memory-clause').split(),
-         # reverse sweep: the same strategy measures 1.7 us faster than the default
-         'rollout_bwd.hip': os.environ.get('MPG_BWD_CFLAGS', '-mllvm -amdgpu-sched-strategy=max-memory-clause').split()}
+         # reverse sweep: the same strategy measures 1.7 us faster than the default; without the SLP vectorizer (which turns the
+         # model adjoint on the serial chain into v_pk_*_f32 plus the register moves that assemble their operand pairs) it
+         # measures another 1.3 us faster (77.3 - 77.6 vs 78.7 - 78.9 us in alternating runs; no effect on the forward sweep)
+         'rollout_bwd.hip': os.environ.get('MPG_BWD_CFLAGS', '-mllvm -amdgpu-sched-strategy=max-memory-clause -fno-slp-vectorize').split()}
 
 
 def hipcc():
