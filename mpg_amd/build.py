@@ -32,7 +32,11 @@ EXTRA = {'env_path_tracking.hip': ['-ffp-contract=off'],
          # reverse sweep: the same strategy measures 1.7 us faster than the default; without the SLP vectorizer (which turns the
          # model adjoint on the serial chain into v_pk_*_f32 plus the register moves that assemble their operand pairs) it
          # measures another 1.3 us faster (77.3 - 77.6 vs 78.7 - 78.9 us in alternating runs; no effect on the forward sweep)
-         'rollout_bwd.hip': os.environ.get('MPG_BWD_CFLAGS', '-mllvm -amdgpu-sched-strategy=max-memory-clause -fno-slp-vectorize').split()}
+         # and with the SLP vectorizer off the iterative-ilp strategy is the best of those that build (75.2 - 75.6 vs 76.6 - 77.5 us
+         # for max-memory-clause, 80 default, 94 max-ilp; iterative-minreg / -maxocc: 2x slower or worse)
+         'rollout_bwd.hip': os.environ.get('MPG_BWD_CFLAGS', '-mllvm -amdgpu-sched-strategy=iterative-ilp -fno-slp-vectorize').split(),
+         # the pendulum instantiations (NADP, config 3) measure 10 us slower under those and keep max-memory-clause with SLP
+         'rollout_bwd_pendulum.hip': ['-mllvm', '-amdgpu-sched-strategy=max-memory-clause']}
 
 
 def hipcc():
