@@ -28,7 +28,12 @@ EXTRA = {'env_path_tracking.hip': ['-ffp-contract=off'],
          # the two rollout sweeps are separate translation units so that each gets the scheduling options that suit it
          # (MPG_FWD_CFLAGS / MPG_BWD_CFLAGS override them in experiments: tools/ab.sh "FWD=... BWD=...")
          # forward sweep: max-memory-clause measures 64.5 us against 68.4 with the default strategy
-         'rollout_fwd.hip': os.environ.get('MPG_FWD_CFLAGS', '-mllvm -amdgpu-sched-strategy=max-memory-clause').split(),
+         # (round 3: with the pendulum instantiations in their own translation unit - iterative-ilp crashes the register allocator on
+         # them - iterative-ilp measures 63.7 - 63.9 us against 64.9 for max-memory-clause)
+         'rollout_fwd.hip': os.environ.get('MPG_FWD_CFLAGS', '-mllvm -amdgpu-sched-strategy=iterative-ilp').split(),
+         # experiments only (tools/ab_flags.sh): per-file flags of the other two engine translation units
+         'fused_kernels.hip': os.environ.get('MPG_FUSED_CFLAGS', '').split(),
+         'mlp_kernels.hip': os.environ.get('MPG_MLP_CFLAGS', '').split(),
          # reverse sweep: the same strategy measures 1.7 us faster than the default; without the SLP vectorizer (which turns the
          # model adjoint on the serial chain into v_pk_*_f32 plus the register moves that assemble their operand pairs) it
          # measures another 1.3 us faster (77.3 - 77.6 vs 78.7 - 78.9 us in alternating runs; no effect on the forward sweep)
@@ -36,7 +41,8 @@ EXTRA = {'env_path_tracking.hip': ['-ffp-contract=off'],
          # for max-memory-clause, 80 default, 94 max-ilp; iterative-minreg / -maxocc: 2x slower or worse)
          'rollout_bwd.hip': os.environ.get('MPG_BWD_CFLAGS', '-mllvm -amdgpu-sched-strategy=iterative-ilp -fno-slp-vectorize').split(),
          # the pendulum instantiations (NADP, config 3) measure 10 us slower under those and keep max-memory-clause with SLP
-         'rollout_bwd_pendulum.hip': ['-mllvm', '-amdgpu-sched-strategy=max-memory-clause']}
+         'rollout_bwd_pendulum.hip': ['-mllvm', '-amdgpu-sched-strategy=max-memory-clause'],
+         'rollout_fwd_pendulum.hip': ['-mllvm', '-amdgpu-sched-strategy=max-memory-clause']}
 
 
 def hipcc():

@@ -220,6 +220,16 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_fwd(const RollArgs a) {
 
 }  // namespace
 
+// Compiled twice, like rollout_bwd.hip: as itself (path tracking) and through rollout_fwd_pendulum.hip (MPG_FWD_PENDULUM_PART)
+// for the pendulum instantiations, so that each environment's sweep gets its own scheduling flags (mpg_amd/build.py).
+#ifdef MPG_FWD_PENDULUM_PART
+void launch_rollout_fwd_pendulum(const RollArgs& fa, long ngroups, hipStream_t s) {
+    if (fa.pack) hipLaunchKernelGGL((k_rollout_fwd<Pendulum, true>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, fa);
+    else hipLaunchKernelGGL((k_rollout_fwd<Pendulum, false>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, fa);
+}
+#else
+void launch_rollout_fwd_pendulum(const RollArgs& fa, long ngroups, hipStream_t s);
+
 int launch_rollout_fwd(const RollArgs& fa_in, int env_kind, long ngroups, int n, hipStream_t s, mpg_prof_t* prof) {
     RollArgs fa = fa_in;
     fa.dbg = nullptr;
@@ -235,7 +245,7 @@ int launch_rollout_fwd(const RollArgs& fa_in, int env_kind, long ngroups, int n,
     else if (env_kind == MPG_ENV_PATH_TRACKING)
         { if (fa.pack) hipLaunchKernelGGL((k_rollout_fwd<PathTracking, true>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, fa); else hipLaunchKernelGGL((k_rollout_fwd<PathTracking, false>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, fa); }
     else
-        { if (fa.pack) hipLaunchKernelGGL((k_rollout_fwd<Pendulum, true>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, fa); else hipLaunchKernelGGL((k_rollout_fwd<Pendulum, false>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, fa); }
+        launch_rollout_fwd_pendulum(fa, ngroups, s);
     mpg_prof_end(prof, 0, s);
     MPG_CHECK_LAUNCH("k_rollout_fwd");
 #ifdef MPG_STAMP
@@ -257,5 +267,6 @@ int launch_rollout_fwd(const RollArgs& fa_in, int env_kind, long ngroups, int n,
     (void)n;
     return MPG_OK;
 }
+#endif   // MPG_FWD_PENDULUM_PART
 
 }  // namespace rollout
