@@ -22,7 +22,7 @@ COMMON = os.environ.get('MPG_EXTRA_CFLAGS', '').split() + ['-O3', '-fPIC', '-std
           '-mllvm', '-disable-promote-alloca-to-lds',
           '-I' + os.path.join(HERE, '..', 'include')]
 # per-file extras: the real-env kernel mirrors the reference op-by-op, so no fused multiply-adds there
-EXTRA = {'env_path_tracking.hip': ['-ffp-contract=off'],
+EXTRA = {'env_path_tracking.hip': ['-ffp-contract=off'] + os.environ.get('MPG_ENV_CFLAGS', '').split(),
          # same reason of a different kind: the step and the fused step+store+reset kernel must round identically
          'env_cart_pole.hip': ['-ffp-contract=off'],
          # the two rollout sweeps are separate translation units so that each gets the scheduling options that suit it
