@@ -493,6 +493,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_critic_fused(const CriticArgs ca
     }
     // ---- forward: the two slices (Q1 workgroups only; wave-uniform branch) ----
     if (slices) {
+#ifdef MPG_AB_CRITIC_SLICES_SEQ      // A/B: the two slices one after the other
 #pragma unroll
         for (int sl = 0; sl < 2; ++sl) {
             forward_group<QIN, 1>(sX2 + sl * GROUP * XS, m.sA, m.sPart, L, w2, r, h1[1 + sl], h2[1 + sl], nullptr, 0, nullptr, &zmax);
@@ -501,6 +502,18 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_critic_fused(const CriticArgs ca
                 sD32[sl * GROUP * MAXOUT + d3_index(tid, 0)] = q.coef[sl];
             }
         }
+#else
+        // the two slices as a pair behind one pair of barriers (forward_group2: the same arithmetic per group).  m.sPart of the
+        // batch group was read by its 16 output lanes above, in front of the barriers inside
+        forward_group2<QIN, 1>(sX2, sX2 + GROUP * XS, m.sA, m.sA1, m.sPart, m.sPartX, L, w2, r, h1[1], h2[1], h1[2], h2[2], &zmax);
+        if (tid < GROUP) {
+#pragma unroll
+            for (int sl = 0; sl < 2; ++sl) {
+                sQ2[sl * GROUP + tid] = gk_in[sl] + q.gpow[sl] * out_preact(sl == 0 ? m.sPart : m.sPartX, b3v, tid, 0);   // mpg_learner.py:266
+                sD32[sl * GROUP * MAXOUT + d3_index(tid, 0)] = q.coef[sl];
+            }
+        }
+#endif
     }
     MPG_TL(4);
     report_activation_range(a.status, zmax);
