@@ -41,7 +41,7 @@ sys.path.insert(0, ROOT)
 
 B_PER_GPU = 4096
 N_STEP = 25
-BURN_IN_STEPS = 200
+BURN_IN_STEPS = int(os.environ.get('MPG_BENCH_BURN_IN', '200'))    # (the multi-rank dry runs of tests/test_dist_gpu.py shorten it)
 # Algorithmic work of the two rollout sweeps per start state (n = 25 -> 26 policy evaluations), DESIGN.md §4.
 #   bytes (HBM): every evaluation stashes / re-reads the two 256-wide hidden activations in float32 (2 x 1 KiB) plus a
 #                32 B (obs | action) record; the reverse sweep also reads 2 x 32 B of critic input gradients and writes the
@@ -472,6 +472,8 @@ def main():
     wg_ms, wg_n = prof.read(5)
     tgt_ms, tgt_n = prof.read(6)
     crit_ms, crit_n = prof.read(7)
+    xch_ms, xch_n = prof.read(8)                     # the gradient exchange (None on one GPU: there is none)
+    adam_ms, adam_n = prof.read(9)
     prof.stop()
     n_sampled = (a.steps + PROF_EVERY - 1) // PROF_EVERY
     assert fwd_n == n_sampled and bwd_n == n_sampled, (fwd_n, bwd_n, n_sampled)
@@ -485,6 +487,25 @@ def main():
     torch.cuda.synchronize()
     gc.enable()
     per_step = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(a.steps))
+    # env `step` alone (SURVEY section 8d asks for BOTH env rates: step only - worker.py:108 - and step + store + reset, the fused
+    # launch the training step uses - worker.py:108-112): 64 back-to-back launches of mpg_env_step on a scratch copy of the
+    # worker's state, one HIP event pair around the batch on the launch stream (not part of `value`)
+    from mpg_amd import _lib as L
+    e_state, e_act = worker.env._state.clone(), torch.zeros(B_PER_GPU, 2, device=dev)
+    e_obs, e_rew = torch.empty(B_PER_GPU, 6, device=dev), torch.empty(B_PER_GPU, device=dev)
+    e_done, e_di = torch.empty(B_PER_GPU, dtype=torch.uint8, device=dev), torch.empty(B_PER_GPU, dtype=torch.uint8, device=dev)
+    es = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+
+    def env_step_only(k):
+        for _ in range(k):
+            L.call('mpg_env_step', L.c_int(0), L.c_int(B_PER_GPU), L.c_int(6), L.ptr(e_state), L.ptr(e_act), L.ptr(e_obs), L.ptr(e_rew),
+                   L.ptr(e_done), L.ptr(e_di), L.stream())
+    env_step_only(8)
+    es[0].record()
+    env_step_only(64)
+    es[1].record()
+    torch.cuda.synchronize()
+    step_only_ms = es[0].elapsed_time(es[1]) / 64
     finite = bool(torch.isfinite(worker.policy_with_value.params).all().item())
     assert finite and int(worker.policy_with_value.nonfinite.sum().item()) == 0, 'non-finite parameters after the timed region'
     worker.policy_with_value.check_status()          # raises if the split-fp16 engine left its numerical envelope anywhere
@@ -555,10 +576,19 @@ def main():
         'roofline': dominant,
         'roofline_other_rollout_kernel': other,
         'other_kernels_avg_ms': {'k_target_fused': tgt_ms, 'k_critic_fused': crit_ms, 'k_wgrad_multi': wg_ms,
-                                 'k_forward (worker policy)': pol_ms, 'k_step_store_reset (env)': env_ms},
+                                 'k_forward (worker policy)': pol_ms, 'k_step_store_reset (env)': env_ms,
+                                 'k_clip_adam_polyak': adam_ms},
+        # the ONE exchange step per gradient step (all-reduce of the flat [gradients | statistics] buffer), HIP events on the
+        # launch stream around every PROF_EVERY-th exchange of the timed region on rank 0; null on one GPU (none is enqueued)
+        'exchange_ms': xch_ms, 'exchange_launches': xch_n,
         'env_step_kernel': {'kernel': 'k_step_store_reset', 'avg_ms': env_ms, 'launches': env_n,
                             'env_steps_per_sec_kernel_only': B_PER_GPU / (env_ms * 1e-3) if env_ms else None,
                             'algorithmic_bytes_per_env_step': 85},
+        # both env rates of SURVEY section 8d under stable keys (kernel-only, 4096 agents per launch)
+        'env_steps_per_sec_step_only': B_PER_GPU / (step_only_ms * 1e-3),
+        'env_steps_per_sec_step_store_reset': B_PER_GPU / (env_ms * 1e-3) if env_ms else None,
+        'env_step_only_kernel': {'kernel': 'k_step (mpg_env_step)', 'avg_ms': step_only_ms, 'launches': 64,
+                                 'timed_with': 'one HIP event pair around 64 back-to-back launches after the timed region'},
     }
     if world == 1 and not a.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline()

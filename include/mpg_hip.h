@@ -108,16 +108,21 @@ enum {
  * kernels, so timing EVERY launch slows a 0.5 ms step by 6 %); mpg_prof_read waits for the recorded events of a slot
  * and returns their summed duration and count.  A timer takes effect on the calls made with a mpg_cfg_t whose `prof`
  * field points to it (and on the native step driver's env launch).  Slots: 0 k_rollout_fwd, 1 k_rollout_bwd,
- * 2 env step, 3 k_forward, 4 k_backward, 5 k_wgrad, 6 k_target_fused, 7 k_critic_fused.  No reference counterpart
+ * 2 env step, 3 k_forward, 4 k_backward, 5 k_wgrad, 6 k_target_fused, 7 k_critic_fused, 8 the caller's gradient exchange
+ * (mpg_prof_region_begin / _end around whatever the caller enqueues between mpg_step_begin and mpg_step_end: RCCL all-reduce or
+ * the one-shot exchange; the reference's hand-over is optimizer.py:60-94), 9 k_clip_adam_polyak.  No reference counterpart
  * (the reference times with utils/misc.py:39-90 TimerStat on the host).  Not thread-safe: one timer per launching
  * thread. */
-enum { MPG_PROF_SLOTS = 8 };
+enum { MPG_PROF_SLOTS = 10 };
 typedef struct mpg_prof mpg_prof_t;
 int mpg_prof_create(int max_samples, mpg_prof_t** out);
 int mpg_prof_destroy(mpg_prof_t* p);
 int mpg_prof_start(mpg_prof_t* p, int every);
 int mpg_prof_read(mpg_prof_t* p, int slot, double* total_ms, int* count);
 const char* mpg_prof_slot_name(int slot);
+/* time a caller-side region on `stream` under `slot` with the same every-n-th sampling (no-ops for a null or stopped timer) */
+int mpg_prof_region_begin(mpg_prof_t* p, int slot, mpg_stream_t stream);
+int mpg_prof_region_end(mpg_prof_t* p, int slot, mpg_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Vectorised real environment (K1)

@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(HERE, 'libmpg_hip.so')
 HEADER = os.path.join(HERE, '..', 'include', 'mpg_hip.h')
 
 _lib = None
-ABI_VERSION = 6      # the struct mirrors of ops.py (CfgStruct, WCacheStruct, ...) follow include/mpg_hip.h at this version
+ABI_VERSION = 7      # the struct mirrors of ops.py (CfgStruct, WCacheStruct, ...) follow include/mpg_hip.h at this version
 
 
 class MpgError(RuntimeError):

@@ -28,6 +28,22 @@ __device__ __forceinline__ void load_w2(const float* pack, const float* W2, bool
 #endif
 
 
+// Learner-side judge_is_nan (worker.py:95-107 on every worker obs / action, optimizer.py:357-361 on the gradient list).  The
+// ELU's v_med3_f32 DROPS a NaN (the median of (NaN, NaN, 0) is 0), so a NaN in a replay row would leave these kernels as a
+// finite, wrong value that neither the status word nor the gradient NaN guard can see.  Two things restore the reference's
+// behaviour: every thread that loads a network input ORs MPG_STATUS_NAN into the caller's status word when it sees one, and
+// the row's result is poisoned - row_poison() is 0 for a finite row and NaN for a row with a NaN (or an infinity: 0 * inf)
+// among its n inputs; added to the row's TD error / target value it makes the gradient non-finite, which the clip kernel
+// turns into a zeroed step exactly like the reference (`grads = [tf.zeros_like(grad) ...]`).
+__device__ __forceinline__ float row_poison(const float* sXrow, int n) {
+    float z = 0.f;
+    for (int i = 0; i < n; ++i) z = fmaf(sXrow[i], 0.f, z);
+    return z;
+}
+__device__ __forceinline__ void report_nan(int* status, bool saw_nan) {
+    if (status && saw_nan) atomicOr(status, MPG_STATUS_NAN);
+}
+
 constexpr int SMEM_FLOATS = 2 * A_IMG + GROUP * XS + NWAVE * GROUP * MAXOUT + GROUP * MAXOUT + NWAVE * GROUP * XS + 4 * GROUP;
 struct Smem {
     float *sA, *sA1, *sX, *sPart, *sD3, *sPartX, *sQ;
@@ -92,6 +108,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_target_fused(const TargetArgs a)
     float o1[OBS], o2[OBS], ac[ACT], rw = 0.f;
     uint8_t dn = 0;
     long sr = 0;
+    bool saw_nan = false;
 #pragma unroll
     for (int i = 0; i < OBS; ++i) o1[i] = o2[i] = 0.f;
 #pragma unroll
@@ -152,14 +169,23 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_target_fused(const TargetArgs a)
                 if (a.o_done) a.o_done[gr] = (float)dn;
             }
             sRew[tid] = rw;
+            saw_nan |= rw != rw;
 #pragma unroll
             for (int i = 0; i < XS; ++i) sXg[tid / GROUP][(tid % GROUP) * XS + i] = i < OBS ? o2[i < OBS ? i : 0] * a.scale[i] : 0.f;
+#pragma unroll
+            for (int i = 0; i < OBS; ++i) saw_nan |= o2[i] != o2[i];
         }
     } else if (tid < G2 * GROUP * XS) {
         const int g2 = tid / (GROUP * XS), e = tid % (GROUP * XS), row = e / XS, i = e % XS;
         const long gr = (g0 + g2) * GROUP + row;
-        sXg[g2][e] = (gr < a.rows && i < OBS) ? a.obs2[gr * OBS + i] * a.scale[i] : 0.f;
-        if (i == 0) sRew[g2 * GROUP + row] = gr < a.rows ? a.rew[gr] : 0.f;
+        const float xin = (gr < a.rows && i < OBS) ? a.obs2[gr * OBS + i] * a.scale[i] : 0.f;
+        sXg[g2][e] = xin;
+        saw_nan |= xin != xin;
+        if (i == 0) {
+            const float rin = gr < a.rows ? a.rew[gr] : 0.f;
+            sRew[g2 * GROUP + row] = rin;
+            saw_nan |= rin != rin;
+        }
     }
     MPG_TL(3);
     lds_barrier();
@@ -209,14 +235,16 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_target_fused(const TargetArgs a)
         const int g2 = tid / GROUP, row = tid % GROUP;
         const long gr = (g0 + g2) * GROUP + row;
         if (gr < a.rows) {
-            if (half >= 0) a.qpart[(long)half * a.rows + gr] = sQg[g2][half * GROUP + row];
+            const float pz = row_poison(sXg[g2] + row * XS, OBS);               // NaN in s': the target is NaN (see row_poison)
+            if (half >= 0) a.qpart[(long)half * a.rows + gr] = sQg[g2][half * GROUP + row] + pz;
             else {
                 const float q = a.q2 ? fminf(sQg[g2][row], sQg[g2][GROUP + row]) : sQg[g2][row];
-                a.y[gr] = (sRew[tid] + a.rshift) * a.rscale + a.gamma * q;      // mpg_learner.py:132-133
+                a.y[gr] = (sRew[tid] + a.rshift) * a.rscale + a.gamma * q + pz;      // mpg_learner.py:132-133
             }
         }
     }
     report_activation_range(a.status, zmax);
+    report_nan(a.status, saw_nan);
     MPG_TL(23);
     MPG_TL_DUMP(a.dbg);
 }
@@ -266,12 +294,13 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_qloss_fused(const QlossArgs a) {
         const long gr = g * GROUP + tid;
         float e = 0.f;
         if (gr < a.rows) {
-            e = out_preact(m.sPart, net.b3[0], tid, 0) - a.y[gr];
+            e = out_preact(m.sPart, net.b3[0], tid, 0) - a.y[gr] + row_poison(m.sX + tid * XS, QIN);
             st.dz3[gr] = e * a.inv_b;
             if (a.td && qi == 0) a.td[gr] = e;
         }
         m.sD3[d3_index(tid, 0)] = e * a.inv_b;
         m.sQ[tid] = e * e;
+        report_nan(a.status, e != e);
     }
     MPG_TL(4);
     load_w2<PK>(a.pkb[qi], net.W2, true, L, w2);     // same registers, backward image
@@ -311,7 +340,9 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_qslice_fused(const QsliceArgs a)
     if (tid < GROUP * XS) {
         const int row = tid / XS, i = tid % XS;
         const long gr = g * GROUP + row;
-        m.sX[tid] = (gr < total && i < QIN) ? a.xq[gr * QIN + i] : 0.f;
+        const float xin = (gr < total && i < QIN) ? a.xq[gr * QIN + i] : 0.f;
+        m.sX[tid] = xin;
+        report_nan(a.status, xin != xin);
     }
     lds_barrier();
     float w2[128], h1[2][4], h2[2][4], dz1[2][4], dz2[2][4];
@@ -366,7 +397,9 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_qslice_fused2(const QsliceArgs a
     if (tid < 2 * GROUP * XS) {
         const int sl = tid / (GROUP * XS), row = (tid / XS) % GROUP, i = tid % XS;
         const long gr = (sl * gpers + gb) * GROUP + row;
-        sX2[tid] = i < QIN ? a.xq[gr * QIN + i] : 0.f;
+        const float xin = i < QIN ? a.xq[gr * QIN + i] : 0.f;
+        sX2[tid] = xin;
+        report_nan(a.status, xin != xin);
     }
     lds_barrier();
     float w2[128], h1[2][2][4], h2[2][2][4], dz1[2][4], dz2[2][4];
@@ -467,6 +500,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_critic_fused(const CriticArgs ca
     MPG_LOAD2((load_small<QIN, 1>(net, L, r)), (load_w2<PK>(a.pkf[qi], net.W2, false, L, w2)));
     if (tid < GROUP * XS) m.sX[tid] = xv;
     if (slices && tid < 2 * GROUP * XS) sX2[tid] = xv2;
+    report_nan(a.status, xv2 != xv2);           // the critic inputs at the rollout slices (their NaN already sits in G_k and the adjoint)
     lds_barrier();
     MPG_TL(1);
     MPG_TL(2);
@@ -484,12 +518,13 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_critic_fused(const CriticArgs ca
                 yv = (t_rew + a.rshift) * a.rscale + a.gamma * fminf(t_q1, t_q2);   // mpg_learner.py:132-133
                 if (qi == 0) a.y_out[gr] = yv;
             }
-            e = out_preact(m.sPart, b3v, tid, 0) - yv;
+            e = out_preact(m.sPart, b3v, tid, 0) - yv + row_poison(m.sX + tid * XS, QIN);
             st.dz3[gr] = e * a.inv_b;
             if (a.td && qi == 0) a.td[gr] = e;
         }
         m.sD3[d3_index(tid, 0)] = e * a.inv_b;
         m.sQ[tid] = e * e;
+        report_nan(a.status, e != e);           // a NaN in (s, a), in the target or in the reward of this row
     }
     // ---- forward: the two slices (Q1 workgroups only; wave-uniform branch) ----
     if (slices) {

@@ -115,6 +115,17 @@ extern "C" int mpg_prof_read(mpg_prof_t* p, int slot, double* total_ms, int* cou
 
 extern "C" const char* mpg_prof_slot_name(int slot) {
     static const char* const names[MPG_PROF_SLOTS] = {"k_rollout_fwd", "k_rollout_bwd", "env step", "k_forward", "k_backward",
-                                                     "k_wgrad", "k_target_fused", "k_critic_fused"};
+                                                     "k_wgrad", "k_target_fused", "k_critic_fused", "gradient exchange",
+                                                     "k_clip_adam_polyak"};
     return (slot >= 0 && slot < MPG_PROF_SLOTS) ? names[slot] : "";
+}
+
+extern "C" int mpg_prof_region_begin(mpg_prof_t* p, int slot, mpg_stream_t stream) {
+    mpg_prof_begin(p, slot, mpg_stream(stream));
+    return MPG_OK;
+}
+
+extern "C" int mpg_prof_region_end(mpg_prof_t* p, int slot, mpg_stream_t stream) {
+    mpg_prof_end(p, slot, mpg_stream(stream));
+    return MPG_OK;
 }

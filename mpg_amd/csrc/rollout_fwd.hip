@@ -60,6 +60,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_fwd(const RollArgs a) {
         float G = 0.f;                                                  // book lanes: discounted reward sum so far
         float act_first[2] = {0.f, 0.f};
         float f0[WIDE ? 8 : 1] = {};                                    // look-ahead entries of the start observation
+        bool saw_nan = false;                   // learner-side judge_is_nan (worker.py:95-107): start states, first actions, noise
         if (live) {
             // (M == 1: the trajectory IS the batch row - no 64-bit modulo, ~150 instructions, in front of the first loads)
             const long brow = a.M == 1 ? tr : tr % a.rows;
@@ -74,6 +75,16 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_fwd(const RollArgs a) {
 #pragma unroll
                 for (int k = 0; k < ACT; ++k) act_first[k] = a.act0[brow * ACT + k];
             }
+            // (the trajectory lanes compute with these values directly - model step, reward sum, adjoint - so a NaN also reaches
+            // the gradient and its NaN guard; only the networks' ELU drops one, mlp_core.h)
+            float chk = act_first[0] + act_first[1];
+#pragma unroll
+            for (int i = 0; i < OBS; ++i) chk += o[i];
+            if constexpr (WIDE) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) chk += f0[k];
+            }
+            saw_nan |= chk != chk;
         }
         // the whole group's model noise goes to LDS up front (one value per thread), off the serial chain: either the
         // caller's eps or Philox draws.  Visible to the book lanes after the first barrier of the step loop.
@@ -88,7 +99,9 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_fwd(const RollArgs a) {
                 z = sqrtf(-2.f * logf(u01(p.v[0]))) * cosf(6.283185307179586f * u01(p.v[1]));
             }
             sEps[idx] = z;
+            saw_nan |= z != z;
         }
+        if (a.status && saw_nan) atomicOr(a.status, MPG_STATUS_NAN);
         // Per step: B0 (input published) -> layer 1 -> barrier -> layer-2 MFMA block -> output partials -> [book lanes: records
         // of this step, ENV::pre] -> B2 -> [chain lanes: tanh, ENV::finish, publish the next input and sTraj].
         // record the action of step tb, its critic-input part and the discounted reward (book lanes, one step late)

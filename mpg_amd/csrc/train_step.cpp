@@ -189,6 +189,9 @@ extern "C" int mpg_step_end(mpg_train_ctx_t* c, int iteration, mpg_stream_t s) {
         do_polyak[k] = delayed ? 1 : 0;
         if (upd) c->opt_steps[k] = t;
     }
-    return mpg_clip_adam_polyak(c->params, c->adam_m, c->adam_v, c->targets, c->grad, c->clip_scratch, l.sizes, l.n_nets, c->clip,
-                                lr_t, do_adam, do_polyak, c->tau, c->norms, c->nonfinite, c->cfg.wcache[0], c->cfg.wcache[1], s);
+    mpg_prof_begin(c->cfg.prof, 9, mpg_stream(s));
+    const int rc = mpg_clip_adam_polyak(c->params, c->adam_m, c->adam_v, c->targets, c->grad, c->clip_scratch, l.sizes, l.n_nets, c->clip,
+                                        lr_t, do_adam, do_polyak, c->tau, c->norms, c->nonfinite, c->cfg.wcache[0], c->cfg.wcache[1], s);
+    mpg_prof_end(c->cfg.prof, 9, mpg_stream(s));
+    return rc;
 }

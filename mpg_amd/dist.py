@@ -34,56 +34,141 @@ def init_from_env(backend=None):
     return rank, world, local
 
 
+class _HostCounters(object):
+    """One int64 counter per rank in a POSIX shared-memory file (a cache line each): `publish(v)` stores this rank's, `wait(p, v)`
+    spins until rank p's is >= v.  The cross-process half of the IPC-event hand-shake below: an event wait must be ISSUED after
+    the peer has issued the matching record (a wait captures the event's latest record at the time of the call), and that is a
+    fact about the peers' host threads, not about the GPU - so it is settled host to host, without draining any stream."""
+
+    def __init__(self, world, rank, tag):
+        import numpy as np
+        self.world, self.rank = world, rank
+        path = '/dev/shm/mpg_oneshot_%s_%s' % (os.environ.get('MASTER_PORT', '0'), tag)
+        if rank == 0:
+            with open(path, 'wb') as fh:
+                fh.write(b'\0' * (64 * world))
+        dist.barrier()
+        self.a = np.memmap(path, dtype=np.int64, mode='r+', shape=(8 * world,))
+        dist.barrier()
+        if rank == 0:
+            os.unlink(path)              # the mappings keep it alive; nothing is left behind if a rank dies
+
+    def publish(self, v):
+        self.a[8 * self.rank] = v
+
+    def wait(self, p, v):
+        a, i = self.a, 8 * p
+        spins = 0
+        while a[i] < v:
+            spins += 1
+            if spins > 200000000:
+                raise RuntimeError('one-shot all-reduce: rank %d never reached exchange %d' % (p, v))
+
+
 class OneShotAllReduce(object):
-    """One-shot all-reduce of a flat float32 buffer for the ranks of ONE node.
+    """One-shot all-reduce of a flat float32 buffer for the ranks of ONE node (the reference's exchange is
+    the learner -> optimizer gradient hand-over, optimizer.py:60-94, payload mpg_learner.py:448-455).
 
     Every rank owns a staging array [2 parities][world slots][n] in device memory and maps every peer's through HIP IPC
     (torch's CUDA-IPC reductions: hipIpcGetMemHandle / hipIpcOpenMemHandle; HSA_ENABLE_IPC_MODE_LEGACY=0 on this pool).  An
     exchange is
         1. rank r copies its buffer into slot r of EVERY rank's staging array (world device-to-device copies; between GPUs
            these are direct xGMI writes - one hop, all 7 links busy at once, no ring);
-        2. a cross-process barrier: each rank waits for its own copies (stream synchronize) and then for everybody (host
-           barrier of the process group).  No device-side spin-wait between processes: on the test box two ranks TIME-SHARE
-           one GPU, and a kernel polling for a peer that is not scheduled would never return;
+        2. everybody's writes must have landed before anybody sums;
         3. every rank sums the `world` slots of its own array in rank order 0, 1, 2, ... (mpg_sum_slots): every replica computes
            the SAME association of the same numbers, so the replicas stay bit-identical by construction.
-    Two staging parities alternate by call: a rank can run at most one barrier ahead of the slowest one, so nobody overwrites
-    a slot that is still being summed.  What this form is for: the gradient message (821 KB) is latency-bound; a ring
-    all-reduce pays 2 (world - 1) dependent hops, this pays one write + one barrier + one local sum.  Measured here only
-    for correctness (two processes on one GPU); no multi-GPU number is claimed."""
+    Two staging parities alternate by call.
 
-    def __init__(self, n, device):
+    Step 2, `sync='event'` (default, round 4): INTERPROCESS EVENTS (hipEventInterprocess / hipIpcGetEventHandle /
+    hipIpcOpenEventHandle).  Rank r records W_r[parity] on its stream behind its copies and makes its stream wait
+    (hipStreamWaitEvent) for every peer's W_p[parity]; the sum kernel is enqueued behind those waits and S_r[parity] is recorded
+    behind it, which the peers wait for before they overwrite r's slots two exchanges later.  The HOST never waits for the GPU:
+    the only host-side coupling is a per-rank call counter in shared memory (_HostCounters) that orders "peer issued its
+    record" before "I issue my wait" - sub-microsecond when the peers' host threads run ahead of their GPUs, which they do (the
+    native step driver enqueues a 0.24 ms step in ~40 us).  So the launch queue of the native driver no longer drains at the
+    exchange.  There is still no device-side spin between processes (on the test box several ranks time-share ONE GPU).
+    `sync='host'` (MPG_ONESHOT_SYNC=host): the round-3 form - stream.synchronize() + dist.barrier() - kept as the control.
+
+    Validated for correctness only - 2, 4 and 8 processes time-sharing one GPU (tests/test_dist_gpu.py); no multi-GPU number is
+    claimed."""
+
+    def __init__(self, n, device, sync=None):
         from torch.multiprocessing.reductions import reduce_tensor
         from . import _lib as L
         self.L = L
         self.world, self.rank = dist.get_world_size(), dist.get_rank()
         self.n = int(n)
+        self.sync = sync or os.environ.get('MPG_ONESHOT_SYNC', 'event')
+        assert self.sync in ('event', 'host')
         self.stage = torch.zeros(2, self.world, self.n, dtype=torch.float32, device=device)
         torch.cuda.synchronize()
         fn, args = reduce_tensor(self.stage)
+        mine = [(fn, args)]
+        if self.sync == 'event':
+            # W[par]: "my copies of this parity are done"; S[par]: "my sum of this parity is done"
+            self.W = [torch.cuda.Event(enable_timing=False, interprocess=True) for _ in range(2)]
+            self.S = [torch.cuda.Event(enable_timing=False, interprocess=True) for _ in range(2)]
+            for e in self.W + self.S:
+                e.record()               # an interprocess event gets its handle once it has been recorded
+            torch.cuda.synchronize()
+            mine.append([e.ipc_handle() for e in self.W + self.S])
         handles = [None] * self.world
-        dist.all_gather_object(handles, (fn, args))
-        self.peers = []
+        dist.all_gather_object(handles, tuple(mine))
+        self.peers, self.pW, self.pS = [], [], []
+        dev = torch.device(device) if not isinstance(device, torch.device) else device
         for r in range(self.world):
             if r == self.rank:
                 self.peers.append(self.stage)
-            else:
-                f, a = handles[r]
-                self.peers.append(f(*a))           # rebuild_cuda_tensor: opens the peer's allocation
+                self.pW.append(None)
+                self.pS.append(None)
+                continue
+            f, a = handles[r][0]
+            self.peers.append(f(*a))           # rebuild_cuda_tensor: opens the peer's allocation
+            if self.sync == 'event':
+                ev = [torch.cuda.Event.from_ipc_handle(dev, h) for h in handles[r][1]]
+                self.pW.append(ev[:2])
+                self.pS.append(ev[2:])
         self.calls = 0
+        if self.sync == 'event':
+            global _oneshot_tag
+            _oneshot_tag += 1
+            self.ctr = _HostCounters(self.world, self.rank, '%d_%d' % (self.n, _oneshot_tag))
         dist.barrier()
 
     def all_reduce_sum_(self, flat):
         assert flat.numel() == self.n and flat.dtype == torch.float32 and flat.is_contiguous()
         par = self.calls & 1
         self.calls += 1
-        for r in range(self.world):                 # 1. my buffer into slot `rank` of every rank's array
+        L = self.L
+        st = torch.cuda.current_stream()
+        if self.sync == 'host':
+            for r in range(self.world):                 # 1. my buffer into slot `rank` of every rank's array
+                self.peers[r][par, self.rank].copy_(flat, non_blocking=True)
+            st.synchronize()                            # 2. my writes have landed ...
+            dist.barrier()                              #    ... and so have everybody else's
+            L.call('mpg_sum_slots', L.ptr(self.stage[par]), L.c_int(self.world), L.c_int(self.n), L.ptr(flat), L.stream())
+            return flat
+        it = self.calls
+        # 0. a peer's slots of this parity were last read by its sum two exchanges ago: S_p[par], recorded then (the peer's host
+        #    issued that record before it published exchange it - 1, which this rank waited for in exchange it - 1)
+        if it > 2:
+            for p in range(self.world):
+                if p != self.rank:
+                    st.wait_event(self.pS[p][par])
+        for r in range(self.world):                     # 1. my buffer into slot `rank` of every rank's array
             self.peers[r][par, self.rank].copy_(flat, non_blocking=True)
-        torch.cuda.current_stream().synchronize()   # 2. my writes have landed ...
-        dist.barrier()                              #    ... and so have everybody else's
-        L = self.L                                  # 3. fixed-order local sum
-        L.call('mpg_sum_slots', L.ptr(self.stage[par]), L.c_int(self.world), L.c_int(self.n), L.ptr(flat), L.stream())
+        self.W[par].record(st)
+        self.ctr.publish(it)                            # host: "my record of exchange `it` has been issued"
+        for p in range(self.world):                     # 2. behind every peer's writes - a stream wait, not a host wait
+            if p != self.rank:
+                self.ctr.wait(p, it)
+                st.wait_event(self.pW[p][par])
+        L.call('mpg_sum_slots', L.ptr(self.stage[par]), L.c_int(self.world), L.c_int(self.n), L.ptr(flat), L.stream())   # 3.
+        self.S[par].record(st)
         return flat
+
+
+_oneshot_tag = 0
 
 
 def backend():

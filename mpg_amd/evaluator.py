@@ -65,6 +65,7 @@ class Evaluator(object):
                 per_episode[nm + '_mse'] = rms(obs[:, :, j])
                 per_episode[nm + '_mse_25'] = rms(obs[:25, :, j])
         mean = {k: float(v.mean().item()) for k, v in per_episode.items()}
+        pw.check_status()          # NaN observations / actions, the engine's envelope: an evaluation on invalid numbers raises
         return per_episode, mean
 
     def run_evaluation(self, iteration):

@@ -139,6 +139,12 @@ class FusedMPGStep(object):
         self.sync_in()           # a few host scalar copies; the tensor copies only happen after a stock-method call
         s = L.stream()
         L.check(self._lib.mpg_step_begin(self._ref, ctypes.c_int(iteration), s), 'mpg_step_begin')
-        D.all_reduce_sum_(self.learner.flat, force=self.always_exchange)   # the ONE exchange step (no-op on a single GPU)
+        if self.c.grads_exchanged:
+            # the ONE exchange step, timed under the caller's kernel timer (slot 8, HIP events on the launch stream: bench.py's
+            # `exchange_ms`) - a null or stopped timer makes both calls no-ops
+            prof = ctypes.c_void_p(self.c.cfg.prof)
+            self._lib.mpg_prof_region_begin(prof, ctypes.c_int(8), s)
+            D.all_reduce_sum_(self.learner.flat, force=self.always_exchange)
+            self._lib.mpg_prof_region_end(prof, ctypes.c_int(8), s)
         L.check(self._lib.mpg_step_end(self._ref, ctypes.c_int(iteration), s), 'mpg_step_end')
         self.push()

@@ -67,6 +67,7 @@ class SingleProcessOffPolicyOptimizer(object):
             self._fused.step(self.iteration)
             self.learner._lazy_stats = self.learner._mpg_lazy_stats(self.iteration)
             self.iteration += 1
+            self._check_status()
             return
         if self.iteration % self.sampling_interval == 0:                   # optimizer.py:332-337
             sample_batch, count = self.worker.sample_with_count()
@@ -82,6 +83,16 @@ class SingleProcessOffPolicyOptimizer(object):
         self.worker.apply_gradients(self.iteration, self.learner.flat_grad)   # :362
         self.get_stats()
         self.iteration += 1
+        self._check_status()
+
+    def _check_status(self):
+        """judge_is_nan / the engine's numerical envelope (include/mpg_hip.h): every kernel of the step ORs its findings into the
+        shared policy's sticky status word; it is read (one host synchronisation) every `nan_check_interval` iterations, in BOTH
+        branches of step() - the native driver never goes through worker.sample(), which is where the method path reads it
+        (worker.py:95-107, optimizer.py:357-361 of the reference stop the run on the same conditions)."""
+        k = getattr(self.worker, 'nan_check_interval', 100)
+        if k > 0 and self.iteration % k == 0:
+            self.worker.policy_with_value.check_status()
 
     def stop(self):
         pass

@@ -73,11 +73,13 @@ def _run(fn, world=2):
     return sorted(out, key=lambda t: t[0])
 
 
-@pytest.fixture(params=['gloo', 'oneshot'])
+@pytest.fixture(params=['gloo', 'oneshot', 'oneshot-host'])
 def exchange(request, monkeypatch):
-    """the two exchanges of the gradient buffer that a 1-GPU box can run with two ranks: gloo's all-reduce, and the one-shot
-    all-reduce over IPC-mapped staging slots (mpg_amd/dist.py OneShotAllReduce) - spawned workers inherit the variable"""
-    monkeypatch.setenv('MPG_DIST_BACKEND', request.param)
+    """the exchanges of the gradient buffer that a 1-GPU box can run with several ranks: gloo's all-reduce, and the one-shot
+    all-reduce over IPC-mapped staging slots (mpg_amd/dist.py OneShotAllReduce) in its two synchronisation forms - interprocess
+    events (default) and the round-3 host barrier - spawned workers inherit the variables"""
+    monkeypatch.setenv('MPG_DIST_BACKEND', request.param.split('-')[0])
+    monkeypatch.setenv('MPG_ONESHOT_SYNC', 'host' if request.param.endswith('-host') else 'event')
     return request.param
 
 
@@ -132,6 +134,20 @@ def test_native_step_driver_keeps_two_replicas_bit_identical(exchange):
     assert not np.array_equal(out[0][2], out[1][2])               # the ranks really saw different data
 
 
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize('backend', ['gloo', 'oneshot'])
+def test_native_step_driver_keeps_four_replicas_bit_identical(backend, monkeypatch):
+    """The same with FOUR ranks time-sharing the one GPU (nothing had run with more than two ranks, so rank-count
+    dependent state - slot indexing, the two staging parities, the per-peer events - was untested beyond 2)."""
+    monkeypatch.setenv('MPG_DIST_BACKEND', backend)
+    monkeypatch.setenv('MPG_ONESHOT_SYNC', 'event')
+    out = _run(_driver_worker, world=4)
+    for r in range(1, 4):
+        assert np.array_equal(out[0][1], out[r][1]), r
+        assert not np.array_equal(out[0][2], out[r][2])
+    assert np.isfinite(out[0][1]).all()
+
+
 def _oneshot_sum_worker(rank, world, port, q):
     D = _init(rank, world, port)
     n = 205318 + 16                                      # the MPG-v2 gradient buffer
@@ -139,7 +155,7 @@ def _oneshot_sum_worker(rank, world, port, q):
     mine = (torch.randn(n, generator=g) * torch.logspace(-6, 2, n)).float()
     flat = mine.cuda()
     outs = []
-    for k in range(3):                                    # both staging parities and a re-use
+    for k in range(6):                                    # both staging parities, each re-used twice
         buf = flat * float(k + 1)
         D.all_reduce_sum_(buf)
         outs.append(buf.cpu().numpy())
@@ -149,16 +165,23 @@ def _oneshot_sum_worker(rank, world, port, q):
     torch.distributed.destroy_process_group()
 
 
-@pytest.mark.timeout(300)
-def test_oneshot_all_reduce_is_the_in_rank_order_sum_bit_for_bit(monkeypatch):
-    """OneShotAllReduce on its own: three exchanges of a 205 334-float buffer with entries over eight orders of magnitude.
-    Every rank must hold exactly fl(x_0 + x_1) - the rank-order float32 sum - each time."""
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize('world,sync', [(2, 'event'), (2, 'host'), (8, 'event')])
+def test_oneshot_all_reduce_is_the_in_rank_order_sum_bit_for_bit(monkeypatch, world, sync):
+    """OneShotAllReduce on its own: six exchanges of a 205 334-float buffer with entries over eight orders of magnitude (both
+    staging parities, each re-used twice: the slot-reuse waits of the event form are exercised).  Every rank must hold exactly
+    fl(..fl(x_0 + x_1) + .. + x_{world-1}) - the rank-order float32 sum - each time; 2 ranks in both synchronisation forms and
+    8 ranks (all time-sharing the one GPU of the test box) in the event form."""
     monkeypatch.setenv('MPG_DIST_BACKEND', 'oneshot')
-    out = _run(_oneshot_sum_worker)
-    x0, x1 = out[0][1], out[1][1]
-    for k in range(3):
-        ref = (x0 * np.float32(k + 1)) + (x1 * np.float32(k + 1))       # float32 arithmetic, rank order
-        assert np.array_equal(out[0][2][k], ref) and np.array_equal(out[1][2][k], ref), k
+    monkeypatch.setenv('MPG_ONESHOT_SYNC', sync)
+    out = _run(_oneshot_sum_worker, world=world)
+    xs = [out[r][1] for r in range(world)]
+    for k in range(6):
+        ref = xs[0] * np.float32(k + 1)
+        for r in range(1, world):
+            ref = ref + xs[r] * np.float32(k + 1)                       # float32 arithmetic, rank order
+        for r in range(world):
+            assert np.array_equal(out[r][2][k], ref), (k, r)
 
 
 def _rccl_worker(rank, world, port, q):
@@ -217,28 +240,31 @@ def test_rccl_all_reduce_between_step_begin_and_step_end():
     assert np.array_equal(na, nb) and np.array_equal(na, nc)
 
 
-@pytest.mark.parametrize('backend', ['gloo', 'oneshot'])
-def test_bench_in_the_drivers_multi_rank_form(backend):
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize('backend,nproc', [('gloo', 2), ('oneshot', 2), ('gloo', 8), ('oneshot', 8)])
+def test_bench_in_the_drivers_multi_rank_form(backend, nproc):
     """`bench.py` exactly as the driver launches it for N > 1 - `python -m torch.distributed.run --nnodes=1 --nproc-per-node 2
     --master-addr 127.0.0.1 --master-port P bench.py --gpus 2 --steps K --warmup W` - as a dry run on the one GPU of the test
     box (MPG_DIST_BACKEND=gloo / oneshot: both ranks on device 0; RCCL itself refuses two ranks on one device).  Checks the
     launch form, the rendezvous, the barrier-bracketed timed region, the max over ranks and the one JSON line of rank 0:
-    n_gpus 2, weak scaling, whole-job value = 2 x 4096 env-steps per step / time."""
+    n_gpus N, weak scaling, whole-job value = N x 4096 env-steps per step / time.  N = 8 (all eight ranks time-sharing the
+    one GPU) is the driver's SCALE form: rank-count dependent state beyond 2 and the `exchange_ms` key."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, MPG_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY='0')
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', str(_free_port()), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '10', '--warmup', '3',
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(nproc), '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(root, 'bench.py'), '--gpus', str(nproc), '--steps', '10', '--warmup', '3',
            '--no-cpu-baseline']
-    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=850)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
     assert len(lines) == 1, out.stdout[-2000:]                 # rank 0 prints ONE line
     d = json.loads(lines[0])
-    assert d['n_gpus'] == 2 and d['steps'] == 10 and d['warmup'] == 3 and d['scaling'] == 'weak' and d['higher_is_better'] is True
-    assert d['config']['parallelism'] == 'dp2' and d['config']['global_batch'] == 2 * 4096
+    assert d['n_gpus'] == nproc and d['steps'] == 10 and d['warmup'] == 3 and d['scaling'] == 'weak' and d['higher_is_better'] is True
+    assert d['config']['parallelism'] == 'dp%d' % nproc and d['config']['global_batch'] == nproc * 4096
     assert d['config']['dist_backend'].startswith(backend)
-    np.testing.assert_allclose(d['value'], 2 * 4096 / (d['ms_per_step'] * 1e-3), rtol=1e-6)
+    np.testing.assert_allclose(d['value'], nproc * 4096 / (d['ms_per_step'] * 1e-3), rtol=1e-6)
     assert 'roofline' in d and d['vs_baseline'] is None
+    assert d['exchange_ms'] is not None and d['exchange_ms'] > 0 and d['exchange_launches'] > 0

@@ -202,3 +202,69 @@ def test_weight_gradient_is_scale_invariant(scale):
             assert e_got <= 4 * e_ref + 1e-6, (scale, shp, 'vs float64: got %.2e, float32 oracle %.2e' % (e_got, e_ref))
         o += n
     assert int(st.item()) == 0
+
+
+def _stack(alg='MPG-v2', fused=True, **kw):
+    from mpg_amd.buffer import ReplayBuffer
+    from mpg_amd.config import default_args
+    from mpg_amd.learners import MPGLearner
+    from mpg_amd.optimizer import SingleProcessOffPolicyOptimizer
+    from mpg_amd.policy import PolicyWithQs
+    from mpg_amd.worker import OffPolicyWorker
+    a = dict(num_agent=64, batch_size=64, replay_batch_size=256, replay_starts=512, max_buffer_size=512)
+    a.update(kw)
+    args = default_args(alg, **a)
+    worker = OffPolicyWorker(PolicyWithQs, args.env_id, args, 0)
+    learner = MPGLearner(PolicyWithQs, args)
+    rb = ReplayBuffer(args, 0)
+    opt = SingleProcessOffPolicyOptimizer(worker, learner, rb, None, args, sampling_interval=10 ** 9, fused=fused)
+    assert (opt._fused is not None) == fused
+    return opt, worker, learner, rb
+
+
+@pytest.mark.parametrize('field', ['obs', 'act', 'rew', 'obs2'])
+@pytest.mark.parametrize('fused', [True, False])
+def test_nan_in_a_replay_row_is_reported_and_zeroes_the_step(field, fused):
+    """optimizer.py:357-361: a NaN anywhere in the gradient list makes the reference apply ZERO gradients; in TensorFlow a NaN in
+    any field of a replay row reaches that list.  Here the ELU's v_med3_f32 drops a NaN inside the networks, so the learner
+    kernels look at their inputs themselves (csrc/fused_kernels.hip row_poison / report_nan): the row's TD error becomes NaN,
+    the clip kernel sees a non-finite norm and Adam gets zeros (parameters bit-identical after the step on a fresh optimizer
+    state), and MPG_STATUS_NAN is raised for the host to read."""
+    from mpg_amd._lib import MpgError
+    opt, worker, learner, rb = _stack(fused=fused, nan_check_interval=10 ** 9)
+    pw = worker.policy_with_value
+    # a ring no larger than two minibatches, every slot poisoned in ONE field of ONE coordinate: whichever rows are drawn, they carry it
+    t = dict(obs=rb.obs, act=rb.act, rew=rb.rew, obs2=rb.obs2)[field]
+    if t.dim() == 1:
+        t[7::16] = float('nan')
+    else:
+        t[7::16, t.shape[1] - 1] = float('nan')
+    before = pw.params.clone()
+    tbefore = pw.targets.clone()
+    opt.step()
+    torch.cuda.synchronize()
+    assert int(pw.nonfinite.sum().item()) > 0, 'the clip kernel did not see a non-finite gradient'
+    assert torch.equal(pw.params, before), 'a step computed from a NaN row moved the parameters'
+    # (Polyak still runs: (1 - tau) t + tau w with t == w re-rounds the last bit)
+    assert torch.isfinite(pw.targets).all() and (pw.targets - tbefore).abs().max().item() <= 1e-6
+    with pytest.raises(MpgError, match='judge_is_nan'):
+        pw.check_status()
+    assert pw.check_status() == 0                                  # read and cleared
+
+
+@pytest.mark.parametrize('fused', [True, False])
+def test_optimizer_reads_the_status_word_every_nan_check_interval_iterations(fused):
+    """the native step driver never goes through worker.sample(), which was the only place that read the status word; a
+    parameter pushed out of the engine's envelope must stop the run within `nan_check_interval` iterations in BOTH branches
+    of SingleProcessOffPolicyOptimizer.step (the reference's judge_is_nan stop, worker.py:95-107 / optimizer.py:357-361)."""
+    from mpg_amd._lib import MpgError
+    opt, worker, learner, rb = _stack(fused=fused, nan_check_interval=4)
+    pw = worker.policy_with_value
+    for _ in range(4):
+        opt.step()                                                 # clean: iterations 1..4 include one check
+    w2 = pw.net('Q1')[8 * 256 + 256: 8 * 256 + 256 + 256 * 256]
+    w2[300] = 3000.0                                               # beyond |w| < 1023.5
+    pw.refresh_weight_cache()                                      # (re)pack reports it ...
+    with pytest.raises(MpgError, match='envelope'):
+        for _ in range(4):
+            opt.step()                                             # ... and the optimizer reads the word within 4 iterations

@@ -1,0 +1,316 @@
+// Prototype (round 4): PING-PONG geometry for the chain-free forward pass.
+//   workgroup = 512 threads = 8 waves = two TEAMS of four waves (team = wave >> 2: the two waves of a SIMD are w and w + 4, so
+//   every SIMD hosts one wave of each team).  A team evaluates row groups on its own: wave q of a team owns 64 hidden columns
+//   (4 tiles of 16); the hi halves of its 256 x 64 slice of W2 are register-stationary (128 VGPRs), the lo halves are read from a
+//   112 KB LDS image shared by both teams (k-blocks 0..6; k-block 7 stays in 16 VGPRs: the whole lo image does not fit beside
+//   the activation images).  The teams run half a period apart: while one issues its matrix block (96 MFMAs per wave, 1536
+//   cycles of its SIMD's matrix pipe), the other does the vector work around it (epilogue of its previous group, layer 1 + ELU
+//   + fp16 split + image store of its next) - ONE workgroup barrier per interval, matrix pipe and vector issue of every SIMD
+//   busy at the same time with DIFFERENT waves.
+// Question: does a row group cost less than the 4.3 - 4.5 k cycles it costs in every lock-step structure tried in round 3?
+// Build + run:  bash tools/proto/pingpong/run.sh   (on the GPU box)
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cmath>
+#include <vector>
+#include <cstring>
+#include "mlp_core.h"
+
+using namespace mlp;
+
+// ---- the shipped geometry (k_forward's structure), as the reference --------------------------------------------------------
+template <int IN, int OU>
+__global__ void __launch_bounds__(NTHREAD, 2) k_fwd8(const float* params, int in_dim, int out_dim, int rows, const float* x, float* y) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * (A_IMG + GROUP * XS + NWAVE * GROUP * MAXOUT)];
+    float* sA = smem;
+    float* sX = sA + 2 * A_IMG;
+    float* sPart = sX + 2 * GROUP * XS;
+    const Lane L;
+    const Net net = make_net(params, in_dim, out_dim);
+    float w2[128];
+    SmallRegs<IN, OU> r;
+    load_small<IN, OU>(net, L, r);
+    load_w2_fwd(net.W2, L, w2);
+    const long ngroups = (rows + GROUP - 1) / GROUP;
+    const long nunits = (ngroups + 1) / 2;
+    const int tid = threadIdx.x;
+    for (long u = blockIdx.x; u < nunits; u += gridDim.x) {
+        if (tid < 2 * GROUP * XS) {
+            const int g2 = tid / (GROUP * XS), e = tid % (GROUP * XS), row = e / XS, i = e % XS;
+            const long gr = (u * 2 + g2) * GROUP + row;
+            sX[tid] = (gr < rows && i < in_dim) ? x[gr * in_dim + i] : 0.f;
+        }
+        lds_barrier();
+        float h1[2][2][4], h2[2][2][4];
+        forward_group2<IN, OU>(sX, sX + GROUP * XS, sA, sA + A_IMG, sPart, sPart + NWAVE * GROUP * MAXOUT, L, w2, r, h1[0], h2[0], h1[1], h2[1]);
+        if (tid < 2 * GROUP * OU) {
+            const int g2 = tid / (GROUP * OU), row = (tid / OU) % GROUP, o = tid % OU;
+            const long gr = (u * 2 + g2) * GROUP + row;
+            if (gr < rows) y[gr * OU + o] = out_preact(sPart + g2 * NWAVE * GROUP * MAXOUT, net.b3[o], row, o);
+        }
+    }
+}
+
+// ---- ping-pong geometry --------------------------------------------------------------------------------------------------------
+constexpr int TW = 4;                 // waves per team
+constexpr int NT = 4;                 // 16-column tiles per wave
+constexpr int LO_KB = 7;              // k-blocks of the lo image kept in LDS (the last one stays in registers)
+constexpr int LO_FLOATS = TW * LO_KB * NT * 256;      // 28 672 floats = 112 KB
+
+// AB (timing only, wrong numbers): 1 one k-block of the matrix block, 2 no exps, 4 no image stores, 8 no output reduction,
+// 16 the teams in PHASE (both do their vector phase, then both their matrix phase: the lock-step control), 32 no lo reads from LDS
+template <int IN, int OU, int AB = 0>
+__global__ void __launch_bounds__(NTHREAD, 2) k_fwd_pp(const float* params, int in_dim, int out_dim, int rows, const float* x, float* y, const float* pk_hi, const float* pk_lo) {
+    __shared__ __attribute__((aligned(16))) float sLo[LO_FLOATS];
+    __shared__ __attribute__((aligned(16))) float sAimg[2][A_IMG];
+    __shared__ float sPart[2][2][TW * GROUP * MAXOUT];          // [team][parity]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, team = wave >> 2, q = wave & 3, c = lane & 15, rg = lane >> 4;
+    const Net net = make_net(params, in_dim, out_dim);
+    // ---- stationary pieces ----
+    float whi[128];                   // whi[((kb * NT + t) * 4) + r]: packed pair (k0, k0 + 1), k0 = 32 kb + 8 rg + 2 r, column 64 q + 16 t + c
+    float wlo7[16];
+    {   // packed images (host side, main()): f32x4 index ((q * 8 + kb) * NT + t) * 64 + lane
+        const f32x4* ph = reinterpret_cast<const f32x4*>(pk_hi) + (q * 8 * NT) * 64 + lane;
+        const f32x4* pl = reinterpret_cast<const f32x4*>(pk_lo) + (q * 8 * NT) * 64 + lane;
+#pragma unroll
+        for (int v = 0; v < 8 * NT; ++v) {
+            const f32x4 h = ph[v * 64];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) whi[v * 4 + e] = h[e];
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const f32x4 l = pl[(7 * NT + t) * 64];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) wlo7[t * 4 + e] = l[e];
+        }
+        // the LDS part of the lo image: wave (team, q) copies half of its slice's 28 fragments
+        for (int v = team; v < LO_KB * NT; v += 2)
+            *reinterpret_cast<f32x4*>(sLo + (q * LO_KB * NT + v) * 256 + lane * 4) = pl[v * 64];
+    }
+    float w1p[2][NT], b1[NT], b2[NT], w3[NT][OU];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int col = 64 * q + 16 * t + c;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) w1p[s][t] = (4 * s + rg) < in_dim ? net.W1[(4 * s + rg) * H + col] : 0.f;
+        b1[t] = net.b1[col];
+        b2[t] = net.b2[col];
+#pragma unroll
+        for (int o = 0; o < OU; ++o) w3[t][o] = net.W3[col * out_dim + o];
+    }
+    const float b3v = tid < 0 ? 0.f : net.b3[(lane % OU)];
+    auto hfrag = [&](int kb, int t) {
+        const int v = (kb * NT + t) * 4;
+        return __builtin_bit_cast(f16x8, f32x4{whi[v], whi[v + 1], whi[v + 2], whi[v + 3]});
+    };
+    _Float16* sH = reinterpret_cast<_Float16*>(sAimg[team]);
+    const _Float16* bh = sH + rg * PLANE_H + c * ROW_H;
+    const _Float16* bl = bh + IMG_H;
+    const bool odd = c & 1;
+    const int row0 = 4 * rg + (odd ? 2 : 0);
+    const long ngroups = (rows + GROUP - 1) / GROUP;
+    // team T of workgroup b takes groups 2 b + T, 2 b + T + 2 gridDim.x, ...
+    const long gstep = 2L * gridDim.x;
+    const long g_first = 2L * blockIdx.x + team;
+    const long n_it = (ngroups + gstep - 1) / gstep;          // iterations of EVERY team (empty groups at the end do the motions)
+    auto x_load = [&](long g, float (&xa)[2]) {
+        const long gr = g * GROUP + c;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) xa[s] = (g < ngroups && gr < rows && 4 * s + rg < in_dim) ? x[gr * in_dim + 4 * s + rg] : 0.f;
+    };
+    f32x4 acc[NT];
+    float xa[2];
+    x_load(g_first, xa);
+    __syncthreads();                                          // the lo image is complete
+    // vector phase: epilogue of group gp (if any, from acc), layer 1 of group gn (if any)
+    auto vector_phase = [&](long gp, bool have_prev, long gn, bool have_next, int par) {
+        if (have_prev) {
+            float h2[NT][4];
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float a = fmaf(acc[t][j], 1.f / (W_SCALE * A_SCALE), b2[t]);
+                    h2[t][j] = (AB & 2) ? a : __builtin_amdgcn_fmed3f(a, __builtin_amdgcn_exp2f(a * 1.4426950408889634f) - 1.f, 0.f);
+                }
+            float p[OU][4];
+#pragma unroll
+            for (int o = 0; o < OU; ++o)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float s = fmaf(h2[1][j], w3[1][o], h2[0][j] * w3[0][o]) + fmaf(h2[3][j], w3[3][o], h2[2][j] * w3[2][o]);
+                    p[o][j] = (AB & 8) ? s : row_allreduce16(s);
+                }
+            if (c == 0) {
+#pragma unroll
+                for (int o = 0; o < OU; ++o)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) sPart[team][par][(q * GROUP + 4 * rg + j) * MAXOUT + o] = p[o][j];
+            }
+        }
+        if (have_next) {
+            f32x4 z[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) z[t] = f32x4{b1[t], b1[t], b1[t], b1[t]};
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) z[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[s], w1p[s][t], z[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                float h1[4], pn[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    h1[j] = (AB & 2) ? z[t][j] : __builtin_amdgcn_fmed3f(z[t][j], __builtin_amdgcn_exp2f(z[t][j] * 1.4426950408889634f) - 1.f, 0.f);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pn[j] = dpp_mov<0xB1>(h1[j]);
+                const int k = 64 * q + 16 * t + (c & ~1);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const float xx = odd ? pn[2 + u] : h1[u], yy = odd ? h1[2 + u] : pn[u];
+                    float hi, lo;
+                    split_pack2(xx * A_SCALE, yy * A_SCALE, hi, lo);
+                    if (AB & 4) asm volatile("" :: "v"(hi), "v"(lo));
+                    else {
+                        *reinterpret_cast<float*>(sH + h_index(row0 + u, k)) = hi;
+                        *reinterpret_cast<float*>(sH + IMG_H + h_index(row0 + u, k)) = lo;
+                    }
+                }
+            }
+        }
+        (void)gp; (void)gn;
+    };
+    auto matrix_phase = [&](long gnext) {
+        x_load(gnext, xa);                                    // the next group's inputs travel under the matrix block
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < ((AB & 1) ? 1 : 8); ++kb) {
+            const f16x8 ah = *reinterpret_cast<const f16x8*>(bh + 8 * kb), al = *reinterpret_cast<const f16x8*>(bl + 8 * kb);
+            f16x8 wl[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                if (kb < LO_KB && !(AB & 32)) wl[t] = __builtin_bit_cast(f16x8, *reinterpret_cast<const f32x4*>(sLo + ((q * LO_KB + kb) * NT + t) * 256 + lane * 4));
+                else wl[t] = __builtin_bit_cast(f16x8, f32x4{wlo7[t * 4], wlo7[t * 4 + 1], wlo7[t * 4 + 2], wlo7[t * 4 + 3]});
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, hfrag(kb, t), acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wl[t], acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, hfrag(kb, t), acc[t], 0, 0, 0);
+        }
+    };
+    auto output = [&](long g, int par) {                      // the 16 * OU output lanes of the team's first wave
+        if (q == 0 && lane < GROUP * OU && g < ngroups) {
+            const int row = lane / OU, o = lane % OU;
+            const long gr = g * GROUP + row;
+            float zz = b3v;
+#pragma unroll
+            for (int w = 0; w < TW; ++w) zz += sPart[team][par][(w * GROUP + row) * MAXOUT + o];
+            if (gr < rows) y[gr * OU + o] = zz;
+        }
+    };
+    // Team 0: V0 | M0 | V1 | M1 | ... ; team 1 the same one interval later (it opens with an idle interval and team 0 closes with one).
+    // One workgroup barrier per interval.  Iteration i of a team: group g_first + i * gstep.
+    const bool inphase = (AB & 16) != 0;
+    if (team == 1 && !inphase) lds_barrier();
+    for (long i = 0; i <= n_it; ++i) {
+        const long g = g_first + i * gstep;
+        // vector interval: epilogue of iteration i - 1, output of iteration i - 2, layer 1 of iteration i
+        vector_phase(g - gstep, i > 0, g, i < n_it, (int)((i + 1) & 1));
+        if (i >= 2) output(g - 2 * gstep, (int)(i & 1));
+        lds_barrier();
+        if (i == n_it) break;
+        matrix_phase(g + gstep);
+        lds_barrier();
+    }
+    if (team == 0 && !inphase) lds_barrier();
+    // the last two outputs: iteration n_it - 1's partials were written in the last vector interval (parity n_it & 1 ... )
+    lds_barrier();
+    if (n_it >= 1) output(g_first + (n_it - 1) * gstep, (int)((n_it + 1) & 1));
+}
+
+int main() {
+    const int IN = 8, OUT = 1, rows = 65536;
+    const int np = net_size(IN, OUT);
+    std::vector<float> hp(np), hx((size_t)rows * IN);
+    srand(1);
+    auto rnd = [] { return (rand() / (float)RAND_MAX) * 2.f - 1.f; };
+    for (int i = 0; i < np; ++i) hp[i] = rnd() * 0.1f;
+    for (auto& v : hx) v = rnd();
+    float *dp, *dx, *y8, *ypp;
+    hipMalloc(&dp, np * 4); hipMalloc(&dx, hx.size() * 4); hipMalloc(&y8, rows * 4); hipMalloc(&ypp, rows * 4);
+    hipMemcpy(dp, hp.data(), np * 4, hipMemcpyHostToDevice);
+    hipMemcpy(dx, hx.data(), hx.size() * 4, hipMemcpyHostToDevice);
+    // packed hi / lo images in the ping-pong lane order
+    std::vector<float> hh(65536), hl(65536);
+    {
+        const float* W2 = hp.data() + IN * 256 + 256;
+        for (int q = 0; q < 4; ++q) for (int kb = 0; kb < 8; ++kb) for (int t = 0; t < 4; ++t) for (int lane = 0; lane < 64; ++lane) for (int r = 0; r < 4; ++r) {
+            const int c = lane & 15, rg = lane >> 4, k0 = 32 * kb + 8 * rg + 2 * r, col = 64 * q + 16 * t + c;
+            _Float16 h2[2], l2[2];
+            for (int e = 0; e < 2; ++e) {
+                float w = W2[(k0 + e) * 256 + col] * 64.f;
+                h2[e] = (_Float16)w; l2[e] = (_Float16)(w - (float)h2[e]);
+            }
+            const size_t idx = ((((size_t)q * 8 + kb) * 4 + t) * 64 + lane) * 4 + r;
+            memcpy(&hh[idx], h2, 4); memcpy(&hl[idx], l2, 4);
+        }
+    }
+    float *dhh, *dhl;
+    hipMalloc(&dhh, 65536 * 4); hipMalloc(&dhl, 65536 * 4);
+    hipMemcpy(dhh, hh.data(), 65536 * 4, hipMemcpyHostToDevice);
+    hipMemcpy(dhl, hl.data(), 65536 * 4, hipMemcpyHostToDevice);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int rr : {65536, 16384, 8192, 4096}) {
+        float t8 = 0, tpp = 0;
+        hipMemset(ypp, 0, rows * 4);
+        for (int which = 0; which < 2; ++which) {
+            for (int it = 0; it < 20; ++it) {
+                if (which == 0) hipLaunchKernelGGL((k_fwd8<8, 1>), dim3(256), dim3(NTHREAD), 0, 0, dp, IN, OUT, rr, dx, y8);
+                else hipLaunchKernelGGL((k_fwd_pp<8, 1>), dim3(256), dim3(NTHREAD), 0, 0, dp, IN, OUT, rr, dx, ypp, dhh, dhl);
+            }
+            hipEventRecord(e0);
+            for (int it = 0; it < 100; ++it) {
+                if (which == 0) hipLaunchKernelGGL((k_fwd8<8, 1>), dim3(256), dim3(NTHREAD), 0, 0, dp, IN, OUT, rr, dx, y8);
+                else hipLaunchKernelGGL((k_fwd_pp<8, 1>), dim3(256), dim3(NTHREAD), 0, 0, dp, IN, OUT, rr, dx, ypp, dhh, dhl);
+            }
+            hipEventRecord(e1);
+            hipEventSynchronize(e1);
+            float ms;
+            hipEventElapsedTime(&ms, e0, e1);
+            (which == 0 ? t8 : tpp) = ms * 10.f;
+        }
+        std::vector<float> a(rr), b(rr);
+        hipMemcpy(a.data(), y8, rr * 4, hipMemcpyDeviceToHost);
+        hipMemcpy(b.data(), ypp, rr * 4, hipMemcpyDeviceToHost);
+        double md = 0, mx = 0;
+        for (int i = 0; i < rr; ++i) { md = fmax(md, fabs(a[i] - b[i])); mx = fmax(mx, fabs(a[i])); }
+        printf("rows %6d (%4.1f groups / workgroup): shipped pairs %.1f us   ping-pong %.1f us   max |diff| %.2e (max |y| %.2f)  err=%s\n", rr,
+               rr / 16 / 256.0, t8, tpp, md, mx, hipGetErrorString(hipGetLastError()));
+    }
+    auto timepp = [&](auto kern, const char* name) {
+        for (int it = 0; it < 20; ++it) hipLaunchKernelGGL(kern, dim3(256), dim3(NTHREAD), 0, 0, dp, IN, OUT, rows, dx, ypp, dhh, dhl);
+        hipEventRecord(e0);
+        for (int it = 0; it < 100; ++it) hipLaunchKernelGGL(kern, dim3(256), dim3(NTHREAD), 0, 0, dp, IN, OUT, rows, dx, ypp, dhh, dhl);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms;
+        hipEventElapsedTime(&ms, e0, e1);
+        printf("  ping-pong ablation %-52s %.1f us\n", name, ms * 10.f);
+    };
+    timepp(k_fwd_pp<8, 1, 0>, "none");
+    timepp(k_fwd_pp<8, 1, 16>, "teams IN PHASE (lock-step control)");
+    timepp(k_fwd_pp<8, 1, 1>, "one k-block of the matrix block instead of 8");
+    timepp(k_fwd_pp<8, 1, 2>, "no exp (ELU = identity)");
+    timepp(k_fwd_pp<8, 1, 4>, "no image stores");
+    timepp(k_fwd_pp<8, 1, 8>, "no output reduction");
+    timepp(k_fwd_pp<8, 1, 32>, "lo halves from registers only (wrong numbers)");
+    timepp(k_fwd_pp<8, 1, 14>, "matrix block only (no exp, stores, reduction)");
+    timepp(k_fwd_pp<8, 1, 15>, "nothing (one k-block, no exp, stores, reduction)");
+    return 0;
+}
