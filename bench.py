@@ -423,9 +423,14 @@ def main():
     ap.add_argument('--config', default='c2', choices=['c2', 'c3', 'c4'],
                     help='c2 (default): the BASELINE metric - PathTracking MPG n=25 batch 4096; c3: NADP on the pendulum model, batch '
                          '8192; c4: TD3 + prioritized replay, batch 65536 (BASELINE.json configs[2], [3]: side lines, same JSON shape)')
+    ap.add_argument('--engine', default='split', choices=['split', 'f32'],
+                    help='split (default): the product; f32: the same step on libmpg_hip_f32.so, the exact-fp32 engine (the main run '
+                         'starts this form itself as a child process and reports it as exact_fp32_ms_per_step)')
     a = ap.parse_args()
     if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(launch_ranks(a))
+    from mpg_amd import _lib as LIBSEL
+    LIBSEL.select_engine(a.engine)
     if a.config != 'c2':
         return side_config(a)
 
@@ -514,18 +519,31 @@ def main():
         return
     # HBM bytes per launch from the PMC counters (FETCH_SIZE/WRITE_SIZE, separate rocprofv3 --pmc passes, gfx950
     # correction FETCH x2 for wide coalesced reads) - collected by tools/pmc.sh and committed under profiles/
-    traffic = {}
+    traffic, traffic_from = {}, None
     tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
     if os.path.exists(tpath):
         with open(tpath) as fh:
-            traffic = json.load(fh).get('bytes_per_launch', {})
-    # the same command on the exact-fp32 engine (-DMPG_F32_MFMA: v_mfma_f32_16x16x4_f32, no fp16 operands anywhere), measured
-    # once per round through gpurun by tools/profile.sh and committed under profiles/ - reported beside the split-fp16 number
-    exact = {}
-    epath = os.path.join(ROOT, 'profiles', 'exact_fp32_bench.json')
-    if os.path.exists(epath):
-        with open(epath) as fh:
-            exact = json.load(fh)
+            tj = json.load(fh)
+        traffic = tj.get('bytes_per_launch', {})
+        traffic_from = 'profiles/pmc_traffic.json (%s) - a committed PMC profile, NOT a measurement of this run' % tj.get('from', 'tools/pmc.sh')
+    # the same command on the exact-fp32 engine (libmpg_hip_f32.so = -DMPG_F32_MFMA: v_mfma_f32_16x16x4_f32, no fp16 operand
+    # anywhere), measured NOW: a child process (a fresh interpreter that selects the other shared object before its first GPU
+    # call; this process only waits) runs the same K / W after this run's timed region
+    exact = {'ms_per_step': None, 'from': None}
+    if a.engine == 'split' and world == 1 and not os.environ.get('MPG_BENCH_NO_F32'):
+        cmd = [sys.executable, os.path.abspath(__file__), '--gpus', '1', '--steps', str(a.steps), '--warmup', str(a.warmup),
+               '--engine', 'f32', '--no-cpu-baseline']
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+            if r.returncode == 0 and line:
+                d32 = json.loads(line[-1])
+                exact = {'ms_per_step': d32['ms_per_step'], 'from': 'this run: child process `%s` after the timed region' % ' '.join(cmd[1:]),
+                         'rollout_kernels_ms': [d32['roofline']['avg_ms'], d32['roofline_other_rollout_kernel']['avg_ms']]}
+            else:
+                exact['from'] = 'child failed (rc %d): %s' % (r.returncode, r.stderr[-300:])
+        except Exception as e:                       # noqa: BLE001 - a side measurement must not take the line down
+            exact['from'] = 'child failed: %r' % (e,)
 
     def roof(kernel, nbytes, flop, ms, n):
         """Both roofs of a rollout sweep.  With the split-fp16 engine the sweeps sit closer to the HBM roof (the activation
@@ -539,7 +557,7 @@ def main():
         algorithmic = flop * B_PER_GPU / sec / 1e12
         return {'kernel': kernel, 'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': gbs / HBM_PEAK_GBS, 'frac_hbm': gbs / HBM_PEAK_GBS, 'frac_f16_mfma': executed / F16_MFMA_PEAK_TFLOPS,
-                'traffic': tr, 'avg_ms': ms, 'launches': n,
+                'traffic': tr, 'traffic_from': traffic_from if tr else None, 'avg_ms': ms, 'launches': n,
                 'timed_with': 'HIP events on the launch stream around every %d-th launch of the timed region' % PROF_EVERY,
                 'algorithmic_bytes_per_launch': nbytes * B_PER_GPU,
                 'traffic_gbs': (tr / sec / 1e9) if tr else None,
@@ -561,10 +579,13 @@ def main():
         'gc': 'gc.collect()+gc.freeze() before the burn-in, gc.disable() inside the timed region',
         'step_ms_median': per_step[len(per_step) // 2], 'step_ms_min': per_step[0], 'step_ms_max': per_step[-1],
         'step_ms_from': 'second pass of the same %d steps, one HIP event per step (not part of value)' % a.steps,
-        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32-via-split-f16', 'data': 'synthetic',
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32-via-split-f16' if a.engine == 'split' else 'f32', 'data': 'synthetic',
         'schema': 3,     # 3: roofline.frac = HBM view (round 1: fp32-MFMA view), frac_hbm / frac_f16_mfma under stable keys, exact_fp32_*
         'exact_fp32_ms_per_step': exact.get('ms_per_step'),
         'exact_fp32_from': exact.get('from'),
+        'exact_fp32_rollout_kernels_ms': exact.get('rollout_kernels_ms'),
+        'engine': a.engine,
         'dtype_note': 'float32 data and accumulation; the 256x256 hidden-layer products run as fp16 hi/lo split operands on the f16 matrix pipe (3 MFMAs per fp32-equivalent step, more accurate than the fp32 fma chain on a single layer; csrc/mlp_core.h)',
         'config': {'workload': 'PathTrackingEnv, MPG-v2 learner, n=25, M=1, 4096 vectorised envs + replay batch 4096 per '
                                'GPU; step = worker.sample(4096 env-steps) + add_batch + replay + compute_gradient + '

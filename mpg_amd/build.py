@@ -12,6 +12,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(HERE, 'build')
 LIB = os.path.join(HERE, 'libmpg_hip.so')
+# the same sources with -DMPG_F32_MFMA: the exact-fp32 engine (v_mfma_f32_16x16x4_f32) beside the product - what bench.py
+# times as `exact_fp32_ms_per_step` and the parity tests run as the second engine (mpg_amd/_lib.py ENGINES)
+VARIANTS = {'split': (OBJ, LIB, []), 'f32': (os.path.join(HERE, 'build_f32'), os.path.join(HERE, 'libmpg_hip_f32.so'), ['-DMPG_F32_MFMA'])}
 ARCH = os.environ.get('MPG_ARCH', 'gfx950')      # MPG_ARCH=gfx950:xnack- for experiments
 
 # MPG_EXTRA_CFLAGS: ablation / diagnostic builds only (e.g. -DMPG_AB_NODYN); never set in the product build
@@ -20,6 +23,12 @@ COMMON = os.environ.get('MPG_EXTRA_CFLAGS', '').split() + ['-O3', '-fPIC', '-std
           # flattened thread id, whose workgroup size the code then reads from the dispatch packet in HOST memory
           # (microseconds per load; tools/dispatch_ptr_check.py, tests/test_abi.py keep every kernel free of such reads)
           '-mllvm', '-disable-promote-alloca-to-lds',
+          # no SLP vectorizer anywhere: it is what forms v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 out of scalar float32 code, and
+          # single products of such packed FMAs were lost nondeterministically beside matrix instructions ("lost
+          # packed-FMA products"; reproducible at 99.5 % of launches with -DMPG_AB_PKFMA).  With it off no kernel that issues MFMAs
+          # contains a packed fp32 instruction (tools/pk_census.py; tests/test_abi.py keeps it so).  Cost, same-box A/B of the bench
+          # step (round 4): 0.2432 against 0.2400 / 0.2428 ms for the two baselines around it - inside the noise.
+          '-fno-slp-vectorize',
           '-I' + os.path.join(HERE, '..', 'include')]
 # per-file extras: the real-env kernel mirrors the reference op-by-op, so no fused multiply-adds there
 EXTRA = {'env_path_tracking.hip': ['-ffp-contract=off'] + os.environ.get('MPG_ENV_CFLAGS', '').split(),
@@ -39,7 +48,7 @@ EXTRA = {'env_path_tracking.hip': ['-ffp-contract=off'] + os.environ.get('MPG_EN
          # measures another 1.3 us faster (77.3 - 77.6 vs 78.7 - 78.9 us in alternating runs; no effect on the forward sweep)
          # and with the SLP vectorizer off the iterative-ilp strategy is the best of those that build (75.2 - 75.6 vs 76.6 - 77.5 us
          # for max-memory-clause, 80 default, 94 max-ilp; iterative-minreg / -maxocc: 2x slower or worse)
-         'rollout_bwd.hip': os.environ.get('MPG_BWD_CFLAGS', '-mllvm -amdgpu-sched-strategy=iterative-ilp -fno-slp-vectorize').split(),
+         'rollout_bwd.hip': os.environ.get('MPG_BWD_CFLAGS', '-mllvm -amdgpu-sched-strategy=iterative-ilp').split(),
          # the pendulum instantiations (NADP, config 3) measure 10 us slower under those and keep max-memory-clause with SLP
          'rollout_bwd_pendulum.hip': ['-mllvm', '-amdgpu-sched-strategy=max-memory-clause'],
          'rollout_fwd_pendulum.hip': ['-mllvm', '-amdgpu-sched-strategy=max-memory-clause']}
@@ -65,15 +74,23 @@ def _stamp(src, flags):
     return h.hexdigest()
 
 
-def build(force=False, verbose=True, jobs=None):
+def build(force=False, verbose=True, jobs=None, engines=('split', 'f32')):
+    """builds every engine variant (default: both); returns the product's path"""
+    for e in engines:
+        _build_one(e, force, verbose, jobs)
+    return LIB
+
+
+def _build_one(engine, force, verbose, jobs):
     from concurrent.futures import ThreadPoolExecutor
+    OBJ, LIB, vflags = VARIANTS[engine]
     os.makedirs(OBJ, exist_ok=True)
     cc = hipcc()
     objs, todo = [], []
     for s in sources():
         src = os.path.join(CSRC, s)
         obj = os.path.join(OBJ, s + '.o')
-        flags = COMMON + EXTRA.get(s, []) + (['-x', 'hip'] if s.endswith('.hip') else [])
+        flags = COMMON + vflags + EXTRA.get(s, []) + (['-x', 'hip'] if s.endswith('.hip') else [])
         stamp_file = obj + '.stamp'
         stamp = _stamp(src, flags)
         if force or not os.path.exists(obj) or not os.path.exists(stamp_file) or open(stamp_file).read() != stamp:
@@ -99,5 +116,5 @@ def build(force=False, verbose=True, jobs=None):
 
 
 if __name__ == '__main__':
-    build(force='--force' in sys.argv)
+    build(force='--force' in sys.argv, engines=('split',) if '--split-only' in sys.argv else ('split', 'f32'))
     print(LIB)

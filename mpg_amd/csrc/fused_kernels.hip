@@ -28,22 +28,6 @@ __device__ __forceinline__ void load_w2(const float* pack, const float* W2, bool
 #endif
 
 
-// Learner-side judge_is_nan (worker.py:95-107 on every worker obs / action, optimizer.py:357-361 on the gradient list).  The
-// ELU's v_med3_f32 DROPS a NaN (the median of (NaN, NaN, 0) is 0), so a NaN in a replay row would leave these kernels as a
-// finite, wrong value that neither the status word nor the gradient NaN guard can see.  Two things restore the reference's
-// behaviour: every thread that loads a network input ORs MPG_STATUS_NAN into the caller's status word when it sees one, and
-// the row's result is poisoned - row_poison() is 0 for a finite row and NaN for a row with a NaN (or an infinity: 0 * inf)
-// among its n inputs; added to the row's TD error / target value it makes the gradient non-finite, which the clip kernel
-// turns into a zeroed step exactly like the reference (`grads = [tf.zeros_like(grad) ...]`).
-__device__ __forceinline__ float row_poison(const float* sXrow, int n) {
-    float z = 0.f;
-    for (int i = 0; i < n; ++i) z = fmaf(sXrow[i], 0.f, z);
-    return z;
-}
-__device__ __forceinline__ void report_nan(int* status, bool saw_nan) {
-    if (status && saw_nan) atomicOr(status, MPG_STATUS_NAN);
-}
-
 constexpr int SMEM_FLOATS = 2 * A_IMG + GROUP * XS + NWAVE * GROUP * MAXOUT + GROUP * MAXOUT + NWAVE * GROUP * XS + 4 * GROUP;
 struct Smem {
     float *sA, *sA1, *sX, *sPart, *sD3, *sPartX, *sQ;

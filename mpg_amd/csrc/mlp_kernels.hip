@@ -60,6 +60,10 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_forward(const FwdArgs a) {
         saw_nan |= xv != xv;
         if (threadIdx.x < G2 * GROUP * XSW) sX[threadIdx.x] = xv;
         lds_barrier();
+        // a NaN among a row's inputs stays a NaN in its outputs (row_poison, mlp_core.h): read here, while the block is this
+        // unit's - the next unit's inputs are stored in front of the barrier above
+        float pz = 0.f;
+        if (threadIdx.x < G2 * GROUP * OU) pz = row_poison(sX + (threadIdx.x / OU) * XSW, XSW);
         float h1[G2][2][4], h2[G2][2][4];
         if constexpr (G2 == 2)
             forward_group2<IN, OU>(sX, sX + GROUP * XSW, sA, sA + A_IMG, sPart, sPart + NWAVE * GROUP * MAXOUT, L, w2, r, h1[0], h2[0], h1[1],
@@ -81,6 +85,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_forward(const FwdArgs a) {
             if (gr < a.rows) {
                 float z = out_preact(sPart + g2 * NWAVE * GROUP * MAXOUT, b3v, row, o);
                 float y = a.out_tanh ? a.out_scale * tanhf(z) : z;
+                y += pz;
                 if (a.sigma > 0.f) {   // OffPolicyWorker.sample: action += N(0, sigma), worker.py:97-98
                     Philox4 p = philox4x32_10((uint32_t)gr, a.c1, a.c2, 0x5eedu + (uint32_t)o, a.k0, a.k1);
                     float u1 = u01(p.v[0]), u2 = u01(p.v[1]);

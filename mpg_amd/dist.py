@@ -34,35 +34,54 @@ def init_from_env(backend=None):
     return rank, world, local
 
 
-class _HostCounters(object):
-    """One int64 counter per rank in a POSIX shared-memory file (a cache line each): `publish(v)` stores this rank's, `wait(p, v)`
-    spins until rank p's is >= v.  The cross-process half of the IPC-event hand-shake below: an event wait must be ISSUED after
-    the peer has issued the matching record (a wait captures the event's latest record at the time of the call), and that is a
-    fact about the peers' host threads, not about the GPU - so it is settled host to host, without draining any stream."""
+class _HostShm(object):
+    """A POSIX shared-memory file the ranks of one node use for HOST-to-host hand-shakes of the one-shot exchange:
+      * `calls[r]`   - int64 counter per rank (a cache line each): publish(v) / wait(p, v) order "peer issued its event record"
+        before "I issue my wait" (a wait captures the event's latest record at the time of the call - a fact about the peers'
+        host threads, not about the GPU, so it is settled host to host without draining any stream);
+      * `gen[r]`     - the newest event GENERATION whose handles rank r has published;
+      * `handles[g & 1][r]` - the interprocess-event handles (4 x 64 bytes) of rank r's generation g."""
+    HB = 64                                        # sizeof(hipIpcEventHandle_t)
 
     def __init__(self, world, rank, tag):
         import numpy as np
         self.world, self.rank = world, rank
         path = '/dev/shm/mpg_oneshot_%s_%s' % (os.environ.get('MASTER_PORT', '0'), tag)
+        n_i64 = 16 * world
+        nbytes = 8 * n_i64 + 2 * world * 4 * self.HB
         if rank == 0:
             with open(path, 'wb') as fh:
-                fh.write(b'\0' * (64 * world))
+                fh.write(b'\0' * nbytes)
         dist.barrier()
-        self.a = np.memmap(path, dtype=np.int64, mode='r+', shape=(8 * world,))
+        self.raw = np.memmap(path, dtype=np.uint8, mode='r+', shape=(nbytes,))
+        self.a = self.raw[:8 * n_i64].view(np.int64)
+        self.h = self.raw[8 * n_i64:].reshape(2, world, 4, self.HB)
         dist.barrier()
         if rank == 0:
             os.unlink(path)              # the mappings keep it alive; nothing is left behind if a rank dies
 
     def publish(self, v):
-        self.a[8 * self.rank] = v
+        self.a[16 * self.rank] = v
 
-    def wait(self, p, v):
-        a, i = self.a, 8 * p
-        spins = 0
+    def _spin(self, i, v, what):
+        a, spins = self.a, 0
         while a[i] < v:
             spins += 1
             if spins > 200000000:
-                raise RuntimeError('one-shot all-reduce: rank %d never reached exchange %d' % (p, v))
+                raise RuntimeError('one-shot all-reduce: %s %d never reached' % (what, v))
+
+    def wait(self, p, v):
+        self._spin(16 * p, v, 'rank %d, exchange' % p)
+
+    def publish_handles(self, g, handles):
+        import numpy as np
+        for k, hb in enumerate(handles):
+            self.h[g & 1, self.rank, k, :] = np.frombuffer(bytes(hb), dtype=np.uint8)
+        self.a[16 * self.rank + 8] = g + 1           # (x86: stores are not reordered with older stores)
+
+    def peer_handles(self, p, g):
+        self._spin(16 * p + 8, g + 1, 'rank %d, event generation' % p)
+        return [bytes(self.h[g & 1, p, k, :]) for k in range(4)]
 
 
 class OneShotAllReduce(object):
@@ -83,14 +102,20 @@ class OneShotAllReduce(object):
     hipIpcOpenEventHandle).  Rank r records W_r[parity] on its stream behind its copies and makes its stream wait
     (hipStreamWaitEvent) for every peer's W_p[parity]; the sum kernel is enqueued behind those waits and S_r[parity] is recorded
     behind it, which the peers wait for before they overwrite r's slots two exchanges later.  The HOST never waits for the GPU:
-    the only host-side coupling is a per-rank call counter in shared memory (_HostCounters) that orders "peer issued its
-    record" before "I issue my wait" - sub-microsecond when the peers' host threads run ahead of their GPUs, which they do (the
-    native step driver enqueues a 0.24 ms step in ~40 us).  So the launch queue of the native driver no longer drains at the
-    exchange.  There is still no device-side spin between processes (on the test box several ranks time-share ONE GPU).
+    the only host-side coupling is a per-rank call counter in shared memory (_HostShm) that orders "peer issued its record"
+    before "I issue my wait" - sub-microsecond when the peers' host threads run ahead of their GPUs, which they do (the native
+    step driver enqueues a 0.24 ms step in ~40 us).  So the launch queue of the native driver no longer drains at the exchange.
+    There is still no device-side spin between processes (on the test box several ranks time-share ONE GPU).
+    A HIP interprocess event can be recorded 32 times in its life (ROCm 7.2: the 33rd hipStreamWaitEvent on an opened handle
+    returns hipErrorInvalidValue whatever the owner does in between - tools/proto/ipc_event/probe.py), so the events live in
+    GENERATIONS of GEN_LEN exchanges: the next generation's four events are created and their handles published through the
+    shared-memory file while the current one is in use, and opened by the peers at the generation boundary - host work of a few
+    tens of microseconds every GEN_LEN steps, off the GPU's critical path.
     `sync='host'` (MPG_ONESHOT_SYNC=host): the round-3 form - stream.synchronize() + dist.barrier() - kept as the control.
 
     Validated for correctness only - 2, 4 and 8 processes time-sharing one GPU (tests/test_dist_gpu.py); no multi-GPU number is
     claimed."""
+    GEN_LEN = 40          # exchanges per event generation: 20 records per event (+ 1 at creation), under the limit of 32
 
     def __init__(self, n, device, sync=None):
         from torch.multiprocessing.reductions import reduce_tensor
@@ -100,40 +125,40 @@ class OneShotAllReduce(object):
         self.n = int(n)
         self.sync = sync or os.environ.get('MPG_ONESHOT_SYNC', 'event')
         assert self.sync in ('event', 'host')
+        self.dev = torch.device(device) if not isinstance(device, torch.device) else device
         self.stage = torch.zeros(2, self.world, self.n, dtype=torch.float32, device=device)
         torch.cuda.synchronize()
-        fn, args = reduce_tensor(self.stage)
-        mine = [(fn, args)]
-        if self.sync == 'event':
-            # W[par]: "my copies of this parity are done"; S[par]: "my sum of this parity is done"
-            self.W = [torch.cuda.Event(enable_timing=False, interprocess=True) for _ in range(2)]
-            self.S = [torch.cuda.Event(enable_timing=False, interprocess=True) for _ in range(2)]
-            for e in self.W + self.S:
-                e.record()               # an interprocess event gets its handle once it has been recorded
-            torch.cuda.synchronize()
-            mine.append([e.ipc_handle() for e in self.W + self.S])
         handles = [None] * self.world
-        dist.all_gather_object(handles, tuple(mine))
-        self.peers, self.pW, self.pS = [], [], []
-        dev = torch.device(device) if not isinstance(device, torch.device) else device
+        dist.all_gather_object(handles, reduce_tensor(self.stage))
+        self.peers = []
         for r in range(self.world):
             if r == self.rank:
                 self.peers.append(self.stage)
-                self.pW.append(None)
-                self.pS.append(None)
-                continue
-            f, a = handles[r][0]
-            self.peers.append(f(*a))           # rebuild_cuda_tensor: opens the peer's allocation
-            if self.sync == 'event':
-                ev = [torch.cuda.Event.from_ipc_handle(dev, h) for h in handles[r][1]]
-                self.pW.append(ev[:2])
-                self.pS.append(ev[2:])
+            else:
+                f, a = handles[r]
+                self.peers.append(f(*a))           # rebuild_cuda_tensor: opens the peer's allocation
         self.calls = 0
         if self.sync == 'event':
             global _oneshot_tag
             _oneshot_tag += 1
-            self.ctr = _HostCounters(self.world, self.rank, '%d_%d' % (self.n, _oneshot_tag))
+            self.shm = _HostShm(self.world, self.rank, '%d_%d' % (self.n, _oneshot_tag))
+            self.mine, self.theirs = {}, {}        # generation -> [W0, W1, S0, S1] / {peer: [W0, W1, S0, S1]}
+            self._make_generation(0)
+            self._make_generation(1)
+            self._open_generation(0)
         dist.barrier()
+
+    # ---- event generations ----
+    def _make_generation(self, g):
+        ev = [torch.cuda.Event(enable_timing=False, interprocess=True) for _ in range(4)]
+        for e in ev:
+            e.record()                   # an interprocess event gets its handle once it has been recorded
+        self.mine[g] = ev
+        self.shm.publish_handles(g, [e.ipc_handle() for e in ev])
+
+    def _open_generation(self, g):
+        self.theirs[g] = {p: [torch.cuda.Event.from_ipc_handle(self.dev, h) for h in self.shm.peer_handles(p, g)]
+                          for p in range(self.world) if p != self.rank}
 
     def all_reduce_sum_(self, flat):
         assert flat.numel() == self.n and flat.dtype == torch.float32 and flat.is_contiguous()
@@ -149,22 +174,27 @@ class OneShotAllReduce(object):
             L.call('mpg_sum_slots', L.ptr(self.stage[par]), L.c_int(self.world), L.c_int(self.n), L.ptr(flat), L.stream())
             return flat
         it = self.calls
-        # 0. a peer's slots of this parity were last read by its sum two exchanges ago: S_p[par], recorded then (the peer's host
-        #    issued that record before it published exchange it - 1, which this rank waited for in exchange it - 1)
+        g = (it - 1) // self.GEN_LEN
+        if (it - 1) % self.GEN_LEN == 0 and g > 0:      # generation boundary: open the peers' events of g, prepare g + 1, drop g - 2
+            self._open_generation(g)
+            self._make_generation(g + 1)
+            self.mine.pop(g - 2, None)
+            self.theirs.pop(g - 2, None)
+        # 0. a peer's slots of this parity were last read by its sum two exchanges ago: S_p[par] of THAT exchange's generation (the
+        #    peer's host issued that record before it published exchange it - 1, which this rank waited for in exchange it - 1)
         if it > 2:
-            for p in range(self.world):
-                if p != self.rank:
-                    st.wait_event(self.pS[p][par])
+            g2 = (it - 3) // self.GEN_LEN
+            for p, ev in self.theirs[g2].items():
+                st.wait_event(ev[2 + par])
         for r in range(self.world):                     # 1. my buffer into slot `rank` of every rank's array
             self.peers[r][par, self.rank].copy_(flat, non_blocking=True)
-        self.W[par].record(st)
-        self.ctr.publish(it)                            # host: "my record of exchange `it` has been issued"
-        for p in range(self.world):                     # 2. behind every peer's writes - a stream wait, not a host wait
-            if p != self.rank:
-                self.ctr.wait(p, it)
-                st.wait_event(self.pW[p][par])
+        self.mine[g][par].record(st)                    # W[par]
+        self.shm.publish(it)                            # host: "my record of exchange `it` has been issued"
+        for p, ev in self.theirs[g].items():            # 2. behind every peer's writes - a stream wait, not a host wait
+            self.shm.wait(p, it)
+            st.wait_event(ev[par])
         L.call('mpg_sum_slots', L.ptr(self.stage[par]), L.c_int(self.world), L.c_int(self.n), L.ptr(flat), L.stream())   # 3.
-        self.S[par].record(st)
+        self.mine[g][2 + par].record(st)                # S[par]
         return flat
 
 

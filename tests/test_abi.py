@@ -39,10 +39,21 @@ def test_code_object_is_gfx950_only(built):
 
 
 def test_product_path_fails_loudly_without_library(monkeypatch, tmp_path):
-    monkeypatch.setattr(L, '_lib', None)
-    monkeypatch.setattr(L, 'LIB_PATH', str(tmp_path / 'nope.so'))
+    monkeypatch.setattr(L, '_libs', {})
+    monkeypatch.setattr(L, 'ENGINES', {'split': str(tmp_path / 'nope.so'), 'f32': str(tmp_path / 'nope_f32.so')})
     with pytest.raises(L.MpgError):
         L.lib()
+
+
+def test_exact_fp32_engine_is_built_beside_the_product_with_the_same_abi(built):
+    """mpg_amd/build.py builds the library twice from the same sources: the product and libmpg_hip_f32.so (-DMPG_F32_MFMA, the
+    exact-fp32 hidden-layer engine that bench.py times as exact_fp32_ms_per_step and the parity tests run as the second engine).
+    Same exports, same ABI version; only the product contains f16 matrix instructions."""
+    f32 = L.ENGINES['f32']
+    assert os.path.exists(f32) and os.path.dirname(f32) == os.path.dirname(built)
+    lib = ctypes.CDLL(f32)
+    assert not [n for n in L.declared_symbols() if not hasattr(lib, n)]
+    assert lib.mpg_abi_version() == ctypes.CDLL(built).mpg_abi_version()
 
 
 def test_product_package_never_imports_the_oracle():
@@ -112,3 +123,18 @@ def test_library_sources_read_no_environment_variables():
     for f in sorted(os.listdir(csrc)):
         if f.endswith(('.hip', '.h', '.cpp')):
             assert not re.search(r'\bgetenv\s*\(', open(os.path.join(csrc, f)).read()), f
+
+
+def test_no_packed_fp32_arithmetic_beside_matrix_instructions():
+    """Containment of the lost packed-FMA products BY CONSTRUCTION: in the round-2 weight-gradient
+    kernel single products of v_pk_fma_f32 were lost nondeterministically (99.5 % of launches with the explicit packed form,
+    tools/pk_anomaly.sh), only in a kernel that also issues MFMAs.  The library is therefore built without the SLP vectorizer
+    (mpg_amd/build.py COMMON) and tools/pk_census.py lists, from the ISA of every translation unit as the shipped flags compile
+    it, the kernels that contain v_pk_{fma,mul,add}_f32: none of them may contain a matrix instruction."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('pk_census', os.path.join(os.path.dirname(__file__), '..', 'tools', 'pk_census.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rows = mod.census()
+    beside = [(f, mod.demangle(k), c) for f, k, c, mf in rows if mf]
+    assert beside == [], beside

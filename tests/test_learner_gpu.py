@@ -127,8 +127,18 @@ def test_evaluator_metrics_vs_reference(golden):
         assert (np.abs(got - g['per_episode_f64'][:, j]) <= 4 * e32 + 2e-6 * np.abs(g['per_episode_f64'][:, j]) + 1e-9).all(), k
 
 
+@pytest.fixture(params=['split', 'f32'])
+def engine(request):
+    """both builds of the library (mpg_amd/_lib.py ENGINES): the split-fp16 product and the exact-fp32 engine it is measured
+    against (libmpg_hip_f32.so, -DMPG_F32_MFMA) - model.py:39-43 is plain float32; every library call of the test goes to the
+    selected shared object"""
+    from mpg_amd import _lib as L
+    with L.engine(request.param):
+        yield request.param
+
+
 @pytest.mark.parametrize('name', ['c2_mpg_v2_B4096', 'c3_nadp_B8192', 'c4_td3_B65536'])
-def test_bench_size_cases_vs_reference(golden, name):
+def test_bench_size_cases_vs_reference(golden, name, engine):
     """BASELINE.json configs at their FULL batch sizes against the reference itself: MPG-v2 at B = 4096 (C2, the bench
     workload), NADP on the pendulum model at B = 8192 (C3), TD3 at B = 65 536 (C4).  Inputs are seeded draws regenerated
     here (tests/golden_inputs.py); the fixture holds what the unmodified reference computed from them.  Every gradient
@@ -175,7 +185,7 @@ def test_bench_size_cases_vs_reference(golden, name):
         assert int(pw.nonfinite.sum().item()) == 0
 
 
-def test_trained_networks_vs_reference(golden):
+def test_trained_networks_vs_reference(golden, engine):
     """The bench workload's gradient (MPG-v2, B = 4096, iterations 100 and 9000) on TRAINED networks: the online weights after
     20 000 iterations of the HIP path at the reference's default learning rates (tools/train_export.py: evaluation return
     -4365 -> -5; tests/golden/trained_weights.npz), every output computed by the unmodified reference from them
@@ -210,7 +220,7 @@ def test_trained_networks_vs_reference(golden):
         for k in ('value_mean', 'policy_total_loss', 'policy_gradient_norm', 'q_loss1', 'q_gradient_norm1', 'q_loss2', 'q_gradient_norm2'):
             np.testing.assert_allclose(st[k], g[p + k], rtol=5e-5, atol=1e-6, err_msg=k)
     assert int(pw.nonfinite.sum().item()) == 0 and pw.check_status() == 0
-    print('trained nets: worst error / allowance = %.2f' % worst)
+    print('trained nets (%s engine): worst error / allowance = %.2f' % (engine, worst))
 
 
 @pytest.mark.parametrize('name,reps', [('c2_mpg_v2_B4096', 3000), ('c3_nadp_B8192', 600), ('c4_td3_B65536', 200)])

@@ -23,8 +23,8 @@ run() {
   unset MPG_FWD_CFLAGS MPG_BWD_CFLAGS
   extra="$spec"
   if [[ "$spec" == FWD=* ]]; then fwd="${spec#FWD=}"; fwd="${fwd%% BWD=*}"; extra="${spec#* BWD=}"; bwd="${extra%% EXTRA=*}"; extra="${extra#* EXTRA=}"; [[ "$extra" == "$bwd" ]] && extra=""; export MPG_FWD_CFLAGS="$fwd" MPG_BWD_CFLAGS="$bwd"; fi
-  MPG_EXTRA_CFLAGS="$extra" python3 -m mpg_amd.build > /tmp/build.log 2>&1 || { echo "BUILD FAILED"; tail -5 /tmp/build.log; return; }
-  MPG_EXTRA_CFLAGS="$extra" python3 bench.py --steps $STEPS --warmup 30 --no-cpu-baseline 2>/dev/null | tail -1 | python3 -c "
+  MPG_EXTRA_CFLAGS="$extra" python3 -m mpg_amd.build --split-only > /tmp/build.log 2>&1 || { echo "BUILD FAILED"; tail -5 /tmp/build.log; return; }
+  MPG_EXTRA_CFLAGS="$extra" MPG_BENCH_NO_F32=1 python3 bench.py --steps $STEPS --warmup 30 --no-cpu-baseline 2>/dev/null | tail -1 | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read()); o=d['other_kernels_avg_ms']
 r={d['roofline']['kernel'][:13]:d['roofline']['avg_ms'], d['roofline_other_rollout_kernel']['kernel'][:13]:d['roofline_other_rollout_kernel']['avg_ms']}
@@ -34,4 +34,4 @@ echo "== [baseline]"; run ""
 for V in "$@"; do echo "== [$V]"; run "$V"; done
 echo "== [baseline]"; run ""
 unset MPG_FWD_CFLAGS MPG_BWD_CFLAGS
-python3 -m mpg_amd.build > /tmp/build.log 2>&1
+python3 -m mpg_amd.build --split-only > /tmp/build.log 2>&1

@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Census of packed-fp32 vector instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) in the shipped ISA, per kernel and
+translation unit, as the shipped flags compile it (cross-compiles, no GPU needed).  DESIGN.md sections 4.6 / 4.12: single products
+of packed FMAs were lost nondeterministically next to matrix instructions in the weight-gradient kernel; the containment rule
+is "no packed fp32 arithmetic in a kernel that issues MFMAs" - this tool is the check (tests/test_abi.py runs it).
+    python3 tools/pk_census.py [--extra "<flags>"] [file.hip ...]"""
+import os
+import re
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+from mpg_amd import build as B   # noqa: E402
+
+PK = re.compile(r'^\s*(v_pk_(?:fma|mul|add)_f32)\b')
+MFMA = re.compile(r'^\s*v_mfma_')
+
+
+def census(files=None, extra=()):
+    """[(file, kernel, {opcode: count}, n_mfma)] for every kernel that contains a packed-fp32 instruction"""
+    out = []
+    for f in files or [s for s in B.sources() if s.endswith('.hip')]:
+        flags = B.COMMON + B.EXTRA.get(f, []) + list(extra) + ['-x', 'hip', '--offload-device-only', '-S']
+        asm = subprocess.run([B.hipcc()] + flags + [os.path.join(B.CSRC, f), '-o', '-'], capture_output=True, text=True, check=True).stdout
+        cur, counts, mf = None, {}, 0
+        for line in asm.splitlines():
+            m = re.match(r'^(_Z\w+):', line)
+            if m:
+                if cur and counts:
+                    out.append((f, cur, counts, mf))
+                cur, counts, mf = m.group(1), {}, 0
+                continue
+            p = PK.match(line)
+            if p:
+                counts[p.group(1)] = counts.get(p.group(1), 0) + 1
+            elif MFMA.match(line):
+                mf += 1
+        if cur and counts:
+            out.append((f, cur, counts, mf))
+    return out
+
+
+def demangle(n):
+    s = subprocess.run(['c++filt', n], capture_output=True, text=True).stdout.strip()
+    return re.sub(r'\(anonymous namespace\)::', '', s).split('(')[0].replace('void ', '')
+
+
+if __name__ == '__main__':
+    args = sys.argv[1:]
+    extra = []
+    if args and args[0] == '--extra':
+        extra = args[1].split()
+        args = args[2:]
+    rows = census(args or None, extra)
+    for f, k, c, mf in rows:
+        print('%-26s %-58s mfma=%-4d %s' % (f, demangle(k)[:58], mf, ' '.join('%s=%d' % kv for kv in sorted(c.items()))))
+    print('%d kernels with packed fp32 arithmetic, %d of them beside matrix instructions' % (len(rows), sum(1 for r in rows if r[3])))

@@ -52,6 +52,26 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_fwd8(const float* params, int in
     }
 }
 
+// ---- TRANSPOSED activation image (variant 128) ----------------------------------------------------------------------------
+// One 32-byte slot per contraction index k: the 16 batch rows of the group, fp16, rows contiguous - what a C-layout lane holds
+// (rows 4 rg .. 4 rg + 3 of ONE column) is one aligned 8-byte chunk, so the image store is ONE ds_write_b64 per tile and image
+// (no DPP exchange, no selects).  The MFMA A operand (row l & 15, 8 consecutive k) comes back through ds_read_b64_tr_b16, the
+// hardware transpose read: two reads of 4 k each per operand.  Slot order inside a k-block and an XOR on the chunk position make
+// both the stores (16 lanes of a row quad) and the transposed reads (32-lane halves) bank-conflict free without padding:
+//   k = 32 kb + 8 g + j  ->  slot = 32 kb + 16 (g >> 1) + 8 (j >> 2) + 4 (g & 1) + (j & 3),  chunk' = chunk ^ ((slot >> 2) & 3)
+constexpr int TR_IMG_BYTES = 256 * 32;            // one image (hi or lo): 8 KB, no padding
+__device__ __forceinline__ int tr_slot(int k) { const int kb = k >> 5, g = (k >> 3) & 3, j = k & 7; return 32 * kb + 16 * (g >> 1) + 8 * (j >> 2) + 4 * (g & 1) + (j & 3); }
+__device__ __forceinline__ int tr_byte(int slot, int chunk) { return slot * 32 + 8 * (chunk ^ ((slot >> 2) & 3)); }
+// (a, b) -> packed fp16 words of a * S = hi + lo, two v_fma_mix per word (scale, conversion and packing in one instruction each)
+__device__ __forceinline__ void split2_mix(float a, float b, float S, unsigned& hi, unsigned& lo) {
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hi) : "v"(a), "v"(S));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hi) : "v"(b), "v"(S));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(lo) : "v"(a), "v"(S), "v"(hi));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lo) : "v"(b), "v"(S), "v"(hi));
+}
+typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
 // ---- ping-pong geometry --------------------------------------------------------------------------------------------------------
 constexpr int TW = 4;                 // waves per team
 constexpr int NT = 4;                 // 16-column tiles per wave
@@ -60,6 +80,8 @@ constexpr int LO_FLOATS = TW * LO_KB * NT * 256;      // 28 672 floats = 112 KB
 
 // AB (timing only, wrong numbers): 1 one k-block of the matrix block, 2 no exps, 4 no image stores, 8 no output reduction,
 // 16 the teams in PHASE (both do their vector phase, then both their matrix phase: the lock-step control), 32 no lo reads from LDS
+// 64 (correct numbers): leaner vector phase - the x16 image scale folded into layer 1 / the epilogue, image halves stored with
+//    16-bit LDS stores straight from the packed conversions (no DPP exchange, no selects)
 template <int IN, int OU, int AB = 0>
 __global__ void __launch_bounds__(NTHREAD, 2) k_fwd_pp(const float* params, int in_dim, int out_dim, int rows, const float* x, float* y, const float* pk_hi, const float* pk_lo) {
     __shared__ __attribute__((aligned(16))) float sLo[LO_FLOATS];
@@ -93,12 +115,13 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_fwd_pp(const float* params, int 
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int col = 64 * q + 16 * t + c;
+        constexpr float SC = (AB & 64) ? A_SCALE : 1.f;       // leaner form: layer 1 and the hidden layer produce 16 h directly
 #pragma unroll
-        for (int s = 0; s < 2; ++s) w1p[s][t] = (4 * s + rg) < in_dim ? net.W1[(4 * s + rg) * H + col] : 0.f;
-        b1[t] = net.b1[col];
-        b2[t] = net.b2[col];
+        for (int s = 0; s < 2; ++s) w1p[s][t] = (4 * s + rg) < in_dim ? net.W1[(4 * s + rg) * H + col] * SC : 0.f;
+        b1[t] = net.b1[col] * SC;
+        b2[t] = net.b2[col] * SC;
 #pragma unroll
-        for (int o = 0; o < OU; ++o) w3[t][o] = net.W3[col * out_dim + o];
+        for (int o = 0; o < OU; ++o) w3[t][o] = net.W3[col * out_dim + o] / SC;
     }
     const float b3v = tid < 0 ? 0.f : net.b3[(lane % OU)];
     auto hfrag = [&](int kb, int t) {
@@ -132,8 +155,13 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_fwd_pp(const float* params, int 
             for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
+                    if constexpr (AB & 64) {
+                        const float a = fmaf(acc[t][j], 1.f / W_SCALE, b2[t]);          // 16 z
+                        h2[t][j] = __builtin_amdgcn_fmed3f(a, fmaf(__builtin_amdgcn_exp2f(a * (1.4426950408889634f / A_SCALE)), A_SCALE, -A_SCALE), 0.f);
+                    } else {
                     const float a = fmaf(acc[t][j], 1.f / (W_SCALE * A_SCALE), b2[t]);
                     h2[t][j] = (AB & 2) ? a : __builtin_amdgcn_fmed3f(a, __builtin_amdgcn_exp2f(a * 1.4426950408889634f) - 1.f, 0.f);
+                    }
                 }
             float p[OU][4];
 #pragma unroll
@@ -158,6 +186,38 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_fwd_pp(const float* params, int 
             for (int s = 0; s < 2; ++s)
 #pragma unroll
                 for (int t = 0; t < NT; ++t) z[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[s], w1p[s][t], z[t], 0, 0, 0);
+            if constexpr (AB & 128) {
+                char* img = reinterpret_cast<char*>(sAimg[team]);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    float h[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) h[j] = __builtin_amdgcn_fmed3f(z[t][j], __builtin_amdgcn_exp2f(z[t][j] * 1.4426950408889634f) - 1.f, 0.f);
+                    unsigned h01, l01, h23, l23;
+                    split2_mix(h[0], h[1], A_SCALE, h01, l01);
+                    split2_mix(h[2], h[3], A_SCALE, h23, l23);
+                    const int byte = tr_byte(tr_slot(64 * q + 16 * t + c), rg);
+                    *reinterpret_cast<u32x2*>(img + byte) = u32x2{h01, h23};
+                    *reinterpret_cast<u32x2*>(img + TR_IMG_BYTES + byte) = u32x2{l01, l23};
+                }
+            } else if constexpr (AB & 64) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    float h[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        h[j] = __builtin_amdgcn_fmed3f(z[t][j], fmaf(__builtin_amdgcn_exp2f(z[t][j] * (1.4426950408889634f / A_SCALE)), A_SCALE, -A_SCALE), 0.f);
+                    const int k = 64 * q + 16 * t + c;
+                    _Float16* ph = sH + h_index(4 * rg, k);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const _Float16 hi = (_Float16)h[j];
+                        const _Float16 lo = (_Float16)(h[j] - (float)hi);
+                        ph[j * ROW_H] = hi;
+                        ph[IMG_H + j * ROW_H] = lo;
+                    }
+                }
+            } else
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 float h1[4], pn[4];
@@ -188,7 +248,24 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_fwd_pp(const float* params, int 
         for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kb = 0; kb < ((AB & 1) ? 1 : 8); ++kb) {
-            const f16x8 ah = *reinterpret_cast<const f16x8*>(bh + 8 * kb), al = *reinterpret_cast<const f16x8*>(bl + 8 * kb);
+            f16x8 ah, al;
+            if constexpr (AB & 128) {
+                typedef __attribute__((address_space(3))) s16x4* lds_p;
+                const char* img = reinterpret_cast<const char*>(sAimg[team]);
+                // lane 4 q' + p' of its 16-lane group supplies block row q' (k = 32 kb + 8 rg + q' (+ 4)), chunk p'
+                const int qq = (lane >> 2) & 3, pp = lane & 3;
+                const int s0 = 32 * kb + 16 * (rg >> 1) + 4 * (rg & 1) + qq, s1 = s0 + 8;
+                const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(img + tr_byte(s0, pp)));
+                const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(img + tr_byte(s1, pp)));
+                const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(img + TR_IMG_BYTES + tr_byte(s0, pp)));
+                const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(img + TR_IMG_BYTES + tr_byte(s1, pp)));
+                typedef short s16x8 __attribute__((__vector_size__(8 * sizeof(short))));
+                ah = __builtin_bit_cast(f16x8, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
+                al = __builtin_bit_cast(f16x8, __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
+            } else {
+                ah = *reinterpret_cast<const f16x8*>(bh + 8 * kb);
+                al = *reinterpret_cast<const f16x8*>(bl + 8 * kb);
+            }
             f16x8 wl[NT];
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
@@ -293,6 +370,17 @@ int main() {
         printf("rows %6d (%4.1f groups / workgroup): shipped pairs %.1f us   ping-pong %.1f us   max |diff| %.2e (max |y| %.2f)  err=%s\n", rr,
                rr / 16 / 256.0, t8, tpp, md, mx, hipGetErrorString(hipGetLastError()));
     }
+    for (int variant = 0; variant < 2; ++variant) {
+        hipMemset(ypp, 0, rows * 4);
+        if (variant == 0) hipLaunchKernelGGL((k_fwd_pp<8, 1, 64>), dim3(256), dim3(NTHREAD), 0, 0, dp, IN, OUT, rows, dx, ypp, dhh, dhl);
+        else hipLaunchKernelGGL((k_fwd_pp<8, 1, 128>), dim3(256), dim3(NTHREAD), 0, 0, dp, IN, OUT, rows, dx, ypp, dhh, dhl);
+        std::vector<float> a(rows), b(rows);
+        hipMemcpy(a.data(), y8, rows * 4, hipMemcpyDeviceToHost);
+        hipMemcpy(b.data(), ypp, rows * 4, hipMemcpyDeviceToHost);
+        double md = 0;
+        for (int i = 0; i < rows; ++i) md = fmax(md, fabs(a[i] - b[i]));
+        printf("%s variant vs shipped: max |diff| %.2e  err=%s\n", variant ? "transposed-image" : "lean", md, hipGetErrorString(hipGetLastError()));
+    }
     auto timepp = [&](auto kern, const char* name) {
         for (int it = 0; it < 20; ++it) hipLaunchKernelGGL(kern, dim3(256), dim3(NTHREAD), 0, 0, dp, IN, OUT, rows, dx, ypp, dhh, dhl);
         hipEventRecord(e0);
@@ -304,6 +392,10 @@ int main() {
         printf("  ping-pong ablation %-52s %.1f us\n", name, ms * 10.f);
     };
     timepp(k_fwd_pp<8, 1, 0>, "none");
+    timepp(k_fwd_pp<8, 1, 64>, "LEAN vector phase (correct numbers)");
+    timepp(k_fwd_pp<8, 1, 64 + 16>, "LEAN vector phase, teams in phase");
+    timepp(k_fwd_pp<8, 1, 128>, "TRANSPOSED image (ds_write_b64 / ds_read_b64_tr_b16, correct numbers)");
+    timepp(k_fwd_pp<8, 1, 128 + 16>, "TRANSPOSED image, teams in phase");
     timepp(k_fwd_pp<8, 1, 16>, "teams IN PHASE (lock-step control)");
     timepp(k_fwd_pp<8, 1, 1>, "one k-block of the matrix block instead of 8");
     timepp(k_fwd_pp<8, 1, 2>, "no exp (ELU = identity)");
