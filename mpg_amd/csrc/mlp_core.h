@@ -62,6 +62,28 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 // group holds each row once: MI355X_MICROARCH.md §LDS), the writer's ds_write_b32 pairs are 2-way (free).  Two images: hi, lo.
 constexpr int ROW_H = 72, PLANE_H = GROUP * ROW_H, IMG_H = 4 * PLANE_H;      // 4608 halves = 9216 B per image
 __device__ __forceinline__ int h_index(int row, int k) { return ((k >> 3) & 3) * PLANE_H + row * ROW_H + 8 * (k >> 5) + (k & 7); }
+#ifdef MPG_TR_IMAGE
+// TRANSPOSED activation image (round 4): one 32-byte slot per contraction index k holding the group's 16 rows as fp16, rows
+// contiguous - what a C-layout lane owns (rows 4 rg .. 4 rg + 3 of ONE column) is one aligned 8-byte chunk, so the image store
+// is ONE ds_write_b64 per tile and image: no DPP exchange with the neighbouring column, no selects.  The MFMA A operand (row
+// l & 15, 8 consecutive k) comes back through ds_read_b64_tr_b16, gfx950's transposing LDS read (two reads of 4 k each per
+// operand; EXEC is all ones wherever the engine runs).  Slot order inside a k-block and an XOR on the chunk position make the
+// stores (the 16 lanes of a row quad) and the transposed reads (32-lane halves) bank-conflict free with no padding:
+//   k = 32 kb + 8 g + j  ->  slot = 32 kb + 16 (g >> 1) + 8 (j >> 2) + 4 (g & 1) + (j & 3),   chunk' = chunk ^ ((slot >> 2) & 3)
+// Same values as the row-major image (hi = fp16(16 x), lo = fp16(16 x - hi)): results are bit-identical.
+constexpr int TR_IMG_BYTES = 256 * 32;            // one image (hi or lo): 8 KB
+__device__ __forceinline__ int tr_slot(int k) { const int g = (k >> 3) & 3, j = k & 7; return (k & ~31) + 16 * (g >> 1) + 8 * (j >> 2) + 4 * (g & 1) + (j & 3); }
+__device__ __forceinline__ int tr_byte(int slot, int chunk) { return slot * 32 + 8 * (chunk ^ ((slot >> 2) & 3)); }
+// (a, b) -> packed fp16 words of a * S = hi + lo: two v_fma_mix per word do scale, conversion and packing at once
+__device__ __forceinline__ void split2_mix(float a, float b, float S, unsigned& hi, unsigned& lo) {
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hi) : "v"(a), "v"(S));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hi) : "v"(b), "v"(S));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(lo) : "v"(a), "v"(S), "v"(hi));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lo) : "v"(b), "v"(S), "v"(hi));
+}
+typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+#endif
 constexpr float W_SCALE = 64.f;          // stationary weights are stored as W * 64
 constexpr float A_SCALE = 16.f;          // activations enter the LDS images as x * 16
 // Envelope of the split engine (include/mpg_hip.h, "Numerical envelope"): a first-layer activation at or beyond H_LIMIT would
@@ -257,6 +279,24 @@ __device__ __forceinline__ void store_c_to_a_f32(float* sA, const Lane& L, const
 // of each tile; columns c and c^1 are adjacent k, so the pair of lanes exchanges values through one DPP quad_perm and each
 // lane writes packed (k even, k odd) words: even lanes the rows j = 0,1, odd lanes the rows j = 2,3 - 8 ds_write_b32 per
 // lane like the float32 image, and the reader's 8 consecutive k are one aligned 16-byte read per image.
+#ifdef MPG_TR_IMAGE
+__device__ __forceinline__ void store_c_to_a(float* sA, const Lane& L, const float (&v)[2][4]) {
+    char* img = reinterpret_cast<char*>(sA);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        unsigned h01, l01, h23, l23;
+        split2_mix(v[t][0], v[t][1], A_SCALE, h01, l01);
+        split2_mix(v[t][2], v[t][3], A_SCALE, h23, l23);
+        const int byte = tr_byte(tr_slot(32 * L.wave + 16 * t + L.c), L.rg);
+#ifdef MPG_AB_NO_IMGWRITE
+        asm volatile("" :: "v"(h01), "v"(l01), "v"(h23), "v"(l23));
+#else
+        *reinterpret_cast<u32x2*>(img + byte) = u32x2{h01, h23};
+        *reinterpret_cast<u32x2*>(img + TR_IMG_BYTES + byte) = u32x2{l01, l23};
+#endif
+    }
+}
+#else
 __device__ __forceinline__ void store_c_to_a(float* sA, const Lane& L, const float (&v)[2][4]) {
     _Float16* sH = reinterpret_cast<_Float16*>(sA);
     const bool odd = L.c & 1;
@@ -281,6 +321,7 @@ __device__ __forceinline__ void store_c_to_a(float* sA, const Lane& L, const flo
         }
     }
 }
+#endif   // MPG_TR_IMAGE
 #else
 __device__ __forceinline__ void store_c_to_a(float* sA, const Lane& L, const float (&v)[2][4]) { store_c_to_a_f32(sA, L, v); }
 #endif
@@ -383,9 +424,27 @@ __device__ __forceinline__ void mfma_16x256x32(const float* sA, const Lane& L, c
         return __builtin_bit_cast(f16x8, f32x4{w[4 * v], w[4 * v + 1], w[4 * v + 2], w[4 * v + 3]});
     };
     f32x4 m0 = {0.f, 0.f, 0.f, 0.f}, m1 = m0;
+#ifdef MPG_TR_IMAGE
+    // lane 4 q' + p' of its 16-lane group supplies block row q' (k = 32 kb + 8 rg + q', + 4 for the second read), chunk p'
+    typedef __attribute__((address_space(3))) s16x4* lds_p;
+    const char* img = reinterpret_cast<const char*>(sA);
+    const int s0 = 16 * (L.rg >> 1) + 4 * (L.rg & 1) + ((L.lane >> 2) & 3);
+    const char* t0 = img + tr_byte(s0, L.lane & 3);
+    const char* t1 = img + tr_byte(s0 + 8, L.lane & 3);
+    (void)bh; (void)bl;
+#endif
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
+#ifdef MPG_TR_IMAGE
+        const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(t0 + 1024 * kb));
+        const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(t1 + 1024 * kb));
+        const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(t0 + TR_IMG_BYTES + 1024 * kb));
+        const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(t1 + TR_IMG_BYTES + 1024 * kb));
+        const f16x8 ah = __builtin_bit_cast(f16x8, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
+        const f16x8 al = __builtin_bit_cast(f16x8, __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
+#else
         const f16x8 ah = *reinterpret_cast<const f16x8*>(bh + 8 * kb), al = *reinterpret_cast<const f16x8*>(bl + 8 * kb);
+#endif
         const int v0 = (kb * 2 + 0) * 2, v1 = (kb * 2 + 1) * 2;
         m0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, frag(v0), m0, 0, 0, 0);
         m1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, frag(v1), m1, 0, 0, 0);

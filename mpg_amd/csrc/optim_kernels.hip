@@ -46,9 +46,13 @@ __device__ __forceinline__ int pack_index(int k, int n) {
 __device__ __forceinline__ void pack_store(float* __restrict__ image, int k, int n, float w) { image[pack_index(k, n)] = w; }
 #endif
 
-// every parameter the update writes is checked against the envelope of the split engine (one compare in a memory-bound kernel)
-__device__ __forceinline__ void range_check(int* status, float w) {
-    if (status && !(fabsf(w) < mlp::P_LIMIT)) atomicOr(status, MPG_STATUS_PARAMETER_RANGE);
+// every hidden-kernel (W2) and output-kernel (W3) entry the update writes is checked against the envelope of the split engine
+// (one compare in a memory-bound kernel).  `e` = index relative to the network's W2 (-1: no weight cache bound): W2 is [0, HH),
+// b2 [HH, HH + 256), W3 and b3 follow.  The first layer and the hidden biases have no fp16 envelope (they are float32 operands of
+// the fp32 MFMA / the accumulator) and are not flagged; a NaN anywhere still is (the comparison is false).
+__device__ __forceinline__ void range_check(int* status, float w, int e) {
+    const bool enveloped = (e >= 0 && e < HH) || e >= HH + MPG_HIDDEN;
+    if (status && (enveloped ? !(fabsf(w) < mlp::P_LIMIT) : w != w)) atomicOr(status, MPG_STATUS_PARAMETER_RANGE);
 }
 
 // Parallel form of the clip.  (1) per-network partial sums of squares, one per 256-element block, MPG_CLIP_PARTS slots
@@ -175,6 +179,7 @@ __global__ void k_adam_polyak(const Segs sg, float* __restrict__ w, float* __res
     if (i >= sg.n[k]) return;
     const int j = sg.off[k] + i;
     float wj = w[j];
+    const int e = sg.w2_off[k] >= 0 ? i - sg.w2_off[k] : -1;  // index relative to the network's W2 (weight cache, range_check)
     if (sg.do_adam[k]) {
         bool bad = false;                                     // optimizer.py:357-361: if ANY gradient is non-finite,
         if (skip)                                             // the whole list is replaced by zeros
@@ -182,10 +187,9 @@ __global__ void k_adam_polyak(const Segs sg, float* __restrict__ w, float* __res
         float mj = m[j], vj = v[j];
         adam_update(bad ? 0.f : grad[j], sg.lr_t[k], mj, vj, wj);
         m[j] = mj; v[j] = vj; w[j] = wj;
-        range_check(sg.status_w, wj);
+        range_check(sg.status_w, wj, e);
     }
     // weight cache: the element's two packed copies are rewritten by the thread that owns it
-    const int e = sg.w2_off[k] >= 0 ? i - sg.w2_off[k] : -1;
     const bool in_w2 = e >= 0 && e < HH;
     if (in_w2 && sg.do_adam[k] && sg.cache_w) {
         const int row = e >> 8, col = e & 255;
@@ -195,7 +199,7 @@ __global__ void k_adam_polyak(const Segs sg, float* __restrict__ w, float* __res
     if (sg.do_polyak[k] && target) {
         const float tj = polyak_mix(tau, wj, target[j]);
         target[j] = tj;
-        range_check(sg.status_t, tj);
+        range_check(sg.status_t, tj, e);
         if (in_w2 && sg.cache_t) {
             const int row = e >> 8, col = e & 255;
             pack_store(sg.cache_t + (size_t)(2 * k) * HH, row, col, tj);
@@ -237,12 +241,12 @@ __global__ void __launch_bounds__(256) k_clip_adam_polyak(const Segs sg, float* 
     if (!live) return;
     const float gc = g_in * (clip * fminf(1.f / nrm, 1.f / clip));
     grad[j] = gc;
+    const int e = sg.w2_off[k] >= 0 ? i - sg.w2_off[k] : -1;
     if (adam) {
         adam_update(bad ? 0.f : gc, sg.lr_t[k], mj, vj, wj);
         m[j] = mj; v[j] = vj; w[j] = wj;
-        range_check(sg.status_w, wj);
+        range_check(sg.status_w, wj, e);
     }
-    const int e = sg.w2_off[k] >= 0 ? i - sg.w2_off[k] : -1;
     const bool in_w2 = e >= 0 && e < HH;
     if (in_w2 && sg.do_adam[k] && sg.cache_w) {
         const int row = e >> 8, col = e & 255;
@@ -252,7 +256,7 @@ __global__ void __launch_bounds__(256) k_clip_adam_polyak(const Segs sg, float* 
     if (polyak) {
         const float tj = polyak_mix(tau, wj, t_in);
         target[j] = tj;
-        range_check(sg.status_t, tj);
+        range_check(sg.status_t, tj, e);
         if (in_w2 && sg.cache_t) {
             const int row = e >> 8, col = e & 255;
             pack_store(sg.cache_t + (size_t)(2 * k) * HH, row, col, tj);

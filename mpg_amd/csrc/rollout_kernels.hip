@@ -206,6 +206,7 @@ int run_rollout_bwd(const mpg_cfg_t* cfg, const float* policy_params, int rows, 
 extern "C" size_t mpg_rollout_pg_workspace_bytes(const mpg_cfg_t* cfg, int rows, int M, int n, int n_select,
                                                  int all_steps_param_grad) {
     if (!cfg_ok(cfg) || rows <= 0 || M <= 0 || n <= 0 || n >= MAXN || n_select <= 0 || n_select > MAXSEL) return 0;
+    if (cfg->obs_dim > 6 && (all_steps_param_grad || M != 1)) return 0;     // refused by mpg_rollout_pg (look-ahead observations)
     return pg_layout(cfg, rows, M, n, n_select, all_steps_param_grad).total;
 }
 
@@ -219,6 +220,10 @@ extern "C" int mpg_rollout_pg(const mpg_cfg_t* cfg, const float* policy_params, 
     MPG_REQUIRE(rows > 0 && M > 0 && n > 0 && n < MAXN && n_select > 0 && n_select <= MAXSEL, "mpg_rollout_pg: bad sizes");
     const long R = (long)rows * M;
     MPG_REQUIRE(!all_steps_param_grad || R % GROUP == 0, "mpg_rollout_pg: all_steps_param_grad needs rows*M %% 16 == 0");
+    // look-ahead observations (obs_dim > 6): the WIDE reverse sweep folds the model observations' look-ahead adjoints assuming M == 1
+    // and only step 0 is differentiated through the parameters - refused BEFORE anything is launched or written
+    MPG_REQUIRE(cfg->obs_dim <= 6 || (!all_steps_param_grad && M == 1),
+                "mpg_rollout_pg: look-ahead observations need M == 1 and the step-0 parameter gradient");
     for (int k = 0; k < n_select; ++k) MPG_REQUIRE(select[k] >= 0 && select[k] <= n, "mpg_rollout_pg: slice out of range");
     const PgLayout l = pg_layout(cfg, rows, M, n, n_select, all_steps_param_grad);
     if (ws_bytes < l.total) {
@@ -266,10 +271,7 @@ extern "C" int mpg_rollout_pg(const mpg_cfg_t* cfg, const float* policy_params, 
     // (obs_dim > 6) only step 0 is ever differentiated through the parameters here and its input is the caller's batch itself
     XSpec xs = xspec(SA, od, nullptr, 0, cfg->obs_scale, od);
     xs.ld0 = SAW;
-    if (od > 6) {
-        MPG_REQUIRE(!all_steps_param_grad && M == 1, "mpg_rollout_pg: look-ahead observations need M == 1 and the step-0 parameter gradient");
-        xs = xspec(obs0, od, nullptr, 0, cfg->obs_scale, od);
-    }
+    if (od > 6) xs = xspec(obs0, od, nullptr, 0, cfg->obs_scale, od);     // (M == 1, step-0 gradient: checked before the first launch)
     return launch_wgrad(cfg, od, 2 * ad, ad, (int)(T * R), xs, H1, H2, DZ1, DZ2, DZ3, inv_b_global / (float)M, grad, slabs, s);
 }
 

@@ -17,6 +17,7 @@ struct PackArgs {
     float* cache;
     int n_nets;
     int w2_off[8];
+    int w3_n[8];      // entries of the output kernel W3 (256 * out_dim), which follows W2 and b2
     int* status;      // nullable: MPG_STATUS_PARAMETER_RANGE is OR-ed into it
 };
 
@@ -26,6 +27,11 @@ __global__ void k_pack(const PackArgs a) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;       // 0 .. 65535
     const float* W2 = a.base + a.w2_off[net];
     float* out = a.cache + ((size_t)net * 2 + dir) * (mlp::H * mlp::H);
+    // the output kernel W3 has the same envelope (the reverse layer's 16 * out * |W3| operands must stay in fp16 range, mlp_core.h)
+    // although it has no packed image: whatever route the parameters arrived by (set_weights, checkpoint restore, a broadcast), the
+    // (re)pack is where they are checked - the direction-0 blocks scan it
+    if (dir == 0 && idx < a.w3_n[net] && a.status && !(fabsf(W2[mlp::H * mlp::H + mlp::H + idx]) < mlp::P_LIMIT))
+        atomicOr(a.status, MPG_STATUS_PARAMETER_RANGE);
 #ifdef MPG_SPLIT
     // word ((wave*32 + v)*64 + lane)*4 + r, v = (kb*2 + t)*2 + part: the packed pair (k0, k0 + 1), k0 = 32 kb + 8 (lane>>4) + 2 r,
     // of output column n = 32 wave + 16 t + (lane&15); part 0 = hi halves, 1 = lo halves of W * W_SCALE (mlp_core.h)
@@ -86,7 +92,10 @@ extern "C" int mpg_weight_cache_pack(const mpg_wcache_t* wc, mpg_stream_t stream
     MPG_REQUIRE(wc_ok(wc), "mpg_weight_cache_pack: incomplete descriptor");
     PackArgs a;
     a.base = wc->params; a.cache = wc->packed; a.n_nets = wc->n_nets; a.status = wc->status;
-    for (int k = 0; k < 8; ++k) a.w2_off[k] = k < wc->n_nets ? mlp::wcache_w2_offset(wc, k) : 0;
+    for (int k = 0; k < 8; ++k) {
+        a.w2_off[k] = k < wc->n_nets ? mlp::wcache_w2_offset(wc, k) : 0;
+        a.w3_n[k] = k < wc->n_nets ? mlp::H * wc->out_dim[k] : 0;
+    }
     hipLaunchKernelGGL(k_pack, dim3(mlp::H * mlp::H / 256, 2 * wc->n_nets), dim3(256), 0, mpg_stream(stream), a);
     MPG_CHECK_LAUNCH("k_pack");
     return MPG_OK;

@@ -69,7 +69,9 @@ def check_gradients(got, ref32, ref64_sub, nets, where='', bar=1e-4, factor=4.0,
         # networks the model-free-weighted policy gradient has norm 1e-3 and the REFERENCE's float32 run is 1.1e-4 off its
         # float64 run (trained_c2 fixture, iteration 9000; this engine: 5e-5)
         assert e_got <= bar, (where, name, shp, 'rel-L2 vs reference float64', e_got)
-        assert e <= bar + e_ref, (where, name, shp, 'rel-L2 vs reference float32', e, 'reference float32 vs float64', e_ref)
+        # (the allowance for the reference's own distance applies only where that distance is itself a sizeable part
+        # of the bar - the trained-network case; everywhere else the plain bar holds on ALL elements, sampled or not)
+        assert e <= (bar + e_ref if e_ref > 0.5 * bar else bar), (where, name, shp, 'rel-L2 vs reference float32', e, 'reference float32 vs float64', e_ref)
         allow = factor * e_ref + FLOOR
         assert e_got <= allow, (where, name, shp, 'vs float64: got %.3e, reference float32 %.3e' % (e_got, e_ref))
         worst = max(worst, e_got / allow)

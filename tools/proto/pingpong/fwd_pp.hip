@@ -149,6 +149,8 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_fwd_pp(const float* params, int 
     __syncthreads();                                          // the lo image is complete
     // vector phase: epilogue of group gp (if any, from acc), layer 1 of group gn (if any)
     auto vector_phase = [&](long gp, bool have_prev, long gn, bool have_next, int par) {
+        if constexpr ((AB & 256) != 0) __builtin_amdgcn_s_setprio(3);     // 256: the vector-phase wave outranks its SIMD partner's MFMA stream
+        if constexpr ((AB & 512) != 0) __builtin_amdgcn_s_setprio(0);     // 512: the other way round
         if (have_prev) {
             float h2[NT][4];
 #pragma unroll
@@ -243,6 +245,8 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_fwd_pp(const float* params, int 
         (void)gp; (void)gn;
     };
     auto matrix_phase = [&](long gnext) {
+        if constexpr ((AB & 256) != 0) __builtin_amdgcn_s_setprio(0);
+        if constexpr ((AB & 512) != 0) __builtin_amdgcn_s_setprio(3);
         x_load(gnext, xa);                                    // the next group's inputs travel under the matrix block
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -292,21 +296,35 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_fwd_pp(const float* params, int 
     };
     // Team 0: V0 | M0 | V1 | M1 | ... ; team 1 the same one interval later (it opens with an idle interval and team 0 closes with one).
     // One workgroup barrier per interval.  Iteration i of a team: group g_first + i * gstep.
+    // 1024: TEAM-LOCAL barriers (an LDS arrival counter per team, polled with s_sleep) instead of workgroup barriers: the two teams
+    // are then coupled only through the matrix pipe and the LDS they share - no team ever waits for the other one's phase to end
+    __shared__ unsigned sTeamCnt[2];
+    if (tid < 2) sTeamCnt[tid] = 0;
+    __syncthreads();
+    unsigned tb_target = 0;
+    auto team_barrier = [&]() {
+        tb_target += TW;
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                 // lgkmcnt(0): this wave's LDS stores are in
+        if (lane == 0) __hip_atomic_fetch_add(&sTeamCnt[team], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        while (__hip_atomic_load(&sTeamCnt[team], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < tb_target) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    };
     const bool inphase = (AB & 16) != 0;
-    if (team == 1 && !inphase) lds_barrier();
+    constexpr bool TEAMBAR = (AB & 1024) != 0;
+    if (team == 1 && !inphase && !TEAMBAR) lds_barrier();
     for (long i = 0; i <= n_it; ++i) {
         const long g = g_first + i * gstep;
         // vector interval: epilogue of iteration i - 1, output of iteration i - 2, layer 1 of iteration i
         vector_phase(g - gstep, i > 0, g, i < n_it, (int)((i + 1) & 1));
         if (i >= 2) output(g - 2 * gstep, (int)(i & 1));
-        lds_barrier();
+        if constexpr (TEAMBAR) team_barrier(); else lds_barrier();
         if (i == n_it) break;
         matrix_phase(g + gstep);
-        lds_barrier();
+        if constexpr (TEAMBAR) team_barrier(); else lds_barrier();
     }
-    if (team == 0 && !inphase) lds_barrier();
+    if (team == 0 && !inphase && !TEAMBAR) lds_barrier();
     // the last two outputs: iteration n_it - 1's partials were written in the last vector interval (parity n_it & 1 ... )
-    lds_barrier();
+    if constexpr (TEAMBAR) team_barrier(); else lds_barrier();
     if (n_it >= 1) output(g_first + (n_it - 1) * gstep, (int)((n_it + 1) & 1));
 }
 
@@ -370,16 +388,17 @@ int main() {
         printf("rows %6d (%4.1f groups / workgroup): shipped pairs %.1f us   ping-pong %.1f us   max |diff| %.2e (max |y| %.2f)  err=%s\n", rr,
                rr / 16 / 256.0, t8, tpp, md, mx, hipGetErrorString(hipGetLastError()));
     }
-    for (int variant = 0; variant < 2; ++variant) {
+    for (int variant = 0; variant < 3; ++variant) {
         hipMemset(ypp, 0, rows * 4);
         if (variant == 0) hipLaunchKernelGGL((k_fwd_pp<8, 1, 64>), dim3(256), dim3(NTHREAD), 0, 0, dp, IN, OUT, rows, dx, ypp, dhh, dhl);
-        else hipLaunchKernelGGL((k_fwd_pp<8, 1, 128>), dim3(256), dim3(NTHREAD), 0, 0, dp, IN, OUT, rows, dx, ypp, dhh, dhl);
+        else if (variant == 1) hipLaunchKernelGGL((k_fwd_pp<8, 1, 128>), dim3(256), dim3(NTHREAD), 0, 0, dp, IN, OUT, rows, dx, ypp, dhh, dhl);
+        else hipLaunchKernelGGL((k_fwd_pp<8, 1, 128 + 1024>), dim3(256), dim3(NTHREAD), 0, 0, dp, IN, OUT, rows, dx, ypp, dhh, dhl);
         std::vector<float> a(rows), b(rows);
         hipMemcpy(a.data(), y8, rows * 4, hipMemcpyDeviceToHost);
         hipMemcpy(b.data(), ypp, rows * 4, hipMemcpyDeviceToHost);
         double md = 0;
         for (int i = 0; i < rows; ++i) md = fmax(md, fabs(a[i] - b[i]));
-        printf("%s variant vs shipped: max |diff| %.2e  err=%s\n", variant ? "transposed-image" : "lean", md, hipGetErrorString(hipGetLastError()));
+        printf("%s variant vs shipped: max |diff| %.2e  err=%s\n", variant == 2 ? "team-barrier" : variant ? "transposed-image" : "lean", md, hipGetErrorString(hipGetLastError()));
     }
     auto timepp = [&](auto kern, const char* name) {
         for (int it = 0; it < 20; ++it) hipLaunchKernelGGL(kern, dim3(256), dim3(NTHREAD), 0, 0, dp, IN, OUT, rows, dx, ypp, dhh, dhl);
@@ -396,6 +415,14 @@ int main() {
     timepp(k_fwd_pp<8, 1, 64 + 16>, "LEAN vector phase, teams in phase");
     timepp(k_fwd_pp<8, 1, 128>, "TRANSPOSED image (ds_write_b64 / ds_read_b64_tr_b16, correct numbers)");
     timepp(k_fwd_pp<8, 1, 128 + 16>, "TRANSPOSED image, teams in phase");
+    timepp(k_fwd_pp<8, 1, 128 + 1024>, "TRANSPOSED image, TEAM-LOCAL barriers");
+    timepp(k_fwd_pp<8, 1, 1024>, "original image, TEAM-LOCAL barriers");
+    timepp(k_fwd_pp<8, 1, 128 + 256>, "TRANSPOSED image, vector phase at s_setprio 3");
+    timepp(k_fwd_pp<8, 1, 128 + 512>, "TRANSPOSED image, matrix phase at s_setprio 3");
+    timepp(k_fwd_pp<8, 1, 128 + 2>, "TRANSPOSED image, no exp");
+    timepp(k_fwd_pp<8, 1, 128 + 4>, "TRANSPOSED image, no image stores (old path stores skipped)");
+    timepp(k_fwd_pp<8, 1, 128 + 8>, "TRANSPOSED image, no output reduction");
+    timepp(k_fwd_pp<8, 1, 128 + 32>, "TRANSPOSED image, lo from registers only");
     timepp(k_fwd_pp<8, 1, 16>, "teams IN PHASE (lock-step control)");
     timepp(k_fwd_pp<8, 1, 1>, "one k-block of the matrix block instead of 8");
     timepp(k_fwd_pp<8, 1, 2>, "no exp (ELU = identity)");
