@@ -576,6 +576,128 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_critic_fused(const CriticArgs ca
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// The same launch BALANCED over the chip (round 4).  k_critic_fused gives a CU one Q1 workgroup (three forward and three reverse
+// passes behind two image loads) and then one Q2 workgroup (one + one pass behind two more image loads): four 256 KB image loads
+// in sequence per CU, ~9k cycles each - more than half of the kernel.  Here every workgroup takes FOUR row groups of ONE kind -
+// 3/4 of the workgroups the critic Q1 (replay-batch groups, then the groups of slice 0, then those of slice n), 1/4 the critic Q2
+// (replay-batch groups) - so a CU runs one workgroup: eight passes behind TWO image loads.  The four forward passes run as two
+// pairs (forward_group2), the reverse passes one by one.  Same device functions on the same operands as k_critic_fused:
+// bit-identical stashes, targets, losses, returns and input gradients.  Needs rows / 16 divisible by 4.
+template <int QIN, bool PK>
+__global__ void __launch_bounds__(NTHREAD, 2) k_critic_fused4(const CriticArgs ca) {
+    constexpr int G4 = 4;
+    __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
+    __shared__ __attribute__((aligned(16))) float sX4[G4 * GROUP * XS];
+    __shared__ __attribute__((aligned(16))) float sD34[G4 * GROUP * MAXOUT];
+    __shared__ float sQ4[G4 * GROUP];
+    const QlossArgs& a = ca.ql;
+    const QsliceArgs& q = ca.qs;
+    const Smem m(smem);
+    const Lane L;
+    const int tid = threadIdx.x;
+    const long ngroups = a.rows / GROUP;                       // row groups of the replay batch == of each slice
+    const long nq1 = 3 * ngroups / G4;                         // workgroups of Q1: units [0, 3 ngroups) = replay | slice 0 | slice n
+    const bool q2wg = (long)blockIdx.x >= nq1;
+    const int qi = q2wg ? 1 : 0;
+    const long u0 = (q2wg ? (long)blockIdx.x - nq1 : (long)blockIdx.x) * G4;
+    const int kind = q2wg ? 0 : (int)(u0 / ngroups);           // 0: replay batch, 1: slice 0, 2: slice n (workgroup-uniform)
+    const long g0 = u0 - (long)kind * ngroups;                 // the workgroup's groups: g0 .. g0 + 3 of that kind
+    const bool slices = kind > 0;
+    const int sl = kind > 0 ? kind - 1 : 0;
+    const Net net = make_net(a.q[qi], QIN, 1);
+    const CriticStash st = a.st[qi];
+    // inputs of the four groups: one (row, column) per thread, requested ahead of the weight image (see k_critic_fused)
+    float xv = 0.f;
+    {
+        const int u4 = tid / (GROUP * XS), e = tid % (GROUP * XS), row = e / XS, i = e % XS;
+        const long gr = (g0 + u4) * GROUP + row;
+        if (i < QIN) {
+            if (slices) xv = q.xq[((long)sl * a.rows + gr) * QIN + i];
+            else xv = i < a.x.d0 ? a.x.x0[gr * a.x.ld0 + i] * a.x.scale[i] : a.x.x1[gr * a.x.ld1 + (i - a.x.d0)];
+        }
+    }
+    float t_y = 0.f, t_rew = 0.f, t_q1 = 0.f, t_q2 = 0.f, gk_in = 0.f;
+    const float b3v = net.b3[0];
+    if (tid < G4 * GROUP) {
+        const long gr = (g0 + tid / GROUP) * GROUP + tid % GROUP;
+        if (slices) gk_in = q.gk[(long)sl * a.rows + gr];
+        else if (a.qpart) { t_rew = a.rew[gr]; t_q1 = a.qpart[gr]; t_q2 = a.qpart[(long)a.rows + gr]; }
+        else t_y = a.y[gr];
+    }
+    float w2[128], h1[G4][2][4], h2[G4][2][4], dz1[2][4], dz2[2][4];
+    float zmax = 0.f;
+    SmallRegs<QIN, 1> r;
+    MPG_LOAD2((load_small<QIN, 1>(net, L, r)), (load_w2<PK>(a.pkf[qi], net.W2, false, L, w2)));
+    sX4[tid] = xv;
+    if (slices) report_nan(a.status, xv != xv);
+    lds_barrier();
+    // ---- forward: two pairs of groups behind one image ----
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        forward_group2<QIN, 1>(sX4 + (2 * p) * GROUP * XS, sX4 + (2 * p + 1) * GROUP * XS, m.sA, m.sA1, m.sPart, m.sPartX, L, w2, r,
+                               h1[2 * p], h2[2 * p], h1[2 * p + 1], h2[2 * p + 1], &zmax);
+        if (!slices) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                stash_store(st.h1, g0 + 2 * p + e, L, h1[2 * p + e]);
+                stash_store(st.h2, g0 + 2 * p + e, L, h2[2 * p + e]);
+            }
+        }
+        if (tid < G4 * GROUP && (tid >> 5) == p) {          // the 32 output lanes of this pair (wave 0: ordered against the next pair by its barrier)
+            const int u4 = tid / GROUP, row = tid % GROUP;
+            const long gr = (g0 + u4) * GROUP + row;
+            const float qv = out_preact((u4 & 1) ? m.sPartX : m.sPart, b3v, row, 0);
+            if (slices) {
+                sQ4[tid] = gk_in + q.gpow[sl] * qv;                                             // mpg_learner.py:266
+                sD34[u4 * GROUP * MAXOUT + d3_index(row, 0)] = q.coef[sl];
+            } else {    // err = Q(s~,a) - y; dL/dq = err / B_global   (mpg_learner.py:331-336)
+                float yv = t_y;
+                if (a.qpart) {
+                    yv = (t_rew + a.rshift) * a.rscale + a.gamma * fminf(t_q1, t_q2);          // mpg_learner.py:132-133
+                    if (qi == 0) a.y_out[gr] = yv;
+                }
+                const float e = qv - yv + row_poison(sX4 + tid * XS, QIN);
+                st.dz3[gr] = e * a.inv_b;
+                if (a.td && qi == 0) a.td[gr] = e;
+                sD34[u4 * GROUP * MAXOUT + d3_index(row, 0)] = e * a.inv_b;
+                sQ4[tid] = e * e;
+                report_nan(a.status, e != e);
+            }
+        }
+    }
+    report_activation_range(a.status, zmax);
+    load_w2<PK>(a.pkb[qi], net.W2, true, L, w2);     // same registers, backward image
+    lds_barrier();
+    if (tid >= 64 && tid < 64 + G4) {                 // per-group sums (a lane of wave 1 each, fixed order)
+        const int u4 = tid - 64;
+        float s1 = 0.f, s2 = 0.f;
+        for (int i = 0; i < GROUP; ++i) { const float v = sQ4[u4 * GROUP + i]; s1 += v; s2 += v * v; }
+        if (slices) {
+            q.ret_part[((long)sl * ngroups + g0 + u4) * 2] = s1;
+            q.ret_part[((long)sl * ngroups + g0 + u4) * 2 + 1] = s2;
+        } else {
+            a.loss_part[qi * ngroups + g0 + u4] = 0.5f * a.inv_b * s1;
+        }
+    }
+    // ---- reverse: the four groups behind the transposed image ----
+#pragma unroll
+    for (int u4 = 0; u4 < G4; ++u4) {
+        if (slices) {
+            backward_group<QIN, 1, true>(sD34 + u4 * GROUP * MAXOUT, m.sA, m.sA1, m.sPartX, L, w2, r, h1[u4], h2[u4], dz1, dz2);
+            if (tid < GROUP * QIN) {
+                const int row = tid / QIN, i = tid % QIN;
+                const long gr = ((long)sl * ngroups + g0 + u4) * GROUP + row;
+                q.gxq[gr * QIN + i] = dx_reduce(m.sPartX, row, i);
+            }
+        } else {
+            backward_group<QIN, 1, false>(sD34 + u4 * GROUP * MAXOUT, m.sA, m.sA1, m.sPartX, L, w2, r, h1[u4], h2[u4], dz1, dz2);
+            stash_store(st.dz1, g0 + u4, L, dz1);
+            stash_store(st.dz2, g0 + u4, L, dz2);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 struct WgradMulti {
     int n_jobs;
     WgradArgs a[3];
@@ -815,6 +937,17 @@ int launch_critic_fused(const mpg_cfg_t* cfg, const float* const* q_params, int 
     c.dbg = s_dbg;
 #endif
     mpg_prof_begin(mpg_prof_of(cfg), 7, s);
+    // balanced form (k_critic_fused4): four groups of one kind per workgroup, two image loads per CU instead of four - once there is
+    // at least one workgroup per CU that way and the groups divide evenly
+#ifndef MPG_CRITIC4_MIN_GROUPS
+#define MPG_CRITIC4_MIN_GROUPS 256
+#endif
+    const bool packed = a.pkf[0] && a.pkb[0] && (n_q < 2 || (a.pkf[1] && a.pkb[1]));
+    if (packed && ngroups >= MPG_CRITIC4_MIN_GROUPS && ngroups % 4 == 0 && (qin == 8 || qin == 5)) {
+        const int nwg = (3 + (n_q == 2 ? 1 : 0)) * (ngroups / 4);
+        if (qin == 8) hipLaunchKernelGGL((k_critic_fused4<8, true>), dim3(nwg), dim3(NTHREAD), 0, s, c);
+        else hipLaunchKernelGGL((k_critic_fused4<5, true>), dim3(nwg), dim3(NTHREAD), 0, s, c);
+    } else
     if (qin == 8) { if (a.pkf[0] && a.pkb[0] && (n_q < 2 || (a.pkf[1] && a.pkb[1]))) hipLaunchKernelGGL((k_critic_fused<8, true>), dim3(ngroups, n_q), dim3(NTHREAD), 0, s, c); else hipLaunchKernelGGL((k_critic_fused<8, false>), dim3(ngroups, n_q), dim3(NTHREAD), 0, s, c); }
     else if (qin == 5) { if (a.pkf[0] && a.pkb[0] && (n_q < 2 || (a.pkf[1] && a.pkb[1]))) hipLaunchKernelGGL((k_critic_fused<5, true>), dim3(ngroups, n_q), dim3(NTHREAD), 0, s, c); else hipLaunchKernelGGL((k_critic_fused<5, false>), dim3(ngroups, n_q), dim3(NTHREAD), 0, s, c); }
     else { mpg_set_error("launch_critic_fused: unsupported dims"); return MPG_EINVAL; }
