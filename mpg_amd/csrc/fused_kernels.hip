@@ -590,6 +590,11 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_critic_fused4(const CriticArgs c
     __shared__ __attribute__((aligned(16))) float sX4[G4 * GROUP * XS];
     __shared__ __attribute__((aligned(16))) float sD34[G4 * GROUP * MAXOUT];
     __shared__ float sQ4[G4 * GROUP];
+    __shared__ __attribute__((aligned(16))) float sA2[A_IMG];                 // the second dz2 image of a reverse pair
+    __shared__ __attribute__((aligned(16))) float sPartX2[NWAVE * GROUP * XS];
+    // h1 / h2 of the FIRST forward pair wait here for their reverse pass (64 KB; holding all four groups in registers spills):
+    // float4 index (slot * 512 + thread), slot = (group of the pair * 2 + layer) * 2 + tile - every lane re-reads what it wrote
+    __shared__ __attribute__((aligned(16))) float sHold[8 * NTHREAD * 4];
     const QlossArgs& a = ca.ql;
     const QsliceArgs& q = ca.qs;
     const Smem m(smem);
@@ -624,7 +629,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_critic_fused4(const CriticArgs c
         else if (a.qpart) { t_rew = a.rew[gr]; t_q1 = a.qpart[gr]; t_q2 = a.qpart[(long)a.rows + gr]; }
         else t_y = a.y[gr];
     }
-    float w2[128], h1[G4][2][4], h2[G4][2][4], dz1[2][4], dz2[2][4];
+    float w2[128], h1[2][2][4], h2[2][2][4], dz1[2][4], dz2[2][4];      // h1 / h2: the pair in flight
     float zmax = 0.f;
     SmallRegs<QIN, 1> r;
     MPG_LOAD2((load_small<QIN, 1>(net, L, r)), (load_w2<PK>(a.pkf[qi], net.W2, false, L, w2)));
@@ -635,13 +640,23 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_critic_fused4(const CriticArgs c
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
         forward_group2<QIN, 1>(sX4 + (2 * p) * GROUP * XS, sX4 + (2 * p + 1) * GROUP * XS, m.sA, m.sA1, m.sPart, m.sPartX, L, w2, r,
-                               h1[2 * p], h2[2 * p], h1[2 * p + 1], h2[2 * p + 1], &zmax);
+                               h1[0], h2[0], h1[1], h2[1], &zmax);
         if (!slices) {
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                stash_store(st.h1, g0 + 2 * p + e, L, h1[2 * p + e]);
-                stash_store(st.h2, g0 + 2 * p + e, L, h2[2 * p + e]);
+                stash_store(st.h1, g0 + 2 * p + e, L, h1[e]);
+                stash_store(st.h2, g0 + 2 * p + e, L, h2[e]);
             }
+        }
+        if (p == 0) {       // park the first pair's activations in LDS; the second pair's stay in registers for the reverse passes
+            f32x4* hold = reinterpret_cast<f32x4*>(sHold) + tid;
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    hold[((e * 2 + 0) * 2 + t) * NTHREAD] = f32x4{h1[e][t][0], h1[e][t][1], h1[e][t][2], h1[e][t][3]};
+                    hold[((e * 2 + 1) * 2 + t) * NTHREAD] = f32x4{h2[e][t][0], h2[e][t][1], h2[e][t][2], h2[e][t][3]};
+                }
         }
         if (tid < G4 * GROUP && (tid >> 5) == p) {          // the 32 output lanes of this pair (wave 0: ordered against the next pair by its barrier)
             const int u4 = tid / GROUP, row = tid % GROUP;
@@ -679,20 +694,39 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_critic_fused4(const CriticArgs c
             a.loss_part[qi * ngroups + g0 + u4] = 0.5f * a.inv_b * s1;
         }
     }
-    // ---- reverse: the four groups behind the transposed image ----
+    // ---- reverse: the four groups as two pairs behind the transposed image (backward_group2): the second pair (registers)
+    //      first, then the first pair (back from LDS) ----
+    float dz1b[2][4], dz2b[2][4];
 #pragma unroll
-    for (int u4 = 0; u4 < G4; ++u4) {
+    for (int pass = 0; pass < 2; ++pass) {
+        const int p = 1 - pass, ua = 2 * p, ub = 2 * p + 1;
+        if (pass == 1) {
+            const f32x4* hold = reinterpret_cast<const f32x4*>(sHold) + tid;
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const f32x4 x1 = hold[((e * 2 + 0) * 2 + t) * NTHREAD], x2 = hold[((e * 2 + 1) * 2 + t) * NTHREAD];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { h1[e][t][j] = x1[j]; h2[e][t][j] = x2[j]; }
+                }
+        }
         if (slices) {
-            backward_group<QIN, 1, true>(sD34 + u4 * GROUP * MAXOUT, m.sA, m.sA1, m.sPartX, L, w2, r, h1[u4], h2[u4], dz1, dz2);
-            if (tid < GROUP * QIN) {
-                const int row = tid / QIN, i = tid % QIN;
-                const long gr = ((long)sl * ngroups + g0 + u4) * GROUP + row;
-                q.gxq[gr * QIN + i] = dx_reduce(m.sPartX, row, i);
+            backward_group2<QIN, 1, true>(sD34 + ua * GROUP * MAXOUT, sD34 + ub * GROUP * MAXOUT, m.sA, sA2, m.sA1, m.sPartX, sPartX2, L, w2, r,
+                                          h1[0], h2[0], h1[1], h2[1], dz1, dz2, dz1b, dz2b);
+            if (tid < 2 * GROUP * QIN) {
+                const int e = tid / (GROUP * QIN), rem = tid % (GROUP * QIN), row = rem / QIN, i = rem % QIN;
+                const long gr = ((long)sl * ngroups + g0 + ua + e) * GROUP + row;
+                q.gxq[gr * QIN + i] = dx_reduce(e ? sPartX2 : m.sPartX, row, i);
             }
+            if (pass == 0) lds_barrier();            // the second pass rewrites the partials these lanes are reading
         } else {
-            backward_group<QIN, 1, false>(sD34 + u4 * GROUP * MAXOUT, m.sA, m.sA1, m.sPartX, L, w2, r, h1[u4], h2[u4], dz1, dz2);
-            stash_store(st.dz1, g0 + u4, L, dz1);
-            stash_store(st.dz2, g0 + u4, L, dz2);
+            backward_group2<QIN, 1, false>(sD34 + ua * GROUP * MAXOUT, sD34 + ub * GROUP * MAXOUT, m.sA, sA2, m.sA1, m.sPartX, sPartX2, L, w2, r,
+                                           h1[0], h2[0], h1[1], h2[1], dz1, dz2, dz1b, dz2b);
+            stash_store(st.dz1, g0 + ua, L, dz1);
+            stash_store(st.dz2, g0 + ua, L, dz2);
+            stash_store(st.dz1, g0 + ub, L, dz1b);
+            stash_store(st.dz2, g0 + ub, L, dz2b);
         }
     }
 }

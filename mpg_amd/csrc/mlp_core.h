@@ -802,6 +802,87 @@ __device__ __forceinline__ void backward_group(const float* sD3, float* sA, floa
     backward_rest<IN, OU, WANT_DX>(sD3, sA, sA1, sPartX, L, w2t, r, h1, dz1);
 }
 
+// Two row groups through the reverse layer behind ONE pair of barriers (the reverse twin of forward_group2): dz2 of both into
+// their images, barrier, the matrix block of both (the same transposed register image, back to back on the matrix pipe), both
+// epilogues, barrier.  The float32 dz1 image of the dx product (sA1) is wave-private, so the two groups use it one after the
+// other with no barrier.  Same arithmetic per group as backward_group: bit-identical results.
+template <int IN, int OU, bool WANT_DX>
+__device__ __forceinline__ void backward_group2(const float* sD3a, const float* sD3b, float* sAa, float* sAb, float* sA1,
+                                                float* sPartXa, float* sPartXb, const Lane& L, const float (&w2t)[128],
+                                                const SmallRegs<IN, OU>& r, const float (&h1a)[2][4], const float (&h2a)[2][4],
+                                                const float (&h1b)[2][4], const float (&h2b)[2][4], float (&dz1a)[2][4],
+                                                float (&dz2a)[2][4], float (&dz1b)[2][4], float (&dz2b)[2][4]) {
+    auto dz2_phase = [&](const float* sD3, float* sA, const float (&h2)[2][4], float (&dz2)[2][4]) {
+        f32x4 d3v[OU];
+#pragma unroll
+        for (int o = 0; o < OU; ++o) d3v[o] = *reinterpret_cast<const f32x4*>(sD3 + d3_index(4 * L.rg, o));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                float dh = 0.f;
+#pragma unroll
+                for (int o = 0; o < OU; ++o) dh = fmaf(d3v[o][j], r.w3[t][o], dh);
+                dz2[t][j] = dh * elu_grad_from_out(h2[t][j]);
+            }
+        }
+#ifdef MPG_SPLIT
+        int e[4];
+        row_exponents<OU>(sD3, L, e);
+        float sc[2][4];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sc[t][j] = ldexpf(dz2[t][j], -e[j]);
+        store_c_to_a(sA, L, sc);
+#else
+        store_c_to_a(sA, L, dz2);
+#endif
+    };
+    dz2_phase(sD3a, sAa, h2a, dz2a);
+    dz2_phase(sD3b, sAb, h2b, dz2b);
+    lds_barrier();
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, b0 = a0, b1 = a0;
+    mfma_16x256x32(sAa, L, w2t, a0, a1);
+    mfma_16x256x32(sAb, L, w2t, b0, b1);
+    auto rest = [&](const float* sD3, float* sPartX, f32x4& acc0, f32x4& acc1, const float (&h1)[2][4], float (&dz1)[2][4]) {
+#ifdef MPG_SPLIT
+        int e[4];
+        row_exponents<OU>(sD3, L, e);
+#endif
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#ifdef MPG_SPLIT
+            acc0[j] = ldexpf(acc0[j], e[j]);
+            acc1[j] = ldexpf(acc1[j], e[j]);
+#endif
+            dz1[0][j] = acc0[j] * elu_grad_from_out(h1[0][j]);
+            dz1[1][j] = acc1[j] * elu_grad_from_out(h1[1][j]);
+        }
+        if (WANT_DX) {
+            store_c_to_a_f32(sA1, L, dz1);
+            __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): this wave reads back only what it wrote itself
+            __builtin_amdgcn_wave_barrier();
+            const float* base = sA1 + L.c * LDA + L.rg * KS + 8 * L.wave;
+            const f32x4 q0 = *reinterpret_cast<const f32x4*>(base), q1 = *reinterpret_cast<const f32x4*>(base + 4);
+            f32x4 dx = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dx = __builtin_amdgcn_mfma_f32_16x16x4f32(q0[q], r.w1t[q], dx, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dx = __builtin_amdgcn_mfma_f32_16x16x4f32(q1[q], r.w1t[4 + q], dx, 0, 0, 0);
+            if (L.c < xs_of<IN>()) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sPartX[(L.wave * GROUP + L.row(j)) * xs_of<IN>() + L.c] = dx[j];
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);          // the second group's dz1 overwrites the image this wave has just read
+            __builtin_amdgcn_wave_barrier();
+        }
+    };
+    rest(sD3a, sPartXa, a0, a1, h1a, dz1a);
+    rest(sD3b, sPartXb, b0, b1, h1b, dz1b);
+    lds_barrier();
+}
+
 // all XS partial sums of one row: ds_read_b128 pairs in two batches of four waves (32 VGPRs in flight; all sixteen
 // reads at once cost 64 VGPRs at a point where the reverse sweep has none to spare)
 template <int XSW = XS>
