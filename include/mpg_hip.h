@@ -217,6 +217,14 @@ int mpg_q_targets(const mpg_cfg_t* cfg, const float* policy_t, const float* q1t,
                   const float* rew, const float* obs_tp1, const float* smooth_eps, float smooth_sigma,
                   float smooth_clip, float* y, void* ws, size_t ws_bytes, mpg_stream_t stream);
 
+/* TD3Learner.get_batch_data with a prioritized buffer (learners/td3.py:94-101): the clipped double-Q target y (td3.py:69-81,
+ * as mpg_q_targets with smooth_eps) AND the plain Q1 target y1 of the priorities' td error (td3.py:83-92: y1 = r~ + gamma
+ * Q1t(s~', pi_t(s~'))) from ONE evaluation of the target policy.  Same values as the two mpg_q_targets calls.  Workspace:
+ * mpg_q_targets_workspace_bytes. */
+int mpg_td3_targets(const mpg_cfg_t* cfg, const float* policy_t, const float* q1t, const float* q2t, int rows,
+                    const float* rew, const float* obs_tp1, const float* smooth_eps, float smooth_sigma,
+                    float smooth_clip, float* y, float* y1, void* ws, size_t ws_bytes, mpg_stream_t stream);
+
 /* n-step return of MPG-v1 (mpg_learner.py:155-169) once the real-env rollout exists (mpg_env_step x n):
  *   y = sum_t gamma^t r~_t + gamma^n Q1t(s~_n, pi_t(s~_n)).  rewards [n][rows] RAW, last_obs [rows][obs_dim].
  * Workspace: mpg_q_targets_workspace_bytes. */

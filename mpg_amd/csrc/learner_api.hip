@@ -99,6 +99,69 @@ __global__ void __launch_bounds__(1024) k_td3_dy(int rows, const float* __restri
     }
 }
 
+// Large batches (TD3 at B = 65 536: the one-block forms above walk 64 rows per thread, 18 - 34 us each): the same element-wise
+// work over a grid, block b leaving the sums of its contiguous run of rows in part[b] (+ part[PARTS + b]); k_finish_parts adds the
+// partials in block order.  Fixed order at both levels: deterministic.
+constexpr int ERR_PARTS = 64;
+__global__ void __launch_bounds__(1024) k_q_err_mb(int rows, const float* __restrict__ q, const float* __restrict__ y, float inv_b,
+                                                   float* __restrict__ dz3, float* __restrict__ td, float* __restrict__ part) {
+    __shared__ float red[1024];
+    const int per = (rows + gridDim.x - 1) / gridDim.x, r0 = blockIdx.x * per, r1 = min(rows, r0 + per);
+    float s = 0.f;
+    for (int i = r0 + threadIdx.x; i < r1; i += 1024) {
+        const float e = q[i] - y[i];
+        dz3[i] = e * inv_b;
+        if (td) td[i] = e;
+        s += e * e;
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+__global__ void __launch_bounds__(1024) k_td3_dy_mb(int rows, const float* __restrict__ q1, const float* __restrict__ q2, float inv_b,
+                                                    float* __restrict__ dy1, float* __restrict__ dy2, float* __restrict__ part) {
+    __shared__ float red[2][1024];
+    const int per = (rows + gridDim.x - 1) / gridDim.x, r0 = blockIdx.x * per, r1 = min(rows, r0 + per);
+    float s = 0.f, s2 = 0.f;
+    for (int i = r0 + threadIdx.x; i < r1; i += 1024) {
+        const bool first = q1[i] <= q2[i];
+        const float m = first ? q1[i] : q2[i];
+        dy1[i] = first ? -inv_b : 0.f;
+        dy2[i] = first ? 0.f : -inv_b;
+        s += m;
+        s2 += m * m;
+    }
+    red[0][threadIdx.x] = s;
+    red[1][threadIdx.x] = s2;
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + w];
+            red[1][threadIdx.x] += red[1][threadIdx.x + w];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { part[blockIdx.x] = red[0][0]; part[ERR_PARTS + blockIdx.x] = red[1][0]; }
+}
+// out0 = scale0 * sum_b part[b]; out1 (nullable) = scale1 * sum_b part[PARTS + b]
+__global__ void k_finish_parts(int n_part, const float* __restrict__ part, float scale0, float scale1, float* __restrict__ out0,
+                               float* __restrict__ out1) {
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int b = 0; b < n_part; ++b) s += part[b];
+        out0[0] = scale0 * s;
+    } else if (threadIdx.x == 64 && out1) {
+        float s = 0.f;
+        for (int b = 0; b < n_part; ++b) s += part[ERR_PARTS + b];
+        out1[0] = scale1 * s;
+    }
+}
+constexpr int ERR_MB_MIN_ROWS = 8192;          // below: the one-block forms (one launch instead of two)
+
 // ga[row][k] = dx1[row][od + k] + dx2[row][od + k]
 __global__ void k_sum_action_grad(int rows, int od, int ad, const float* __restrict__ dx1, const float* __restrict__ dx2,
                                   float* __restrict__ ga) {
@@ -194,6 +257,47 @@ extern "C" int mpg_q_targets(const mpg_cfg_t* cfg, const float* policy_t, const 
     return MPG_OK;
 }
 
+// TD3 with prioritized replay needs TWO targets per minibatch: the clipped double-Q target with target-policy smoothing
+// (td3.py:69-81) and the plain Q1 target of the priorities' td error (td3.py:83-92).  Both start from pi_t(s~'): evaluated ONCE
+// here (the two mpg_q_targets calls of the method path evaluate it twice - one 65 536-row network pass, ~40 us, of every step).
+extern "C" int mpg_td3_targets(const mpg_cfg_t* cfg, const float* policy_t, const float* q1t, const float* q2t, int rows,
+                               const float* rew, const float* obs_tp1, const float* smooth_eps, float smooth_sigma,
+                               float smooth_clip, float* y, float* y1, void* ws, size_t ws_bytes, mpg_stream_t stream) {
+    MPG_REQUIRE(cfg_ok(cfg) && policy_t && q1t && q2t && rew && obs_tp1 && y && y1 && ws && rows > 0, "mpg_td3_targets: bad argument");
+    if (ws_bytes < mpg_q_targets_workspace_bytes(cfg, rows)) {
+        mpg_set_error("mpg_td3_targets: workspace too small");
+        return MPG_EWORKSPACE;
+    }
+    hipStream_t s = mpg_stream(stream);
+    Carver cv(ws, ws_bytes);
+    float* a = cv.take((size_t)rows * cfg->act_dim);
+    float* q1 = cv.take(rows);
+    float* q2 = cv.take(rows);
+    const int od = cfg->obs_dim, ad = cfg->act_dim;
+    int rc = launch_forward(cfg, policy_t, od, 2 * ad, ad, rows, xspec(obs_tp1, od, nullptr, 0, cfg->obs_scale, od),
+                            policy_out(cfg), a, ad, nullptr, nullptr, s);
+    if (rc) return rc;
+    const XSpec xq = xspec(obs_tp1, od, a, ad, cfg->obs_scale, od);
+    rc = launch_forward(cfg, q1t, od + ad, 1, 1, rows, xq, linear_out(), q1, 1, nullptr, nullptr, s);      // Q1t(s~', pi_t(s~')): y1
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_combine_target, dim3((rows + 255) / 256), dim3(256), 0, s, rows, rew, q1, (const float*)nullptr, cfg->rew_shift,
+                       cfg->rew_scale, cfg->gamma, y1);
+    MPG_CHECK_LAUNCH("k_combine_target");
+    if (smooth_eps) {
+        const int n = rows * ad;
+        hipLaunchKernelGGL(k_smooth, dim3((n + 255) / 256), dim3(256), 0, s, n, a, smooth_eps, smooth_sigma, smooth_clip);
+        MPG_CHECK_LAUNCH("k_smooth");
+        rc = launch_forward(cfg, q1t, od + ad, 1, 1, rows, xq, linear_out(), q1, 1, nullptr, nullptr, s);
+        if (rc) return rc;
+    }
+    rc = launch_forward(cfg, q2t, od + ad, 1, 1, rows, xq, linear_out(), q2, 1, nullptr, nullptr, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_combine_target, dim3((rows + 255) / 256), dim3(256), 0, s, rows, rew, q1, q2, cfg->rew_shift, cfg->rew_scale,
+                       cfg->gamma, y);
+    MPG_CHECK_LAUNCH("k_combine_target");
+    return MPG_OK;
+}
+
 extern "C" int mpg_nstep_targets(const mpg_cfg_t* cfg, const float* policy_t, const float* q1t, int rows, int n,
                                  const float* rewards, const float* last_obs, float* y, void* ws, size_t ws_bytes,
                                  mpg_stream_t stream) {
@@ -223,7 +327,7 @@ extern "C" int mpg_nstep_targets(const mpg_cfg_t* cfg, const float* policy_t, co
 extern "C" size_t mpg_q_loss_grad_workspace_bytes(const mpg_cfg_t* cfg, int rows) {
     if (!cfg_ok(cfg) || rows <= 0) return 0;
     const int in = cfg->obs_dim + cfg->act_dim;
-    return 4 * pad256(stash_floats(rows)) + 2 * pad256(rows) + pad256(wgrad_workspace_floats(rows, in, 1));
+    return 4 * pad256(stash_floats(rows)) + 2 * pad256(rows) + pad256(wgrad_workspace_floats(rows, in, 1)) + pad256(2 * ERR_PARTS);
 }
 
 extern "C" int mpg_q_loss_grad(const mpg_cfg_t* cfg, const float* q_params, int rows, const float* obs, const float* act,
@@ -245,9 +349,14 @@ extern "C" int mpg_q_loss_grad(const mpg_cfg_t* cfg, const float* q_params, int 
     float* q = cv.take(rows);
     float* dz3 = cv.take(rows);
     float* slabs = cv.take(wgrad_workspace_floats(rows, in, 1));
+    float* parts = cv.take(2 * ERR_PARTS);
     const XSpec xq = xspec(obs, od, act, ad, cfg->obs_scale, od);
     int rc = launch_forward(cfg, q_params, in, 1, 1, rows, xq, linear_out(), q, 1, h1, h2, s);
     if (rc) return rc;
+    if (rows >= ERR_MB_MIN_ROWS) {
+        hipLaunchKernelGGL(k_q_err_mb, dim3(ERR_PARTS), dim3(1024), 0, s, rows, q, y, inv_b_global, dz3, td, parts);
+        hipLaunchKernelGGL(k_finish_parts, dim3(1), dim3(128), 0, s, ERR_PARTS, parts, 0.5f * inv_b_global, 0.f, loss_sum, (float*)nullptr);
+    } else
     hipLaunchKernelGGL(k_q_err, dim3(1), dim3(1024), 0, s, rows, q, y, inv_b_global, dz3, td, loss_sum);
     MPG_CHECK_LAUNCH("k_q_err");
     rc = launch_backward(cfg, q_params, in, 1, 1, rows, dz3, 1, nullptr, 0, 0, 1.f, h1, h2, dz1, dz2, nullptr, nullptr, 0, s);
@@ -259,7 +368,8 @@ extern "C" size_t mpg_td3_policy_grad_workspace_bytes(const mpg_cfg_t* cfg, int 
     if (!cfg_ok(cfg) || rows <= 0) return 0;
     const int od = cfg->obs_dim, ad = cfg->act_dim, qin = od + ad;
     return 8 * pad256(stash_floats(rows)) + 2 * pad256((size_t)rows * ad) + 4 * pad256(rows) +
-           2 * pad256((size_t)rows * qin) + pad256((size_t)rows * ad) + pad256(wgrad_workspace_floats(rows, od, 2 * ad));
+           2 * pad256((size_t)rows * qin) + pad256((size_t)rows * ad) + pad256(wgrad_workspace_floats(rows, od, 2 * ad)) +
+           pad256(2 * ERR_PARTS);
 }
 
 extern "C" int mpg_td3_policy_grad(const mpg_cfg_t* cfg, const float* policy_params, const float* q1, const float* q2,
@@ -283,6 +393,7 @@ extern "C" int mpg_td3_policy_grad(const mpg_cfg_t* cfg, const float* policy_par
     float* dx1 = cv.take((size_t)rows * qin); float* dx2 = cv.take((size_t)rows * qin);
     float* ga = cv.take((size_t)rows * ad);
     float* slabs = cv.take(wgrad_workspace_floats(rows, od, 2 * ad));
+    float* parts = cv.take(2 * ERR_PARTS);
     const OutSpec po = policy_out(cfg);
     const XSpec xp = xspec(obs, od, nullptr, 0, cfg->obs_scale, od);
     int rc = launch_forward(cfg, policy_params, od, 2 * ad, ad, rows, xp, po, a, ad, hp1, hp2, s);        // td3.py:123
@@ -292,6 +403,10 @@ extern "C" int mpg_td3_policy_grad(const mpg_cfg_t* cfg, const float* policy_par
     if (rc) return rc;
     rc = launch_forward(cfg, q2, qin, 1, 1, rows, xq, linear_out(), qv2, 1, h21, h22, s);                  // :125
     if (rc) return rc;
+    if (rows >= ERR_MB_MIN_ROWS) {
+        hipLaunchKernelGGL(k_td3_dy_mb, dim3(ERR_PARTS), dim3(1024), 0, s, rows, qv1, qv2, inv_b_global, dy1, dy2, parts);
+        hipLaunchKernelGGL(k_finish_parts, dim3(1), dim3(128), 0, s, ERR_PARTS, parts, 1.f, 1.f, qmin_sum, qmin_sqsum);
+    } else
     hipLaunchKernelGGL(k_td3_dy, dim3(1), dim3(1024), 0, s, rows, qv1, qv2, inv_b_global, dy1, dy2, qmin_sum, qmin_sqsum);
     MPG_CHECK_LAUNCH("k_td3_dy");
     rc = launch_backward(cfg, q1, qin, 1, 1, rows, dy1, 1, nullptr, 0, 0, 1.f, h11, h12, nullptr, nullptr, nullptr, dx1, qin, s);

@@ -301,17 +301,23 @@ class TD3Learner(_LearnerBase):
 
     def get_batch_data(self, batch_data, rb, indexes, smooth_eps=None):
         self._get_batch(batch_data)
-        self.batch_data['batch_targets'] = self.compute_clipped_double_q_target(smooth_eps)
         self._y1 = None
+        if self.args.buffer_type != 'normal' and self.num_batch_reuse == 1:
+            # the priorities' td error y1 - Q1(s, a) (td3.py:83-92): y1 shares the target policy's pass with the clipped double-Q
+            # target (mpg_td3_targets: pi_t(s') once, not twice), and Q1 on the batch is what the critic-loss pass of
+            # compute_gradient evaluates anyway, on the same weights: keep y1 and finish there (two network passes less)
+            pw, b = self.policy_with_value, self.batch_data
+            rows = b['batch_obs'].shape[0]
+            if smooth_eps is None:
+                smooth_eps = torch.randn(rows, self.cfg.act_dim, generator=self._noise_gen, device=self.device)
+            self.batch_data['batch_targets'], self._y1 = ops.td3_targets(
+                self.cfg, pw.net('policy', True), pw.net('Q1', True), pw.net('Q2', True), b['batch_rewards'], b['batch_obs_tp1'],
+                smooth_eps, smooth_sigma=self.args.policy_smoothing_sigma, smooth_clip=self.args.policy_smoothing_clip)
+            self.info_for_buffer.update(dict(td_error=None, rb=rb, indexes=indexes))
+            return
+        self.batch_data['batch_targets'] = self.compute_clipped_double_q_target(smooth_eps)
         if self.args.buffer_type != 'normal':
-            if self.num_batch_reuse == 1:
-                # the priorities' td error y1 - Q1(s, a) (td3.py:83-92) needs Q1 on the batch - which the critic-loss pass of
-                # compute_gradient evaluates anyway, on the same weights: keep y1 and finish there (one network pass less)
-                pw, b = self.policy_with_value, self.batch_data
-                self._y1 = ops.q_targets(self.cfg, pw.net('policy', True), pw.net('Q1', True), None, b['batch_rewards'], b['batch_obs_tp1'])
-                self.info_for_buffer.update(dict(td_error=None, rb=rb, indexes=indexes))
-            else:
-                self.info_for_buffer.update(dict(td_error=self.compute_td_error(), rb=rb, indexes=indexes))
+            self.info_for_buffer.update(dict(td_error=self.compute_td_error(), rb=rb, indexes=indexes))
 
     def compute_gradient(self, batch_data, rb, indexes, iteration, smooth_eps=None):
         """td3.py:150-188"""

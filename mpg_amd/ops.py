@@ -198,6 +198,20 @@ def q_targets(cfg, policy_t, q1t, q2t, rew, obs_tp1, smooth_eps=None, smooth_sig
     return y
 
 
+def td3_targets(cfg, policy_t, q1t, q2t, rew, obs_tp1, smooth_eps, smooth_sigma=0.2, smooth_clip=0.5):
+    """(y, y1): the smoothed clipped double-Q target and the plain Q1 target of the priorities' td error from ONE evaluation of
+    the target policy (mpg_td3_targets; td3.py:69-92)."""
+    rows = obs_tp1.shape[0]
+    y = torch.empty(rows, dtype=torch.float32, device=obs_tp1.device)
+    y1 = torch.empty(rows, dtype=torch.float32, device=obs_tp1.device)
+    nb = L.lib().mpg_q_targets_workspace_bytes(ctypes.byref(cfg), L.c_int(rows))
+    ws = workspace(obs_tp1.device, nb)
+    L.call('mpg_td3_targets', ctypes.byref(cfg), L.ptr(_f32(policy_t)), L.ptr(_f32(q1t)), L.ptr(_f32(q2t)), L.c_int(rows),
+           L.ptr(_f32(rew)), L.ptr(_f32(obs_tp1)), L.ptr(_f32(smooth_eps) if smooth_eps is not None else None),
+           L.c_float(smooth_sigma), L.c_float(smooth_clip), L.ptr(y), L.ptr(y1), L.ptr(ws), L.c_size_t(ws.numel()), L.stream())
+    return y, y1
+
+
 def nstep_targets(cfg, policy_t, q1t, rewards, last_obs):
     n, rows = rewards.shape
     y = torch.empty(rows, dtype=torch.float32, device=last_obs.device)
