@@ -62,8 +62,8 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 // group holds each row once: MI355X_MICROARCH.md §LDS), the writer's ds_write_b32 pairs are 2-way (free).  Two images: hi, lo.
 constexpr int ROW_H = 72, PLANE_H = GROUP * ROW_H, IMG_H = 4 * PLANE_H;      // 4608 halves = 9216 B per image
 __device__ __forceinline__ int h_index(int row, int k) { return ((k >> 3) & 3) * PLANE_H + row * ROW_H + 8 * (k >> 5) + (k & 7); }
-#ifdef MPG_TR_IMAGE
-// TRANSPOSED activation image (round 4): one 32-byte slot per contraction index k holding the group's 16 rows as fp16, rows
+// TRANSPOSED activation image (round 4; the ping-pong kernels of mlp_pingpong.hip always use it, the lock-step engine with
+// -DMPG_TR_IMAGE - an A/B variant that measured null on the rollout sweeps): one 32-byte slot per contraction index k holding the group's 16 rows as fp16, rows
 // contiguous - what a C-layout lane owns (rows 4 rg .. 4 rg + 3 of ONE column) is one aligned 8-byte chunk, so the image store
 // is ONE ds_write_b64 per tile and image: no DPP exchange with the neighbouring column, no selects.  The MFMA A operand (row
 // l & 15, 8 consecutive k) comes back through ds_read_b64_tr_b16, gfx950's transposing LDS read (two reads of 4 k each per
@@ -83,7 +83,6 @@ __device__ __forceinline__ void split2_mix(float a, float b, float S, unsigned& 
 }
 typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-#endif
 constexpr float W_SCALE = 64.f;          // stationary weights are stored as W * 64
 constexpr float A_SCALE = 16.f;          // activations enter the LDS images as x * 16
 // Envelope of the split engine (include/mpg_hip.h, "Numerical envelope"): a first-layer activation at or beyond H_LIMIT would

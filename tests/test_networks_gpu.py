@@ -268,3 +268,4 @@ def test_tanh_policy_with_action_range_is_refused():
     cfg = ops.make_cfg('PathTracking-v0', policy_out_activation='tanh', action_range=2.0)
     with pytest.raises(L.MpgError):
         ops.policy_action(cfg, dev(mlp_weights_flat(rng, 6, 4)), dev(rng.standard_normal((16, 6))))
+

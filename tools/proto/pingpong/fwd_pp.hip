@@ -59,18 +59,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_fwd8(const float* params, int in
 // hardware transpose read: two reads of 4 k each per operand.  Slot order inside a k-block and an XOR on the chunk position make
 // both the stores (16 lanes of a row quad) and the transposed reads (32-lane halves) bank-conflict free without padding:
 //   k = 32 kb + 8 g + j  ->  slot = 32 kb + 16 (g >> 1) + 8 (j >> 2) + 4 (g & 1) + (j & 3),  chunk' = chunk ^ ((slot >> 2) & 3)
-constexpr int TR_IMG_BYTES = 256 * 32;            // one image (hi or lo): 8 KB, no padding
-__device__ __forceinline__ int tr_slot(int k) { const int kb = k >> 5, g = (k >> 3) & 3, j = k & 7; return 32 * kb + 16 * (g >> 1) + 8 * (j >> 2) + 4 * (g & 1) + (j & 3); }
-__device__ __forceinline__ int tr_byte(int slot, int chunk) { return slot * 32 + 8 * (chunk ^ ((slot >> 2) & 3)); }
-// (a, b) -> packed fp16 words of a * S = hi + lo, two v_fma_mix per word (scale, conversion and packing in one instruction each)
-__device__ __forceinline__ void split2_mix(float a, float b, float S, unsigned& hi, unsigned& lo) {
-    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hi) : "v"(a), "v"(S));
-    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hi) : "v"(b), "v"(S));
-    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(lo) : "v"(a), "v"(S), "v"(hi));
-    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lo) : "v"(b), "v"(S), "v"(hi));
-}
-typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+// (tr_slot / tr_byte / split2_mix / TR_IMG_BYTES now live in mlp_core.h: the product kernels of mlp_pingpong.hip use them)
 
 // ---- ping-pong geometry --------------------------------------------------------------------------------------------------------
 constexpr int TW = 4;                 // waves per team
