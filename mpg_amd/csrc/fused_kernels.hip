@@ -1017,7 +1017,7 @@ int launch_wgrad_multi(const mpg_cfg_t* cfg, const WgradJob* jobs, int n_jobs, c
     for (int j = 0; j < n_jobs; ++j) {
         const WgradJob& jb = jobs[j];
         WgradArgs& a = m.a[j];
-        a.in_dim = jb.in_dim; a.out_dim = jb.out_dim; a.rows = jb.rows; a.x = jb.x;
+        a.no_thin = 0; a.in_dim = jb.in_dim; a.out_dim = jb.out_dim; a.rows = jb.rows; a.x = jb.x;
         a.h1 = jb.h1; a.h2 = jb.h2; a.dz1 = jb.dz1; a.dz2 = jb.dz2; a.dz3 = jb.dz3; a.slabs = jb.slabs;
         const long ngroups = (jb.rows + GROUP - 1) / GROUP;
         a.groups_per_chunk = wgrad_groups_per_chunk(ngroups);

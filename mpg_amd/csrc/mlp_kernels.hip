@@ -283,9 +283,10 @@ size_t wgrad_workspace_floats(int rows, int in_dim, int out_dim) {
 }
 
 int launch_wgrad(const mpg_cfg_t* cfg, int in_dim, int out_dim, int ou, int rows, const XSpec& x, const float* h1, const float* h2,
-                 const float* dz1, const float* dz2, const float* dz3, float inv_b, float* grad, float* ws, hipStream_t s) {
-    MPG_REQUIRE(rows > 0 && h1 && h2 && dz1 && dz2 && dz3 && grad && ws, "launch_wgrad: bad argument");
+                 const float* dz1, const float* dz2, const float* dz3, float inv_b, float* grad, float* ws, hipStream_t s, bool no_thin) {
+    MPG_REQUIRE(rows > 0 && h1 && h2 && (dz1 || no_thin) && dz2 && dz3 && grad && ws, "launch_wgrad: bad argument");
     WgradArgs a;
+    a.no_thin = no_thin ? 1 : 0;
     a.in_dim = in_dim; a.out_dim = out_dim; a.rows = rows; a.x = x;
     a.h1 = h1; a.h2 = h2; a.dz1 = dz1; a.dz2 = dz2; a.dz3 = dz3; a.slabs = ws;
     (void)inv_b;

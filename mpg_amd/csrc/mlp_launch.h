@@ -66,8 +66,10 @@ int launch_backward(const mpg_cfg_t* cfg, const float* params, int in_dim, int o
 size_t wgrad_workspace_floats(int rows, int in_dim, int out_dim);
 // inv_b: the scale the upstream gradients carry (1/B_global, / M for tiled rollouts); informational - the fp16 split operands are
 // centred per chunk from the data itself (mlp_wgrad.h)
+// no_thin: only dW2 is computed (the thin parts of `grad` are left ZERO: the caller adds them - rollout_common.h thin_floats)
 int launch_wgrad(const mpg_cfg_t* cfg, int in_dim, int out_dim, int ou, int rows, const XSpec& x, const float* h1, const float* h2,
-                 const float* dz1, const float* dz2, const float* dz3, float inv_b, float* grad, float* ws, hipStream_t s);
+                 const float* dz1, const float* dz2, const float* dz3, float inv_b, float* grad, float* ws, hipStream_t s,
+                 bool no_thin = false);
 
 // ---- fused critic-side kernels (one 16-row group per workgroup; callers fall back to the unfused launchers when a
 // configuration is not covered) ----------------------------------------------------------------------------------

@@ -8,6 +8,7 @@ namespace mlp {
 
 struct WgradArgs {
     int in_dim, out_dim, rows, groups_per_chunk;
+    int no_thin;            // only dW2: the thin parts were accumulated elsewhere (reverse sweep, THIN) - their slab entries are zeros
     XSpec x;
     const float *h1, *h2, *dz1, *dz2, *dz3;
     float* slabs;
@@ -174,7 +175,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int sl, con
 #ifdef MPG_AB_WG_NOTHIN
     const bool has_thin = false;
 #else
-    const bool has_thin = tg < g1;
+    const bool has_thin = tg < g1 && !a.no_thin;
 #endif
 
     // ---- dW2 on the matrix pipe.  A operand: this wave's 32 rows of dW2 = 2 fragments of H1 per row group, straight

@@ -6,10 +6,20 @@ namespace {
 
 // WIDE: observations with look-ahead entries (see the forward sweep): the adjoint of a MODEL observation's look-ahead entries
 // folds into the adjoint of entry ENV::FUT_SRC, which they copy; the start observation's are inputs.
-template <class ENV, bool PK, bool WIDE = false>
+// THIN: the thin parameter gradients (dW1, db1, db2, dW3, db3) of EVERY step are accumulated here (rollout_common.h,
+// thin_floats): used with stash_all (NADP) when M == 1.
+template <class ENV, bool PK, bool WIDE = false, bool THIN = false>
 __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_bwd(const RollBwdArgs a) {
     constexpr int OBS = ENV::OBS, ACT = ENV::ACT;
+    static_assert(!(THIN && WIDE), "THIN is built for the base observation widths");
     constexpr int NIN = WIDE ? 16 : OBS, XSW = xs_of<NIN>();
+    // per-lane running sums of the thin gradients, in LDS (registers: none to spare): [quad][thread] float4, slot order
+    // gb1[2] gb2[2] gW3[2][ACT] gW1[2][OBS] (+ padding); the own lanes' db3 in sB3; the step's scaled network inputs of the 16
+    // rows in sXin, double-buffered by step parity (written at the top of a step, read behind its last barrier)
+    constexpr int NACC = 4 + 2 * ACT + 2 * OBS, TQ = (NACC + 3) / 4;
+    __shared__ __attribute__((aligned(16))) float sThin[THIN ? TQ * NTHREAD * 4 : 4];
+    __shared__ __attribute__((aligned(16))) float sXin[THIN ? 2 * GROUP * 8 : 4];
+    __shared__ float sB3[THIN ? GROUP * 2 : 1];
     const int nf = WIDE ? a.obs_dim - OBS : 0, OD = OBS + nf, QIN = OD + ACT;
     __shared__ __attribute__((aligned(16))) float smem[2 * A_IMG + GROUP * MAXOUT + NWAVE * GROUP * XSW];
     float* sA = smem;
@@ -42,6 +52,11 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_bwd(const RollBwdArgs a)
     load_small<NIN, ACT>(net, L, r);
     const long R = (long)a.rows * a.M;
     const long ngroups = (R + GROUP - 1) / GROUP;
+    if constexpr (THIN) {
+#pragma unroll
+        for (int q = 0; q < TQ; ++q) reinterpret_cast<f32x4*>(sThin)[q * NTHREAD + tid] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (tid < GROUP) sB3[2 * tid] = sB3[2 * tid + 1] = 0.f;          // (each trajectory lane owns its two slots)
+    }
 #ifdef MPG_STAMP
     if ((tid & 63) == 0) {
         for (int k = 0; k < 10; ++k) g_st_acc[tid >> 6][k] = 0;
@@ -122,12 +137,44 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_bwd(const RollBwdArgs a)
                     sD3[d3_index(tid, k)] = d;
                     if (live && a.DZ3 && (a.stash_all || t == 0))
                         a.DZ3[((long)(a.stash_all ? t : 0) * R + tr) * ACT + k] = d;
+                    if constexpr (THIN) sB3[tid * 2 + k] += d;                       // db3 (rows beyond the batch carry d = 0)
+                }
+                if constexpr (THIN) {       // this step's network input of the row, as the forward sweep published it (obs * scale)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) sXin[(t & 1) * GROUP * 8 + tid * 8 + i] = i < OBS ? o[i] * a.obs_scale[i] : 0.f;
                 }
             }
             float dz1[2][4], dz2[2][4];
             lds_barrier();
             MPG_STAMP_AT(0);
             backward_dz2<NIN, ACT>(sD3, sA, L, r, h2_cur, dz2);
+            if constexpr (THIN) {           // db2 += dz2, dW3 += h2 dz3^T: everything is at hand here (sD3 is stable until the step's last barrier)
+                f32x4* th = reinterpret_cast<f32x4*>(sThin) + tid;
+                f32x4 q0 = th[0];                                                    // gb1[0..1] gb2[0..1]
+                float gw3[2][ACT];
+                f32x4 q1 = th[NTHREAD];
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                    for (int k = 0; k < ACT; ++k) gw3[tt][k] = q1[tt * ACT + k];
+#pragma unroll
+                for (int k = 0; k < ACT; ++k) {
+                    const f32x4 d3 = *reinterpret_cast<const f32x4*>(sD3 + d3_index(4 * L.rg, k));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        gw3[0][k] = fmaf(h2_cur[0][j], d3[j], gw3[0][k]);
+                        gw3[1][k] = fmaf(h2_cur[1][j], d3[j], gw3[1][k]);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { q0[2] += dz2[0][j]; q0[3] += dz2[1][j]; }
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                    for (int k = 0; k < ACT; ++k) q1[tt * ACT + k] = gw3[tt][k];
+                th[0] = q0;
+                th[NTHREAD] = q1;
+            }
             // all global loads of the step are issued HERE, behind the dz2 phase: h1 is consumed after the MFMA block,
             // the record and h2 stash of step t-1 in the next iteration (software pipeline)
 #ifdef MPG_AB_NO_H1
@@ -154,9 +201,9 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_bwd(const RollBwdArgs a)
                 backward_rest<NIN, ACT, true>(sD3, sA, sA1, sPartX, L, w2t, r, h1, dz1);
             else
                 backward_rest<NIN, ACT, false>(sD3, sA, sA1, sPartX, L, w2t, r, h1, dz1);
-            if (a.DZ1 && (a.stash_all || t == 0)) {
+            if (a.DZ2 && (a.stash_all || t == 0)) {
                 const long sg = (long)(a.stash_all ? t : 0) * ngroups + g;
-                stash_store(a.DZ1, sg, L, dz1);
+                if (!THIN) stash_store(a.DZ1, sg, L, dz1);          // (THIN: dz1 is consumed below, no stash)
                 stash_store(a.DZ2, sg, L, dz2);
             }
             if (own) {
@@ -178,6 +225,31 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_bwd(const RollBwdArgs a)
                     rec_cur[i] = rec_pre[i];
                 }
             }
+            if constexpr (THIN) {           // db1 += dz1, dW1 += x^T dz1 (behind the step's last barrier: the other seven waves
+                                            // do this while wave 0's trajectory lanes run the serial chain)
+                f32x4* th = reinterpret_cast<f32x4*>(sThin) + tid;
+                f32x4 q0 = th[0];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { q0[0] += dz1[0][j]; q0[1] += dz1[1][j]; }
+                th[0] = q0;
+                float gw1[2][OBS];
+                constexpr int BASE = 4 + 2 * ACT;                    // float index of gW1[0][0] in the lane's slots
+#pragma unroll
+                for (int e = 0; e < 2 * OBS; ++e) gw1[e / OBS][e % OBS] = sThin[((BASE + e) / 4 * NTHREAD + tid) * 4 + (BASE + e) % 4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float* xr = sXin + (t & 1) * GROUP * 8 + L.row(j) * 8;
+                    const f32x4 x0 = *reinterpret_cast<const f32x4*>(xr), x1 = *reinterpret_cast<const f32x4*>(xr + 4);
+#pragma unroll
+                    for (int i = 0; i < OBS; ++i) {
+                        const float xv = i < 4 ? x0[i & 3] : x1[i & 3];
+                        gw1[0][i] = fmaf(xv, dz1[0][j], gw1[0][i]);
+                        gw1[1][i] = fmaf(xv, dz1[1][j], gw1[1][i]);
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 2 * OBS; ++e) sThin[((BASE + e) / 4 * NTHREAD + tid) * 4 + (BASE + e) % 4] = gw1[e / OBS][e % OBS];
+            }
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
@@ -191,6 +263,40 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_bwd(const RollBwdArgs a)
             for (int k = 0; k < 8; ++k) a.dbg[((long)blockIdx.x * NWAVE + (tid >> 6)) * 8 + k] = (float)g_st_acc[tid >> 6][k];
 #endif
     }
+    if constexpr (THIN) {
+        // this workgroup's partial: the four row quads (lanes c, c + 16, c + 32, c + 48 of a wave) of every column summed in a fixed
+        // order by the quad-0 lane, written in the network's flat layout without W2
+        __syncthreads();
+        if (L.rg == 0) {
+            const int out_dim = 2 * ACT;
+            float* dst = a.thin_part + (size_t)blockIdx.x * thin_floats(OBS, out_dim);
+            float* dW1 = dst, *db1 = dW1 + OBS * H, *db2 = db1 + H, *dW3 = db2 + H, *db3 = dW3 + H * out_dim;
+            auto acc = [&](int slot) {
+                float s4 = 0.f;
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) s4 += sThin[((slot / 4) * NTHREAD + tid + 16 * rq) * 4 + slot % 4];
+                return s4;
+            };
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                const int col = L.col(tt);
+                db1[col] = acc(tt);
+                db2[col] = acc(2 + tt);
+#pragma unroll
+                for (int k = 0; k < ACT; ++k) dW3[col * out_dim + k] = acc(4 + tt * ACT + k);
+#pragma unroll
+                for (int k = ACT; k < 2 * ACT; ++k) dW3[col * out_dim + k] = 0.f;           // the unused log-std half (SURVEY B-5)
+#pragma unroll
+                for (int i = 0; i < OBS; ++i) dW1[i * H + col] = acc(4 + 2 * ACT + tt * OBS + i);
+            }
+            if (tid < 2 * ACT) {
+                float s3 = 0.f;
+                if (tid < ACT)
+                    for (int row = 0; row < GROUP; ++row) s3 += sB3[row * 2 + tid];
+                db3[tid] = s3;
+            }
+        }
+    }
 }
 
 }  // namespace
@@ -200,7 +306,8 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_bwd(const RollBwdArgs a)
 // those flags and keep the previous ones.
 #ifdef MPG_BWD_PENDULUM_PART
 void launch_rollout_bwd_pendulum(const RollBwdArgs& ba, long ngroups, hipStream_t s) {
-    if (ba.pack) hipLaunchKernelGGL((k_rollout_bwd<Pendulum, true>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, ba);
+    if (ba.thin_part) hipLaunchKernelGGL((k_rollout_bwd<Pendulum, true, false, true>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, ba);
+    else if (ba.pack) hipLaunchKernelGGL((k_rollout_bwd<Pendulum, true>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, ba);
     else hipLaunchKernelGGL((k_rollout_bwd<Pendulum, false>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, ba);
 }
 #else
@@ -218,6 +325,8 @@ int launch_rollout_bwd(const RollBwdArgs& ba_in, int env_kind, long ngroups, int
     mpg_prof_begin(prof, 1, s);
     if (env_kind == MPG_ENV_PATH_TRACKING && ba.obs_dim > PathTracking::OBS)
         { if (ba.pack) hipLaunchKernelGGL((k_rollout_bwd<PathTracking, true, true>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, ba); else hipLaunchKernelGGL((k_rollout_bwd<PathTracking, false, true>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, ba); }
+    else if (env_kind == MPG_ENV_PATH_TRACKING && ba.thin_part)
+        hipLaunchKernelGGL((k_rollout_bwd<PathTracking, true, false, true>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, ba);
     else if (env_kind == MPG_ENV_PATH_TRACKING)
         { if (ba.pack) hipLaunchKernelGGL((k_rollout_bwd<PathTracking, true>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, ba); else hipLaunchKernelGGL((k_rollout_bwd<PathTracking, false>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, ba); }
     else

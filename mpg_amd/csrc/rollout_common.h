@@ -230,8 +230,19 @@ struct RollBwdArgs {
     int stash_all;                      // 0: parameter gradient through step 0 only (MPG); 1: every step (NADP)
     float *DZ1, *DZ2, *DZ3;             // stashes for the weight gradient: T = stash_all ? n+1 : 1 steps
     const float* pack;                  // nullable: packed backward image of the policy's W2
+    float* thin_part;                   // THIN instantiations only: [gridDim.x][thin_floats(OBS, 2 ACT)] per-workgroup sums (below)
     float* dbg;                         // diagnostic builds only
 };
+
+// "Thin" parameter gradients accumulated INSIDE the reverse sweep (round 4; NADP, nadp.py:128-194: the policy's parameter gradient
+// flows through all n + 1 evaluations).  dW1, db1, db2, dW3, db3 need dz1, dz2, h2, dz3 and the network input of every (step,
+// row) - all of which the reverse sweep holds in registers / LDS at the moment it produces them.  Left to the weight-gradient
+// launch they are two more 218 MB stashes to write here and to read there (config 3: k_wgrad<4,1> moved 872 MB in 250 us, the
+// largest kernel of the step).  With THIN the sweep keeps per-lane running sums in LDS (the other seven waves do this while
+// wave 0 runs the serial chain), leaves one partial vector per workgroup and skips the dz1 stash; the weight-gradient launch then
+// reads only h1 and dz2 for dW2 and k_thin_reduce adds the partials.  Layout of a partial = the network's flat layout without W2:
+// [W1 (in x 256) | b1 | b2 | W3 (256 x out) | b3].
+__host__ __device__ inline int thin_floats(int in_dim, int out_dim) { return in_dim * H + H + H + H * out_dim + out_dim; }
 
 inline void fill_roll(RollArgs& a, const mpg_cfg_t* cfg, const float* policy, int rows, int M, int n) {
     a.policy = policy; a.rows = rows; a.M = M; a.n = n;

@@ -94,6 +94,23 @@ __global__ void k_qest(int rows, int M, int n_sel, const QestCoef qc, const floa
     }
 }
 
+// grad[thin positions] = sum over the reverse sweep's workgroups of their partial thin gradients (rollout_common.h thin_floats; fixed
+// order: deterministic).  i < w1n: W1 | b1 go in front of W2; the rest (b2 | W3 | b3) behind it.
+__global__ void k_thin_reduce(const float* __restrict__ part, int n_part, int n_thin, int w1b1, float* __restrict__ grad) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_thin) return;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    int k = 0;
+    for (; k + 3 < n_part; k += 4) {
+        acc[0] += part[(size_t)k * n_thin + i];
+        acc[1] += part[(size_t)(k + 1) * n_thin + i];
+        acc[2] += part[(size_t)(k + 2) * n_thin + i];
+        acc[3] += part[(size_t)(k + 3) * n_thin + i];
+    }
+    for (; k < n_part; ++k) acc[0] += part[(size_t)k * n_thin + i];
+    grad[i < w1b1 ? i : i + H * H] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------
@@ -117,8 +134,12 @@ inline bool cfg_ok(const mpg_cfg_t* c) {
 
 
 struct PgLayout {
-    size_t h, sa, xq, gk, q, dyq, hq, gxq, dz, dz3, slabs, small, total;
+    size_t h, sa, xq, gk, q, dyq, hq, gxq, dz, dz3, slabs, small, thin, total;
 };
+
+// the thin gradients ride in the reverse sweep (rollout_common.h) when every step is differentiated through the parameters, the
+// trajectories are the batch rows and the packed backward image exists (the THIN instantiations are packed-image kernels)
+inline bool thin_in_sweep(const mpg_cfg_t* cfg, int M, int stash_all) { return stash_all && M == 1 && cfg->obs_dim <= 6; }
 
 PgLayout pg_layout(const mpg_cfg_t* cfg, int rows, int M, int n, int n_sel, int stash_all) {
     PgLayout l;
@@ -135,8 +156,9 @@ PgLayout pg_layout(const mpg_cfg_t* cfg, int rows, int M, int n, int n_sel, int 
     l.dz3 = (size_t)T * R * cfg->act_dim;
     l.slabs = wgrad_workspace_floats((int)(T * stash_floats(R) / H), cfg->obs_dim, 2 * cfg->act_dim);
     l.small = 64;
+    l.thin = thin_in_sweep(cfg, M, stash_all) ? (size_t)256 * thin_floats(cfg->obs_dim, 2 * cfg->act_dim) : 0;
     l.total = 2 * pad256(l.h) + pad256(l.sa) + pad256(l.xq) + 3 * pad256(l.gk) + 2 * pad256(l.hq) + pad256(l.gxq) +
-              2 * pad256(l.dz) + pad256(l.dz3) + pad256(l.slabs) + 2 * pad256(l.small);
+              2 * pad256(l.dz) + pad256(l.dz3) + pad256(l.slabs) + 2 * pad256(l.small) + pad256(l.thin);
     return l;
 }
 
@@ -178,7 +200,7 @@ int run_rollout_fwd(const mpg_cfg_t* cfg, const float* policy_params, int rows, 
 
 int run_rollout_bwd(const mpg_cfg_t* cfg, const float* policy_params, int rows, int M, int n, const int* select, int n_select,
                     const float* rho, const float* H1, const float* H2, const float* SA, const float* GXQ,
-                    int all_steps_param_grad, float* DZ1, float* DZ2, float* DZ3, hipStream_t s) {
+                    int all_steps_param_grad, float* DZ1, float* DZ2, float* DZ3, hipStream_t s, float* thin_part = nullptr) {
     const long R = (long)rows * M;
     const long ngroups = (R + GROUP - 1) / GROUP;
     const int od = cfg->obs_dim, ad = cfg->act_dim;
@@ -198,6 +220,7 @@ int run_rollout_bwd(const mpg_cfg_t* cfg, const float* policy_params, int rows, 
     ba.stash_all = all_steps_param_grad ? 1 : 0;
     ba.DZ1 = DZ1; ba.DZ2 = DZ2; ba.DZ3 = DZ3;
     ba.pack = weight_cache_lookup(cfg, make_net(policy_params, od, 2 * ad).W2, 1);
+    ba.thin_part = thin_part;
     return launch_rollout_bwd(ba, cfg->env_kind, ngroups, n, s, cfg->prof);
 }
 
@@ -239,6 +262,9 @@ extern "C" int mpg_rollout_pg(const mpg_cfg_t* cfg, const float* policy_params, 
     float* HQ1 = cv.take(l.hq); float* HQ2 = cv.take(l.hq); float* GXQ = cv.take(l.gxq);
     float* DZ1 = cv.take(l.dz); float* DZ2 = cv.take(l.dz); float* DZ3 = cv.take(l.dz3);
     float* slabs = cv.take(l.slabs);
+    float* thin_part = l.thin ? cv.take(l.thin) : nullptr;
+    // (the THIN reverse sweep is a packed-image kernel: without the caller's weight cache the thin parts stay in the wgrad launch)
+    if (thin_part && !weight_cache_lookup(cfg, make_net(policy_params, cfg->obs_dim, 2 * cfg->act_dim).W2, 1)) thin_part = nullptr;
 
     // ---- forward sweep ----
     int rc = run_rollout_fwd(cfg, policy_params, rows, M, n, select, n_select, obs0, eps, noise_seed, noise_ctr, H1, H2, SA, XQ,
@@ -262,7 +288,7 @@ extern "C" int mpg_rollout_pg(const mpg_cfg_t* cfg, const float* policy_params, 
 
     // ---- reverse sweep ----
     rc = run_rollout_bwd(cfg, policy_params, rows, M, n, select, n_select, cf.rho, H1, H2, SA, GXQ, all_steps_param_grad, DZ1, DZ2,
-                         DZ3, s);
+                         DZ3, s, thin_part);
     if (rc) return rc;
 
     // ---- policy weight gradient from the stashes (step 0 only, or every step for NADP) ----
@@ -272,7 +298,14 @@ extern "C" int mpg_rollout_pg(const mpg_cfg_t* cfg, const float* policy_params, 
     XSpec xs = xspec(SA, od, nullptr, 0, cfg->obs_scale, od);
     xs.ld0 = SAW;
     if (od > 6) xs = xspec(obs0, od, nullptr, 0, cfg->obs_scale, od);     // (M == 1, step-0 gradient: checked before the first launch)
-    return launch_wgrad(cfg, od, 2 * ad, ad, (int)(T * R), xs, H1, H2, DZ1, DZ2, DZ3, inv_b_global / (float)M, grad, slabs, s);
+    rc = launch_wgrad(cfg, od, 2 * ad, ad, (int)(T * R), xs, H1, H2, DZ1, DZ2, DZ3, inv_b_global / (float)M, grad, slabs, s,
+                      thin_part != nullptr);
+    if (rc || !thin_part) return rc;
+    // dW2 came from the launch above (its thin parts are zeros); the thin parts are the sum of the sweep's per-workgroup partials
+    const int n_thin = thin_floats(od, 2 * ad), n_part = (int)std::min<long>(256, (R + GROUP - 1) / GROUP);
+    hipLaunchKernelGGL(k_thin_reduce, dim3((n_thin + 255) / 256), dim3(256), 0, s, thin_part, n_part, n_thin, od * H + H, grad);
+    MPG_CHECK_LAUNCH("k_thin_reduce");
+    return MPG_OK;
 }
 
 extern "C" size_t mpg_rollout_q_target_workspace_bytes(const mpg_cfg_t* cfg, int rows) {
