@@ -386,18 +386,20 @@ def side_config(a):
     ms = 1e3 * dt / a.steps
     dom = max(slots, key=lambda k: slots[k]['ms_per_step']) if slots else None
     executed = (c['flop_per_row'] + 2 * c['hidden_flop_per_row']) * B / (ms * 1e-3) / 1e12
+    algorithmic = c['flop_per_row'] * B / (ms * 1e-3) / 1e12
     out = {
         'metric': c['metric'], 'value': world * B * a.steps / dt, 'unit': 'rows/s', 'grad_steps_per_sec': a.steps / dt,
         'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'f32-via-split-f16', 'data': 'synthetic', 'schema': 3,
         'config': {'workload': c['workload'], 'global_batch': world * B, 'parallelism': 'dp%d' % world, 'dist_backend': D.backend()},
         'device': _device_info(),
-        # whole-step matrix view (the step is a chain of weight-stationary launches, all on the f16 pipe): executed flop =
-        # algorithmic flop with the hidden-layer part counted 3x
+        # whole-step matrix view (the step is a chain of weight-stationary launches, all on the f16 pipe).  `achieved` / `frac`
+        # count ALGORITHMIC flop (the 3x of the split-fp16 emulation is overhead, not work); the executed view (the
+        # hidden-layer part counted 3x) stays under frac_f16_mfma
         'roofline': {'bound': 'mfma', 'kernel': 'whole gradient step (%s dominates: %.3f ms of it)' % (dom, slots[dom]['ms_per_step']) if dom else 'whole gradient step',
-                     'achieved': executed, 'peak': F16_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': executed / F16_MFMA_PEAK_TFLOPS,
-                     'frac_f16_mfma': executed / F16_MFMA_PEAK_TFLOPS, 'traffic': None,
-                     'algorithmic_tflops': c['flop_per_row'] * B / (ms * 1e-3) / 1e12,
+                     'achieved': algorithmic, 'peak': F16_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': algorithmic / F16_MFMA_PEAK_TFLOPS,
+                     'frac_f16_mfma': executed / F16_MFMA_PEAK_TFLOPS, 'executed_f16_tflops': executed, 'traffic': None,
+                     'algorithmic_tflops': algorithmic,
                      'timed_with': 'wall clock over the timed region (kernel groups by HIP events on the launch stream below)'},
         'kernel_groups_ms_per_step': slots,
     }

@@ -180,7 +180,10 @@ int mpg_sum_slots(const float* slots, int n_slots, int n, float* out, mpg_stream
 
 /* Hyper-parameters of one config (host memory, read at call time). */
 typedef struct {
-    int obs_dim, act_dim;       /* path tracking: 6 + num_future_data (0 <= num_future_data <= 8), 2; pendulum: 4, 1 */
+    int obs_dim, act_dim;       /* path tracking: 6 + num_future_data (0 <= num_future_data <= 8), 2; pendulum: 4, 1.
+                                   LIMIT: the reference accepts any num_future_data (path_tracking_env.py:385-402); every entry
+                                   point that evaluates a network returns MPG_EINVAL for obs_dim > 14 (first layers are at most
+                                   16 wide); the env entry points serve num_future_data <= MPG_ENV_MAX_FUTURE = 10 */
     int policy_out_act;         /* MPG_ACT_TANH (train_script.py:267) or MPG_ACT_LINEAR (train_script4mujoco.py:371) */
     float action_range;         /* <= 0: none; pendulum 3.0 -> a = range*tanh(mean) (policy.py:197-199) */
     float obs_scale[16];        /* 'scale' preprocessor, preprocessor.py:142-143 (train_script.py: [1,1,2,1,2.4,1/1200] + [1]*num_future_data) */
@@ -224,6 +227,15 @@ int mpg_q_targets(const mpg_cfg_t* cfg, const float* policy_t, const float* q1t,
 int mpg_td3_targets(const mpg_cfg_t* cfg, const float* policy_t, const float* q1t, const float* q2t, int rows,
                     const float* rew, const float* obs_tp1, const float* smooth_eps, float smooth_sigma,
                     float smooth_clip, float* y, float* y1, void* ws, size_t ws_bytes, mpg_stream_t stream);
+
+/* out[0 .. n) ~ N(0, 1) from Philox4x32-10(seed, ctr) + Box-Muller: the target-policy smoothing noise of TD3 (td3.py:74,
+ * tf.random.normal in the reference) without a framework kernel; the same (seed, ctr) gives the same numbers in the native step
+ * driver and in the method-by-method path. */
+int mpg_normal_fill(int n, uint64_t seed, uint64_t ctr, float* out, mpg_stream_t stream);
+
+/* TD3Learner.compute_td_error (td3.py:83-92) finished from what the step already has: out = (y1 - y) - td with td = Q1(s~, a) - y
+ * from mpg_q_loss_grad and (y, y1) from mpg_td3_targets; signed (mpg_per_update takes |.| + eps). */
+int mpg_td3_priority_errors(int rows, const float* y1, const float* y, const float* td, float* out, mpg_stream_t stream);
 
 /* n-step return of MPG-v1 (mpg_learner.py:155-169) once the real-env rollout exists (mpg_env_step x n):
  *   y = sum_t gamma^t r~_t + gamma^n Q1t(s~_n, pi_t(s~_n)).  rewards [n][rows] RAW, last_obs [rows][obs_dim].
@@ -436,6 +448,11 @@ int mpg_per_init(double* sum_tree, double* min_tree, int* stamp, int capacity, m
 int mpg_per_update(double* sum_tree, double* min_tree, int* stamp, int capacity, int n, const int* idx,
                    const float* prio, double alpha, double eps, float* max_priority, mpg_stream_t stream);
 
+/* PrioritizedReplayBuffer.add for n consecutive ring slots start, start + 1, ... (mod ring_capacity): their leaves enter at the
+ * current max priority (buffer.py:127-136).  idx_scratch / prio_scratch: n ints / floats of device scratch. */
+int mpg_per_add(double* sum_tree, double* min_tree, int* stamp, int capacity, int ring_capacity, int start, int n,
+                double alpha, float* max_priority, int* idx_scratch, float* prio_scratch, mpg_stream_t stream);
+
 /* PrioritizedReplayBuffer._sample_proportional + IS weights (buffer.py:138-160):
  *   mass_i = u_i * sum(0, n_storage)  (inclusive end, buffer.py:141);  idx_i = find_prefixsum_idx(mass_i)
  *   (segment_tree.py:114-140);  w_i = (p_i/sum * n_storage)^-beta / max_w  with max_w from the min tree.
@@ -448,7 +465,7 @@ int mpg_per_sample(const double* sum_tree, const double* min_tree, int capacity,
  * Native step driver  - SingleProcessOffPolicyOptimizer.step, optimizer.py:330-362
  * ---------------------------------------------------------------------------------------------- */
 
-/* One training iteration of the MPG learner enqueued by native code, so that the ~45 kernel launches of a step are
+/* One training iteration of the MPG learner (round 4: also NADP and TD3 + prioritized replay) enqueued by native code, so that the ~45 kernel launches of a step are
  * not paced by the Python interpreter.  It calls exactly the entry points above, in the reference's order:
  *   mpg_step_begin:  [every sampling_interval-th iteration: sample_iters x (policy + N(0,sigma) -> env.step ->
  *                    ring add -> env.reset)]  (worker.py:91-119, optimizer.py:332-337);  replay (uniform indices +
@@ -460,7 +477,10 @@ int mpg_per_sample(const double* sum_tree, const double* min_tree, int capacity,
  * All pointers are device buffers owned by the caller; counters are advanced in place (host fields). */
 typedef struct {
     mpg_cfg_t cfg;
-    int learner_version;              /* 1: MPG-v1 (n-step real-env target), 2: MPG-v2 (clipped double-Q target) */
+    int learner_version;              /* 1: MPG-v1 (n-step real-env target), 2: MPG-v2 (clipped double-Q target),
+                                         3: NADP (learners/nadp.py:209-241: networks [Q1 | policy]; n = the Q-target AND policy
+                                            rollout horizon, n_select / select / eta / total_ite unused),
+                                         4: TD3 (learners/td3.py:150-188: networks [Q1 | Q2 | policy]; n, M, select unused) */
     int num_agent, sample_iters;      /* worker: sample_iters env steps of num_agent agents per sampling call */
     int sampling_interval;            /* optimizer.py:331 (10 in the reference) */
     int batch, n, M, n_select, select[4];
@@ -497,6 +517,17 @@ typedef struct {
     uint8_t *l_done, *l_done_intended;
     void *ws0, *ws1;
     size_t ws0_bytes, ws1_bytes;
+    /* TD3 (learner_version 4) */
+    float smooth_sigma, smooth_clip;  /* target policy smoothing, td3.py:74-76 (noise: mpg_normal_fill(learner_seed, learner_counter)) */
+    int prioritized;                  /* != 0: PrioritizedReplayBuffer (buffer.py:94-189) - the fields below; 0: uniform replay */
+    double *per_sum, *per_min;        /* segment trees, 2 * per_capacity doubles each (mpg_per_init) */
+    int* per_stamp;
+    int per_capacity;
+    float* per_max_priority;
+    double per_alpha, per_beta, per_eps;
+    float* b_weights;                 /* [batch] IS weights of the draw (buffer.py:146-160; the TD3 loss does not use them) */
+    float* scratch;                   /* max(batch * (act_dim + 3), 2 * num_agent) floats: smoothing noise | y1 | td | priority errors
+                                         (and the index / priority pairs of a ring add) */
 } mpg_train_ctx_t;
 
 /* workspace requirements of a context (ws0: targets / critic; ws1: rollout) */

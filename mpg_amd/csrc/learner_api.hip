@@ -162,6 +162,29 @@ __global__ void k_finish_parts(int n_part, const float* __restrict__ part, float
 }
 constexpr int ERR_MB_MIN_ROWS = 8192;          // below: the one-block forms (one launch instead of two)
 
+// out[i] ~ N(0, 1): Philox4x32-10(key = seed, counter = (i / 4, ctr)), Box-Muller on two of the four words per pair of outputs
+__global__ void k_normal_fill(int n, uint32_t k0, uint32_t k1, uint32_t c1, uint32_t c2, float* __restrict__ out) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;          // one Philox draw = four normals
+    if (4 * q >= n) return;
+    const Philox4 p = philox4x32_10((uint32_t)q, c1, c2, 0x6e6f726du, k0, k1);
+    const float r0 = sqrtf(-2.f * logf(u01(p.v[0]))), r1 = sqrtf(-2.f * logf(u01(p.v[2])));
+    float s0, c0, s1, cc1;
+    sincosf(6.283185307179586f * u01(p.v[1]), &s0, &c0);
+    sincosf(6.283185307179586f * u01(p.v[3]), &s1, &cc1);
+    const float z[4] = {r0 * c0, r0 * s0, r1 * cc1, r1 * s1};
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (4 * q + e < n) out[4 * q + e] = z[e];
+}
+
+// the priorities' td error of TD3 (td3.py:83-92): y1 - Q1(s, a) = (y1 - y) - (Q1(s, a) - y), the last term being the `td` output of
+// the critic-loss pass
+__global__ void k_td3_priority(int n, const float* __restrict__ y1, const float* __restrict__ y, const float* __restrict__ td,
+                               float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (y1[i] - y[i]) - td[i];
+}
+
 // ga[row][k] = dx1[row][od + k] + dx2[row][od + k]
 __global__ void k_sum_action_grad(int rows, int od, int ad, const float* __restrict__ dx1, const float* __restrict__ dx2,
                                   float* __restrict__ ga) {
@@ -295,6 +318,21 @@ extern "C" int mpg_td3_targets(const mpg_cfg_t* cfg, const float* policy_t, cons
     hipLaunchKernelGGL(k_combine_target, dim3((rows + 255) / 256), dim3(256), 0, s, rows, rew, q1, q2, cfg->rew_shift, cfg->rew_scale,
                        cfg->gamma, y);
     MPG_CHECK_LAUNCH("k_combine_target");
+    return MPG_OK;
+}
+
+extern "C" int mpg_normal_fill(int n, uint64_t seed, uint64_t ctr, float* out, mpg_stream_t stream) {
+    MPG_REQUIRE(out && n > 0, "mpg_normal_fill: bad argument");
+    hipLaunchKernelGGL(k_normal_fill, dim3(((n + 3) / 4 + 255) / 256), dim3(256), 0, mpg_stream(stream), n, (uint32_t)seed,
+                       (uint32_t)(seed >> 32), (uint32_t)ctr, (uint32_t)(ctr >> 32), out);
+    MPG_CHECK_LAUNCH("k_normal_fill");
+    return MPG_OK;
+}
+
+extern "C" int mpg_td3_priority_errors(int rows, const float* y1, const float* y, const float* td, float* out, mpg_stream_t stream) {
+    MPG_REQUIRE(y1 && y && td && out && rows > 0, "mpg_td3_priority_errors: bad argument");
+    hipLaunchKernelGGL(k_td3_priority, dim3((rows + 255) / 256), dim3(256), 0, mpg_stream(stream), rows, y1, y, td, out);
+    MPG_CHECK_LAUNCH("k_td3_priority");
     return MPG_OK;
 }
 

@@ -121,6 +121,15 @@ int rebuild(int capacity, double* sum_tree, double* min_tree, hipStream_t s) {
 
 inline bool pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
 
+// idx[i] = (start + i) % ring_capacity, prio[i] = *max_priority: the leaves of freshly added transitions (buffer.py:127-136)
+__global__ void k_per_add_fill(int n, int start, int ring_capacity, const float* __restrict__ max_priority, int* __restrict__ idx,
+                               float* __restrict__ prio) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    idx[i] = (start + i) % ring_capacity;
+    prio[i] = max_priority[0];
+}
+
 }  // namespace
 
 extern "C" int mpg_per_init(double* sum_tree, double* min_tree, int* stamp, int capacity, mpg_stream_t stream) {
@@ -155,3 +164,15 @@ extern "C" int mpg_per_sample(const double* sum_tree, const double* min_tree, in
     MPG_CHECK_LAUNCH("k_sample");
     return MPG_OK;
 }
+
+extern "C" int mpg_per_add(double* sum_tree, double* min_tree, int* stamp, int capacity, int ring_capacity, int start, int n,
+                           double alpha, float* max_priority, int* idx_scratch, float* prio_scratch, mpg_stream_t stream) {
+    MPG_REQUIRE(sum_tree && min_tree && stamp && max_priority && idx_scratch && prio_scratch && n > 0 && ring_capacity > 0 &&
+                    ring_capacity <= capacity && start >= 0 && start < ring_capacity,
+                "mpg_per_add: bad argument");
+    hipLaunchKernelGGL(k_per_add_fill, dim3((n + 255) / 256), dim3(256), 0, mpg_stream(stream), n, start, ring_capacity, max_priority,
+                       idx_scratch, prio_scratch);
+    MPG_CHECK_LAUNCH("k_per_add_fill");
+    return mpg_per_update(sum_tree, min_tree, stamp, capacity, n, idx_scratch, prio_scratch, alpha, 0.0, nullptr, stream);
+}
+

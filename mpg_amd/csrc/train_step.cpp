@@ -19,7 +19,7 @@ Layout layout(const mpg_train_ctx_t* c) {
     Layout l;
     l.q_size = net_size(c->cfg.obs_dim + c->cfg.act_dim, 1);
     l.p_size = net_size(c->cfg.obs_dim, 2 * c->cfg.act_dim);
-    l.n_nets = c->learner_version == 2 ? 3 : 2;
+    l.n_nets = (c->learner_version == 2 || c->learner_version == 4) ? 3 : 2;        // MPG-v2 / TD3: double Q
     int o = 0;
     for (int k = 0; k < l.n_nets; ++k) {
         l.sizes[k] = k == l.n_nets - 1 ? l.p_size : l.q_size;
@@ -61,10 +61,83 @@ double polynomial_decay(const float* sched, long long step) {       // policy.py
 
 inline bool exchanged(const mpg_train_ctx_t* c) { return c->world_size > 1 || c->grads_exchanged != 0; }
 
+inline bool is_mpg(const mpg_train_ctx_t* c) { return c->learner_version == 1 || c->learner_version == 2; }
+
 bool ctx_ok(const mpg_train_ctx_t* c) {
-    return c && (c->learner_version == 1 || c->learner_version == 2) && c->num_agent > 0 && c->batch > 0 && c->n > 0 &&
-           c->M > 0 && c->n_select > 0 && c->n_select <= 4 && (c->learner_version == 2 ? 2 : 1) + 2 * c->n_select <= 8 && c->world_size > 0 && c->sampling_interval > 0 &&
-           c->num_batch_reuse > 0 && c->ring_capacity > 0 && c->params && c->targets && c->grad && c->ws0 && c->ws1;
+    if (!c || c->learner_version < 1 || c->learner_version > 4) return false;
+    const bool common = c->num_agent > 0 && c->batch > 0 && c->world_size > 0 && c->sampling_interval > 0 && c->num_batch_reuse > 0 &&
+                        c->ring_capacity > 0 && c->params && c->targets && c->grad && c->ws0 && c->ws1;
+    if (!common) return false;
+    if (is_mpg(c))
+        return c->n > 0 && c->M > 0 && c->n_select > 0 && c->n_select <= 4 && (c->learner_version == 2 ? 2 : 1) + 2 * c->n_select <= 8;
+    if (c->learner_version == 3) return c->n > 0 && c->num_batch_reuse == 1;
+    // TD3: the scratch block, and the trees when the replay is prioritized
+    return c->scratch && c->num_batch_reuse == 1 &&
+           (!c->prioritized || (c->per_sum && c->per_min && c->per_stamp && c->per_capacity >= c->ring_capacity && c->per_max_priority && c->b_weights));
+}
+
+// ---- worker.sample + replay_buffer.add_batch (optimizer.py:332-337, worker.py:91-119), the plain form (NADP, TD3) ----
+int sample_and_add(mpg_train_ctx_t* c, const float* policy, mpg_stream_t s) {
+    const int od = c->cfg.obs_dim, kind = c->cfg.env_kind;
+    for (int it = 0; it < c->sample_iters; ++it) {
+        TRY(mpg_policy_action(&c->cfg, policy, c->num_agent, c->w_obs, c->explore_sigma, c->worker_seed, c->noise_ctr++, c->w_act, s));
+        MPG_REQUIRE(c->num_agent <= c->ring_capacity, "mpg_step_begin: ring smaller than one sample");
+        mpg_prof_begin(c->cfg.prof, 2, mpg_stream(s));
+        TRY(mpg_env_step_store_reset(kind, c->num_agent, od, c->env_state, c->w_act, c->ring_capacity, c->ring_next, c->ring_obs,
+                                     c->ring_act, c->ring_rew, c->ring_obs2, c->ring_done, c->env_seed, c->env_ctr++, c->w_obs, c->w_done, s));
+        mpg_prof_end(c->cfg.prof, 2, mpg_stream(s));
+        if (c->learner_version == 4 && c->prioritized)       // new transitions enter at the max priority (buffer.py:127-136)
+            TRY(mpg_per_add(c->per_sum, c->per_min, c->per_stamp, c->per_capacity, c->ring_capacity, c->ring_next, c->num_agent,
+                            c->per_alpha, c->per_max_priority, reinterpret_cast<int*>(c->scratch), c->scratch + c->num_agent, s));
+        c->ring_next = (c->ring_next + c->num_agent) % c->ring_capacity;
+        c->ring_size = std::min(c->ring_size + c->num_agent, c->ring_capacity);
+    }
+    return MPG_OK;
+}
+
+// ---- NADPLearner.compute_gradient, learners/nadp.py:209-241 (networks [Q1 | policy]) ----
+int nadp_gradients(mpg_train_ctx_t* c, const Layout& l, mpg_stream_t s) {
+    const float* q1 = c->params;
+    const float* policy = c->params + l.off[1];
+    const float* q1t = c->targets;
+    const float inv_b = 1.f / ((float)c->batch * (float)c->world_size);
+    float* stats = c->grad + l.n_grad;
+    // n-step model-rollout target from the stored (s, a) (nadp.py:87-126), critic loss (:173-184), policy loss -R_n with the
+    // parameter gradient through all n + 1 evaluations (:128-194); noise counters as NADPLearner does (2 k, 2 k + 1)
+    TRY(mpg_rollout_q_target(&c->cfg, policy, q1t, c->batch, c->n, c->b_obs, c->b_act, nullptr, c->learner_seed, 2 * c->learner_counter,
+                             c->b_targets, c->ws0, c->ws0_bytes, s));
+    TRY(mpg_q_loss_grad(&c->cfg, q1, c->batch, c->b_obs, c->b_act, c->b_targets, inv_b, stats, c->grad + l.off[0], nullptr, c->ws0,
+                        c->ws0_bytes, s));
+    const int sel[2] = {0, c->n};
+    const float w[2] = {0.f, 1.f};
+    return mpg_rollout_pg(&c->cfg, policy, q1, c->batch, 1, c->n, sel, 2, w, c->b_obs, nullptr, c->learner_seed, 2 * c->learner_counter + 1,
+                          inv_b, 1, stats + 2, stats + 4, c->grad + l.off[1], c->ws1, c->ws1_bytes, s);
+}
+
+// ---- TD3Learner.compute_gradient, learners/td3.py:150-188 (networks [Q1 | Q2 | policy]) + the priority update of
+//      optimizer.py:351-353 ----
+int td3_gradients(mpg_train_ctx_t* c, const Layout& l, mpg_stream_t s) {
+    const int ad = c->cfg.act_dim, B = c->batch;
+    const float *q1 = c->params, *q2 = c->params + l.off[1], *policy = c->params + l.off[2];
+    const float *q1t = c->targets, *q2t = c->targets + l.off[1], *policy_t = c->targets + l.off[2];
+    const float inv_b = 1.f / ((float)B * (float)c->world_size);
+    float* stats = c->grad + l.n_grad;
+    float* eps = c->scratch;                          // [B][ad] smoothing noise
+    float* y1 = eps + (size_t)B * ad;                 // [B] the priorities' plain Q1 target
+    float* td = y1 + B;                               // [B] Q1(s, a) - y
+    float* perr = td + B;                             // [B] y1 - Q1(s, a)
+    TRY(mpg_normal_fill(B * ad, c->learner_seed, c->learner_counter, eps, s));
+    TRY(mpg_td3_targets(&c->cfg, policy_t, q1t, q2t, B, c->b_rew, c->b_obs2, eps, c->smooth_sigma, c->smooth_clip, c->b_targets, y1,
+                        c->ws0, c->ws0_bytes, s));
+    TRY(mpg_q_loss_grad(&c->cfg, q1, B, c->b_obs, c->b_act, c->b_targets, inv_b, stats, c->grad + l.off[0], td, c->ws0, c->ws0_bytes, s));
+    TRY(mpg_q_loss_grad(&c->cfg, q2, B, c->b_obs, c->b_act, c->b_targets, inv_b, stats + 1, c->grad + l.off[1], nullptr, c->ws0,
+                        c->ws0_bytes, s));
+    if (c->prioritized) {
+        TRY(mpg_td3_priority_errors(B, y1, c->b_targets, td, perr, s));
+        TRY(mpg_per_update(c->per_sum, c->per_min, c->per_stamp, c->per_capacity, B, c->idx, perr, c->per_alpha, c->per_eps,
+                           c->per_max_priority, s));
+    }
+    return mpg_td3_policy_grad(&c->cfg, policy, q1, q2, B, c->b_obs, inv_b, stats + 2, stats + 3, c->grad + l.off[2], c->ws1, c->ws1_bytes, s);
 }
 
 }  // namespace
@@ -72,6 +145,12 @@ bool ctx_ok(const mpg_train_ctx_t* c) {
 extern "C" int mpg_step_workspace_bytes(const mpg_train_ctx_t* c, size_t* ws0, size_t* ws1) {
     MPG_REQUIRE(c && ws0 && ws1, "mpg_step_workspace_bytes: null pointer");
     *ws0 = std::max(mpg_q_targets_workspace_bytes(&c->cfg, c->batch), mpg_q_loss_grad_workspace_bytes(&c->cfg, c->batch));
+    if (c->learner_version == 3) {
+        *ws0 = std::max(*ws0, mpg_rollout_q_target_workspace_bytes(&c->cfg, c->batch));
+        *ws1 = mpg_rollout_pg_workspace_bytes(&c->cfg, c->batch, 1, c->n, 2, 1);
+    } else if (c->learner_version == 4) {
+        *ws1 = mpg_td3_policy_grad_workspace_bytes(&c->cfg, c->batch);
+    } else
     *ws1 = mpg_mpg_gradients_workspace_bytes(&c->cfg, c->batch, c->M, c->n, c->n_select, c->learner_version == 2 ? 2 : 1);
     MPG_REQUIRE(*ws0 && *ws1, "mpg_step_workspace_bytes: unsupported configuration");
     return MPG_OK;
@@ -83,6 +162,23 @@ extern "C" int mpg_step_begin(mpg_train_ctx_t* c, int iteration, mpg_stream_t s)
     const int od = c->cfg.obs_dim, ad = c->cfg.act_dim, kind = c->cfg.env_kind;
     const float* policy = c->params + l.off[l.n_nets - 1];
     const float* policy_t = c->targets + l.off[l.n_nets - 1];
+    if (!is_mpg(c)) {        // ---- NADP / TD3: sample, add, replay, gradients (optimizer.py:330-353) ----
+        if (iteration % c->sampling_interval == 0) TRY(sample_and_add(c, policy, s));
+        MPG_REQUIRE(c->ring_size > 0, "mpg_step_begin: empty replay ring");
+        c->replay_times++;
+        if (c->learner_version == 4 && c->prioritized) {
+            TRY(mpg_per_sample(c->per_sum, c->per_min, c->per_capacity, c->ring_size, c->batch, nullptr, c->replay_seed, c->replay_times,
+                               c->per_beta, c->idx, c->b_weights, s));
+            TRY(mpg_replay_gather(c->batch, c->idx, od, ad, c->ring_obs, c->ring_act, c->ring_rew, c->ring_obs2, c->ring_done, c->b_obs,
+                                  c->b_act, c->b_rew, c->b_obs2, c->b_done, s));
+        } else {
+            TRY(mpg_replay_sample_uniform(c->ring_size, c->batch, c->replay_seed, c->replay_times, od, ad, c->ring_obs, c->ring_act,
+                                          c->ring_rew, c->ring_obs2, c->ring_done, c->idx, c->b_obs, c->b_act, c->b_rew, c->b_obs2,
+                                          c->b_done, s));
+        }
+        c->learner_counter++;
+        return c->learner_version == 3 ? nadp_gradients(c, l, s) : td3_gradients(c, l, s);
+    }
     // ---- worker.sample + replay_buffer.add_batch (optimizer.py:332-337, worker.py:91-119) ----
     // MPG-v2 draws its minibatch right after the add: the last env launch gathers it in spare workgroups (the random ring
     // reads overlap the env's sub-steps) except the rows drawn from the slots that launch is writing
@@ -174,7 +270,8 @@ extern "C" int mpg_step_end(mpg_train_ctx_t* c, int iteration, mpg_stream_t s) {
     const Layout l = layout(c);
     // per-network clip_by_global_norm (mpg_learner.py:415-431): on one GPU the partial sums of squares were left in
     // clip_scratch by mpg_mpg_gradients; after an all-reduce they are recomputed from the reduced gradient
-    if (exchanged(c)) TRY(mpg_sq_partials(c->grad, l.sizes, l.n_nets, c->clip_scratch, s));
+    // (NADP / TD3: their gradient launches leave no partials, they are always taken from the gradient buffer)
+    if (exchanged(c) || !is_mpg(c)) TRY(mpg_sq_partials(c->grad, l.sizes, l.n_nets, c->clip_scratch, s));
     // PolicyWithQs.apply_gradients, policy.py:123-156
     const bool delayed = iteration % c->delay_update == 0;
     float lr_t[3];

@@ -32,30 +32,47 @@ class TrainCtx(ctypes.Structure):
         ('idx', _P), ('b_obs', _P), ('b_act', _P), ('b_rew', _P), ('b_obs2', _P), ('b_done', _P), ('b_targets', _P),
         ('params', _P), ('targets', _P), ('adam_m', _P), ('adam_v', _P), ('grad', _P), ('norms', _P), ('clip_scratch', _P), ('nonfinite', _P),
         ('l_env_state', _P), ('l_obs', _P), ('l_act', _P), ('l_rewards', _P), ('l_done', _P), ('l_done_intended', _P),
-        ('ws0', _P), ('ws1', _P), ('ws0_bytes', ctypes.c_size_t), ('ws1_bytes', ctypes.c_size_t)]
+        ('ws0', _P), ('ws1', _P), ('ws0_bytes', ctypes.c_size_t), ('ws1_bytes', ctypes.c_size_t),
+        ('smooth_sigma', ctypes.c_float), ('smooth_clip', ctypes.c_float), ('prioritized', ctypes.c_int),
+        ('per_sum', _P), ('per_min', _P), ('per_stamp', _P), ('per_capacity', ctypes.c_int), ('per_max_priority', _P),
+        ('per_alpha', ctypes.c_double), ('per_beta', ctypes.c_double), ('per_eps', ctypes.c_double),
+        ('b_weights', _P), ('scratch', _P)]
 
 
 class FusedMPGStep(object):
-    """step(iteration) == SingleProcessOffPolicyOptimizer.step for (OffPolicyWorker, ReplayBuffer, MPGLearner) sharing
-    one PolicyWithQs."""
+    """step(iteration) == SingleProcessOffPolicyOptimizer.step for (OffPolicyWorker, replay buffer, learner) sharing one
+    PolicyWithQs: MPGLearner + ReplayBuffer (learner_version 1 / 2), NADPLearner + ReplayBuffer (3), TD3Learner + ReplayBuffer
+    or PrioritizedReplayBuffer (4; the priority update of optimizer.py:351-353 included)."""
 
     def __init__(self, worker, learner, rb, sampling_interval, always_exchange=False):
         from .buffer import PrioritizedReplayBuffer
-        assert not isinstance(rb, PrioritizedReplayBuffer) and learner.args.buffer_type == 'normal'
+        from .learners import MPGLearner, NADPLearner, TD3Learner
+        per = isinstance(rb, PrioritizedReplayBuffer)
+        assert per == (learner.args.buffer_type != 'normal')
         assert learner.policy_with_value is worker.policy_with_value
         self.worker, self.learner, self.rb = worker, learner, rb
         pw, a, dev = worker.policy_with_value, learner.args, worker.device
         self.pw = pw
         c = self.c = TrainCtx()
         c.cfg = pw.cfg
-        c.learner_version = 1 if a.learner_version == 'MPG-v1' else 2
+        if type(learner) is MPGLearner:
+            assert not per
+            c.learner_version = 1 if a.learner_version == 'MPG-v1' else 2
+            sel = list(learner.num_rollout_list_for_policy_update)
+            c.n, c.M, c.n_select = max(sel), learner.M, len(sel)
+            for i, k in enumerate(sel):
+                c.select[i] = k
+        elif type(learner) is NADPLearner:
+            assert not per and learner.n_q == learner.n_pi and learner.num_batch_reuse == 1
+            c.learner_version, c.n, c.M, c.n_select = 3, learner.n_pi, 1, 2
+        else:
+            assert type(learner) is TD3Learner and learner.num_batch_reuse == 1
+            c.learner_version, c.n, c.M, c.n_select = 4, 1, 1, 1
+            c.smooth_sigma, c.smooth_clip = float(a.policy_smoothing_sigma), float(a.policy_smoothing_clip)
         c.num_agent, c.sample_iters = worker.num_agent, max(1, worker.batch_size // worker.num_agent)
         c.sampling_interval = sampling_interval
-        sel = list(learner.num_rollout_list_for_policy_update)
-        c.batch, c.n, c.M, c.n_select = learner.batch_size, max(sel), learner.M, len(sel)
-        for i, k in enumerate(sel):
-            c.select[i] = k
-        c.eta, c.total_ite = a.eta, a.rule_based_bias_total_ite
+        c.batch = learner.batch_size
+        c.eta, c.total_ite = float(getattr(a, 'eta', 0.1)), int(getattr(a, 'rule_based_bias_total_ite', 9000))
         c.clip, c.tau, c.delay_update = float(a.gradient_clip_norm), pw.tau, pw.delay_update
         c.num_batch_reuse, c.world_size = learner.num_batch_reuse, D.world_size()
         # always_exchange: run the collective (and the exchanged-gradient form of the clip) even in a one-process group
@@ -86,6 +103,16 @@ class FusedMPGStep(object):
         c.params, c.targets, c.adam_m, c.adam_v = L.ptr(pw.params), L.ptr(pw.targets), L.ptr(pw.m), L.ptr(pw.v)
         c.grad, c.norms, c.nonfinite = L.ptr(learner.flat), L.ptr(learner.norms), L.ptr(pw.nonfinite)
         c.clip_scratch = L.ptr(learner.clip_scratch)
+        if c.learner_version == 4:
+            self.scratch = torch.empty(max(B * (ad + 3), 2 * n) + 64, **f)
+            c.scratch = L.ptr(self.scratch)
+            c.prioritized = 1 if per else 0
+            if per:
+                t['b_weights'] = torch.empty(B, **f)
+                c.b_weights = L.ptr(t['b_weights'])
+                c.per_sum, c.per_min, c.per_stamp = L.ptr(rb._it_sum), L.ptr(rb._it_min), L.ptr(rb._stamp)
+                c.per_capacity, c.per_max_priority = rb._cap, L.ptr(rb._max_priority)
+                c.per_alpha, c.per_beta, c.per_eps = rb._alpha, rb._beta, rb._eps
         w0, w1 = ctypes.c_size_t(0), ctypes.c_size_t(0)
         L.call('mpg_step_workspace_bytes', ctypes.byref(c), ctypes.byref(w0), ctypes.byref(w1))
         self.ws0 = torch.empty(w0.value + 256, dtype=torch.uint8, device=dev)

@@ -218,6 +218,10 @@ class MPGLearner(_LearnerBase):
         self._lazy_stats = self._mpg_lazy_stats(iteration)
         return out
 
+    def _native_lazy_stats(self, iteration):
+        """what the native step driver leaves in the statistics slots, as get_stats() reports it"""
+        return self._mpg_lazy_stats(iteration)
+
     def _mpg_lazy_stats(self, iteration):
         """stats of mpg_learner.py:433-452, evaluated only when get_stats() is called"""
         pw = self.policy_with_value
@@ -273,11 +277,14 @@ class NADPLearner(_LearnerBase):
                        inv_b_global=inv_b, all_steps_param_grad=True, grad_out=self.grad('policy'), stats_out=stats[2:6],
                        n=self.n_pi, noise_seed=self.seed, noise_ctr=2 * self.counter + 1)
         out = self._finish(iteration, float(self.args.gradient_clip_norm))
-        B = rows * world
-        # evaluated only when get_stats() is called: no elementwise launches in the training loop
-        self._lazy_stats = lambda: dict(q_loss=stats[0], policy_loss=-stats[3] / B, value_mean=stats[2] / B,
-                                        q_gradient_norm=self.norms[0], policy_gradient_norm=self.norms[1])
+        self._lazy_stats = self._native_lazy_stats(iteration)
         return out
+
+    def _native_lazy_stats(self, iteration):
+        """evaluated only when get_stats() is called: no elementwise launches in the training loop"""
+        stats, B = self.flat[self.n_grad:], self.batch_size * D.world_size()
+        return lambda: dict(q_loss=stats[0], policy_loss=-stats[3] / B, value_mean=stats[2] / B,
+                            q_gradient_norm=self.norms[0], policy_gradient_norm=self.norms[1])
 
 
 class TD3Learner(_LearnerBase):
@@ -288,10 +295,15 @@ class TD3Learner(_LearnerBase):
         pw, b = self.policy_with_value, self.batch_data
         rows = b['batch_obs'].shape[0]
         if smooth_eps is None:
-            smooth_eps = torch.randn(rows, self.cfg.act_dim, generator=self._noise_gen, device=self.device)
+            smooth_eps = self._smoothing_noise(rows)
         return ops.q_targets(self.cfg, pw.net('policy', True), pw.net('Q1', True), pw.net('Q2', True), b['batch_rewards'],
                              b['batch_obs_tp1'], smooth_eps=smooth_eps, smooth_sigma=self.args.policy_smoothing_sigma,
                              smooth_clip=self.args.policy_smoothing_clip)
+
+    def _smoothing_noise(self, rows):
+        """target-policy smoothing noise (td3.py:74, tf.random.normal in the reference): the library's Philox stream keyed by
+        (learner seed, the gradient step this batch is fetched for) - the numbers the native step driver draws"""
+        return ops.normal_fill(rows * self.cfg.act_dim, self.seed, self.counter + 1, self.device).view(rows, self.cfg.act_dim)
 
     def compute_td_error(self):
         """td3.py:83-92 (signed)."""
@@ -309,7 +321,7 @@ class TD3Learner(_LearnerBase):
             pw, b = self.policy_with_value, self.batch_data
             rows = b['batch_obs'].shape[0]
             if smooth_eps is None:
-                smooth_eps = torch.randn(rows, self.cfg.act_dim, generator=self._noise_gen, device=self.device)
+                smooth_eps = self._smoothing_noise(rows)
             self.batch_data['batch_targets'], self._y1 = ops.td3_targets(
                 self.cfg, pw.net('policy', True), pw.net('Q1', True), pw.net('Q2', True), b['batch_rewards'], b['batch_obs_tp1'],
                 smooth_eps, smooth_sigma=self.args.policy_smoothing_sigma, smooth_clip=self.args.policy_smoothing_clip)
@@ -339,12 +351,15 @@ class TD3Learner(_LearnerBase):
         ops.td3_policy_grad(self.cfg, pw.net('policy'), pw.net('Q1'), pw.net('Q2'), b['batch_obs'], inv_b_global=inv_b,
                             grad_out=self.grad('policy'), stats_out=stats[2:4])
         out = self._finish(iteration, float(self.args.gradient_clip_norm))
-        B = rows * world
+        self._lazy_stats = self._native_lazy_stats(iteration)
+        return out
+
+    def _native_lazy_stats(self, iteration):
+        stats, B = self.flat[self.n_grad:], self.batch_size * D.world_size()
 
         def lazy():        # evaluated only when get_stats() is called: no elementwise launches in the training loop
             mean = stats[2] / B
             return dict(q_loss1=stats[0], q_loss2=stats[1], policy_loss=-mean, value_mean=mean,
                         value_var=stats[3] / B - mean * mean, q_gradient_norm1=self.norms[0],
                         q_gradient_norm2=self.norms[1], policy_gradient_norm=self.norms[2])
-        self._lazy_stats = lazy
-        return out
+        return lazy

@@ -112,7 +112,11 @@ def make_cfg(env_id='PathTracking-v0', obs_scale=None, rew_scale=None, rew_shift
     pt = env_id == 'PathTracking-v0'
     c = CfgStruct()
     c.obs_dim, c.act_dim = (int(obs_dim) if (pt and obs_dim) else 6, 2) if pt else (4, 1)
-    assert not pt or 6 <= c.obs_dim <= 14, 'PathTracking: obs_dim = 6 + num_future_data, num_future_data <= 8 through the networks'
+    if pt and not 6 <= c.obs_dim <= 14:
+        # the library's own answer for such a cfg is MPG_EINVAL at the first launch (cfg_ok): raise it where the cfg is built
+        raise L.MpgError('MPG_EINVAL: PathTracking observations have 6 + num_future_data entries and the network kernels take first '
+                         'layers up to 16 wide: num_future_data <= 8 through worker / learner / evaluator (got obs_dim %d); the '
+                         'env kernels alone serve num_future_data <= 10' % c.obs_dim)
     if policy_out_activation is None:
         policy_out_activation = 'tanh' if pt else 'linear'
     c.policy_out_act = ACT_TANH if policy_out_activation == 'tanh' else ACT_LINEAR
@@ -210,6 +214,13 @@ def td3_targets(cfg, policy_t, q1t, q2t, rew, obs_tp1, smooth_eps, smooth_sigma=
            L.ptr(_f32(rew)), L.ptr(_f32(obs_tp1)), L.ptr(_f32(smooth_eps) if smooth_eps is not None else None),
            L.c_float(smooth_sigma), L.c_float(smooth_clip), L.ptr(y), L.ptr(y1), L.ptr(ws), L.c_size_t(ws.numel()), L.stream())
     return y, y1
+
+
+def normal_fill(n, seed, ctr, device):
+    """n standard normals from the library's Philox stream (mpg_normal_fill)"""
+    out = torch.empty(n, dtype=torch.float32, device=device)
+    L.call('mpg_normal_fill', L.c_int(n), L.c_u64(seed), L.c_u64(ctr), L.ptr(out), L.stream())
+    return out
 
 
 def nstep_targets(cfg, policy_t, q1t, rewards, last_obs):

@@ -36,9 +36,13 @@ class SingleProcessOffPolicyOptimizer(object):
         self._fused = None
         if fused:
             from .buffer import PrioritizedReplayBuffer
-            from .learners import MPGLearner
-            if type(learner) is MPGLearner and not isinstance(replay_buffer, PrioritizedReplayBuffer) and \
-                    getattr(args, 'buffer_type', 'normal') == 'normal' and not learner.deriv_interval_policy:
+            from .learners import MPGLearner, NADPLearner, TD3Learner
+            per = isinstance(replay_buffer, PrioritizedReplayBuffer)
+            normal = getattr(args, 'buffer_type', 'normal') == 'normal'
+            ok = (type(learner) is MPGLearner and not per and normal and not learner.deriv_interval_policy) or \
+                 (type(learner) is NADPLearner and not per and normal and learner.num_batch_reuse == 1 and learner.n_q == learner.n_pi) or \
+                 (type(learner) is TD3Learner and per == (not normal) and learner.num_batch_reuse == 1)
+            if ok:
                 from .fused import FusedMPGStep
                 self._fused = FusedMPGStep(worker, learner, replay_buffer, sampling_interval, always_exchange=always_exchange)
 
@@ -65,7 +69,7 @@ class SingleProcessOffPolicyOptimizer(object):
             if self.iteration % self.sampling_interval == 0:
                 self.num_sampled_steps += self.worker.num_agent * self._fused.c.sample_iters
             self._fused.step(self.iteration)
-            self.learner._lazy_stats = self.learner._mpg_lazy_stats(self.iteration)
+            self.learner._lazy_stats = self.learner._native_lazy_stats(self.iteration)
             self.iteration += 1
             self._check_status()
             return

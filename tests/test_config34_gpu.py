@@ -233,12 +233,19 @@ def test_config3_end_to_end_worker_ring_nadp_adam():
     """Config 3 end to end on the device (SURVEY.md section 8 f3): OffPolicyWorker on the analytic cart-pole (64 pendulums per launch;
     the reference steps ONE MuJoCo pendulum behind DummyVecEnv, train_script4mujoco.py:328, with explore_sigma None) -> replay
     ring -> NADPLearner on the pendulum MODEL -> clip / Adam / Polyak, in SingleProcessOffPolicyOptimizer's order, plus the
-    Evaluator's pendulum metrics (evaluator.py:185-211).  Learning check: 100-step evaluation episodes (done ignored, like the
-    reference's evaluator) start at about -900 with the initial policy (the pole falls and swings) and must come within -60
-    at one of the first checkpoints - the pole is then held near upright (theta rms < 0.1).  NOT claimed: the reference's
-    plotted base score of -2 (ploter.py:85) - the real environment here is an analytic cart-pole whose parity with MuJoCo is
-    unpinned, NADP's bootstrapped target is unclipped (nadp.py:87-126), and longer runs of this pair drift (value_mean grows
-    positive although every reward is <= 0; tools: scratch run recorded in DESIGN.md section 7)."""
+    Evaluator's pendulum metrics (evaluator.py:185-211).
+
+    The bar comes from the ORACLE's run of the same loop (tools/config3_oracle_run.py: float64 networks and gradients, the
+    oracle's cart-pole, the oracle's Adam; curves under profiles/r04_config3_*): 100-step evaluation returns start near -900
+    (the pole falls and swings); the oracle holds the pole upright from iteration 250 on (return -0.2 .. -1.4, theta rms 0.01 ..
+    0.03 over four seeds), drifts to -1 .. -60 by iteration 750 - and DIVERGES after ~2000 iterations (value mean 3 -> 7000,
+    targets positive although every reward is <= 0: NADP's bootstrapped target is unclipped, nadp.py:87-126, and the model it
+    plans with is not the environment it acts in).  The device run of the same pair (tools/config3_device_run.py, four seeds)
+    reaches -2.8 .. -51 at iteration 250, -16 .. -46 at 1000, has the same excursion at ~2000 (value mean +18) and recovers.
+    So the long-run drift is the algorithm, not the device path.  Checked here: within 1000 iterations the
+    pole is held near upright - return above -30 with theta rms < 0.08 at one of the checkpoints 250 / 500 / 750 / 1000 (this
+    seed: -9.7 at 250) - far from the -900 of the initial policy; NOT claimed: the reference's plotted base score of -2
+    (ploter.py:85; its real environment is MuJoCo, whose parity is unpinned)."""
     from mpg_amd.buffer import ReplayBuffer
     from mpg_amd.config import default_args
     from mpg_amd.evaluator import Evaluator
@@ -259,15 +266,60 @@ def test_config3_end_to_end_worker_ring_nadp_adam():
     m0 = ev.run_evaluation(0)
     assert set(('x_mean', 'theta_var', 'xdot_mse', 'thetadot_mse_25')) <= set(m0)
     best, best_theta = m0['episode_return'], m0['theta_mse']
-    for it in range(500, 2001, 500):
-        for _ in range(500):
+    for it in range(250, 1001, 250):
+        for _ in range(250):
             opt.step()
         m = ev.run_evaluation(it)
         if m['episode_return'] > best:
             best, best_theta = m['episode_return'], m['theta_mse']
     assert len(rb) >= 3000 and rb.obs.shape[1] == 4 and rb.act.shape[1] == 1
-    assert m0['episode_return'] < -300 and best > -60 and best_theta < 0.1, (m0['episode_return'], best, best_theta)
+    assert m0['episode_return'] < -300 and best > -30 and best_theta < 0.08, (m0['episode_return'], best, best_theta)
     assert worker.policy_with_value.check_status() == 0 and int(worker.policy_with_value.nonfinite.sum().item()) == 0
+
+
+def test_nadp_training_trajectory_matches_the_oracle_step_by_step():
+    """Closed-loop parity of learner + optimizer over SEVERAL iterations ("bisect env / worker / learner on the
+    device"): the device NADP learner and the oracle start from the same weights and are fed the same minibatch and the same
+    model noise every iteration; after each of 12 iterations of compute_gradient -> clip -> Adam -> Polyak the device's online and
+    target parameters must track the oracle's (float32 oracle: nadp.py:87-241 restated + the oracle's Adam).  A wrong sign, a
+    missed step counter, a stale target network or a stash mix-up shows up as drift within a few iterations; what is allowed is
+    float32 rounding amplified by Adam's normalisation (measured: 1e-6 relative after 12 steps)."""
+    from mpg_amd.config import default_args
+    from mpg_amd.learners import NADPLearner
+    from mpg_amd.policy import PolicyWithQs
+    from tests.golden_inputs import mlp_weights_flat
+    rng = np.random.Generator(np.random.PCG64(5))
+    B, n = 256, 25
+    args = default_args('NADP', replay_batch_size=B)
+    learner = NADPLearner(PolicyWithQs, args)
+    pw = learner.policy_with_value
+    w = {'Q1': mlp_weights_flat(rng, 5, 1), 'policy': mlp_weights_flat(rng, 4, 2)}
+    flat = np.concatenate([w[k] for k in pw.names])
+    pw.set_flat(flat, flat.copy())
+    cfg = O.Cfg(env='InvertedPendulumConti-v0', select=[25], delay_update=1)
+    tgt = {k: v.copy() for k, v in w.items()}
+    opt = {k: O.AdamState(v.size) for k, v in w.items()}
+    worst = 0.0
+    for it in range(12):
+        obs = (rng.standard_normal((B, 4)) * np.array([0.5, 0.1, 0.5, 0.5])).astype(np.float32)
+        act = rng.uniform(-3, 3, (B, 1)).astype(np.float32)
+        eps_q = rng.standard_normal((n, B)).astype(np.float32)
+        eps_pi = rng.standard_normal((n, B)).astype(np.float32)
+        batch = [dev(obs), dev(act), dev(np.zeros(B)), dev(obs), dev(np.zeros(B))]
+        learner.counter = 0
+        learner.compute_gradient(batch, None, None, it, eps_q=dev(eps_q), eps_pi=dev(eps_pi))
+        pw.apply_gradients(it, learner.flat_grad)
+        nets = O.Nets(cfg, w, flat_targets=tgt, dtype=torch.float32)
+        grads, _ = O.nadp_compute_gradient(cfg, nets, [obs, act], eps_q, eps_pi)
+        g = {'Q1': np.concatenate([x.ravel() for x in grads[:6]]).astype(np.float32),
+             'policy': np.concatenate([x.ravel() for x in grads[6:]]).astype(np.float32)}
+        O.apply_gradients(cfg, w, tgt, opt, g, it, ['Q1', 'policy'])
+        got, gott = pw.params.cpu().numpy(), pw.targets.cpu().numpy()
+        ref, reft = np.concatenate([w[k] for k in pw.names]), np.concatenate([tgt[k] for k in pw.names])
+        e = max(rel_l2(got, ref), rel_l2(gott, reft))
+        worst = max(worst, e)
+        assert e <= 2e-5, (it, e)
+    print('NADP 12-step trajectory: worst relative distance to the oracle %.2e' % worst)
 
 
 def test_worker_nan_is_reported_from_the_device():
@@ -284,3 +336,49 @@ def test_worker_nan_is_reported_from_the_device():
     worker.obs[5, 2] = float('nan')
     with pytest.raises(MpgError, match='judge_is_nan'):
         worker.sample()
+
+
+@pytest.mark.parametrize('alg,per', [('TD3', True), ('TD3', False), ('NADP', False)])
+def test_native_step_driver_equals_method_path_for_td3_and_nadp(alg, per):
+    """Round 4: mpg_step_begin / mpg_step_end also drive NADP (learner_version 3) and TD3 with uniform or prioritized replay (4):
+    sample -> ring add (+ max-priority leaves) -> replay (proportional sampling + gather) -> targets -> critic losses ->
+    priority update (optimizer.py:351-353) -> policy gradient -> clip / Adam / Polyak, enqueued from C++ with no framework
+    kernel in between (the smoothing noise is the library's Philox stream in both paths).  After the same number of iterations
+    the counters, the replay ring, the segment trees and the drawn indices are identical and parameters / Adam moments /
+    targets agree to float32 rounding with the method-by-method path."""
+    from mpg_amd.buffer import PrioritizedReplayBuffer, ReplayBuffer
+    from mpg_amd.config import default_args
+    from mpg_amd.learners import NADPLearner, TD3Learner
+    from mpg_amd.optimizer import SingleProcessOffPolicyOptimizer
+    from mpg_amd.policy import PolicyWithQs
+    from mpg_amd.worker import OffPolicyWorker
+
+    def run(fused):
+        args = default_args(alg, num_agent=64, batch_size=128, replay_batch_size=96, replay_starts=512, max_buffer_size=1000,
+                            buffer_type='priority' if per else 'normal')
+        worker = OffPolicyWorker(PolicyWithQs, args.env_id, args, 0)
+        learner = (NADPLearner if alg == 'NADP' else TD3Learner)(PolicyWithQs, args)
+        rb = (PrioritizedReplayBuffer if per else ReplayBuffer)(args, 0)
+        opt = SingleProcessOffPolicyOptimizer(worker, learner, rb, None, args, sampling_interval=3, fused=fused)
+        assert (opt._fused is not None) == fused
+        for _ in range(9):
+            opt.step()
+        pw = worker.policy_with_value
+        st = learner.get_stats()
+        torch.cuda.synchronize()
+        out = [pw.params.clone(), pw.targets.clone(), pw.m.clone(), pw.v.clone(), rb.obs.clone(), learner.flat.clone()]
+        if per:
+            out += [rb._it_sum.clone(), rb._max_priority.clone()]
+        key = 'q_loss' if alg == 'NADP' else 'q_loss1'
+        return out, (dict(pw.opt_steps), rb._next_idx, len(rb), rb.replay_times, worker._noise_ctr, learner.counter, float(st[key]))
+    a, ca = run(True)
+    b, cb = run(False)
+    assert ca[:6] == cb[:6], (ca, cb)
+    assert abs(ca[6] - cb[6]) <= 1e-5 * abs(cb[6]) + 1e-7
+    assert torch.equal(a[4], b[4])                    # ring observations: the same reset-law draws in the same slots
+    for x, y in zip(a[:4], b[:4]):
+        assert (x - y).abs().max().item() <= 2e-6 * max(1.0, y.abs().max().item())
+    assert ((a[5] - b[5]).norm() / b[5].norm()).item() < 1e-4
+    if per:
+        assert (a[6] - b[6]).abs().max().item() <= 1e-4 * b[6].abs().max().item()     # priorities = |td| of rounding-different nets
+        assert abs(a[7].item() - b[7].item()) <= 1e-4 * abs(b[7].item())

@@ -253,7 +253,8 @@ def test_bench_in_the_drivers_multi_rank_form(backend, nproc):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MPG_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    # (a shorter burn-in than the bench's default 200 steps: N ranks time-share one GPU here, and this is a test of the launch form)
+    env = dict(os.environ, MPG_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY='0', MPG_BENCH_BURN_IN='60')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(nproc), '--master-addr', '127.0.0.1',
            '--master-port', str(_free_port()), os.path.join(root, 'bench.py'), '--gpus', str(nproc), '--steps', '10', '--warmup', '3',
            '--no-cpu-baseline']

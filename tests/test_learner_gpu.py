@@ -254,6 +254,54 @@ def test_repeated_launches_are_bit_identical(name, reps):
     assert differing == 0, '%d of %d launches differ from the majority result' % (differing, reps)
 
 
+@pytest.mark.parametrize('case', ['MPG-v1 B=256', 'MPG-v2 K=3 B=256', 'MPG-v2 B=256'])
+def test_repeated_launches_are_bit_identical_small_batches_and_look_ahead(case):
+    """The same check on the paths the bench-size cases do not take: the reference's own batch size (C1:
+    256 rows - the small-batch launch geometry: one-group target / critic launches, k_wgrad_multi with few groups per chunk),
+    MPG-v1 (25 real-env steps + the n-step target in front of the gradient) and observations with look-ahead entries
+    (num_future_data = 3: the launch-per-stage path with the 16-wide network kernels and the WIDE sweeps).  400 launches each."""
+    from mpg_amd.config import default_args
+    from mpg_amd.learners import MPGLearner
+    from mpg_amd.policy import PolicyWithQs
+    from tests.golden_inputs import reset_law_obs
+    alg = 'MPG-v1' if 'v1' in case else 'MPG-v2'
+    K = 3 if 'K=3' in case else 0
+    B = 256
+    rng = np.random.Generator(np.random.PCG64(len(case)))
+    args = default_args(alg, replay_batch_size=B, num_batch_reuse=1, num_future_data=K)
+    learner = MPGLearner(PolicyWithQs, args)
+    obs = reset_law_obs(rng, B)
+    if K:
+        obs = np.concatenate([obs, rng.normal(0, 1, (B, K)).astype(np.float32)], 1)
+    act = rng.uniform(-1, 1, (B, 2)).astype(np.float32)
+    obs2 = obs + rng.normal(0, 0.05, obs.shape).astype(np.float32)
+    batch = [dev(obs), dev(act), dev(rng.normal(-1, 1, B)), dev(obs2), dev(np.ones(B))]
+    eps = dev(rng.standard_normal((25, B)))
+
+    def run():
+        learner.counter = 0
+        return torch.cat([x.reshape(-1) for x in learner.compute_gradient(batch, None, None, 100, eps=eps)])
+    ref = torch.stack([run().clone() for _ in range(5)]).median(0).values
+    assert torch.isfinite(ref).all()
+    differing = torch.stack([(run() != ref).any() for _ in range(400)]).sum().item()
+    assert differing == 0, '%d of 400 launches differ from the majority result' % differing
+
+
+def test_look_ahead_beyond_eight_entries_is_refused_at_construction():
+    """path_tracking_env.py:385-402 accepts any num_future_data; the network kernels take first layers up to 16 wide, i.e.
+    num_future_data <= 8 (include/mpg_hip.h, mpg_cfg_t.obs_dim).  9 and 10 are served by the ENV kernels only: the classes that
+    build networks refuse them with a defined error when they are constructed, not at the first launch."""
+    from mpg_amd._lib import MpgError
+    from mpg_amd.config import default_args
+    from mpg_amd.envs import PathTrackingEnv
+    from mpg_amd.policy import PolicyWithQs
+    env = PathTrackingEnv(num_future_data=10, num_agent=8)
+    assert env.reset().shape == (8, 16)
+    for K in (9, 10):
+        with pytest.raises(MpgError, match='num_future_data'):
+            PolicyWithQs(**vars(default_args('MPG-v2', num_future_data=K)))
+
+
 def test_replay_buffer_ring_and_gather_bit_exact():
     from mpg_amd.buffer import ReplayBuffer
     from mpg_amd.config import default_args
