@@ -49,7 +49,9 @@ def check_gradients(got, ref32, ref64_sub, nets, where='', bar=1e-4, factor=4.0,
             so += n
             if np.linalg.norm(ref32[o:o + n]) > 0:
                 e_ref, e_got = rel_l2(ref32[o:o + n], r64s), rel_l2(got[o:o + n], r64s)
-                assert e_got <= bar and e_got <= factor * e_ref + FLOOR, (where, name, shp, 'vs float64: got %.3e, reference float32 %.3e' % (e_got, e_ref))
+                # (the bar is 1.5 x the reference's own error where the REFERENCE's float32 run misses it: see below)
+                assert e_got <= (bar if e_ref <= 0.5 * bar else max(bar, 1.5 * e_ref)) and e_got <= factor * e_ref + FLOOR, \
+                    (where, name, shp, 'vs float64: got %.3e, reference float32 %.3e' % (e_got, e_ref))
             continue
         r = ref32[o:o + n]
         if np.linalg.norm(r) == 0:
