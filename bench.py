@@ -508,7 +508,9 @@ def main():
             L.call('mpg_env_step', L.c_int(0), L.c_int(B_PER_GPU), L.c_int(6), L.ptr(e_state), L.ptr(e_act), L.ptr(e_obs), L.ptr(e_rew),
                    L.ptr(e_done), L.ptr(e_di), L.stream())
     env_step_only(8)
-    es[0].record()
+    torch.cuda.synchronize()
+    torch.cuda._sleep(40000000)                      # ~20 ms of spin on the stream: the 64 launches queue up behind it and then
+    es[0].record()                                   # run back to back (enqueued one by one from Python they would be host-paced)
     env_step_only(64)
     es[1].record()
     torch.cuda.synchronize()
@@ -611,7 +613,8 @@ def main():
         'env_steps_per_sec_step_only': B_PER_GPU / (step_only_ms * 1e-3),
         'env_steps_per_sec_step_store_reset': B_PER_GPU / (env_ms * 1e-3) if env_ms else None,
         'env_step_only_kernel': {'kernel': 'k_step (mpg_env_step)', 'avg_ms': step_only_ms, 'launches': 64,
-                                 'timed_with': 'one HIP event pair around 64 back-to-back launches after the timed region'},
+                                 'timed_with': 'one HIP event pair around 64 launches queued behind a spin kernel (back to back on the '
+                                               'GPU, launch boundaries included) after the timed region'},
     }
     if world == 1 and not a.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline()

@@ -68,6 +68,14 @@ __global__ void __launch_bounds__(512) k_rebuild_top(int ntop, double* __restric
 __global__ void k_sample(int capacity, int n_storage, int n, const double* __restrict__ sum_tree,
                          const double* __restrict__ min_tree, const double* __restrict__ u, uint32_t k0, uint32_t k1,
                          uint32_t c1, uint32_t c2, double beta, int* __restrict__ idx, float* __restrict__ is_w) {
+    // the top levels of the sum tree (nodes 1 .. 2047: 16 KB) are staged in LDS once per workgroup: the first 10 of the 19 dependent
+    // reads of a descent at capacity 2^19 then cost an LDS access instead of an L2 round trip (round 3: 41 us for sample + gather at
+    // B = 65 536).  Same values, same comparisons: the indices are bit-identical.
+    constexpr int TOPN = 2048;
+    __shared__ double sTop[TOPN];
+    const int staged = 2 * capacity < TOPN ? 2 * capacity : TOPN;
+    for (int j = threadIdx.x; j < staged; j += blockDim.x) sTop[j] = sum_tree[j];
+    __syncthreads();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     double ui;
@@ -77,10 +85,19 @@ __global__ void k_sample(int capacity, int n_storage, int n, const double* __res
         const Philox4 p = philox4x32_10((uint32_t)i, c1, c2, 0x9e4u, k0, k1);
         ui = ((double)(((uint64_t)p.v[0] << 21) ^ (uint64_t)(p.v[1] >> 11)) + 0.5) * (1.0 / 9007199254740992.0);   // 53-bit uniform in (0,1)
     }
-    const double total = sum_tree[1];                    // == sum(0, len(storage)) bit for bit (unfilled leaves are exact zeros)
+    const double total = sTop[1];                        // == sum(0, len(storage)) bit for bit (unfilled leaves are exact zeros)
     double prefix = ui * total;                          // buffer.py:141
     int node = 1;
-    while (node < capacity) {                            // find_prefixsum_idx, segment_tree.py:133-140
+    while (node < capacity && 2 * node + 1 < staged) {   // find_prefixsum_idx, segment_tree.py:133-140: the staged levels ...
+        const double left = sTop[2 * node];
+        if (left > prefix) {
+            node = 2 * node;
+        } else {
+            prefix -= left;
+            node = 2 * node + 1;
+        }
+    }
+    while (node < capacity) {                            // ... and the rest of the way down
         const double left = sum_tree[2 * node];
         if (left > prefix) {
             node = 2 * node;
