@@ -397,9 +397,15 @@ extern "C" int mpg_q_loss_grad(const mpg_cfg_t* cfg, const float* q_params, int 
     } else
     hipLaunchKernelGGL(k_q_err, dim3(1), dim3(1024), 0, s, rows, q, y, inv_b_global, dz3, td, loss_sum);
     MPG_CHECK_LAUNCH("k_q_err");
-    rc = launch_backward(cfg, q_params, in, 1, 1, rows, dz3, 1, nullptr, 0, 0, 1.f, h1, h2, dz1, dz2, nullptr, nullptr, 0, s);
+    // the thin parameter gradients ride in the backward launch (mlp_launch.h): its per-workgroup partials live where the dz1 stash
+    // would (never larger), the weight-gradient launch reads h1 and dz2 only
+    const bool thin = backward_takes_thin(in, 1);
+    rc = launch_backward(cfg, q_params, in, 1, 1, rows, dz3, 1, nullptr, 0, 0, 1.f, h1, h2, thin ? nullptr : dz1, dz2, nullptr, nullptr, 0, s,
+                         thin ? &xq : nullptr, thin ? dz1 : nullptr);
     if (rc) return rc;
-    return launch_wgrad(cfg, in, 1, 1, rows, xq, h1, h2, dz1, dz2, dz3, inv_b_global, grad, slabs, s);
+    rc = launch_wgrad(cfg, in, 1, 1, rows, xq, h1, h2, dz1, dz2, dz3, inv_b_global, grad, slabs, s, thin);
+    if (rc || !thin) return rc;
+    return launch_thin_reduce(dz1, backward_thin_parts(rows), in, 1, grad, s);
 }
 
 extern "C" size_t mpg_td3_policy_grad_workspace_bytes(const mpg_cfg_t* cfg, int rows) {
@@ -453,8 +459,11 @@ extern "C" int mpg_td3_policy_grad(const mpg_cfg_t* cfg, const float* policy_par
     if (rc) return rc;
     hipLaunchKernelGGL(k_sum_action_grad, dim3((rows * ad + 255) / 256), dim3(256), 0, s, rows, od, ad, dx1, dx2, ga);
     MPG_CHECK_LAUNCH("k_sum_action_grad");
-    rc = launch_backward(cfg, policy_params, od, 2 * ad, ad, rows, ga, ad, a, ad, po.out_tanh, po.out_scale, hp1, hp2, dz1, dz2, dz3,
-                         nullptr, 0, s);
+    const bool thin = backward_takes_thin(od, ad);        // (see mpg_q_loss_grad)
+    rc = launch_backward(cfg, policy_params, od, 2 * ad, ad, rows, ga, ad, a, ad, po.out_tanh, po.out_scale, hp1, hp2, thin ? nullptr : dz1,
+                         dz2, dz3, nullptr, 0, s, thin ? &xp : nullptr, thin ? dz1 : nullptr);
     if (rc) return rc;
-    return launch_wgrad(cfg, od, 2 * ad, ad, rows, xp, hp1, hp2, dz1, dz2, dz3, inv_b_global, grad, slabs, s);
+    rc = launch_wgrad(cfg, od, 2 * ad, ad, rows, xp, hp1, hp2, dz1, dz2, dz3, inv_b_global, grad, slabs, s, thin);
+    if (rc || !thin) return rc;
+    return launch_thin_reduce(dz1, backward_thin_parts(rows), od, 2 * ad, grad, s);
 }

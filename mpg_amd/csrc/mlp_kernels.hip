@@ -163,12 +163,21 @@ struct BwdArgs {
     float *dz1, *dz2, *dz3, *dx;
     int lddx;
     const float* pack;   // nullable: packed backward image of W2
+    XSpec x;             // THIN instantiations only: the network input (for dW1)
+    float* thin_part;    // THIN instantiations only: [gridDim.x][thin_floats(in_dim, out_dim)] per-workgroup sums
 };
 
-template <int IN, int OU, bool WANT_DX, bool PK>
+// THIN: the thin parameter gradients (dW1, db1, db2, dW3, db3) are accumulated here as per-lane running sums over the workgroup's
+// row groups - everything they are made of (x, h2, dz3, dz1, dz2) is in registers or LDS at this point - and written as ONE partial
+// per workgroup (mlp_launch.h thin_floats).  The dz1 stash is not written, the weight-gradient launch reads h1 and dz2 only
+// (launch_wgrad no_thin) and launch_thin_reduce adds the partials: at 65 536 rows that is 67 MB less written here and 134 MB less
+// read there per network (TD3, B = 65 536: k_wgrad 79 -> see DESIGN 4.3).
+template <int IN, int OU, bool WANT_DX, bool PK, bool THIN = false>
 __global__ void __launch_bounds__(NTHREAD, 2) k_backward(const BwdArgs a) {
+    static_assert(!THIN || (!WANT_DX && IN <= 8), "THIN is built for the base input widths, without dx");
     constexpr int XSW = xs_of<IN>();
     __shared__ __attribute__((aligned(16))) float smem[2 * A_IMG + GROUP * MAXOUT + NWAVE * GROUP * XSW];
+    __shared__ __attribute__((aligned(16))) float sXt[THIN ? 2 * GROUP * XSW : 4];      // network input of the group, two parities
     float* sA = smem;
     float* sA1 = sA + A_IMG;
     float* sD3 = sA1 + A_IMG;
@@ -181,7 +190,17 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_backward(const BwdArgs a) {
     load_small<IN, OU>(net, L, r);
     const long ngroups = (a.rows + GROUP - 1) / GROUP;
     const int tid = threadIdx.x;
-    for (long g = blockIdx.x; g < ngroups; g += gridDim.x) {
+    // THIN: running sums of this lane's two columns over its four rows of every group (rows beyond the batch carry dz = 0)
+    float gb1[2] = {0.f, 0.f}, gb2[2] = {0.f, 0.f}, gw3[2][OU], gw1[2][IN], gb3 = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int k = 0; k < OU; ++k) gw3[t][k] = 0.f;
+#pragma unroll
+        for (int i = 0; i < IN; ++i) gw1[t][i] = 0.f;
+    }
+    int par = 0;
+    for (long g = blockIdx.x; g < ngroups; g += gridDim.x, par ^= 1) {
         if (tid < GROUP * OU) {
             const int row = tid / OU, o = tid % OU;
             const long gr = g * GROUP + row;
@@ -195,14 +214,44 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_backward(const BwdArgs a) {
                 if (a.dz3) a.dz3[gr * OU + o] = d;
             }
             sD3[d3_index(row, o)] = d;
+            if constexpr (THIN) gb3 += d;
         }
+        // (the buffer of the other parity may still be read by a slower wave in the previous group's tail; this one was last read
+        // two groups ago, in front of the barrier every wave has passed since)
+        if constexpr (THIN) load_x_group<IN>(a.x, a.rows, g, sXt + par * GROUP * XSW);
         float h1[2][4], h2[2][4], dz1[2][4], dz2[2][4];
         stash_load(a.h1, g, L, h1);
         stash_load(a.h2, g, L, h2);
         lds_barrier();
+        if constexpr (THIN) {           // dW3 += h2 dz3^T (sD3 is stable until backward_group's last barrier)
+#pragma unroll
+            for (int k = 0; k < OU; ++k) {
+                const f32x4 d3 = *reinterpret_cast<const f32x4*>(sD3 + d3_index(4 * L.rg, k));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    gw3[0][k] = fmaf(h2[0][j], d3[j], gw3[0][k]);
+                    gw3[1][k] = fmaf(h2[1][j], d3[j], gw3[1][k]);
+                }
+            }
+        }
         backward_group<IN, OU, WANT_DX>(sD3, sA, sA1, sPartX, L, w2t, r, h1, h2, dz1, dz2);
-        if (a.dz1) stash_store(a.dz1, g, L, dz1);
+        if (!THIN && a.dz1) stash_store(a.dz1, g, L, dz1);
         if (a.dz2) stash_store(a.dz2, g, L, dz2);
+        if constexpr (THIN) {           // db2 += dz2, db1 += dz1, dW1 += x^T dz1
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                gb2[0] += dz2[0][j]; gb2[1] += dz2[1][j];
+                gb1[0] += dz1[0][j]; gb1[1] += dz1[1][j];
+                const float* xr = sXt + par * GROUP * XSW + L.row(j) * XSW;
+                const f32x4 x0 = *reinterpret_cast<const f32x4*>(xr), x1 = *reinterpret_cast<const f32x4*>(xr + 4);
+#pragma unroll
+                for (int i = 0; i < IN; ++i) {
+                    const float xv = i < 4 ? x0[i & 3] : x1[i & 3];
+                    gw1[0][i] = fmaf(xv, dz1[0][j], gw1[0][i]);
+                    gw1[1][i] = fmaf(xv, dz1[1][j], gw1[1][i]);
+                }
+            }
+        }
         if (WANT_DX) {
             if (tid < GROUP * a.in_dim) {
                 const int row = tid / a.in_dim, i = tid % a.in_dim;
@@ -212,13 +261,110 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_backward(const BwdArgs a) {
             lds_barrier();   // sPartX / sD3 are rewritten by the next group
         }
     }
+    if constexpr (THIN) {
+        // this workgroup's partial: the four row quads (lanes c, c + 16, c + 32, c + 48) of every column summed in a fixed order,
+        // written by the quad-0 lane in the network's flat layout without W2
+        auto quad_sum = [](float v) {
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            return v;
+        };
+        float* dst = a.thin_part + (size_t)blockIdx.x * thin_floats(a.in_dim, a.out_dim);
+        float *dW1 = dst, *db1 = dW1 + a.in_dim * H, *db2 = db1 + H, *dW3 = db2 + H, *db3 = dW3 + H * a.out_dim;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int col = L.col(t);
+            const float s1 = quad_sum(gb1[t]), s2 = quad_sum(gb2[t]);
+            if (L.rg == 0) { db1[col] = s1; db2[col] = s2; }
+#pragma unroll
+            for (int k = 0; k < OU; ++k) {
+                const float s3 = quad_sum(gw3[t][k]);
+                if (L.rg == 0) dW3[col * a.out_dim + k] = s3;
+            }
+            if (L.rg == 0)
+                for (int k = OU; k < a.out_dim; ++k) dW3[col * a.out_dim + k] = 0.f;     // unused outputs (SURVEY B-5)
+#pragma unroll
+            for (int i = 0; i < IN; ++i) {
+                const float sw = quad_sum(gw1[t][i]);
+                if (L.rg == 0) dW1[i * H + col] = sw;
+            }
+        }
+        __syncthreads();                                     // every wave is done with sD3
+        if (tid < GROUP * OU) sD3[tid] = gb3;                // [row][o]
+        __syncthreads();
+        if (tid < a.out_dim) {
+            float s3 = 0.f;
+            if (tid < OU)
+                for (int row = 0; row < GROUP; ++row) s3 += sD3[row * OU + tid];
+            db3[tid] = s3;
+        }
+    }
 }
+
+// out[i (+ skip behind skip_from)] = sum over n_part partial arrays of n floats each, in a FIXED association (deterministic): SL lanes per
+// output take the parts sl, sl + SL, ... as four running sums each, then the SL slice sums are added in slice order.  (One lane per
+// output walking 64 - 256 parts is a chain of dependent-latency steps: 20 - 30 us per launch at 256 parts, measured in the TD3 step.)
+template <int SL>
+__global__ void __launch_bounds__(256) k_sum_parts(const float* __restrict__ part, int n_part, int n, int skip_from, int skip,
+                                                   float* __restrict__ out) {
+    constexpr int NO = 256 / SL;                       // outputs per block
+    __shared__ float sR[SL][NO + 1];
+    const int o = threadIdx.x % NO, sl = threadIdx.x / NO;
+    const int i = blockIdx.x * NO + o;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (i < n) {
+        int k = sl;
+        for (; k + 3 * SL < n_part; k += 4 * SL) {
+            acc[0] += part[(size_t)k * n + i];
+            acc[1] += part[(size_t)(k + SL) * n + i];
+            acc[2] += part[(size_t)(k + 2 * SL) * n + i];
+            acc[3] += part[(size_t)(k + 3 * SL) * n + i];
+        }
+        for (; k < n_part; k += SL) acc[0] += part[(size_t)k * n + i];
+    }
+    sR[sl][o] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    __syncthreads();
+    if (sl == 0 && i < n) {
+        float sum = 0.f;
+#pragma unroll
+        for (int q = 0; q < SL; ++q) sum += sR[q][o];
+        out[i < skip_from ? i : i + skip] = sum;
+    }
+}
+
+int launch_thin_reduce(const float* part, int n_part, int in_dim, int out_dim, float* grad, hipStream_t s) {
+    const int n_thin = thin_floats(in_dim, out_dim);
+    // thin positions of the flat gradient: W1 | b1 in front of W2, b2 | W3 | b3 behind it
+    hipLaunchKernelGGL((k_sum_parts<16>), dim3((n_thin + 15) / 16), dim3(256), 0, s, part, n_part, n_thin, in_dim * H + H, H * H, grad);
+    MPG_CHECK_LAUNCH("k_sum_parts (thin)");
+    return MPG_OK;
+}
+
+template <int I, int O>
+static void launch_backward_thin(const BwdArgs& a, int grid, hipStream_t s) {
+    if constexpr (I <= 8) {
+        if (a.pack) hipLaunchKernelGGL((k_backward<I, O, false, true, true>), dim3(grid), dim3(NTHREAD), 0, s, a);
+        else hipLaunchKernelGGL((k_backward<I, O, false, false, true>), dim3(grid), dim3(NTHREAD), 0, s, a);
+    }
+}
+
+bool backward_takes_thin(int in_dim, int ou) {
+#ifdef MPG_AB_NO_BWD_THIN      // A/B build (tools/ab_bwd_thin.sh): thin gradients in the weight-gradient launch, as before round 4
+    return false;
+#endif
+    return in_dim <= 8 && !(in_dim == 7 && ou == 2) && !(in_dim == 8 && ou == 2);
+}
+int backward_thin_parts(int rows) { return grid_for((rows + GROUP - 1) / GROUP); }
 
 int launch_backward(const mpg_cfg_t* cfg, const float* params, int in_dim, int out_dim, int ou, int rows, const float* dy, int lddy,
                     const float* yout, int ldyo, int out_tanh, float out_scale, const float* h1, const float* h2,
-                    float* dz1, float* dz2, float* dz3, float* dx, int lddx, hipStream_t s) {
+                    float* dz1, float* dz2, float* dz3, float* dx, int lddx, hipStream_t s, const XSpec* thin_x, float* thin_part) {
     MPG_REQUIRE(params && rows > 0 && dy && h1 && h2 && (!out_tanh || yout), "launch_backward: bad argument");
+    MPG_REQUIRE(!thin_part || (thin_x && !dx && backward_takes_thin(in_dim, ou) && thin_x->d0 + thin_x->d1 == in_dim),
+                "launch_backward: thin gradients need the network input, no dx and a base input width");
     BwdArgs a;
+    a.thin_part = thin_part;
+    if (thin_x) a.x = *thin_x;
     a.params = params; a.in_dim = in_dim; a.out_dim = out_dim; a.rows = rows; a.dy = dy; a.lddy = lddy;
     a.yout = yout; a.ldyo = ldyo; a.out_tanh = out_tanh; a.out_scale = out_scale; a.h1 = h1; a.h2 = h2;
     a.dz1 = dz1; a.dz2 = dz2; a.dz3 = dz3; a.dx = dx; a.lddx = lddx;
@@ -229,6 +375,10 @@ int launch_backward(const mpg_cfg_t* cfg, const float* params, int in_dim, int o
 #define CALL(I, O)                                                                                                \
     if (a.pack) hipLaunchKernelGGL((k_backward<I, O, true, true>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, a); \
     else hipLaunchKernelGGL((k_backward<I, O, true, false>), dim3(grid_for(ngroups)), dim3(NTHREAD), 0, s, a)
+        MPG_DISPATCH_NET(in_dim, ou, CALL)
+#undef CALL
+    } else if (thin_part) {
+#define CALL(I, O) launch_backward_thin<I, O>(a, grid_for(ngroups), s)
         MPG_DISPATCH_NET(in_dim, ou, CALL)
 #undef CALL
     } else {
@@ -247,7 +397,7 @@ int launch_backward(const mpg_cfg_t* cfg, const float* params, int in_dim, int o
 // weight gradient:  dW2 = H1^T DZ2 on MFMA straight from the G16 stashes (k = batch row), the thin pieces
 // (dW1, db1, db2, dW3, db3) on VALU.  Grid = (8 column slices, chunks of row groups): a workgroup accumulates the
 // 256 x 32 column slice of dW2 over its chunk (wave w: feature tiles 2w, 2w+1), so a chunk's slab is written once
-// by 8 workgroups; k_reduce_slabs sums the <= 32 chunk slabs in a fixed order (deterministic, no float atomics).
+// by 8 workgroups; k_sum_parts sums the chunk slabs in a fixed order (deterministic, no float atomics).
 // -------------------------------------------------------------------------------------------------------
 template <int IN, int OU>
 __global__ void __launch_bounds__(NTHREAD, IN <= 8 ? 4 : 2) k_wgrad(const WgradArgs a) {      // (16-wide: 80 KB of LDS, one workgroup per CU anyway)
@@ -255,23 +405,6 @@ __global__ void __launch_bounds__(NTHREAD, IN <= 8 ? 4 : 2) k_wgrad(const WgradA
     int chunk, sl;
     wgrad_map(blockIdx.x, gridDim.x >> 3, chunk, sl);
     wgrad_body<IN, OU>(a, sl, chunk, sRed);
-}
-
-// out = sum of the chunk slabs in a fixed association, four independent running sums (four loads in flight per thread: one
-// dependent chain over 64 slabs is what made this 19.5 us per launch in the round-3 TD3 profile - 35 MB at 1.8 TB/s)
-__global__ void k_reduce_slabs(const float* __restrict__ slabs, int nslab, int n, float* __restrict__ out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    int k = 0;
-    for (; k + 3 < nslab; k += 4) {
-        acc[0] += slabs[(size_t)k * n + i];
-        acc[1] += slabs[(size_t)(k + 1) * n + i];
-        acc[2] += slabs[(size_t)(k + 2) * n + i];
-        acc[3] += slabs[(size_t)(k + 3) * n + i];
-    }
-    for (; k < nslab; ++k) acc[0] += slabs[(size_t)k * n + i];
-    out[i] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
 }
 
 size_t wgrad_workspace_floats(int rows, int in_dim, int out_dim) {
@@ -300,8 +433,8 @@ int launch_wgrad(const mpg_cfg_t* cfg, int in_dim, int out_dim, int ou, int rows
     mpg_prof_end(mpg_prof_of(cfg), 5, s);
     MPG_CHECK_LAUNCH("k_wgrad");
     const int n = net_size(in_dim, out_dim);
-    hipLaunchKernelGGL(k_reduce_slabs, dim3((n + 255) / 256), dim3(256), 0, s, ws, nch, n, grad);
-    MPG_CHECK_LAUNCH("k_reduce_slabs");
+    hipLaunchKernelGGL((k_sum_parts<4>), dim3((n + 63) / 64), dim3(256), 0, s, ws, nch, n, n, 0, grad);     // the chunk slabs
+    MPG_CHECK_LAUNCH("k_sum_parts (slabs)");
     return MPG_OK;
 }
 

@@ -20,6 +20,9 @@ inline XSpec xspec(const float* x0, int d0, const float* x1, int d1, const float
     return s;
 }
 
+// one partial of the thin parameter gradients = the network's flat layout without W2: W1 [in][H] | b1 | b2 | W3 [H][out] | b3
+__host__ __device__ inline int thin_floats(int in_dim, int out_dim) { return in_dim * H + H + H + H * out_dim + out_dim; }
+
 #ifdef __HIPCC__
 // loads one row group of the network input into sX [16][xs_of<IN>()] (zero padded; width = d0 + d1 columns)
 template <int IN>
@@ -59,7 +62,15 @@ int launch_forward(const mpg_cfg_t* cfg, const float* params, int in_dim, int ou
 // input as seen by the first layer, i.e. after scaling).
 int launch_backward(const mpg_cfg_t* cfg, const float* params, int in_dim, int out_dim, int ou, int rows, const float* dy, int lddy,
                     const float* yout, int ldyo, int out_tanh, float out_scale, const float* h1, const float* h2,
-                    float* dz1, float* dz2, float* dz3, float* dx, int lddx, hipStream_t s);
+                    float* dz1, float* dz2, float* dz3, float* dx, int lddx, hipStream_t s, const XSpec* thin_x = nullptr,
+                    float* thin_part = nullptr);
+// thin_part (with thin_x = the network input, dx == nullptr, backward_takes_thin): the thin parameter gradients (dW1, db1, db2, dW3,
+// db3) are accumulated by the backward launch itself: one partial of thin_floats(in_dim, out_dim) floats per workgroup,
+// backward_thin_parts(rows) of them (never more than the dz1 stash of the same rows holds: callers alias it).  dz1 is then NOT
+// written; follow with launch_wgrad(no_thin = true) and launch_thin_reduce.
+bool backward_takes_thin(int in_dim, int ou);
+int backward_thin_parts(int rows);
+int launch_thin_reduce(const float* part, int n_part, int in_dim, int out_dim, float* grad, hipStream_t s);
 
 // Weight gradient of one network over `rows` rows from stashes; result (net_size floats, fully reduced over rows,
 // accumulate == 0: overwritten) in grad.  ws must hold wgrad_workspace_floats(rows, in_dim, out_dim) floats.

@@ -240,9 +240,9 @@ struct RollBwdArgs {
 // launch they are two more 218 MB stashes to write here and to read there (config 3: k_wgrad<4,1> moved 872 MB in 250 us, the
 // largest kernel of the step).  With THIN the sweep keeps per-lane running sums in LDS (the other seven waves do this while
 // wave 0 runs the serial chain), leaves one partial vector per workgroup and skips the dz1 stash; the weight-gradient launch then
-// reads only h1 and dz2 for dW2 and k_thin_reduce adds the partials.  Layout of a partial = the network's flat layout without W2:
+// reads only h1 and dz2 for dW2 and launch_thin_reduce adds the partials.  Layout of a partial = the network's flat layout without W2:
 // [W1 (in x 256) | b1 | b2 | W3 (256 x out) | b3].
-__host__ __device__ inline int thin_floats(int in_dim, int out_dim) { return in_dim * H + H + H + H * out_dim + out_dim; }
+// (thin_floats: mlp_launch.h)
 
 inline void fill_roll(RollArgs& a, const mpg_cfg_t* cfg, const float* policy, int rows, int M, int n) {
     a.policy = policy; a.rows = rows; a.M = M; a.n = n;

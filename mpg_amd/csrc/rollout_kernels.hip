@@ -94,23 +94,6 @@ __global__ void k_qest(int rows, int M, int n_sel, const QestCoef qc, const floa
     }
 }
 
-// grad[thin positions] = sum over the reverse sweep's workgroups of their partial thin gradients (rollout_common.h thin_floats; fixed
-// order: deterministic).  i < w1n: W1 | b1 go in front of W2; the rest (b2 | W3 | b3) behind it.
-__global__ void k_thin_reduce(const float* __restrict__ part, int n_part, int n_thin, int w1b1, float* __restrict__ grad) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_thin) return;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    int k = 0;
-    for (; k + 3 < n_part; k += 4) {
-        acc[0] += part[(size_t)k * n_thin + i];
-        acc[1] += part[(size_t)(k + 1) * n_thin + i];
-        acc[2] += part[(size_t)(k + 2) * n_thin + i];
-        acc[3] += part[(size_t)(k + 3) * n_thin + i];
-    }
-    for (; k < n_part; ++k) acc[0] += part[(size_t)k * n_thin + i];
-    grad[i < w1b1 ? i : i + H * H] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
-}
-
 // ---------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------
@@ -302,9 +285,8 @@ extern "C" int mpg_rollout_pg(const mpg_cfg_t* cfg, const float* policy_params, 
                       thin_part != nullptr);
     if (rc || !thin_part) return rc;
     // dW2 came from the launch above (its thin parts are zeros); the thin parts are the sum of the sweep's per-workgroup partials
-    const int n_thin = thin_floats(od, 2 * ad), n_part = (int)std::min<long>(256, (R + GROUP - 1) / GROUP);
-    hipLaunchKernelGGL(k_thin_reduce, dim3((n_thin + 255) / 256), dim3(256), 0, s, thin_part, n_part, n_thin, od * H + H, grad);
-    MPG_CHECK_LAUNCH("k_thin_reduce");
+    const int n_part = (int)std::min<long>(256, (R + GROUP - 1) / GROUP);
+    return launch_thin_reduce(thin_part, n_part, od, 2 * ad, grad, s);
     return MPG_OK;
 }
 
