@@ -741,20 +741,42 @@ struct WgradMulti {
     unsigned long long* dbg;   // MPG_TIMELINE builds only
 };
 
+#ifndef MPG_WGM_WAVES
+#define MPG_WGM_WAVES 4
+#endif
 template <int IA, int OA, int IB, int OB>
-__global__ void __launch_bounds__(NTHREAD, 4) k_wgrad_multi(const WgradMulti m) {
+__global__ void __launch_bounds__(NTHREAD, MPG_WGM_WAVES) k_wgrad_multi(const WgradMulti m) {
     constexpr int NQA = wgrad_nq<IA, OA>(), NQB = wgrad_nq<IB, OB>();
     __shared__ __attribute__((aligned(16))) float sRed[NWAVE * (NQA > NQB ? NQA : NQB) * 64];
     int gchunk, sl;
+#ifndef MPG_WG_ROLES            // every workgroup does both, the thin pieces as a tail behind the matrix loop
+    const int role = 0;
     wgrad_map(blockIdx.x, gridDim.x >> 3, gchunk, sl);
+#else
+    // experiment (mlp_wgrad.h): the first half of the grid takes the dW2 slices, the second half the thin pieces of the same (chunk, slice) pairs
+    const int nb = gridDim.x >> 1;
+    const int role = (int)blockIdx.x < nb ? 1 : 2;
+    wgrad_map((int)blockIdx.x - (role == 2 ? nb : 0), nb >> 3, gchunk, sl);
+#endif
     gchunk += m.chunk0;
     int j = 0;
     while (j + 1 < m.n_jobs && gchunk >= m.chunk_off[j + 1]) ++j;
     const int chunk = gchunk - m.chunk_off[j];
     MPG_TL_DECL
     MPG_TL(0);
-    if (m.type[j] == 0) wgrad_body<IA, OA>(m.a[j], sl, chunk, sRed);
-    else wgrad_body<IB, OB>(m.a[j], sl, chunk, sRed);
+#ifndef MPG_WG_ROLES
+    if (role == 0) {
+        if (m.type[j] == 0) wgrad_body<IA, OA, 0>(m.a[j], sl, chunk, sRed);
+        else wgrad_body<IB, OB, 0>(m.a[j], sl, chunk, sRed);
+    } else
+#endif
+    if (role == 1) {
+        if (m.type[j] == 0) wgrad_body<IA, OA, 1>(m.a[j], sl, chunk, sRed);
+        else wgrad_body<IB, OB, 1>(m.a[j], sl, chunk, sRed);
+    } else {
+        if (m.type[j] == 0) wgrad_body<IA, OA, 2>(m.a[j], sl, chunk, sRed);
+        else wgrad_body<IB, OB, 2>(m.a[j], sl, chunk, sRed);
+    }
     MPG_TL(7);
 #ifdef MPG_TIMELINE
     __syncthreads();
@@ -1045,8 +1067,13 @@ int launch_wgrad_multi(const mpg_cfg_t* cfg, const WgradJob* jobs, int n_jobs, c
     m.chunk0 = chunk0;
     if (phases & 1) {
     mpg_prof_begin(mpg_prof_of(cfg), 5, s);
-    if (!pendulum) hipLaunchKernelGGL((k_wgrad_multi<8, 1, 6, 2>), dim3(8 * (off - chunk0)), dim3(NTHREAD), 0, s, m);
-    else hipLaunchKernelGGL((k_wgrad_multi<5, 1, 4, 1>), dim3(8 * (off - chunk0)), dim3(NTHREAD), 0, s, m);
+#ifndef MPG_WG_ROLES
+    const int wg_per_slice = 1;
+#else
+    const int wg_per_slice = 2;
+#endif
+    if (!pendulum) hipLaunchKernelGGL((k_wgrad_multi<8, 1, 6, 2>), dim3(wg_per_slice * 8 * (off - chunk0)), dim3(NTHREAD), 0, s, m);
+    else hipLaunchKernelGGL((k_wgrad_multi<5, 1, 4, 1>), dim3(wg_per_slice * 8 * (off - chunk0)), dim3(NTHREAD), 0, s, m);
     mpg_prof_end(mpg_prof_of(cfg), 5, s);
     }
 #ifdef MPG_TIMELINE

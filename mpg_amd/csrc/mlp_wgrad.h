@@ -23,7 +23,11 @@ template <int IN, int OU>
 constexpr int wgrad_nq() { return 2 * IN + 4 + 2 * OU + OU; }      // thin quantities per lane
 
 // sl: column slice (hidden columns [32 sl, 32 sl + 32)); chunk: which run of row groups; sRed: NWAVE*NQ*64 floats of LDS
-template <int IN, int OU>
+// ROLE 0: the workgroup computes its 256 x 32 slice of dW2 AND the thin pieces of its 32 columns; 1: dW2 only; 2: the thin pieces only.
+// The thin pieces are a chain of load round trips that runs as a tail behind the matrix loop (~5 us of the bench step's k_wgrad_multi,
+// tools/ab_wg_nothin.sh).  -DMPG_WG_ROLES deals the two to different workgroups of k_wgrad_multi (round-4 experiment, tools/ab_wg_roles.sh):
+// 768 workgroups for 512 resident slots, kernel 26.5 -> 25.4 us, step within the noise - not the default.
+template <int IN, int OU, int ROLE = 0>
 __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int sl, const int chunk, float* sRed) {
     constexpr int NQ = wgrad_nq<IN, OU>();
     const Lane L;
@@ -64,27 +68,39 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int sl, con
     // a staged row: [x (8 or 16 floats) | dz3 (OU) | pad] - 12 floats for networks with up to 8 inputs, 20 for the 16-wide ones
     constexpr int XW = xs_of<IN>(), RS = XW + 4, NSLOT = GROUP * RS / 64;
     float* stage = sRed + L.wave * (GROUP * RS);
-    auto thin_accumulate = [&](long g, const Thin& t) {
-        // Every lane fills three slots of the staging corner.  Which array a slot comes from (x0 scaled, x1, dz3, or a
-        // zero pad) is settled by SELECTING the address, and the loads themselves are unconditional: as three nested
-        // branches each slot cost up to three dependent memory round trips (the wait sat inside the branch), ~2 us per
-        // row group on the critic jobs, which were then the longest workgroups of the launch.
-        float v[NSLOT], sc[NSLOT];
-        bool on[NSLOT];
+    // Every lane fills three slots of the staging corner.  Which array a slot comes from (x0 scaled, x1, dz3, or a
+    // zero pad) is settled by SELECTING the address, and the loads themselves are unconditional: as three nested
+    // branches each slot cost up to three dependent memory round trips (the wait sat inside the branch), ~2 us per
+    // row group on the critic jobs, which were then the longest workgroups of the launch.
+    struct Staged {
+        float v[NSLOT];          // raw loads (consumed by stage_write: the ROLE 2 loop requests a group ahead)
+    };
+    auto stage_load = [&](long g, Staged& st) {
 #pragma unroll
         for (int u = 0; u < NSLOT; ++u) {
             const int e = L.lane + 64 * u, row = e / RS, i = e % RS;
             const long gr = g * GROUP + row;
             const bool from_x0 = i < a.in_dim && i < a.x.d0, from_x1 = i < a.in_dim && !from_x0, from_d3 = i >= XW && i - XW < OU;
-            on[u] = gr < a.rows && (from_x0 || from_x1 || from_d3);
+            const bool on = gr < a.rows && (from_x0 || from_x1 || from_d3);
             const float* p = a.dz3;                                      // any valid address for the slots that stay zero
-            if (on[u]) p = from_x0 ? a.x.x0 + gr * a.x.ld0 + i : (from_x1 ? a.x.x1 + gr * a.x.ld1 + (i - a.x.d0) : a.dz3 + gr * OU + (i - XW));
-            v[u] = *p;
-            sc[u] = a.x.scale[i & 15];
-            if (!from_x0) sc[u] = 1.f;
+            if (on) p = from_x0 ? a.x.x0 + gr * a.x.ld0 + i : (from_x1 ? a.x.x1 + gr * a.x.ld1 + (i - a.x.d0) : a.dz3 + gr * OU + (i - XW));
+            st.v[u] = *p;
         }
+    };
+    auto stage_write = [&](long g, const Staged& st) {
 #pragma unroll
-        for (int u = 0; u < NSLOT; ++u) stage[L.lane + 64 * u] = on[u] ? v[u] * sc[u] : 0.f;
+        for (int u = 0; u < NSLOT; ++u) {
+            const int e = L.lane + 64 * u, row = e / RS, i = e % RS;
+            const long gr = g * GROUP + row;
+            const bool from_x0 = i < a.in_dim && i < a.x.d0, from_x1 = i < a.in_dim && !from_x0, from_d3 = i >= XW && i - XW < OU;
+            const bool on = gr < a.rows && (from_x0 || from_x1 || from_d3);
+            float sc = a.x.scale[i & 15];
+            if (!from_x0) sc = 1.f;
+            stage[L.lane + 64 * u] = on ? st.v[u] * sc : 0.f;
+        }
+    };
+    auto thin_accumulate = [&](long g, const Thin& t, const Staged& st) {
+        stage_write(g, st);
 #ifdef MPG_AB_PKFMA_WAIT   // hypothesis test (tools/pk_anomaly.sh): the staged values are fully written before anything reads them
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
@@ -148,12 +164,13 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int sl, con
         __builtin_amdgcn_wave_barrier();
     };
 #ifdef MPG_SPLIT
+    float dz_scale = 1.f;
+    if constexpr (ROLE != 2) {
     // Scale of the DZ2 operand of the split-fp16 product: a power of two taken from the chunk's own data, 2^(4 - e) with e the
     // exponent of max |dL/dz3| over the chunk's rows (|dz2| <= out * max|dz3| * max|W3|, so the scaled operand stays below
     // 32 * max|W3| < 65504 inside the parameter envelope).  A fixed scale of ~B (the 1/B of the loss mean) left per-sample
     // gradients of 1e-3 .. 1e-4 - small TD errors, late-training policy gradients - with 3 .. 0 bits in their fp16 lo halves.
     // The accumulators are scaled back per workgroup, so chunks are free to differ.
-    float dz_scale;
     {
         float mx = 0.f;
         const long r0 = g0 * GROUP * OU, r1 = ((g1 * GROUP < (long)a.rows) ? g1 * GROUP : (long)a.rows) * OU;
@@ -170,18 +187,20 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int sl, con
         e = e < -100 ? -100 : (e > 100 ? 100 : e);
         dz_scale = ldexpf(A_SCALE, -e);
     }
+    }
 #endif
     long tg = g0 + L.wave;
 #ifdef MPG_AB_WG_NOTHIN
     const bool has_thin = false;
 #else
-    const bool has_thin = tg < g1 && !a.no_thin;
+    const bool has_thin = tg < g1 && !a.no_thin && ROLE != 1;
 #endif
 
     // ---- dW2 on the matrix pipe.  A operand: this wave's 32 rows of dW2 = 2 fragments of H1 per row group, straight
     //      from the stash (HBM / Infinity Cache, ~1.5 us away).  B operand: the workgroup's 32-column slice of DZ2 - the
     //      SAME two fragments for all eight waves, so they go through LDS: each wave fetches them for one group of an
     //      8-group tile and every wave reads the tile back (this removes 7/16 of the L2 -> CU traffic). ----
+    if constexpr (ROLE != 2) {
 #ifdef MPG_SPLIT
     // Split-fp16 form (mlp_core.h): the contraction index is the batch row, 32 rows = TWO row groups per
     // v_mfma_f32_16x16x32_f16: lane (c, rg) supplies rows 4rg..4rg+3 of both groups of a pair - exactly the two float4 it
@@ -322,16 +341,21 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int sl, con
         }
     }
 #endif
+    }
     MPG_TL(2);
     __syncthreads();                                      // the staging corners of the thin part alias the B tile
     MPG_TL(3);
     // thin pieces after the matrix loop (their registers are then free): the chunk's groups are dealt round-robin to
     // the 8 waves; the load latency is covered by the other resident waves
     if (has_thin) {
+        // (requesting the next group's loads ahead of the sums - tried in the ROLE 2 form, round 4 - costs 55 registers and was slower:
+        // k_wgrad_multi 25.4 -> 27.8 us)
         for (; tg < g1; tg += NWAVE) {
             Thin tcur;
+            Staged scur;
             thin_load(tg, tcur);
-            thin_accumulate(tg, tcur);
+            stage_load(tg, scur);
+            thin_accumulate(tg, tcur, scur);
         }
     }
     MPG_TL(4);
@@ -343,13 +367,16 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int sl, con
     float* sb2 = sW2 + H * H;
     float* sW3 = sb2 + H;
     float* sb3 = sW3 + H * a.out_dim;
+    if constexpr (ROLE != 2) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+        for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                sW2[(16 * (2 * L.wave + u) + 4 * L.rg + j) * H + 32 * sl + 16 * t + L.c] = acc[u][t][j];
+                for (int j = 0; j < 4; ++j)
+                    sW2[(16 * (2 * L.wave + u) + 4 * L.rg + j) * H + 32 * sl + 16 * t + L.c] = acc[u][t][j];
+    }
+    if constexpr (ROLE == 1) return;                      // (the thin entries of the slab belong to the ROLE 2 workgroup of this slice)
     MPG_TL(5);
     // thin pieces: sum over the 8 waves and the 4 row quads through LDS in a fixed order
     __syncthreads();   // the staging corners used above alias this scratch

@@ -65,6 +65,23 @@ __global__ void __launch_bounds__(512) k_rebuild_top(int ntop, double* __restric
     }
 }
 
+// Touched-path update (batch << capacity): only the ancestors of the n updated leaves are recomputed, level by level, by ONE workgroup
+// (a level's nodes read the level below, written by other threads of the same workgroup: block-wide barrier + fence per level).
+// Several leaves under one ancestor recompute the same left (+|min) right from the same children - identical values, so the duplicate
+// stores are harmless and the tree content stays bit-identical to the full rebuild's (and to SegmentTree.__setitem__'s, :90-97).
+__global__ void __launch_bounds__(1024) k_update_paths(int capacity, int n, const int* __restrict__ idx, double* __restrict__ sum_tree,
+                                                        double* __restrict__ min_tree) {
+    for (int node_shift = 1; (capacity >> node_shift) >= 1; ++node_shift) {
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            const int node = (capacity + idx[i]) >> node_shift;
+            sum_tree[node] = sum_tree[2 * node] + sum_tree[2 * node + 1];
+            min_tree[node] = fmin(min_tree[2 * node], min_tree[2 * node + 1]);
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
 __global__ void k_sample(int capacity, int n_storage, int n, const double* __restrict__ sum_tree,
                          const double* __restrict__ min_tree, const double* __restrict__ u, uint32_t k0, uint32_t k1,
                          uint32_t c1, uint32_t c2, double beta, int* __restrict__ idx, float* __restrict__ is_w) {
@@ -167,6 +184,13 @@ extern "C" int mpg_per_update(double* sum_tree, double* min_tree, int* stamp, in
                        max_priority);
     hipLaunchKernelGGL(k_unstamp, g, b, 0, s, n, idx, stamp);
     MPG_CHECK_LAUNCH("mpg_per_update");
+    // n log2(capacity) node updates by one workgroup against 2 * capacity by the whole chip: the paths win for small batches (B = 256
+    // into 2^19 leaves: 19 levels of 256 nodes)
+    if ((long)n * 64 <= (long)capacity) {
+        hipLaunchKernelGGL(k_update_paths, dim3(1), dim3(1024), 0, s, capacity, n, idx, sum_tree, min_tree);
+        MPG_CHECK_LAUNCH("k_update_paths");
+        return MPG_OK;
+    }
     return rebuild(capacity, sum_tree, min_tree, s);
 }
 

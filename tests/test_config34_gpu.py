@@ -199,6 +199,45 @@ def test_segment_tree_primitives_bit_exact_vs_reference(golden):
     np.testing.assert_array_equal(e_idx, [st.find_prefixsum_idx(0.0), st.find_prefixsum_idx(t2)])
 
 
+def test_touched_path_update_equals_full_rebuild():
+    """Small batches into a large tree (n * 64 <= capacity) update only the ancestors of the touched leaves (k_update_paths); the
+    tree content must stay bit-identical to the full rebuild's - checked against the oracle's SegmentTree on the device's leaf values,
+    with duplicate indices and neighbouring leaves (shared ancestors) in the batch."""
+    import mpg_amd._lib as L
+    cap, alpha = 1 << 16, 0.6
+    s = torch.empty(2 * cap, dtype=torch.float64, device=DEV)
+    m = torch.empty(2 * cap, dtype=torch.float64, device=DEV)
+    stamp = torch.empty(cap, dtype=torch.int32, device=DEV)
+    L.call('mpg_per_init', L.ptr(s), L.ptr(m), L.ptr(stamp), L.c_int(cap), L.stream())
+    rng = np.random.default_rng(5)
+
+    def update(idx, prio):
+        d_idx, d_prio = dev(idx, torch.int32), dev(prio)
+        L.call('mpg_per_update', L.ptr(s), L.ptr(m), L.ptr(stamp), L.c_int(cap), L.c_int(len(idx)),
+               L.ptr(d_idx), L.ptr(d_prio), L.c_double(alpha), L.c_double(1e-6), L.ptr(None), L.stream())
+        torch.cuda.synchronize()
+    n_fill = 50000
+    update(np.arange(n_fill), rng.uniform(0.01, 2.0, n_fill).astype(np.float32))            # full rebuild (n * 64 > capacity)
+    st, mt = O.SegmentTreeOracle(cap, lambda a, b: a + b, 0.0), O.SegmentTreeOracle(cap, min, float('inf'))
+    leaves = s[cap:].cpu().numpy()
+    for i in range(n_fill):
+        st.set(i, float(leaves[i]))
+        mt.set(i, float(leaves[i]))
+    np.testing.assert_array_equal(s.cpu().numpy()[1:], st.v[1:])
+    for n in (1, 7, 256, 1000):                                                               # touched paths (n * 64 <= capacity)
+        idx = rng.integers(0, n_fill, n)
+        idx[: n // 4] = idx[n // 2: n // 2 + n // 4]                                          # duplicates
+        if n >= 7:
+            idx[-3:] = [100, 101, 102]                                                        # neighbours
+        update(idx, rng.uniform(0.001, 5.0, n).astype(np.float32))
+        leaves = s[cap:].cpu().numpy()
+        for i in set(int(k) for k in idx):
+            st.set(i, float(leaves[i]))
+            mt.set(i, float(leaves[i]))
+        np.testing.assert_array_equal(s.cpu().numpy()[1:], st.v[1:])
+        np.testing.assert_array_equal(m.cpu().numpy()[1:], mt.v[1:])
+
+
 def test_prioritized_replay_at_config4_sizes():
     """capacity 2^19, batch 65536: proportional sampling follows the priorities; round trip add -> sample -> update."""
     from mpg_amd.buffer import PrioritizedReplayBuffer

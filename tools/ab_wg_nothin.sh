@@ -1,0 +1,9 @@
+cd $GRAFT_REPO_ROOT
+export MPG_BENCH_NO_F32=1
+for V in "" "-DMPG_AB_WG_NOTHIN" "" "-DMPG_AB_WG_NOTHIN"; do
+  echo "== [$V]"; MPG_EXTRA_CFLAGS="$V" python3 -m mpg_amd.build --split-only > /tmp/b.log 2>&1 || tail -3 /tmp/b.log
+  python bench.py --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('ms/step %.4f' % d['ms_per_step'], d['roofline']['avg_ms'] if 'avg_ms' in d['roofline'] else '', {k:round(v,4) for k,v in d.get('other_kernels_avg_ms',{}).items()})"
+done
+python3 -m mpg_amd.build --split-only > /tmp/b.log 2>&1
