@@ -343,6 +343,18 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int sl, con
 #endif
     }
     MPG_TL(2);
+#ifdef MPG_AB_WG_W2_FIRST      // diagnosis build (tools/proto/pk_repro): dW2 leaves its registers before the thin pieces start
+    if constexpr (ROLE != 2) {
+        float* sW2e = a.slabs + (size_t)chunk * net_size(a.in_dim, a.out_dim) + a.in_dim * H + H;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    sW2e[(16 * (2 * L.wave + u) + 4 * L.rg + j) * H + 32 * sl + 16 * t + L.c] = acc[u][t][j];
+    }
+#endif
     __syncthreads();                                      // the staging corners of the thin part alias the B tile
     MPG_TL(3);
     // thin pieces after the matrix loop (their registers are then free): the chunk's groups are dealt round-robin to
@@ -367,6 +379,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int sl, con
     float* sb2 = sW2 + H * H;
     float* sW3 = sb2 + H;
     float* sb3 = sW3 + H * a.out_dim;
+#ifndef MPG_AB_WG_W2_FIRST
     if constexpr (ROLE != 2) {
 #pragma unroll
         for (int u = 0; u < 2; ++u)
@@ -376,6 +389,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int sl, con
                 for (int j = 0; j < 4; ++j)
                     sW2[(16 * (2 * L.wave + u) + 4 * L.rg + j) * H + 32 * sl + 16 * t + L.c] = acc[u][t][j];
     }
+#endif
     if constexpr (ROLE == 1) return;                      // (the thin entries of the slab belong to the ROLE 2 workgroup of this slice)
     MPG_TL(5);
     // thin pieces: sum over the 8 waves and the 4 row quads through LDS in a fixed order

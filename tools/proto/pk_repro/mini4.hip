@@ -1,0 +1,195 @@
+// The compiler's own instruction sequence for one step of mini2.hip (-DK_EXEC=0 -DSTEPS=1), transplanted into an asm block with its
+// register numbers, and CHECKED against scalar arithmetic on the same operands (mini2 only detects launch-to-launch differences).
+// x comes through a wave-private LDS corner (eight ds_read_b128 whose returns overlap the packed FMAs: s_waitcnt lgkmcnt(7..0)),
+// dz sits in v[4:11].  Second half of the grid: v_mfma_f32_16x16x32_f16 on registers (-DNEIGHBOR=0: nothing).
+//   hipcc --offload-arch=gfx950 -O3 -o mini4 mini4.hip && ./mini4 [launches] [steps] [mfma_iters]
+// -DCUT=n drops parts of the sequence (see the source) to find what is needed.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+#ifndef NEIGHBOR
+#define NEIGHBOR 1
+#endif
+#ifndef LOADED
+#define LOADED 0
+#endif
+#ifndef CUT
+#define CUT 0
+#endif
+constexpr int RS = 12;
+
+__global__ void __launch_bounds__(512, 4) k_mini4(int steps, int mfma_iters, unsigned long long* bad, float* sink, const float* __restrict__ dz, float* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) float lds[8 * 16 * RS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, rg = lane >> 4;
+    if (blockIdx.x >= gridDim.x / 2) {
+#if NEIGHBOR
+        f16x8 a, b;
+        for (int j = 0; j < 8; ++j) { a[j] = (_Float16)(0.01f * (lane + j)); b[j] = (_Float16)(0.02f * (lane - j)); }
+        f32x4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+        for (int it = 0; it < mfma_iters; ++it)
+#pragma unroll
+            for (int u = 0; u < 12; ++u) acc[u & 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc[u & 3], 0, 0, 0);
+        sink[blockIdx.x * 512 + threadIdx.x] = acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3];
+#endif
+        return;
+    }
+    float* stage = lds + wave * (16 * RS);
+    unsigned long long nlo = 0, nhi = 0;
+    float d0[4], d1[4];
+    const f32x4* dzp = reinterpret_cast<const f32x4*>(dz) + ((size_t)blockIdx.x * 512 + threadIdx.x) * 2;
+#if LOADED      // dz arrives in v[4:11] by two global_load_dwordx4 INSIDE the sequence (as in the compiled kernel), not by v_mov
+    {
+        const f32x4 a = dzp[0], b = dzp[1];
+        for (int j = 0; j < 4; ++j) { d0[j] = a[j]; d1[j] = b[j]; }
+    }
+#else
+    for (int j = 0; j < 4; ++j) { d0[j] = 1.1e-3f * (1 + ((lane + j) & 7)); d1[j] = -0.9e-3f * (1 + ((lane + 3 * j) & 15)); }
+#endif
+    float seed = 0.37f + 0.013f * lane;
+    for (int s = 0; s < steps; ++s) {
+        for (int u = 0; u < 3; ++u) { stage[lane + 64 * u] = seed; seed = seed * 0.75f + 0.11f + 0.001f * u; }
+        __builtin_amdgcn_wave_barrier();
+        const unsigned addr = (unsigned)(size_t)(stage + 4 * rg * RS) & 0xffff;
+        float o[16];
+        asm volatile(
+#if LOADED
+            "global_load_dwordx4 v[4:7], %25, off\n"
+            "global_load_dwordx4 v[8:11], %25, off offset:16\n"
+            "v_mov_b32 v40, %24\n"
+            "s_waitcnt vmcnt(0)\n"
+#else
+            "v_mov_b32 v4, %16\n v_mov_b32 v5, %17\n v_mov_b32 v6, %18\n v_mov_b32 v7, %19\n"
+            "v_mov_b32 v8, %20\n v_mov_b32 v9, %21\n v_mov_b32 v10, %22\n v_mov_b32 v11, %23\n"
+            "v_mov_b32 v40, %24\n"
+            "s_nop 4\n"
+#endif
+            "ds_read_b128 v[12:15], v40\n"
+            "ds_read_b128 v[16:19], v40 offset:16\n"
+            "ds_read_b128 v[20:23], v40 offset:48\n"
+            "ds_read_b128 v[24:27], v40 offset:64\n"
+            "ds_read_b128 v[28:31], v40 offset:96\n"
+            "ds_read_b128 v[32:35], v40 offset:112\n"
+            "ds_read_b128 v[36:39], v40 offset:144\n"
+            "ds_read_b128 v[40:43], v40 offset:160\n"
+#if CUT == 1      // every LDS return has landed before the first packed FMA
+            "s_waitcnt lgkmcnt(0)\n s_nop 7\n"
+#else
+            "s_waitcnt lgkmcnt(7)\n"
+#endif
+            "v_pk_fma_f32 v[50:51], v[12:13], v[4:5], 0 op_sel_hi:[1,0,0]\n"
+            "v_pk_fma_f32 v[12:13], v[12:13], v[8:9], 0 op_sel_hi:[1,0,0]\n"
+            "v_pk_fma_f32 v[52:53], v[14:15], v[4:5], 0 op_sel_hi:[1,0,0]\n"
+            "v_pk_fma_f32 v[14:15], v[14:15], v[8:9], 0 op_sel_hi:[1,0,0]\n"
+            "s_waitcnt lgkmcnt(6)\n"
+            "v_pk_fma_f32 v[54:55], v[16:17], v[4:5], 0 op_sel_hi:[1,0,0]\n"
+            "v_pk_fma_f32 v[16:17], v[16:17], v[8:9], 0 op_sel_hi:[1,0,0]\n"
+            "v_pk_fma_f32 v[56:57], v[18:19], v[4:5], 0 op_sel_hi:[1,0,0]\n"
+            "v_pk_fma_f32 v[18:19], v[18:19], v[8:9], 0 op_sel_hi:[1,0,0]\n"
+            "s_waitcnt lgkmcnt(5)\n"
+            "v_pk_fma_f32 v[50:51], v[20:21], v[4:5], v[50:51] op_sel:[0,1,0]\n"
+            "v_pk_fma_f32 v[12:13], v[20:21], v[8:9], v[12:13] op_sel:[0,1,0]\n"
+            "v_pk_fma_f32 v[20:21], v[22:23], v[4:5], v[52:53] op_sel:[0,1,0]\n"
+            "v_mov_b32_e32 v46, v7\n"
+            "v_pk_fma_f32 v[14:15], v[22:23], v[8:9], v[14:15] op_sel:[0,1,0]\n"
+            "s_waitcnt lgkmcnt(4)\n"
+            "v_pk_fma_f32 v[22:23], v[24:25], v[4:5], v[54:55] op_sel:[0,1,0]\n"
+            "v_pk_fma_f32 v[16:17], v[24:25], v[8:9], v[16:17] op_sel:[0,1,0]\n"
+            "v_pk_fma_f32 v[4:5], v[26:27], v[4:5], v[56:57] op_sel:[0,1,0]\n"
+            "v_pk_fma_f32 v[8:9], v[26:27], v[8:9], v[18:19] op_sel:[0,1,0]\n"
+            "s_waitcnt lgkmcnt(3)\n"
+            "v_pk_fma_f32 v[18:19], v[28:29], v[6:7], v[50:51] op_sel_hi:[1,0,1]\n"
+            "v_pk_fma_f32 v[20:21], v[30:31], v[6:7], v[20:21] op_sel_hi:[1,0,1]\n"
+            "v_mov_b32_e32 v48, v11\n"
+            "v_pk_fma_f32 v[12:13], v[28:29], v[10:11], v[12:13] op_sel_hi:[1,0,1]\n"
+            "v_pk_fma_f32 v[14:15], v[30:31], v[10:11], v[14:15] op_sel_hi:[1,0,1]\n"
+            "s_waitcnt lgkmcnt(2)\n"
+            "v_pk_fma_f32 v[22:23], v[32:33], v[6:7], v[22:23] op_sel_hi:[1,0,1]\n"
+            "v_pk_fma_f32 v[16:17], v[32:33], v[10:11], v[16:17] op_sel_hi:[1,0,1]\n"
+            "v_pk_fma_f32 v[24:25], v[34:35], v[6:7], v[4:5] op_sel_hi:[1,0,1]\n"
+            "v_pk_fma_f32 v[26:27], v[34:35], v[10:11], v[8:9] op_sel_hi:[1,0,1]\n"
+            "s_waitcnt lgkmcnt(1)\n"
+            "v_pk_fma_f32 v[4:5], v[36:37], v[46:47], v[18:19] op_sel_hi:[1,0,1]\n"
+            "v_pk_fma_f32 v[6:7], v[38:39], v[46:47], v[20:21] op_sel_hi:[1,0,1]\n"
+            "v_pk_fma_f32 v[8:9], v[36:37], v[48:49], v[12:13] op_sel_hi:[1,0,1]\n"
+            "v_pk_fma_f32 v[10:11], v[38:39], v[48:49], v[14:15] op_sel_hi:[1,0,1]\n"
+            "s_waitcnt lgkmcnt(0)\n"
+            "v_pk_fma_f32 v[12:13], v[40:41], v[46:47], v[22:23] op_sel_hi:[1,0,1]\n"
+            "v_pk_fma_f32 v[16:17], v[40:41], v[48:49], v[16:17] op_sel_hi:[1,0,1]\n"
+            "v_pk_fma_f32 v[14:15], v[42:43], v[46:47], v[24:25] op_sel_hi:[1,0,1]\n"
+            "v_pk_fma_f32 v[18:19], v[42:43], v[48:49], v[26:27] op_sel_hi:[1,0,1]\n"
+            "s_nop 4\n"
+            // gW1[0][0..7] = v4 v5 v6 v7 v12 v13 v14 v15;  gW1[1][0..7] = v8 v9 v10 v11 v16 v17 v18 v19
+            "v_mov_b32 %0, v4\n v_mov_b32 %1, v5\n v_mov_b32 %2, v6\n v_mov_b32 %3, v7\n v_mov_b32 %4, v12\n v_mov_b32 %5, v13\n v_mov_b32 %6, v14\n v_mov_b32 %7, v15\n"
+            "v_mov_b32 %8, v8\n v_mov_b32 %9, v9\n v_mov_b32 %10, v10\n v_mov_b32 %11, v11\n v_mov_b32 %12, v16\n v_mov_b32 %13, v17\n v_mov_b32 %14, v18\n v_mov_b32 %15, v19\n"
+            : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7]),
+              "=&v"(o[8]), "=&v"(o[9]), "=&v"(o[10]), "=&v"(o[11]), "=&v"(o[12]), "=&v"(o[13]), "=&v"(o[14]), "=&v"(o[15])
+            : "v"(d0[0]), "v"(d0[1]), "v"(d0[2]), "v"(d0[3]), "v"(d1[0]), "v"(d1[1]), "v"(d1[2]), "v"(d1[3]), "v"(addr), "v"(dzp)
+            : "memory", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23",
+              "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43",
+              "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57");
+        // scalar reference: gW1[t][i] = sum_j x[4 rg + j][i] * dt[j], j ascending, fused multiply-adds (what the packed chain computes per half)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float r = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float xv = stage[(4 * rg + j) * RS + i], dv = t == 0 ? d0[j] : d1[j];
+                    asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(r) : "v"(xv), "v"(dv));
+                }
+                const bool ne = __float_as_uint(o[t * 8 + i]) != __float_as_uint(r);
+                if (i & 1) nhi += ne; else nlo += ne;
+            }
+        if (out && s == steps - 1) {           // the last step's results as they are, for a launch-to-launch comparison on the host
+            f32x4* op = reinterpret_cast<f32x4*>(out + ((size_t)blockIdx.x * 512 + threadIdx.x) * 16);
+            op[0] = f32x4{o[0], o[1], o[2], o[3]}; op[1] = f32x4{o[4], o[5], o[6], o[7]};
+            op[2] = f32x4{o[8], o[9], o[10], o[11]}; op[3] = f32x4{o[12], o[13], o[14], o[15]};
+        }
+        __builtin_amdgcn_wave_barrier();
+#if !LOADED
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { d0[j] = d0[j] * 0.5f + 6e-4f; d1[j] = d1[j] * 0.5f - 5e-4f; }
+#endif
+    }
+    if (nlo) atomicAdd(bad, nlo);
+    if (nhi) atomicAdd(bad + 1, nhi);
+}
+
+int main(int argc, char** argv) {
+    const int launches = argc > 1 ? atoi(argv[1]) : 100, steps = argc > 2 ? atoi(argv[2]) : 500, mfma_iters = argc > 3 ? atoi(argv[3]) : 3000;
+    unsigned long long* bad;
+    float* sink;
+    (void)hipMalloc(&bad, 16);
+    (void)hipMalloc(&sink, 512 * 512 * sizeof(float));
+    (void)hipMemset(bad, 0, 16);
+    float* dz;
+    {
+        const size_t n = (size_t)256 * 512 * 8;
+        float* h = (float*)malloc(n * 4);
+        srand(3);
+        for (size_t i = 0; i < n; ++i) h[i] = (rand() / (float)RAND_MAX - 0.5f) * 2e-3f;
+        (void)hipMalloc(&dz, n * 4);
+        (void)hipMemcpy(dz, h, n * 4, hipMemcpyHostToDevice);
+    }
+    float* out;
+    const size_t nout = (size_t)256 * 512 * 16;
+    (void)hipMalloc(&out, nout * 4);
+    float *first = (float*)malloc(nout * 4), *cur = (float*)malloc(nout * 4);
+    int differing_launches = 0;
+    for (int l = 0; l < launches; ++l) {
+        hipLaunchKernelGGL(k_mini4, dim3(512), dim3(512), 0, 0, steps, mfma_iters, bad, sink, dz, out);
+        if (hipDeviceSynchronize() != hipSuccess) { printf("launch failed\n"); return 2; }
+        (void)hipMemcpy(l == 0 ? first : cur, out, nout * 4, hipMemcpyDeviceToHost);
+        if (l > 0 && memcmp(first, cur, nout * 4) != 0) ++differing_launches;
+    }
+    unsigned long long h[2];
+    (void)hipMemcpy(h, bad, 16, hipMemcpyDeviceToHost);
+    printf("NEIGHBOR=%d CUT=%d LOADED=%d: %llu low-half and %llu high-half accumulators of %.3g differ from the scalar chain on the same operands\n", NEIGHBOR, CUT, LOADED, h[0], h[1],
+           (double)launches * 256 * 512 * steps * 8);
+    printf("   stored results: %d of %d launches differ from the first\n", differing_launches, launches - 1);
+    return 0;
+}
