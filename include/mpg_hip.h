@@ -180,10 +180,10 @@ int mpg_sum_slots(const float* slots, int n_slots, int n, float* out, mpg_stream
 
 /* Hyper-parameters of one config (host memory, read at call time). */
 typedef struct {
-    int obs_dim, act_dim;       /* path tracking: 6 + num_future_data (0 <= num_future_data <= 8), 2; pendulum: 4, 1.
-                                   LIMIT: the reference accepts any num_future_data (path_tracking_env.py:385-402); every entry
-                                   point that evaluates a network returns MPG_EINVAL for obs_dim > 14 (first layers are at most
-                                   16 wide); the env entry points serve num_future_data <= MPG_ENV_MAX_FUTURE = 10 */
+    int obs_dim, act_dim;       /* path tracking: 6 + num_future_data (0 <= num_future_data <= MPG_ENV_MAX_FUTURE = 10), 2;
+                                   pendulum: 4, 1.  LIMIT: the reference accepts any num_future_data
+                                   (path_tracking_env.py:385-402); every entry point returns MPG_EINVAL for obs_dim > 16 (first
+                                   layers: policy up to 16 wide, critics up to 24; obs_scale[16]) */
     int policy_out_act;         /* MPG_ACT_TANH (train_script.py:267) or MPG_ACT_LINEAR (train_script4mujoco.py:371) */
     float action_range;         /* <= 0: none; pendulum 3.0 -> a = range*tanh(mean) (policy.py:197-199) */
     float obs_scale[16];        /* 'scale' preprocessor, preprocessor.py:142-143 (train_script.py: [1,1,2,1,2.4,1/1200] + [1]*num_future_data) */
@@ -275,7 +275,7 @@ int mpg_q_loss_grad(const mpg_cfg_t* cfg, const float* q_params, int rows, const
  *   grad    flat policy gradient (68612 floats path tracking) of the loss, reduced over this GPU's rows, NOT clipped.
  * Look-ahead observations (cfg->obs_dim > 6, num_future_data of path_tracking_env.py:246-270): the start observation's
  * look-ahead entries are inputs, every model observation's are copies of delta_y (:262-268) and their adjoint folds into
- * delta_y's; this case needs M == 1 and all_steps_param_grad == 0 (MPG_EINVAL otherwise). */
+ * delta_y's; any M and either parameter-gradient mode (round 4). */
 size_t mpg_rollout_pg_workspace_bytes(const mpg_cfg_t* cfg, int rows, int M, int n, int n_select,
                                       int all_steps_param_grad);
 int mpg_rollout_pg(const mpg_cfg_t* cfg, const float* policy_params, const float* q1_params, int rows, int M,

@@ -211,7 +211,7 @@ inline OutSpec linear_out() {
 inline bool cfg_ok(const mpg_cfg_t* c) {
     // policy_out_activation='tanh' WITH an action_range would be range*tanh(tanh(z)) in the reference (policy.py:176-177,
     // 197-199); the kernels implement range*tanh(z) / tanh(z) / z only, so that combination is refused, not approximated
-    return c && ((c->obs_dim >= 6 && c->obs_dim <= 14 && c->act_dim == 2) || (c->obs_dim == 4 && c->act_dim == 1)) &&
+    return c && ((c->obs_dim >= 6 && c->obs_dim <= 16 && c->act_dim == 2) || (c->obs_dim == 4 && c->act_dim == 1)) &&
            !(c->policy_out_act == MPG_ACT_TANH && c->action_range > 0.f);
 }
 

@@ -27,11 +27,12 @@ constexpr int KS = 68;         // stride between the 4 k-phases of a row; (LDA, 
 constexpr int XS = 8;          // row stride of the small LDS input block for networks with up to 8 inputs
 // Networks with 9 .. 16 inputs (observations with look-ahead terms, path_tracking_env.py:385-402: obs_dim = 6 + num_future_data;
 // SURVEY f3) run the same engine with a 16-wide input block: template parameter IN = 16 stands for "up to 16, the actual width
-// is Net::in_dim", layer 1 is four k-steps of the fp32 MFMA instead of two, the dx partials are 16 wide.
+// is Net::in_dim", layer 1 is four k-steps of the fp32 MFMA instead of two, the dx partials are 16 wide.  IN = 24: up to 24
+// inputs (the critics of num_future_data = 9, 10: 17 / 18 inputs) - six k-steps, a second 16-column tile of dx partials.
 template <int IN>
-__host__ __device__ constexpr int xs_of() { return IN <= 8 ? 8 : 16; }
+__host__ __device__ constexpr int xs_of() { return IN <= 8 ? 8 : (IN <= 16 ? 16 : 24); }
 template <int IN>
-__host__ __device__ constexpr int l1_steps() { return IN <= 8 ? 2 : 4; }
+__host__ __device__ constexpr int l1_steps() { return IN <= 8 ? 2 : (IN <= 16 ? 4 : 6); }
 constexpr int MAXOUT = 2;      // outputs ever *used* (policy mean: act_dim <= 2; critic: 1)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -490,16 +491,21 @@ template <int IN, int OU>
 struct SmallRegs {
     float w1p[l1_steps<IN>()][2];   // layer-1 MFMA B operand: W1[4q + rg][col(t)] (0 beyond in_dim), index [q][t]
     float w1t[8];      // dx MFMA B operand: W1[c][32w + 4q + rg] (0 for c >= in_dim), q = 0..7
+    float w1t2[IN > 16 ? 8 : 1];   // the same for input columns 16 + c (24-wide networks)
     float b1[2], b2[2];
     float w3[2][OU];   // W3[col(t)][o]
 };
 
 template <int IN, int OU>
 __device__ __forceinline__ void load_small(const Net& n, const Lane& L, SmallRegs<IN, OU>& r) {
-    static_assert(IN <= 16, "layer-1 MFMA covers K <= 16");
-    // masks by the network's actual width (== IN for the exact instantiations, <= 16 for the wide one)
+    static_assert(IN <= 24, "layer-1 MFMA covers K <= 24");
+    // masks by the network's actual width (== IN for the exact instantiations, <= 16 / <= 24 for the wide ones)
 #pragma unroll
     for (int q = 0; q < 8; ++q) r.w1t[q] = L.c < n.in_dim ? n.W1[L.c * H + 32 * L.wave + 4 * q + L.rg] : 0.f;
+    if constexpr (IN > 16) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) r.w1t2[q] = 16 + L.c < n.in_dim ? n.W1[(16 + L.c) * H + 32 * L.wave + 4 * q + L.rg] : 0.f;
+    }
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int col = L.col(t);
@@ -509,6 +515,32 @@ __device__ __forceinline__ void load_small(const Net& n, const Lane& L, SmallReg
         r.b2[t] = n.b2[col];
 #pragma unroll
         for (int o = 0; o < OU; ++o) r.w3[t][o] = n.W3[col * n.out_dim + o];
+    }
+}
+
+// dx partial of this wave's 32 hidden columns on the matrix pipe (exact fp32 MFMA): A = dz1 (a0 | a1: this wave's own columns of the
+// float32 LDS image), B = W1^T; one 16-column tile of input columns, a second one for the 24-wide networks
+template <int IN, int OU>
+__device__ __forceinline__ void dx_partials(const SmallRegs<IN, OU>& r, const Lane& L, const f32x4& a0, const f32x4& a1, float* sPartX) {
+    f32x4 dx = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dx = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[q], r.w1t[q], dx, 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dx = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[q], r.w1t[4 + q], dx, 0, 0, 0);
+    if (L.c < xs_of<IN>()) {        // columns beyond in_dim carry zero weights: they are written as zeros
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sPartX[(L.wave * GROUP + L.row(j)) * xs_of<IN>() + L.c] = dx[j];
+    }
+    if constexpr (IN > 16) {
+        f32x4 dx2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dx2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[q], r.w1t2[q], dx2, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dx2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[q], r.w1t2[4 + q], dx2, 0, 0, 0);
+        if (16 + L.c < xs_of<IN>()) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sPartX[(L.wave * GROUP + L.row(j)) * xs_of<IN>() + 16 + L.c] = dx2[j];
+        }
     }
 }
 
@@ -774,15 +806,7 @@ __device__ __forceinline__ void backward_rest(const float* sD3, float* sA, float
         __builtin_amdgcn_wave_barrier();
         const float* base = sA1 + L.c * LDA + L.rg * KS + 8 * L.wave;
         const f32x4 a0 = *reinterpret_cast<const f32x4*>(base), a1 = *reinterpret_cast<const f32x4*>(base + 4);
-        f32x4 dx = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int q = 0; q < 4; ++q) dx = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[q], r.w1t[q], dx, 0, 0, 0);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) dx = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[q], r.w1t[4 + q], dx, 0, 0, 0);
-        if (L.c < xs_of<IN>()) {        // columns beyond in_dim carry zero weights: they are written as zeros
-#pragma unroll
-            for (int j = 0; j < 4; ++j) sPartX[(L.wave * GROUP + L.row(j)) * xs_of<IN>() + L.c] = dx[j];
-        }
+        dx_partials<IN, OU>(r, L, a0, a1, sPartX);
     }
     MPG_STAMP_AT(4);
     if (FINAL_BARRIER) {
@@ -864,15 +888,7 @@ __device__ __forceinline__ void backward_group2(const float* sD3a, const float* 
             __builtin_amdgcn_wave_barrier();
             const float* base = sA1 + L.c * LDA + L.rg * KS + 8 * L.wave;
             const f32x4 q0 = *reinterpret_cast<const f32x4*>(base), q1 = *reinterpret_cast<const f32x4*>(base + 4);
-            f32x4 dx = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int q = 0; q < 4; ++q) dx = __builtin_amdgcn_mfma_f32_16x16x4f32(q0[q], r.w1t[q], dx, 0, 0, 0);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) dx = __builtin_amdgcn_mfma_f32_16x16x4f32(q1[q], r.w1t[4 + q], dx, 0, 0, 0);
-            if (L.c < xs_of<IN>()) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) sPartX[(L.wave * GROUP + L.row(j)) * xs_of<IN>() + L.c] = dx[j];
-            }
+            dx_partials<IN, OU>(r, L, q0, q1, sPartX);
             __builtin_amdgcn_s_waitcnt(0xC07F);          // the second group's dz1 overwrites the image this wave has just read
             __builtin_amdgcn_wave_barrier();
         }

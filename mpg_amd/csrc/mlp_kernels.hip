@@ -111,6 +111,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_forward(const FwdArgs a) {
     else if ((in_dim) > 8 && (in_dim) <= 16 && (ou) == 1) { CALL(16, 1); }    \
     else if ((in_dim) == 7 && (ou) == 2) { CALL(16, 2); }                     \
     else if ((in_dim) == 8 && (ou) == 2) { CALL(16, 2); }                     \
+    else if ((in_dim) > 16 && (in_dim) <= 24 && (ou) == 1) { CALL(24, 1); }   \
     else {                                                                    \
         mpg_set_error("unsupported network shape in=%d used-out=%d", (in_dim), (ou)); \
         return MPG_EINVAL;                                                    \

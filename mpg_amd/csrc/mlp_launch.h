@@ -9,14 +9,14 @@ struct XSpec {              // network input = [x0 (d0 columns, column i < n_sca
     int d0, ld0;            // ld = row stride in floats
     const float* x1;
     int d1, ld1;
-    float scale[16];
+    float scale[24];        // 1 beyond n_scaled (n_scaled <= 16: mpg_cfg_t.obs_scale has 16 entries)
     int n_scaled;
 };
 
 inline XSpec xspec(const float* x0, int d0, const float* x1, int d1, const float* scale, int n_scaled) {
     XSpec s;
     s.x0 = x0; s.d0 = d0; s.ld0 = d0; s.x1 = x1; s.d1 = d1; s.ld1 = d1; s.n_scaled = n_scaled;
-    for (int i = 0; i < 16; ++i) s.scale[i] = (scale && i < n_scaled) ? scale[i] : 1.f;
+    for (int i = 0; i < 24; ++i) s.scale[i] = (scale && i < n_scaled && i < 16) ? scale[i] : 1.f;
     return s;
 }
 

@@ -94,7 +94,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int sl, con
             const long gr = g * GROUP + row;
             const bool from_x0 = i < a.in_dim && i < a.x.d0, from_x1 = i < a.in_dim && !from_x0, from_d3 = i >= XW && i - XW < OU;
             const bool on = gr < a.rows && (from_x0 || from_x1 || from_d3);
-            float sc = a.x.scale[i & 15];
+            float sc = a.x.scale[i < 24 ? i : 0];
             if (!from_x0) sc = 1.f;
             stage[L.lane + 64 * u] = on ? st.v[u] * sc : 0.f;
         }

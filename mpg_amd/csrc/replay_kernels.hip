@@ -28,7 +28,7 @@ __global__ void k_add(int capacity, int next_idx, int n, int od, int ad, const f
 
 // one transition: every load is issued before the first store (written as dependent load/store pairs the 15 random
 // reads of a row serialise on HBM latency: 11 us for 4096 rows instead of 3)
-constexpr int MAXOD = 16, MAXAD = 2;       // 16: PathTracking observations with look-ahead entries (6 + num_future_data <= 14)
+constexpr int MAXOD = 16, MAXAD = 2;       // 16: PathTracking observations with look-ahead entries (6 + num_future_data <= 16)
 template <int WOD>
 __device__ __forceinline__ void gather_row_w(const Ring& r, long s, long i, int od, int ad, float* __restrict__ o_obs,
                                            float* __restrict__ o_act, float* __restrict__ o_rew,

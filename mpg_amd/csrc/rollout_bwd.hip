@@ -119,7 +119,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_bwd(const RollBwdArgs a)
                             if constexpr (WIDE) {
                                 if (t > 0) {
 #pragma unroll
-                                    for (int k = 0; k < 8; ++k)
+                                    for (int k = 0; k < MAXF; ++k)
                                         if (k < nf) lam[ENV::FUT_SRC] += gx[OBS + k] * a.obs_scale[OBS + k];
                                 }
                             }
@@ -214,7 +214,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_bwd(const RollBwdArgs a)
                     for (int i = 0; i < OBS; ++i) lam[i] += dxr[i] * a.obs_scale[i];
                     if constexpr (WIDE) {       // t > 0 here: the observation of this step came out of the model
 #pragma unroll
-                        for (int k = 0; k < 8; ++k)
+                        for (int k = 0; k < MAXF; ++k)
                             if (k < nf) lam[ENV::FUT_SRC] += dxr[OBS + k] * a.obs_scale[OBS + k];
                     }
                 }

@@ -14,6 +14,7 @@ using namespace mlp;
 
 constexpr int MAXN = 32;      // horizon limit (reference default n = 25)
 constexpr int MAXSEL = 4;     // slices entering the loss (reference default {0, 25})
+constexpr int MAXF = MPG_ENV_MAX_FUTURE;   // look-ahead entries of an observation (path_tracking_env.py:385-402)
 constexpr int SAW = 8;        // floats per (step, trajectory) record: obs | action
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -4,7 +4,7 @@
 namespace rollout {
 namespace {
 
-// WIDE: observations with look-ahead entries (obs_dim = ENV::OBS + nf, nf <= 8): the networks run the 16-wide form of
+// WIDE: observations with look-ahead entries (obs_dim = ENV::OBS + nf, nf <= MPG_ENV_MAX_FUTURE = 10): the networks run the 16-wide form of
 // the engine (mlp_core.h), the six base entries evolve with the model and the look-ahead entries of every MODEL observation are
 // copies of entry ENV::FUT_SRC (path_tracking_env.py:262-268), the start observation's come from the batch.
 template <class ENV, bool PK, bool WIDE = false>
@@ -59,7 +59,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_fwd(const RollArgs a) {
         float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};        // book lanes: the model state (as observation)
         float G = 0.f;                                                  // book lanes: discounted reward sum so far
         float act_first[2] = {0.f, 0.f};
-        float f0[WIDE ? 8 : 1] = {};                                    // look-ahead entries of the start observation
+        float f0[WIDE ? MAXF : 1] = {};                                    // look-ahead entries of the start observation
         bool saw_nan = false;                   // learner-side judge_is_nan (worker.py:95-107): start states, first actions, noise
         if (live) {
             // (M == 1: the trajectory IS the batch row - no 64-bit modulo, ~150 instructions, in front of the first loads)
@@ -69,7 +69,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_fwd(const RollArgs a) {
             for (int i = 0; i < OBS; ++i) o[i] = src[i];
             if constexpr (WIDE) {
 #pragma unroll
-                for (int k = 0; k < 8; ++k) f0[k] = k < nf ? src[OBS + k] : 0.f;
+                for (int k = 0; k < MAXF; ++k) f0[k] = k < nf ? src[OBS + k] : 0.f;
             }
             if (a.act0) {
 #pragma unroll
@@ -82,7 +82,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_fwd(const RollArgs a) {
             for (int i = 0; i < OBS; ++i) chk += o[i];
             if constexpr (WIDE) {
 #pragma unroll
-                for (int k = 0; k < 8; ++k) chk += f0[k];
+                for (int k = 0; k < MAXF; ++k) chk += f0[k];
             }
             saw_nan |= chk != chk;
         }
@@ -130,7 +130,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_fwd(const RollArgs a) {
             for (int i = 0; i < XSW; ++i) {
                 float v = 0.f;
                 if (i < OBS) v = ob[i] * a.obs_scale[i];
-                else if (WIDE && i - OBS < nf) v = (first ? f0[(i - OBS) & 7] : ob[ENV::FUT_SRC]) * a.obs_scale[i];
+                else if (WIDE && i - OBS < nf) v = (first ? f0[i - OBS < MAXF ? i - OBS : 0] : ob[ENV::FUT_SRC]) * a.obs_scale[i];
                 sX[tid * XSW + i] = v;
             }
         };
@@ -207,7 +207,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_fwd(const RollArgs a) {
                             for (int i = 0; i < OBS; ++i) xq[i] = o[i] * a.obs_scale[i];
                             if constexpr (WIDE) {
 #pragma unroll
-                                for (int k = 0; k < 8; ++k)
+                                for (int k = 0; k < MAXF; ++k)
                                     if (k < nf) xq[OBS + k] = (t == 0 ? f0[k] : o[ENV::FUT_SRC]) * a.obs_scale[OBS + k];
                             }
                             a.GK[(long)ks * R + tr] = G;

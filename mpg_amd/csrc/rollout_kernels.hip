@@ -110,19 +110,37 @@ struct Carver {
 inline size_t pad256(size_t nfloat) { return ((nfloat * sizeof(float) + 255) & ~size_t(255)) + 256; }
 
 inline bool cfg_ok(const mpg_cfg_t* c) {
-    return c && ((c->obs_dim >= 6 && c->obs_dim <= 14 && c->act_dim == 2 && c->env_kind == MPG_ENV_PATH_TRACKING) ||
+    return c && ((c->obs_dim >= 6 && c->obs_dim <= 16 && c->act_dim == 2 && c->env_kind == MPG_ENV_PATH_TRACKING) ||
                  (c->obs_dim == 4 && c->act_dim == 1 && c->env_kind == MPG_ENV_INVERTED_PENDULUM)) &&
            !(c->policy_out_act == MPG_ACT_TANH && c->action_range > 0.f);   // see learner_api.hip:cfg_ok
 }
 
 
 struct PgLayout {
-    size_t h, sa, xq, gk, q, dyq, hq, gxq, dz, dz3, slabs, small, thin, total;
+    size_t h, sa, xq, gk, q, dyq, hq, gxq, dz, dz3, slabs, small, thin, xw, total;
 };
 
 // the thin gradients ride in the reverse sweep (rollout_common.h) when every step is differentiated through the parameters, the
 // trajectories are the batch rows and the packed backward image exists (the THIN instantiations are packed-image kernels)
 inline bool thin_in_sweep(const mpg_cfg_t* cfg, int M, int stash_all) { return stash_all && M == 1 && cfg->obs_dim <= 6; }
+// observations with look-ahead entries: the first layer's inputs of the stashed steps are written out for the weight-gradient launch
+// (k_wide_inputs) unless they are the caller's batch itself (M == 1, step 0 only)
+inline bool wide_inputs_needed(const mpg_cfg_t* cfg, int M, int stash_all) { return cfg->obs_dim > 6 && (M > 1 || stash_all); }
+
+// out [T][R][od] (raw, the scale is applied by the consumer): step 0 - the caller's batch row of the trajectory (look-ahead entries
+// computed by the env); steps t > 0 - the model state's base entries and, for every look-ahead entry, a copy of entry fut_src
+// (PathTrackingModel._get_obs, path_tracking_env.py:262-268)
+__global__ void k_wide_inputs(int T, long R, int rows, int od, int obs_base, int fut_src, const float* __restrict__ obs0,
+                              const float* __restrict__ SA, float* __restrict__ out) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)T * R * od) return;
+    const int i = (int)(idx % od);
+    const long tr = (idx / od) % R, t = idx / od / R;
+    float v;
+    if (t == 0) v = obs0[(tr % rows) * od + i];
+    else v = SA[(t * R + tr) * SAW + (i < obs_base ? i : fut_src)];
+    out[idx] = v;
+}
 
 PgLayout pg_layout(const mpg_cfg_t* cfg, int rows, int M, int n, int n_sel, int stash_all) {
     PgLayout l;
@@ -140,8 +158,9 @@ PgLayout pg_layout(const mpg_cfg_t* cfg, int rows, int M, int n, int n_sel, int 
     l.slabs = wgrad_workspace_floats((int)(T * stash_floats(R) / H), cfg->obs_dim, 2 * cfg->act_dim);
     l.small = 64;
     l.thin = thin_in_sweep(cfg, M, stash_all) ? (size_t)256 * thin_floats(cfg->obs_dim, 2 * cfg->act_dim) : 0;
+    l.xw = wide_inputs_needed(cfg, M, stash_all) ? (size_t)T * R * cfg->obs_dim : 0;
     l.total = 2 * pad256(l.h) + pad256(l.sa) + pad256(l.xq) + 3 * pad256(l.gk) + 2 * pad256(l.hq) + pad256(l.gxq) +
-              2 * pad256(l.dz) + pad256(l.dz3) + pad256(l.slabs) + 2 * pad256(l.small) + pad256(l.thin);
+              2 * pad256(l.dz) + pad256(l.dz3) + pad256(l.slabs) + 2 * pad256(l.small) + pad256(l.thin) + pad256(l.xw);
     return l;
 }
 
@@ -212,7 +231,6 @@ int run_rollout_bwd(const mpg_cfg_t* cfg, const float* policy_params, int rows, 
 extern "C" size_t mpg_rollout_pg_workspace_bytes(const mpg_cfg_t* cfg, int rows, int M, int n, int n_select,
                                                  int all_steps_param_grad) {
     if (!cfg_ok(cfg) || rows <= 0 || M <= 0 || n <= 0 || n >= MAXN || n_select <= 0 || n_select > MAXSEL) return 0;
-    if (cfg->obs_dim > 6 && (all_steps_param_grad || M != 1)) return 0;     // refused by mpg_rollout_pg (look-ahead observations)
     return pg_layout(cfg, rows, M, n, n_select, all_steps_param_grad).total;
 }
 
@@ -226,10 +244,6 @@ extern "C" int mpg_rollout_pg(const mpg_cfg_t* cfg, const float* policy_params, 
     MPG_REQUIRE(rows > 0 && M > 0 && n > 0 && n < MAXN && n_select > 0 && n_select <= MAXSEL, "mpg_rollout_pg: bad sizes");
     const long R = (long)rows * M;
     MPG_REQUIRE(!all_steps_param_grad || R % GROUP == 0, "mpg_rollout_pg: all_steps_param_grad needs rows*M %% 16 == 0");
-    // look-ahead observations (obs_dim > 6): the WIDE reverse sweep folds the model observations' look-ahead adjoints assuming M == 1
-    // and only step 0 is differentiated through the parameters - refused BEFORE anything is launched or written
-    MPG_REQUIRE(cfg->obs_dim <= 6 || (!all_steps_param_grad && M == 1),
-                "mpg_rollout_pg: look-ahead observations need M == 1 and the step-0 parameter gradient");
     for (int k = 0; k < n_select; ++k) MPG_REQUIRE(select[k] >= 0 && select[k] <= n, "mpg_rollout_pg: slice out of range");
     const PgLayout l = pg_layout(cfg, rows, M, n, n_select, all_steps_param_grad);
     if (ws_bytes < l.total) {
@@ -246,6 +260,7 @@ extern "C" int mpg_rollout_pg(const mpg_cfg_t* cfg, const float* policy_params, 
     float* DZ1 = cv.take(l.dz); float* DZ2 = cv.take(l.dz); float* DZ3 = cv.take(l.dz3);
     float* slabs = cv.take(l.slabs);
     float* thin_part = l.thin ? cv.take(l.thin) : nullptr;
+    float* XW = l.xw ? cv.take(l.xw) : nullptr;
     // (the THIN reverse sweep is a packed-image kernel: without the caller's weight cache the thin parts stay in the wgrad launch)
     if (thin_part && !weight_cache_lookup(cfg, make_net(policy_params, cfg->obs_dim, 2 * cfg->act_dim).W2, 1)) thin_part = nullptr;
 
@@ -277,10 +292,17 @@ extern "C" int mpg_rollout_pg(const mpg_cfg_t* cfg, const float* policy_params, 
     // ---- policy weight gradient from the stashes (step 0 only, or every step for NADP) ----
     const int T = all_steps_param_grad ? n + 1 : 1;
     // the first layer's input of every stashed step: the (obs | action) records hold the six base entries; with look-ahead entries
-    // (obs_dim > 6) only step 0 is ever differentiated through the parameters here and its input is the caller's batch itself
+    // (obs_dim > 6) it is the caller's batch itself (M == 1, step 0 only) or written out by k_wide_inputs
     XSpec xs = xspec(SA, od, nullptr, 0, cfg->obs_scale, od);
     xs.ld0 = SAW;
-    if (od > 6) xs = xspec(obs0, od, nullptr, 0, cfg->obs_scale, od);     // (M == 1, step-0 gradient: checked before the first launch)
+    if (od > 6) xs = xspec(obs0, od, nullptr, 0, cfg->obs_scale, od);
+    if (XW) {
+        const long nx = (long)T * R * od;
+        hipLaunchKernelGGL(k_wide_inputs, dim3((unsigned)((nx + 255) / 256)), dim3(256), 0, s, T, R, rows, od, PathTracking::OBS,
+                           PathTracking::FUT_SRC, obs0, SA, XW);
+        MPG_CHECK_LAUNCH("k_wide_inputs");
+        xs = xspec(XW, od, nullptr, 0, cfg->obs_scale, od);
+    }
     rc = launch_wgrad(cfg, od, 2 * ad, ad, (int)(T * R), xs, H1, H2, DZ1, DZ2, DZ3, inv_b_global / (float)M, grad, slabs, s,
                       thin_part != nullptr);
     if (rc || !thin_part) return rc;

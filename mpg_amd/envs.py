@@ -61,8 +61,8 @@ class _DeviceVecEnv(object):
 
 class PathTrackingEnv(_DeviceVecEnv):
     """PathTrackingEnv(num_future_data, num_agent) - path_tracking_env.py:356-487.  Observations have 6 + num_future_data
-    entries: the six base entries and the look-ahead delta-y terms of :385-402.  The env serves 0 <= num_future_data <= 10;
-    the networks take first layers up to 16 wide, i.e. num_future_data <= 8 through worker / learner / evaluator (the
+    entries: the six base entries and the look-ahead delta-y terms of :385-402.  The env, worker, learner and evaluator
+    serve 0 <= num_future_data <= 10 (policy inputs up to 16 wide, critic inputs up to 18: the 16- and 24-wide network kernels; the
     shipped parser default is 0, train_script.py:90; with look-ahead entries the learner takes the launch-per-stage path, the
     fused kernels are built for the base widths)."""
     kind, act_dim = 0, 2

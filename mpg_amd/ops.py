@@ -108,15 +108,14 @@ class Profiler(object):
 def make_cfg(env_id='PathTracking-v0', obs_scale=None, rew_scale=None, rew_shift=0.0, gamma=0.98,
              policy_out_activation=None, action_range=None, obs_dim=None):
     """Defaults are the reference's (train_script.py:202-306 / train_script4mujoco.py:296-411).  obs_dim: 6 + num_future_data
-    for PathTracking (train_script.py:794-811), up to 14."""
+    for PathTracking (train_script.py:794-811), up to 16 (num_future_data <= 10, the env's own limit here)."""
     pt = env_id == 'PathTracking-v0'
     c = CfgStruct()
     c.obs_dim, c.act_dim = (int(obs_dim) if (pt and obs_dim) else 6, 2) if pt else (4, 1)
-    if pt and not 6 <= c.obs_dim <= 14:
+    if pt and not 6 <= c.obs_dim <= 16:
         # the library's own answer for such a cfg is MPG_EINVAL at the first launch (cfg_ok): raise it where the cfg is built
-        raise L.MpgError('MPG_EINVAL: PathTracking observations have 6 + num_future_data entries and the network kernels take first '
-                         'layers up to 16 wide: num_future_data <= 8 through worker / learner / evaluator (got obs_dim %d); the '
-                         'env kernels alone serve num_future_data <= 10' % c.obs_dim)
+        raise L.MpgError('MPG_EINVAL: PathTracking observations have 6 + num_future_data entries and the env and network kernels serve '
+                         'num_future_data <= 10 (policy inputs up to 16 wide, critic inputs up to 18; got obs_dim %d)' % c.obs_dim)
     if policy_out_activation is None:
         policy_out_activation = 'tanh' if pt else 'linear'
     c.policy_out_act = ACT_TANH if policy_out_activation == 'tanh' else ACT_LINEAR

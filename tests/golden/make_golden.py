@@ -17,6 +17,7 @@ same float32-rounded inputs - the error yard-stick of SURVEY.md §8c):
   pendulum_model_ref.npz InvertedPendulumModel.rollout_out x 25 (a7)
   mpg_{v1,v2}_H{H}_B{B}.npz   MPGLearner.compute_gradient (a11-a17) at iterations 100 and 9000
   mpg_v2_H256_B64_K3.npz      the same with num_future_data = 3 (obs_dim 9, first layers 9 / 11 wide)
+  mpg_v2_H256_B64_K10.npz     the same with num_future_data = 10 (obs_dim 16, first layers 16 / 18 wide)
   nadp_H{H}_B{B}.npz     NADPLearner.compute_gradient on the pendulum model (a18)
   td3_H{H}_B{B}.npz      TD3Learner.compute_gradient with recorded smoothing noise (a19)
   segment_tree_ref.npz   SumSegmentTree / MinSegmentTree primitives (a22)
@@ -624,6 +625,7 @@ ROUND2 = {'replay_buffer': fx_replay_buffer, 'evaluator': fx_evaluator, 'env_fut
 ROUND2.update({n: (lambda n=n: fx_bench_case(n)) for n in BENCH_CASES})
 ROUND2['trained_c2'] = lambda: fx_bench_case('c2_mpg_v2_B4096', trained=True)      # round 3
 ROUND2['mpg_future'] = lambda: fx_mpg('MPG-v2', 256, 64, seed=12, K=3)               # round 3: num_future_data = 3
+ROUND2['mpg_future10'] = lambda: fx_mpg('MPG-v2', 256, 64, seed=13, K=10)           # round 4: num_future_data = 10 (obs_dim 16, critics 18 wide)
 
 
 def main():

@@ -32,7 +32,7 @@ def _learner(g, version, B=64, K=0):
     return learner
 
 
-@pytest.mark.parametrize('version,K', [('v2', 0), ('v1', 0), ('v2', 3)])
+@pytest.mark.parametrize('version,K', [('v2', 0), ('v1', 0), ('v2', 3), ('v2', 10)])
 def test_compute_gradient_vs_reference_golden(golden, version, K):
     """The full list the reference's MPGLearner.compute_gradient returns (clipped q1, (q2), policy gradients) and its
     stats, on the same minibatch, weights and model noise.  <= 1e-4 relative L2 per array.
@@ -287,10 +287,11 @@ def test_repeated_launches_are_bit_identical_small_batches_and_look_ahead(case):
     assert differing == 0, '%d of 400 launches differ from the majority result' % differing
 
 
-def test_look_ahead_beyond_eight_entries_is_refused_at_construction():
-    """path_tracking_env.py:385-402 accepts any num_future_data; the network kernels take first layers up to 16 wide, i.e.
-    num_future_data <= 8 (include/mpg_hip.h, mpg_cfg_t.obs_dim).  9 and 10 are served by the ENV kernels only: the classes that
-    build networks refuse them with a defined error when they are constructed, not at the first launch."""
+def test_look_ahead_nine_and_ten_entries_are_served_and_eleven_refused():
+    """path_tracking_env.py:385-402 accepts any num_future_data; here the env, the 16-wide policy kernels and the 24-wide critic kernels
+    serve num_future_data <= 10 (include/mpg_hip.h, mpg_cfg_t.obs_dim <= 16) through worker, ring, learner and optimizer - round 4; the
+    reference-generated golden at K = 10 is test_compute_gradient_vs_reference_golden[v2-10].  11 is refused with a defined error when
+    the classes are constructed, not at the first launch."""
     from mpg_amd._lib import MpgError
     from mpg_amd.config import default_args
     from mpg_amd.envs import PathTrackingEnv
@@ -298,8 +299,12 @@ def test_look_ahead_beyond_eight_entries_is_refused_at_construction():
     env = PathTrackingEnv(num_future_data=10, num_agent=8)
     assert env.reset().shape == (8, 16)
     for K in (9, 10):
-        with pytest.raises(MpgError, match='num_future_data'):
-            PolicyWithQs(**vars(default_args('MPG-v2', num_future_data=K)))
+        pw = PolicyWithQs(**vars(default_args('MPG-v2', num_future_data=K)))
+        assert pw.obs_dim == 6 + K and pw.dims['Q1'][0] == 8 + K
+    with pytest.raises(MpgError, match='num_future_data'):
+        PolicyWithQs(**vars(default_args('MPG-v2', num_future_data=11)))
+    with pytest.raises((MpgError, ValueError, AssertionError)):
+        PathTrackingEnv(num_future_data=11, num_agent=8)
 
 
 def test_replay_buffer_ring_and_gather_bit_exact():
@@ -399,9 +404,9 @@ def test_mpg_v1_with_look_ahead_observations_vs_oracle():
                       where='MPG-v1 K=2')
 
 
-@pytest.mark.parametrize('fused', [False, True])
-def test_training_loop_with_look_ahead_observations(fused):
-    """num_future_data = 3 through worker, replay ring, learner and optimizer (train_script.py:90,146-147; worker.py:38;
+@pytest.mark.parametrize('fused,K', [(False, 3), (True, 3), (True, 10)])
+def test_training_loop_with_look_ahead_observations(fused, K):
+    """num_future_data = 3 (and 10: 16-wide policy, 18-wide critics - the 24-column network kernels) through worker, replay ring, learner and optimizer (train_script.py:90,146-147; worker.py:38;
     mpg_learner.py:35,48): observations are 9 wide, the first layers 9 / 11 wide.  The gradient of a minibatch of the worker's
     own transitions equals the oracle's on the same minibatch, weights and model noise; the loop runs, stays finite and learns
     the critic."""
@@ -411,18 +416,17 @@ def test_training_loop_with_look_ahead_observations(fused):
     from mpg_amd.optimizer import SingleProcessOffPolicyOptimizer
     from mpg_amd.policy import PolicyWithQs
     from mpg_amd.worker import OffPolicyWorker
-    K = 3
     torch.manual_seed(0)                          # the model noise of the checked gradient (everything else is Philox-keyed)
     args = default_args('MPG-v2', num_agent=64, batch_size=512, replay_batch_size=256, replay_starts=1024, max_buffer_size=8192,
                         value_lr_schedule=[1e-3, 100000, 1e-4], num_future_data=K)
-    assert args.obs_dim == 9 and len(args.obs_scale) == 9
+    assert args.obs_dim == 6 + K and len(args.obs_scale) == 6 + K
     worker = OffPolicyWorker(PolicyWithQs, args.env_id, args, 0)
     learner = MPGLearner(PolicyWithQs, args)
     rb = ReplayBuffer(args, 0)
     opt = SingleProcessOffPolicyOptimizer(worker, learner, rb, None, args, fused=fused)
     assert (opt._fused is not None) == fused
     pw = worker.policy_with_value
-    assert rb.obs.shape[1] == 9 and pw.dims['policy'] == (9, 4) and pw.dims['Q1'] == (11, 1)
+    assert rb.obs.shape[1] == 6 + K and pw.dims['policy'] == (6 + K, 4) and pw.dims['Q1'] == (8 + K, 1)
     # the look-ahead entries in the ring are the env's (path_tracking_env.py:385-402), not copies of delta_y
     o = rb.obs[:len(rb)].cpu().numpy()
     assert np.abs(o[:, 6:] - o[:, 3:4]).max() > 1e-3
@@ -436,7 +440,7 @@ def test_training_loop_with_look_ahead_observations(fused):
     grads = learner.compute_gradient(batch, None, None, 500, eps=eps)
     got = torch.cat([x.reshape(-1) for x in grads]).cpu().numpy()
     learner.counter = 0
-    cfg = O.Cfg(obs_dim=9, obs_scale=list(O.OBS_SCALE_PT) + [1.] * K)
+    cfg = O.Cfg(obs_dim=6 + K, obs_scale=list(O.OBS_SCALE_PT) + [1.] * K)
     flat, tflat = pw.params.cpu().numpy(), pw.targets.cpu().numpy()
     off = np.cumsum([0] + list(pw.sizes))
     w = {n: flat[off[i]:off[i + 1]] for i, n in enumerate(pw.names)}
@@ -585,20 +589,22 @@ def test_fast_path_still_learns_path_tracking():
     assert int(worker.policy_with_value.nonfinite.sum().item()) == 0
 
 
-def test_deriv_interval_policy_learner_path(golden):
+@pytest.mark.parametrize('K', [0, 3])
+def test_deriv_interval_policy_learner_path(golden, K):
     """deriv_interval_policy=True (mpg_learner.py:247-248): the learner routes through the fine-grained entry points;
-    critic gradients are the default path's, the policy gradient is the clipped full-BPTT gradient of the same loss."""
-    g = golden('mpg_v2_H256_B64.npz')
-    base = _learner(g, 'v2')
+    critic gradients are the default path's, the policy gradient is the clipped full-BPTT gradient of the same loss.
+    K = 3: the same with look-ahead observations (round 4: any combination the reference accepts)."""
+    g = golden('mpg_v2_H256_B64%s.npz' % ('_K%d' % K if K else ''))
+    base = _learner(g, 'v2', K=K)
     batch = [dev(g[k]) for k in ('batch_obs', 'batch_actions', 'batch_rewards', 'batch_obs_tp1', 'batch_dones')]
     ref = torch.cat([x.reshape(-1) for x in base.compute_gradient(batch, None, None, 100, eps=dev(g['eps']))]).cpu().numpy()
-    full = _learner(g, 'v2')
+    full = _learner(g, 'v2', K=K)
     full.deriv_interval_policy = True
     got = torch.cat([x.reshape(-1) for x in full.compute_gradient(batch, None, None, 100, eps=dev(g['eps']))]).cpu().numpy()
     pw = full.policy_with_value
     nq = pw.offsets[2]
     assert rel_l2(got[:nq], ref[:nq]) < 2e-6
-    ocfg = O.Cfg()
+    ocfg = O.Cfg(obs_dim=6 + K, obs_scale=list(O.OBS_SCALE_PT) + [1.] * K)
     nets = O.Nets(ocfg, {n: g['w_' + n] for n in pw.names}, dtype=torch.float64)
     reduced, _, _ = O.model_rollout_for_policy_update(ocfg, nets, torch.as_tensor(g['batch_obs']).double(),
                                                       torch.as_tensor(g['eps']).double(), rollout_policy='policy')

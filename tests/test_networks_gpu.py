@@ -38,7 +38,8 @@ def test_mlp_forward_vs_oracle(rows, shape):
     flat = rand_net(rng, din, dout)
     x = rng.standard_normal((rows, din)).astype(np.float32)
     scale = rng.uniform(0.5, 2.0, din)
-    y = ops.mlp_forward(dev(flat), din, dout, used, act, dev(x), in_scale=scale, n_scaled=din).cpu().numpy()
+    scale[16:] = 1.0                      # the scale vector has 16 entries (mpg_cfg_t.obs_scale: the observation part of an input)
+    y = ops.mlp_forward(dev(flat), din, dout, used, act, dev(x), in_scale=scale[:16], n_scaled=min(din, 16)).cpu().numpy()
     ws = O.unflatten(flat, din, 256, dout, dtype=torch.float64)
     ref = O.mlp(ws, torch.as_tensor(x, dtype=torch.float64) * torch.as_tensor(scale.astype(np.float32)).double(),
                 'tanh' if act else 'linear').numpy()[:, :used]
@@ -46,9 +47,11 @@ def test_mlp_forward_vs_oracle(rows, shape):
 
 
 @pytest.mark.parametrize('rows', [1, 17, 4099])
-@pytest.mark.parametrize('shape', [(7, 4, 2, 1), (9, 4, 2, 1), (14, 4, 2, 1), (9, 1, 1, 0), (11, 1, 1, 0), (16, 1, 1, 0)])
+@pytest.mark.parametrize('shape', [(7, 4, 2, 1), (9, 4, 2, 1), (14, 4, 2, 1), (16, 4, 2, 1), (9, 1, 1, 0), (11, 1, 1, 0), (16, 1, 1, 0), (17, 1, 1, 0), (18, 1, 1, 0),
+                                   (24, 1, 1, 0)])
 def test_mlp_forward_wide_first_layer_vs_oracle(rows, shape):
-    """first layers 7 .. 16 wide (observations with look-ahead entries, num_future_data <= 8): the 16-column instantiations"""
+    """first layers 7 .. 24 wide (observations with look-ahead entries, num_future_data <= 10: policy 6 + K, critics 8 + K): the 16- and
+    24-column instantiations"""
     test_mlp_forward_vs_oracle(rows, shape)
 
 
@@ -154,7 +157,7 @@ def test_q_loss_grad_vs_golden(golden, fixture, loss_keys):
             o += n
 
 
-@pytest.mark.parametrize('rows,K', [(1, 0), (17, 0), (300, 0), (4096, 0), (17, 1), (300, 3), (4096, 8)])
+@pytest.mark.parametrize('rows,K', [(1, 0), (17, 0), (300, 0), (4096, 0), (17, 1), (300, 3), (4096, 8), (300, 9), (4096, 10)])
 def test_q_loss_grad_vs_oracle_autograd_ragged(rows, K):
     """K look-ahead entries (num_future_data): critic input 8 + K wide"""
     from mpg_amd import ops

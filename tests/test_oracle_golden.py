@@ -102,7 +102,7 @@ def _check_grads(got_flat, g, key, cfg, names, H):
             assert e_got <= 4 * e_ref + 1e-6, (key, nm, e_got, e_ref)
 
 
-@pytest.mark.parametrize('version,H,K', [('v2', 32, 0), ('v1', 32, 0), ('v2', 256, 0), ('v1', 256, 0), ('v2', 256, 3)])
+@pytest.mark.parametrize('version,H,K', [('v2', 32, 0), ('v1', 32, 0), ('v2', 256, 0), ('v1', 256, 0), ('v2', 256, 3), ('v2', 256, 10)])
 def test_mpg_compute_gradient(golden, version, H, K):
     """K = num_future_data (train_script.py:90,146-147): observations carry K look-ahead entries, first layers 6+K / 8+K wide"""
     g = golden('mpg_%s_H%d_B64%s.npz' % (version, H, '_K%d' % K if K else ''))
