@@ -175,11 +175,26 @@ int main(int argc, char** argv) {
     (void)hipMemcpy(dz, h.data(), ndz * 4, hipMemcpyHostToDevice);
     for (size_t i = 0; i < nx; ++i) h[i] = (rand() / (float)RAND_MAX - 0.5f) * 2.f;
     (void)hipMemcpy(xs, h.data(), nx * 4, hipMemcpyHostToDevice);
+    // argv[4]: a code object holding k_mini2 (assembled from an edited copy of the compiler's own assembly: asm_bisect.sh) to launch
+    // instead of the compiled kernel
+    hipFunction_t fn = nullptr;
+    if (argc > 4) {
+        hipModule_t mod;
+        if (hipModuleLoad(&mod, argv[4]) != hipSuccess || hipModuleGetFunction(&fn, mod, "_Z7k_mini2PKfS0_iPf") != hipSuccess) {
+            printf("cannot load %s\n", argv[4]);
+            return 2;
+        }
+    }
     std::vector<float> first(nout), cur(nout);
     int bad = 0;
     size_t lo = 0, hi = 0, other = 0, hist[20] = {0};
     for (int l = 0; l < launches; ++l) {
         (void)hipMemset(out, 0xff, nout * 4);
+        if (fn) {
+            int ni = neighbor_iters;
+            void* args[] = {&dz, &xs, &ni, &out};
+            if (hipModuleLaunchKernel(fn, grid, 1, 1, 512, 1, 1, 0, 0, args, nullptr) != hipSuccess) { printf("module launch failed\n"); return 2; }
+        } else
         hipLaunchKernelGGL(k_mini2, dim3(grid), dim3(512), 0, 0, dz, xs, neighbor_iters, out);
         if (hipDeviceSynchronize() != hipSuccess) { printf("launch failed\n"); return 2; }
         (void)hipMemcpy(cur.data(), out, nout * 4, hipMemcpyDeviceToHost);

@@ -11,6 +11,9 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #ifndef NEIGHBOR
 #define NEIGHBOR 1
 #endif
+#ifndef MFMA_KIND
+#define MFMA_KIND 0      // 0: v_mfma_f32_16x16x32_f16   1: v_mfma_f32_16x16x4_f32   2: v_fma_f32 (no matrix instruction)
+#endif
 
 __global__ void __launch_bounds__(512, 4) k_mini3(int steps, int mfma_iters, unsigned long long* bad, float* sink) {
     const int lane = threadIdx.x & 63;
@@ -21,12 +24,22 @@ __global__ void __launch_bounds__(512, 4) k_mini3(int steps, int mfma_iters, uns
         f32x4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
         for (int it = 0; it < mfma_iters; ++it)
 #pragma unroll
-            for (int u = 0; u < 12; ++u) acc[u & 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc[u & 3], 0, 0, 0);
+            for (int u = 0; u < 12; ++u) {
+#if MFMA_KIND == 1
+                acc[u & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32((float)a[u & 7], (float)b[u & 7], acc[u & 3], 0, 0, 0);
+#elif MFMA_KIND == 2      // not a matrix instruction at all: an 8-byte VOP3 in the same loop shape
+                acc[u & 3][0] = __builtin_fmaf(acc[u & 3][0], 0.999f, 0.001f * (float)a[0]);
+#else
+                acc[u & 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc[u & 3], 0, 0, 0);
+#endif
+            }
         sink[blockIdx.x * 512 + threadIdx.x] = acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3];
 #endif
         return;
     }
     unsigned long long nlo = 0, nhi = 0;
+    unsigned per[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long nzero = 0, nother = 0;          // a deviating low half that is exactly 0 (= its addend: the product is missing) / x * the OTHER register of the pair      // low-half mismatches by instruction of the block
     float x[8], d[4], e[4];
     for (int i = 0; i < 8; ++i) x[i] = 0.37f + 0.013f * (lane + 7 * i);
     for (int j = 0; j < 4; ++j) { d[j] = 1.1e-3f * (1 + ((lane + j) & 7)); e[j] = -0.9e-3f * (1 + ((lane + 3 * j) & 15)); }
@@ -63,6 +76,14 @@ __global__ void __launch_bounds__(512, 4) k_mini3(int steps, int mfma_iters, uns
             asm volatile("v_fma_f32 %0, %1, %2, 0" : "=v"(r0) : "v"(x[xi]), "v"(sp[q]));
             asm volatile("v_fma_f32 %0, %1, %2, 0" : "=v"(r1) : "v"(x[xi + 1]), "v"(sp[q]));
             nlo += __float_as_uint(p[2 * q]) != __float_as_uint(r0);
+            per[q] += __float_as_uint(p[2 * q]) != __float_as_uint(r0);
+            if (__float_as_uint(p[2 * q]) != __float_as_uint(r0)) {
+                const float oth[8] = {d[1], e[1], d[1], e[1], d[0], e[0], d[3], e[2]};
+                float ro;
+                asm volatile("v_fma_f32 %0, %1, %2, 0" : "=v"(ro) : "v"(x[xi]), "v"(oth[q]));
+                nzero += p[2 * q] == 0.f;
+                nother += __float_as_uint(p[2 * q]) == __float_as_uint(ro);
+            }
             nhi += __float_as_uint(p[2 * q + 1]) != __float_as_uint(r1);
         }
         // next step's operands
@@ -73,20 +94,38 @@ __global__ void __launch_bounds__(512, 4) k_mini3(int steps, int mfma_iters, uns
     }
     if (nlo) atomicAdd(bad, nlo);
     if (nhi) atomicAdd(bad + 1, nhi);
+    for (int q = 0; q < 8; ++q)
+        if (per[q]) atomicAdd(bad + 2 + q, (unsigned long long)per[q]);
+    if (nzero) atomicAdd(bad + 10, nzero);
+    if (nother) atomicAdd(bad + 11, nother);
 }
 
 int main(int argc, char** argv) {
     const int launches = argc > 1 ? atoi(argv[1]) : 100, steps = argc > 2 ? atoi(argv[2]) : 2000, mfma_iters = argc > 3 ? atoi(argv[3]) : 3000;
     unsigned long long* bad;
     float* sink;
-    (void)hipMalloc(&bad, 16);
+    (void)hipMalloc(&bad, 96);
     (void)hipMalloc(&sink, 512 * 512 * sizeof(float));
-    (void)hipMemset(bad, 0, 16);
-    for (int l = 0; l < launches; ++l) hipLaunchKernelGGL(k_mini3, dim3(512), dim3(512), 0, 0, steps, mfma_iters, bad, sink);
+    (void)hipMemset(bad, 0, 96);
+    // argv[4]: a code object with k_mini3 assembled from an edited copy of the compiler's assembly (mini3_align.sh places the MFMA loop)
+    hipFunction_t fn = nullptr;
+    if (argc > 4) {
+        hipModule_t mod;
+        if (hipModuleLoad(&mod, argv[4]) != hipSuccess || hipModuleGetFunction(&fn, mod, "_Z7k_mini3iiPyPf") != hipSuccess) { printf("cannot load %s\n", argv[4]); return 2; }
+    }
+    for (int l = 0; l < launches; ++l) {
+        if (fn) {
+            int st = steps, mi = mfma_iters;
+            void* args[] = {&st, &mi, &bad, &sink};
+            if (hipModuleLaunchKernel(fn, 512, 1, 1, 512, 1, 1, 0, 0, args, nullptr) != hipSuccess) { printf("module launch failed\n"); return 2; }
+        } else
+            hipLaunchKernelGGL(k_mini3, dim3(512), dim3(512), 0, 0, steps, mfma_iters, bad, sink);
+    }
     if (hipDeviceSynchronize() != hipSuccess) { printf("launch failed\n"); return 2; }
-    unsigned long long h[2];
-    (void)hipMemcpy(h, bad, 16, hipMemcpyDeviceToHost);
-    printf("NEIGHBOR=%d: %llu low halves and %llu high halves of %.3g packed FMAs differ from the scalar v_fma_f32 of the same operands\n", NEIGHBOR, h[0], h[1],
+    unsigned long long h[12];
+    (void)hipMemcpy(h, bad, 96, hipMemcpyDeviceToHost);
+    printf("NEIGHBOR=%d MFMA_KIND=%d: %llu low halves and %llu high halves of %.3g packed FMAs differ from the scalar v_fma_f32 of the same operands\n", NEIGHBOR, MFMA_KIND, h[0], h[1],
            (double)launches * 256 * 512 * steps * 8);
+    if (h[0]) printf("   low halves by instruction (1-4, 7: op_sel_hi:[1,0,0]; 5, 6, 8: op_sel:[0,1,0]): %llu %llu %llu %llu %llu %llu %llu %llu\n   of these: exactly 0 (the product is missing) %llu, the product with the OTHER register of the src1 pair %llu\n", h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[10], h[11]);
     return 0;
 }
