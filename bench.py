@@ -515,6 +515,25 @@ def main():
     es[1].record()
     torch.cuda.synchronize()
     step_only_ms = es[0].elapsed_time(es[1]) / 64
+    # ... and env step + store + reset alone (mpg_env_step_store_reset on scratch copies of the worker's state and a scratch ring): in the
+    # training step it is part of the fused worker launch (mpg_worker_step: policy pass + env), whose time is reported separately
+    r_cap = 4 * B_PER_GPU
+    r_obs, r_obs2 = torch.empty(r_cap, 6, device=dev), torch.empty(r_cap, 6, device=dev)
+    r_act, r_rew, r_done = torch.empty(r_cap, 2, device=dev), torch.empty(r_cap, device=dev), torch.empty(r_cap, dtype=torch.uint8, device=dev)
+
+    def env_step_store_reset(k):
+        for j in range(k):
+            L.call('mpg_env_step_store_reset', L.c_int(0), L.c_int(B_PER_GPU), L.c_int(6), L.ptr(e_state), L.ptr(e_act), L.c_int(r_cap),
+                   L.c_int((j % 4) * B_PER_GPU), L.ptr(r_obs), L.ptr(r_act), L.ptr(r_rew), L.ptr(r_obs2), L.ptr(r_done), L.c_u64(7), L.c_u64(j),
+                   L.ptr(e_obs), L.ptr(e_done), L.stream())
+    env_step_store_reset(8)
+    torch.cuda.synchronize()
+    torch.cuda._sleep(40000000)
+    es[0].record()
+    env_step_store_reset(64)
+    es[1].record()
+    torch.cuda.synchronize()
+    step_store_reset_ms = es[0].elapsed_time(es[1]) / 64
     finite = bool(torch.isfinite(worker.policy_with_value.params).all().item())
     assert finite and int(worker.policy_with_value.nonfinite.sum().item()) == 0, 'non-finite parameters after the timed region'
     worker.policy_with_value.check_status()          # raises if the split-fp16 engine left its numerical envelope anywhere
@@ -601,17 +620,21 @@ def main():
         'roofline': dominant,
         'roofline_other_rollout_kernel': other,
         'other_kernels_avg_ms': {'k_target_fused': tgt_ms, 'k_critic_fused': crit_ms, 'k_wgrad_multi': wg_ms,
-                                 'k_forward (worker policy)': pol_ms, 'k_step_store_reset (env)': env_ms,
+                                 # (one launch when the native driver runs the path-tracking worker: policy pass + env step)
+                                 'k_forward (worker policy)': pol_ms,
+                                 ('k_policy_step_store_reset (worker policy + env)' if not pol_ms else 'k_step_store_reset (env)'): env_ms,
                                  'k_clip_adam_polyak': adam_ms},
         # the ONE exchange step per gradient step (all-reduce of the flat [gradients | statistics] buffer), HIP events on the
         # launch stream around every PROF_EVERY-th exchange of the timed region on rank 0; null on one GPU (none is enqueued)
         'exchange_ms': xch_ms, 'exchange_launches': xch_n,
-        'env_step_kernel': {'kernel': 'k_step_store_reset', 'avg_ms': env_ms, 'launches': env_n,
-                            'env_steps_per_sec_kernel_only': B_PER_GPU / (env_ms * 1e-3) if env_ms else None,
-                            'algorithmic_bytes_per_env_step': 85},
+        'env_step_kernel': {'kernel': 'k_step_store_reset (mpg_env_step_store_reset)', 'avg_ms': step_store_reset_ms, 'launches': 64,
+                            'env_steps_per_sec_kernel_only': B_PER_GPU / (step_store_reset_ms * 1e-3),
+                            'algorithmic_bytes_per_env_step': 85,
+                            'timed_with': 'like env_step_only_kernel (stand-alone; inside the training step the env rides in the worker launch)'},
+        'worker_launch': {'kernel': 'k_policy_step_store_reset' if not pol_ms else 'k_step_store_reset', 'avg_ms': env_ms, 'launches': env_n},
         # both env rates of SURVEY section 8d under stable keys (kernel-only, 4096 agents per launch)
         'env_steps_per_sec_step_only': B_PER_GPU / (step_only_ms * 1e-3),
-        'env_steps_per_sec_step_store_reset': B_PER_GPU / (env_ms * 1e-3) if env_ms else None,
+        'env_steps_per_sec_step_store_reset': B_PER_GPU / (step_store_reset_ms * 1e-3),
         'env_step_only_kernel': {'kernel': 'k_step (mpg_env_step)', 'avg_ms': step_only_ms, 'launches': 64,
                                  'timed_with': 'one HIP event pair around 64 launches queued behind a spin kernel (back to back on the '
                                                'GPU, launch boundaries included) after the timed region'},

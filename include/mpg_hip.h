@@ -323,6 +323,17 @@ int mpg_env_step_store_reset_draw(int env_kind, int n, int obs_dim, float* state
                                   const mpg_replay_draw_t* draw, int rows, float* b_obs, float* b_act, float* b_rew,
                                   float* b_obs2, mpg_stream_t stream);
 
+/* OffPolicyWorker.sample's inner body (worker.py:95-112) as ONE launch for the path-tracking env with six-entry observations:
+ * mpg_policy_action (deterministic action + N(0, explore_sigma) noise keyed by noise_seed / noise_ctr, written to act_out [n][2])
+ * followed by mpg_env_step_store_reset (draw == NULL) or mpg_env_step_store_reset_draw - the policy pass of a 16-agent group by one
+ * workgroup, whose first wave then steps those agents.  obs_io [n][6]: the current observations in, the next ones out.  Actions,
+ * ring rows, env state and observations are bit-identical to the two stand-alone calls'.  MPG_EINVAL for any other env / width. */
+int mpg_worker_step(const mpg_cfg_t* cfg, const float* policy_params, int n, float* state, float* obs_io, float explore_sigma,
+                    uint64_t noise_seed, uint64_t noise_ctr, float* act_out, int capacity, int next_idx, float* ring_obs,
+                    float* ring_act, float* ring_rew, float* ring_obs2, uint8_t* ring_done, uint64_t env_seed, uint64_t env_ctr,
+                    uint8_t* done_out /* nullable */, const mpg_replay_draw_t* draw /* nullable */, int rows, float* b_obs,
+                    float* b_act, float* b_rew, float* b_obs2, mpg_stream_t stream);
+
 size_t mpg_mpg_gradients_workspace_bytes(const mpg_cfg_t* cfg, int rows, int M, int n, int n_select, int n_q);
 int mpg_mpg_gradients(const mpg_cfg_t* cfg, int n_q, const float* params, const float* target_params, int rows,
                       float* obs, float* act, float* rew, float* obs_tp1, const float* y_in,

@@ -12,6 +12,85 @@
 // env_kind MPG_ENV_INVERTED_PENDULUM is dispatched to env_cart_pole.hip.
 #include "env_internal.h"
 
+// The worker's policy pass rides in the env launch (k_policy_step_store_reset, below).  The network engine is compiled here as
+// every other translation unit compiles it - contraction allowed - although this file is built with -ffp-contract=off for the
+// environment's op-by-op arithmetic: the pragma is lexical, the environment code below is back under "off".
+#pragma clang fp contract(fast)
+#include "mlp_core.h"
+
+namespace worker_policy {
+using namespace mlp;
+
+struct Args {
+    const float* params;       // policy network, Keras order
+    const float* pack;         // nullable: packed forward image of W2 (weight cache)
+    int* status;               // nullable: MPG_STATUS_* word of the caller
+    int out_tanh;
+    float out_scale, sigma;
+    uint32_t k0, k1, c1, c2;   // exploration-noise key and counter
+    float scale[8];            // obs_scale (1 beyond obs_dim)
+};
+
+constexpr int SMEM_FLOATS = A_IMG + GROUP * 8 + NWAVE * GROUP * MAXOUT;
+
+// One 16-row group of mpg_policy_action: k_forward<6, 2, PK, 1> (mlp_kernels.hip) for unit g - the same device functions on the
+// same operands in the same order, so the actions are bit-identical to the stand-alone launch's (tests: native step driver ==
+// method-by-method path).  The group's actions go to act_out (global) and to sAct [16][2] for the env lanes of wave 0.
+template <bool PK>
+__device__ __forceinline__ void group(const Args& a, int rows, const float* __restrict__ obs, long g, float* smem, float* sAct,
+                                      float* __restrict__ act_out) {
+    constexpr int IN = 6, OU = 2, XSW = 8;
+    float* sA = smem;
+    float* sX = sA + A_IMG;
+    float* sPart = sX + GROUP * XSW;
+    const Lane L;
+    const Net net = make_net(a.params, IN, 2 * OU);
+    float w2[128];
+    SmallRegs<IN, OU> r;
+    float xv = 0.f;
+    if (threadIdx.x < GROUP * XSW) {
+        const int row = threadIdx.x / XSW, i = threadIdx.x % XSW;
+        const long gr = g * GROUP + row;
+        if (gr < rows && i < IN) xv = obs[gr * IN + i] * a.scale[i];
+    }
+    float b3v = 0.f;
+    if (threadIdx.x < GROUP * OU) b3v = net.b3[threadIdx.x % OU];
+    float zmax = 0.f;
+    bool saw_nan = false;
+    load_small<IN, OU>(net, L, r);
+    if constexpr (PK) load_w2_packed(a.pack, L, w2); else load_w2_fwd(net.W2, L, w2);
+    saw_nan |= xv != xv;
+    if (threadIdx.x < GROUP * XSW) sX[threadIdx.x] = xv;
+    lds_barrier();
+    float pz = 0.f;
+    if (threadIdx.x < GROUP * OU) pz = row_poison(sX + (threadIdx.x / OU) * XSW, XSW);
+    float h1[2][4], h2[2][4];
+    forward_group<IN, OU>(sX, sA, sPart, L, w2, r, h1, h2, nullptr, 0, nullptr, &zmax);
+    const int tid = threadIdx.x;
+    if (tid < GROUP * OU) {
+        const int row = (tid / OU) % GROUP, o = tid % OU;
+        const long gr = g * GROUP + row;
+        float y = 0.f;
+        if (gr < rows) {
+            float z = out_preact(sPart, b3v, row, o);
+            y = a.out_tanh ? a.out_scale * tanhf(z) : z;
+            y += pz;
+            if (a.sigma > 0.f) {   // OffPolicyWorker.sample: action += N(0, sigma), worker.py:97-98
+                Philox4 p = philox4x32_10((uint32_t)gr, a.c1, a.c2, 0x5eedu + (uint32_t)o, a.k0, a.k1);
+                float u1 = u01(p.v[0]), u2 = u01(p.v[1]);
+                y = add_gauss_noise(y, a.sigma, u1, u2);
+            }
+            saw_nan |= y != y;
+            act_out[gr * OU + o] = y;
+        }
+        sAct[tid] = y;
+    }
+    report_activation_range(a.status, zmax);
+    if (a.status && saw_nan) atomicOr(a.status, MPG_STATUS_NAN);
+}
+}  // namespace worker_policy
+#pragma clang fp contract(off)
+
 namespace {
 
 #ifdef MPG_TIMELINE   // diagnostic build only (tools/timeline.sh)
@@ -480,6 +559,48 @@ __global__ void __launch_bounds__(64) k_step_store_reset(int n, float* __restric
     ENV_TL(8);
 }
 
+// OffPolicyWorker.sample's whole inner body (worker.py:95-112) in ONE launch: the policy pass of a 16-agent group by a 512-thread
+// workgroup, then env.step -> ring -> env.reset of those 16 agents by the four-lane form on wave 0 (k_step_store_reset's body).  The
+// stand-alone pair is two launches of one wave per CU each (7 + 14 us at 4096 agents); fused, the env lanes start the moment their
+// group's actions exist.  Blocks beyond the policy groups gather the minibatch about to be drawn (predraw_row).
+template <bool PK>
+__global__ void __launch_bounds__(mlp::NTHREAD, 2) k_policy_step_store_reset(const worker_policy::Args pa, int n, float* __restrict__ st,
+                                                                              float* __restrict__ obs_io, float* __restrict__ act_out,
+                                                                              RingPtrs ring, int capacity, int next_idx, uint32_t k0,
+                                                                              uint32_t k1, uint32_t c1, uint32_t c2,
+                                                                              uint8_t* __restrict__ done_out, PreDraw pd) {
+    if ((int)blockIdx.x >= pd.env_blocks) {
+        const int gr = ((int)blockIdx.x - pd.env_blocks) * mlp::NTHREAD + threadIdx.x;
+        if (gr < pd.rows) predraw_row(pd, ring, capacity, next_idx, n, gr);
+        return;
+    }
+    __shared__ __attribute__((aligned(16))) float smem[worker_policy::SMEM_FLOATS];
+    __shared__ __attribute__((aligned(16))) float s_quad[16 * 100];
+    __shared__ float sAct[mlp::GROUP * 2];
+    worker_policy::group<PK>(pa, n, obs_io, blockIdx.x, smem, sAct, act_out);
+    if (threadIdx.x >= 64) return;                     // the env lanes: wave 0, four lanes per agent (it wrote sAct itself: LDS is in
+    __builtin_amdgcn_wave_barrier();                   // order within a wave)
+    const int i = blockIdx.x * mlp::GROUP + (threadIdx.x >> 2), q = threadIdx.x & 3;
+    if (i >= n) return;
+    Agent ag = load_agent(st, n, i);
+    const float2 an = make_float2(sAct[2 * (threadIdx.x >> 2)], sAct[2 * (threadIdx.x >> 2) + 1]);
+    const size_t slot = (size_t)((next_idx + i) % capacity);
+    if (q == 0) {
+        write_obs(ring.obs, (int)slot, 6, ag);                  // obs before the step
+        reinterpret_cast<float2*>(ring.act)[slot] = an;
+    }
+    const StepOut o = step_agent_quad(ag, an, q, s_quad + (threadIdx.x >> 2) * 100);
+    if (q == 1) {
+        write_obs(ring.obs2, (int)slot, 6, ag);
+        ring.rew[slot] = o.reward;
+        ring.done[slot] = o.done ? 1 : 0;
+        if (done_out) done_out[i] = o.done ? 1 : 0;
+    }
+    if (o.done) reset_agent(ag, i, k0, k1, c1, c2);
+    if (q == 2) store_agent(st, n, i, ag);
+    if (q == 3) write_obs(obs_io, i, 6, ag);
+}
+
 inline bool pt_obs_dim_ok(int od) { return od >= 6 && od <= 6 + MPG_ENV_MAX_FUTURE; }
 
 }  // namespace
@@ -579,4 +700,54 @@ extern "C" int mpg_env_step_store_reset_draw(int env_kind, int n, int obs_dim, f
     pd.o_obs = b_obs; pd.o_act = b_act; pd.o_rew = b_rew; pd.o_obs2 = b_obs2;
     return step_store_reset_impl(env_kind, n, obs_dim, state, action, capacity, next_idx, ring_obs, ring_act, ring_rew, ring_obs2,
                                  ring_done, seed, ctr, obs_out, done_out, pd, stream);
+}
+
+// worker.py:95-112 for the path-tracking env with six-entry observations: mpg_policy_action + mpg_env_step_store_reset(_draw) as one
+// launch (bit-identical actions, ring rows, states and observations).  obs_io [n][6]: the current observations in, the next ones out.
+extern "C" int mpg_worker_step(const mpg_cfg_t* cfg, const float* policy_params, int n, float* state, float* obs_io, float explore_sigma,
+                               uint64_t noise_seed, uint64_t noise_ctr, float* act_out, int capacity, int next_idx, float* ring_obs,
+                               float* ring_act, float* ring_rew, float* ring_obs2, uint8_t* ring_done, uint64_t env_seed,
+                               uint64_t env_ctr, uint8_t* done_out, const mpg_replay_draw_t* draw, int rows, float* b_obs, float* b_act,
+                               float* b_rew, float* b_obs2, mpg_stream_t stream) {
+    MPG_REQUIRE(cfg && cfg->env_kind == MPG_ENV_PATH_TRACKING && cfg->obs_dim == 6 && cfg->act_dim == 2,
+                "mpg_worker_step: path-tracking env with obs_dim 6 only");
+    MPG_REQUIRE(policy_params && n > 0 && state && obs_io && act_out && capacity >= n && next_idx >= 0 && next_idx < capacity && ring_obs &&
+                    ring_act && ring_rew && ring_obs2 && ring_done,
+                "mpg_worker_step: bad argument");
+    // (the same refusal as mpg_policy_action's cfg_ok: tanh output WITH an action range is not what the reference computes)
+    MPG_REQUIRE(!(cfg->policy_out_act == MPG_ACT_TANH && cfg->action_range > 0.f), "mpg_worker_step: tanh policy with an action range");
+    PreDraw pd{};
+    if (draw) {
+        MPG_REQUIRE(rows > 0 && b_obs && b_act && b_rew && b_obs2 && draw->n_storage > 0 && draw->n_storage <= capacity,
+                    "mpg_worker_step: incomplete draw");
+        pd.rows = rows; pd.n_storage = draw->n_storage;
+        pd.k0 = (uint32_t)draw->seed; pd.k1 = (uint32_t)(draw->seed >> 32);
+        pd.c1 = (uint32_t)draw->ctr; pd.c2 = (uint32_t)(draw->ctr >> 32);
+        pd.o_idx = draw->idx_out; pd.o_done = draw->done_out;
+        pd.o_obs = b_obs; pd.o_act = b_act; pd.o_rew = b_rew; pd.o_obs2 = b_obs2;
+    }
+    pd.env_blocks = (n + mlp::GROUP - 1) / mlp::GROUP;
+    worker_policy::Args pa;
+    pa.params = policy_params;
+    pa.pack = mlp::weight_cache_lookup(cfg, mlp::make_net(policy_params, 6, 4).W2, 0);
+    pa.status = mpg_status_of(cfg);
+    const bool ranged = cfg->action_range > 0.f;
+    pa.out_tanh = (cfg->policy_out_act == MPG_ACT_TANH || ranged) ? 1 : 0;
+    pa.out_scale = ranged ? cfg->action_range : 1.f;
+    pa.sigma = explore_sigma;
+    pa.k0 = (uint32_t)noise_seed; pa.k1 = (uint32_t)(noise_seed >> 32); pa.c1 = (uint32_t)noise_ctr; pa.c2 = (uint32_t)(noise_ctr >> 32);
+    for (int i = 0; i < 8; ++i) pa.scale[i] = i < 6 ? cfg->obs_scale[i] : 1.f;
+    RingPtrs ring{ring_obs, ring_act, ring_rew, ring_obs2, ring_done};
+    const int blocks = pd.env_blocks + (pd.rows + mlp::NTHREAD - 1) / mlp::NTHREAD;
+    hipStream_t s = mpg_stream(stream);
+    mpg_prof_begin(mpg_prof_of(cfg), 2, s);
+    if (pa.pack)
+        hipLaunchKernelGGL((k_policy_step_store_reset<true>), dim3(blocks), dim3(mlp::NTHREAD), 0, s, pa, n, state, obs_io, act_out, ring, capacity,
+                           next_idx, (uint32_t)env_seed, (uint32_t)(env_seed >> 32), (uint32_t)env_ctr, (uint32_t)(env_ctr >> 32), done_out, pd);
+    else
+        hipLaunchKernelGGL((k_policy_step_store_reset<false>), dim3(blocks), dim3(mlp::NTHREAD), 0, s, pa, n, state, obs_io, act_out, ring, capacity,
+                           next_idx, (uint32_t)env_seed, (uint32_t)(env_seed >> 32), (uint32_t)env_ctr, (uint32_t)(env_ctr >> 32), done_out, pd);
+    mpg_prof_end(mpg_prof_of(cfg), 2, s);
+    MPG_CHECK_LAUNCH("mpg_worker_step");
+    return MPG_OK;
 }

@@ -89,7 +89,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_forward(const FwdArgs a) {
                 if (a.sigma > 0.f) {   // OffPolicyWorker.sample: action += N(0, sigma), worker.py:97-98
                     Philox4 p = philox4x32_10((uint32_t)gr, a.c1, a.c2, 0x5eedu + (uint32_t)o, a.k0, a.k1);
                     float u1 = u01(p.v[0]), u2 = u01(p.v[1]);
-                    y += a.sigma * sqrtf(-2.f * logf(u1)) * cosf(6.283185307179586f * u2);
+                    y = add_gauss_noise(y, a.sigma, u1, u2);
                 }
                 saw_nan |= y != y;
                 a.y[gr * a.ldy + o] = y;

@@ -6,10 +6,11 @@
 
 #include "../../include/mpg_hip.h"
 
-#define MPG_ABI_VERSION 7   // 3: caller-owned handles (mpg_wcache_t, mpg_prof_t) instead of process-wide state
+#define MPG_ABI_VERSION 8   // 3: caller-owned handles (mpg_wcache_t, mpg_prof_t) instead of process-wide state
                             // 4: mpg_replay_draw_t gained the pre-gathered window, mpg_env_step_store_reset_draw
                             // 5: status words (mpg_cfg_t.status, mpg_wcache_t.status), step entry points for TD3 / NADP
                             // 6: mpg_cfg_t.obs_scale has 16 entries (observations with look-ahead entries: obs_dim up to 14)
+                            // 8: mpg_worker_step
                             // 7: MPG_PROF_SLOTS 10 (gradient exchange, k_clip_adam_polyak), mpg_prof_region_begin / _end
 
 void mpg_set_error(const char* fmt, ...);
@@ -73,6 +74,18 @@ __host__ __device__ static inline Philox4 philox4x32_10(uint32_t c0, uint32_t c1
 
 // u32 -> float in the open interval (0,1): 24 random mantissa bits, centred.
 __host__ __device__ static inline float u01(uint32_t u) { return ((float)(u >> 8) + 0.5f) * 5.9604644775390625e-08f; }
+#ifdef __HIPCC__
+// y + sigma * N(0, 1), the normal deviate by Box-Muller from two uniforms on the HARDWARE transcendentals (v_log_f32 = log2,
+// v_sqrt_f32, v_cos_f32 whose argument is in revolutions): single instructions with explicitly separate roundings, so that every
+// translation unit produces the same bits whatever its -ffp-contract mode.  (The library's logf / cosf are expanded by the backend
+// with or without fused steps depending on that mode - the worker's policy pass exists in two translation units, mlp_kernels.hip
+// and env_path_tracking.hip, which must agree bit for bit.)
+__device__ __forceinline__ float add_gauss_noise(float y, float sigma, float u1, float u2) {
+    const float r2 = __builtin_amdgcn_logf(u1) * -1.3862943611198906f;       // -2 ln u1 = (-2 ln 2) log2 u1  (u1 in (0, 1))
+    const float n = __builtin_amdgcn_sqrtf(r2) * __builtin_amdgcn_cosf(u2);   // sqrt(-2 ln u1) cos(2 pi u2)
+    return __builtin_fmaf(sigma, n, y);
+}
+#endif
 
 // sum over the 256 threads of a block of one value each, fixed tree order; `red` = 256 floats of LDS.  Shared by every
 // kernel that produces the clip's per-block partial sums of squares, so that they are bit-identical.

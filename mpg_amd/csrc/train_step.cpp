@@ -77,15 +77,30 @@ bool ctx_ok(const mpg_train_ctx_t* c) {
 }
 
 // ---- worker.sample + replay_buffer.add_batch (optimizer.py:332-337, worker.py:91-119), the plain form (NADP, TD3) ----
+// worker.py:95-112 as one launch (mpg_worker_step) where it exists: path-tracking env, six-entry observations
+inline bool worker_step_fused(const mpg_train_ctx_t* c) {
+#ifdef MPG_AB_NO_WORKER_FUSION      // A/B build (tools/ab_worker.sh): the policy pass and the env step as two launches (rounds 1 - 3)
+    return false;
+#else
+    return c->cfg.env_kind == MPG_ENV_PATH_TRACKING && c->cfg.obs_dim == 6 && c->cfg.act_dim == 2;
+#endif
+}
+
 int sample_and_add(mpg_train_ctx_t* c, const float* policy, mpg_stream_t s) {
     const int od = c->cfg.obs_dim, kind = c->cfg.env_kind;
     for (int it = 0; it < c->sample_iters; ++it) {
-        TRY(mpg_policy_action(&c->cfg, policy, c->num_agent, c->w_obs, c->explore_sigma, c->worker_seed, c->noise_ctr++, c->w_act, s));
         MPG_REQUIRE(c->num_agent <= c->ring_capacity, "mpg_step_begin: ring smaller than one sample");
+        if (worker_step_fused(c)) {     // policy pass + env.step -> ring -> env.reset in one launch
+            TRY(mpg_worker_step(&c->cfg, policy, c->num_agent, c->env_state, c->w_obs, c->explore_sigma, c->worker_seed, c->noise_ctr++,
+                                c->w_act, c->ring_capacity, c->ring_next, c->ring_obs, c->ring_act, c->ring_rew, c->ring_obs2, c->ring_done,
+                                c->env_seed, c->env_ctr++, c->w_done, nullptr, 0, nullptr, nullptr, nullptr, nullptr, s));
+        } else {
+        TRY(mpg_policy_action(&c->cfg, policy, c->num_agent, c->w_obs, c->explore_sigma, c->worker_seed, c->noise_ctr++, c->w_act, s));
         mpg_prof_begin(c->cfg.prof, 2, mpg_stream(s));
         TRY(mpg_env_step_store_reset(kind, c->num_agent, od, c->env_state, c->w_act, c->ring_capacity, c->ring_next, c->ring_obs,
                                      c->ring_act, c->ring_rew, c->ring_obs2, c->ring_done, c->env_seed, c->env_ctr++, c->w_obs, c->w_done, s));
         mpg_prof_end(c->cfg.prof, 2, mpg_stream(s));
+        }
         if (c->learner_version == 4 && c->prioritized)       // new transitions enter at the max priority (buffer.py:127-136)
             TRY(mpg_per_add(c->per_sum, c->per_min, c->per_stamp, c->per_capacity, c->ring_capacity, c->ring_next, c->num_agent,
                             c->per_alpha, c->per_max_priority, reinterpret_cast<int*>(c->scratch), c->scratch + c->num_agent, s));
@@ -187,32 +202,43 @@ extern "C" int mpg_step_begin(mpg_train_ctx_t* c, int iteration, mpg_stream_t s)
     int fresh_start = 0;
     if (iteration % c->sampling_interval == 0) {
         for (int it = 0; it < c->sample_iters; ++it) {
-            TRY(mpg_policy_action(&c->cfg, policy, c->num_agent, c->w_obs, c->explore_sigma, c->worker_seed, c->noise_ctr++,
-                                  c->w_act, s));
             MPG_REQUIRE(c->num_agent <= c->ring_capacity, "mpg_step_begin: ring smaller than one sample");
-            // env.step -> ring slot (next + i) % capacity -> env.reset of the done agents, one launch
-            mpg_prof_begin(c->cfg.prof, 2, mpg_stream(s));
 #ifdef MPG_AB_NO_PREDRAW
-            if (false) {
+            const bool predraw = false;
 #else
-            if (draws_now && it == c->sample_iters - 1 && kind == MPG_ENV_PATH_TRACKING && od == 6) {
+            const bool predraw = draws_now && it == c->sample_iters - 1 && kind == MPG_ENV_PATH_TRACKING && od == 6;
 #endif
-                mpg_replay_draw_t pd = {};
+            mpg_replay_draw_t pd = {};
+            if (predraw) {
                 pd.n_storage = std::min(c->ring_size + c->num_agent, c->ring_capacity);
                 pd.seed = c->replay_seed; pd.ctr = c->replay_times + 1;
                 pd.idx_out = c->idx; pd.done_out = c->b_done;
-                TRY(mpg_env_step_store_reset_draw(kind, c->num_agent, od, c->env_state, c->w_act, c->ring_capacity, c->ring_next,
-                                                  c->ring_obs, c->ring_act, c->ring_rew, c->ring_obs2, c->ring_done, c->env_seed,
-                                                  c->env_ctr++, c->w_obs, c->w_done, &pd, c->batch, c->b_obs, c->b_act, c->b_rew,
-                                                  c->b_obs2, s));
                 pre_gathered = true;
                 fresh_start = c->ring_next;
-            } else {
-                TRY(mpg_env_step_store_reset(kind, c->num_agent, od, c->env_state, c->w_act, c->ring_capacity, c->ring_next,
-                                             c->ring_obs, c->ring_act, c->ring_rew, c->ring_obs2, c->ring_done, c->env_seed,
-                                             c->env_ctr++, c->w_obs, c->w_done, s));
             }
-            mpg_prof_end(c->cfg.prof, 2, mpg_stream(s));
+            if (worker_step_fused(c)) {
+                // the policy pass, env.step -> ring slot (next + i) % capacity -> env.reset of the done agents (and the draw): one launch
+                TRY(mpg_worker_step(&c->cfg, policy, c->num_agent, c->env_state, c->w_obs, c->explore_sigma, c->worker_seed, c->noise_ctr++,
+                                    c->w_act, c->ring_capacity, c->ring_next, c->ring_obs, c->ring_act, c->ring_rew, c->ring_obs2,
+                                    c->ring_done, c->env_seed, c->env_ctr++, c->w_done, predraw ? &pd : nullptr, c->batch, c->b_obs, c->b_act,
+                                    c->b_rew, c->b_obs2, s));
+            } else {
+                TRY(mpg_policy_action(&c->cfg, policy, c->num_agent, c->w_obs, c->explore_sigma, c->worker_seed, c->noise_ctr++,
+                                      c->w_act, s));
+                // env.step -> ring slot (next + i) % capacity -> env.reset of the done agents, one launch
+                mpg_prof_begin(c->cfg.prof, 2, mpg_stream(s));
+                if (predraw) {
+                    TRY(mpg_env_step_store_reset_draw(kind, c->num_agent, od, c->env_state, c->w_act, c->ring_capacity, c->ring_next,
+                                                      c->ring_obs, c->ring_act, c->ring_rew, c->ring_obs2, c->ring_done, c->env_seed,
+                                                      c->env_ctr++, c->w_obs, c->w_done, &pd, c->batch, c->b_obs, c->b_act, c->b_rew,
+                                                      c->b_obs2, s));
+                } else {
+                    TRY(mpg_env_step_store_reset(kind, c->num_agent, od, c->env_state, c->w_act, c->ring_capacity, c->ring_next,
+                                                 c->ring_obs, c->ring_act, c->ring_rew, c->ring_obs2, c->ring_done, c->env_seed,
+                                                 c->env_ctr++, c->w_obs, c->w_done, s));
+                }
+                mpg_prof_end(c->cfg.prof, 2, mpg_stream(s));
+            }
             c->ring_next = (c->ring_next + c->num_agent) % c->ring_capacity;
             c->ring_size = std::min(c->ring_size + c->num_agent, c->ring_capacity);
         }

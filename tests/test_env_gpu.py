@@ -135,6 +135,47 @@ def test_fused_step_store_reset_equals_separate_calls():
     assert torch.equal(obs_a, obs_b) and torch.equal(env_a._state, env_b._state) and bool(done_b.all())
 
 
+@pytest.mark.parametrize('n,sigma,cache', [(300, 0.0, False), (4096, 0.3, True), (17, 0.3, False)])
+def test_worker_step_equals_policy_action_plus_env_step_store_reset(n, sigma, cache):
+    """mpg_worker_step (worker.py:95-112 as ONE launch: the policy pass of a 16-agent group, then env.step -> ring -> env.reset of those
+    agents on the group's first wave) == mpg_policy_action + mpg_env_step_store_reset, bit for bit: actions (with exploration noise),
+    ring rows (wrapping), env state, next observations, done flags - ragged agent counts, with and without the packed weight cache."""
+    import ctypes
+    import mpg_amd._lib as L
+    from mpg_amd import ops
+    from mpg_amd.envs import PathTrackingEnv
+    from tests.golden_inputs import mlp_weights_flat
+    rng = np.random.Generator(np.random.PCG64(n))
+    cap, nxt = 3 * n + 5, 2 * n + 9                   # next + n wraps around the ring
+    pol = torch.as_tensor(mlp_weights_flat(rng, 6, 4)).cuda()
+    cfg = ops.make_cfg()
+    wc = None
+    if cache:                                         # the packed-image instantiation: cfg.wcache[0] -> the policy's images
+        wc = ops.WeightCache(pol, [(6, 4)])
+        cfg.wcache[0] = wc.pointer
+    env_a, env_b = PathTrackingEnv(num_agent=n, seed=4), PathTrackingEnv(num_agent=n, seed=4)
+    obs_a, obs_b = env_a.reset().clone(), env_b.reset().clone()
+    ring_a = [torch.zeros(cap, 6).cuda(), torch.zeros(cap, 2).cuda(), torch.zeros(cap).cuda(), torch.zeros(cap, 6).cuda(),
+              torch.zeros(cap, dtype=torch.uint8).cuda()]
+    ring_b = [torch.zeros_like(t) for t in ring_a]
+    done_a, done_b = torch.empty(n, dtype=torch.uint8).cuda(), torch.empty(n, dtype=torch.uint8).cuda()
+    # two calls
+    act_a = ops.policy_action(cfg, pol, obs_a, explore_sigma=sigma, seed=11, ctr=5)
+    L.call('mpg_env_step_store_reset', L.c_int(0), L.c_int(n), L.c_int(6), L.ptr(env_a._state), L.ptr(act_a), L.c_int(cap), L.c_int(nxt),
+           *[L.ptr(t) for t in ring_a], L.c_u64(env_a.seed), L.c_u64(env_a._ctr), L.ptr(obs_a), L.ptr(done_a), L.stream())
+    # one call
+    act_b = torch.empty(n, 2).cuda()
+    L.call('mpg_worker_step', ctypes.byref(cfg), L.ptr(pol), L.c_int(n), L.ptr(env_b._state), L.ptr(obs_b), L.c_float(sigma), L.c_u64(11),
+           L.c_u64(5), L.ptr(act_b), L.c_int(cap), L.c_int(nxt), *[L.ptr(t) for t in ring_b], L.c_u64(env_b.seed), L.c_u64(env_b._ctr),
+           L.ptr(done_b), L.ptr(None), L.c_int(0), L.ptr(None), L.ptr(None), L.ptr(None), L.ptr(None), L.stream())
+    torch.cuda.synchronize()
+    assert torch.equal(act_a, act_b)
+    for x, y in zip(ring_a, ring_b):
+        assert torch.equal(x, y)
+    assert torch.equal(obs_a, obs_b) and torch.equal(env_a._state, env_b._state) and torch.equal(done_a, done_b)
+    del wc
+
+
 def test_pre_gathered_draw_equals_the_draw_inside_the_gradient_launch():
     """mpg_env_step_store_reset_draw + mpg_mpg_gradients(draw.pre_gathered = 1) == mpg_env_step_store_reset +
     mpg_mpg_gradients(draw): same ring, same minibatch (indices, five columns), same targets and gradients, bit for bit -
