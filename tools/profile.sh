@@ -21,6 +21,13 @@ for i in 1 2 3; do python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-base
 python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 # 4. the side configurations (BASELINE.json configs[2], [3]) and the kernels' register / spill / LDS usage
 for c in c3 c4; do MPG_BENCH_NO_F32=1 python3 bench.py --config $c --no-cpu-baseline > $OUT/bench_$c.json 2>/dev/null; done
+export MPG_BENCH_NO_F32=1
+for c in c3 c4; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$c -- python3 bench.py --config $c --no-cpu-baseline > /dev/null 2> $OUT/trace_$c.log
+  cp $(ls $OUT/trace_$c/*/*kernel_stats.csv | head -1) $OUT/kernel_stats_$c.csv
+  rm -rf $OUT/trace_$c
+done
+unset MPG_BENCH_NO_F32
 python3 tools/kernel_resources.py > $OUT/kernel_resources.txt 2>&1
 rm -rf $OUT/trace/*/*.db $OUT/pmc/pass*/*/*.db 2>/dev/null
 head -12 $OUT/kernel_stats.csv | cut -c1-150
