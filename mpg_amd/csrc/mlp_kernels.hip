@@ -408,11 +408,30 @@ __global__ void __launch_bounds__(NTHREAD, IN <= 8 ? 4 : 2) k_wgrad(const WgradA
     wgrad_body<IN, OU>(a, sl, chunk, sRed);
 }
 
+#ifdef MPG_SPLIT
+// dW2 only (the thin pieces were accumulated elsewhere: launch_wgrad no_thin), 64-column slices: four workgroups per chunk re-read the
+// chunk's H1 through L2 instead of eight
+template <int IN, int OU>
+__global__ void __launch_bounds__(NTHREAD, 4) k_wgrad_w2(const WgradArgs a) {
+    __shared__ __attribute__((aligned(16))) float sRed[4 * 4 * 2 * 64 * 2 * 2];   // the B tile: 4 pairs x 4 tiles x (hi, lo) x 64 lanes x 2 groups x 8 bytes
+    int chunk, sl;
+    wgrad_map4(blockIdx.x, gridDim.x >> 2, chunk, sl);
+    wgrad_body<IN, OU, 1, 4>(a, sl, chunk, sRed);
+}
+#endif
+
+#ifdef MPG_SPLIT
+template <int I, int O>
+static void launch_wgrad_w2(const WgradArgs& a, int nch, hipStream_t s) {
+    if constexpr (I <= 8) hipLaunchKernelGGL((k_wgrad_w2<I, O>), dim3(4 * nch), dim3(NTHREAD), 0, s, a);
+}
+#endif
+
 size_t wgrad_workspace_floats(int rows, int in_dim, int out_dim) {
     const long ngroups = (rows + GROUP - 1) / GROUP;
     // the single-job launch cuts finer than the multi-job one: room for whichever is used
-    const int gp = wgrad_groups_per_chunk(ngroups, true), gpm = wgrad_groups_per_chunk(ngroups, false);
-    const long nch = std::max((ngroups + gp - 1) / gp, (ngroups + gpm - 1) / gpm);
+    const int gp = wgrad_groups_per_chunk(ngroups, true), gpm = wgrad_groups_per_chunk(ngroups, false), gpw = wgrad_groups_per_chunk_w2(ngroups);
+    const long nch = std::max(std::max((ngroups + gp - 1) / gp, (ngroups + gpm - 1) / gpm), (ngroups + gpw - 1) / gpw);
     return (size_t)nch * net_size(in_dim, out_dim);
 }
 
@@ -425,12 +444,25 @@ int launch_wgrad(const mpg_cfg_t* cfg, int in_dim, int out_dim, int ou, int rows
     a.h1 = h1; a.h2 = h2; a.dz1 = dz1; a.dz2 = dz2; a.dz3 = dz3; a.slabs = ws;
     (void)inv_b;
     const long ngroups = (rows + GROUP - 1) / GROUP;
-    a.groups_per_chunk = wgrad_groups_per_chunk(ngroups, true);
+#if defined(MPG_SPLIT) && !defined(MPG_AB_NO_WGRAD_W2)
+    const bool w2_only = no_thin && backward_takes_thin(in_dim, ou);       // (the base input widths: where the thin pieces can live elsewhere)
+#else
+    const bool w2_only = false;
+#endif
+    a.groups_per_chunk = w2_only ? wgrad_groups_per_chunk_w2(ngroups) : wgrad_groups_per_chunk(ngroups, true);
     const int nch = (int)((ngroups + a.groups_per_chunk - 1) / a.groups_per_chunk);
     mpg_prof_begin(mpg_prof_of(cfg), 5, s);
+    if (w2_only) {
+#ifdef MPG_SPLIT
+#define CALL(I, O) launch_wgrad_w2<I, O>(a, nch, s)
+        MPG_DISPATCH_NET(in_dim, ou, CALL)
+#undef CALL
+#endif
+    } else {
 #define CALL(I, O) hipLaunchKernelGGL((k_wgrad<I, O>), dim3(8 * nch), dim3(NTHREAD), 0, s, a)
     MPG_DISPATCH_NET(in_dim, ou, CALL)
 #undef CALL
+    }
     mpg_prof_end(mpg_prof_of(cfg), 5, s);
     MPG_CHECK_LAUNCH("k_wgrad");
     const int n = net_size(in_dim, out_dim);

@@ -27,17 +27,23 @@ constexpr int wgrad_nq() { return 2 * IN + 4 + 2 * OU + OU; }      // thin quant
 // The thin pieces are a chain of load round trips that runs as a tail behind the matrix loop (~5 us of the bench step's k_wgrad_multi,
 // tools/ab_wg_nothin.sh).  -DMPG_WG_ROLES deals the two to different workgroups of k_wgrad_multi (round-4 experiment, tools/ab_wg_roles.sh):
 // 768 workgroups for 512 resident slots, kernel 26.5 -> 25.4 us, step within the noise - not the default.
-template <int IN, int OU, int ROLE = 0>
+// NT: 16-column tiles of DZ2 per workgroup (2: a 32-column slice, 8 workgroups per chunk; 4: a 64-column slice, 4 per chunk - the dW2-only
+// role of the launches that carry no thin pieces: every workgroup of a chunk re-reads the chunk's H1 through L2, and halving that traffic
+// is worth 18 - 23 % of the kernel, tools/ab_wg_half_a.sh)
+template <int IN, int OU, int ROLE = 0, int NT = 2>
 __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int sl, const int chunk, float* sRed) {
+    static_assert(NT == 2 || ROLE == 1, "wide column slices are built for the dW2-only role");
     constexpr int NQ = wgrad_nq<IN, OU>();
     const Lane L;
     const int tid = threadIdx.x;
     const long ngroups = (a.rows + GROUP - 1) / GROUP;
     const long g0 = (long)chunk * a.groups_per_chunk;
     const long g1 = (g0 + a.groups_per_chunk < ngroups) ? g0 + a.groups_per_chunk : ngroups;
-    f32x4 acc[2][2];
+    f32x4 acc[2][NT];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) acc[u][0] = acc[u][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[u][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     float gW1[2][IN], gb1[2] = {0.f, 0.f}, gb2[2] = {0.f, 0.f}, gW3[2][OU], gb3[OU];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -234,16 +240,14 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int sl, con
     for (long tile = g0; tile < g1; tile += NWAVE) {
 #endif
         const long gb = tile + L.wave;
-        f32x4 b0 = zero4, b1 = zero4;
-        if (gb < g1) {
-            b0 = DZ2[(gb * 16 + 2 * sl) * 64 + L.lane];
-            b1 = DZ2[(gb * 16 + 2 * sl + 1) * 64 + L.lane];
-        }
-        // this wave's group of the tile, split once for all eight readers
-        f32x2 bh[2], bl[2];
+        f32x4 bt[NT];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const f32x4& b = t == 0 ? b0 : b1;
+        for (int t = 0; t < NT; ++t) bt[t] = gb < g1 ? DZ2[(gb * 16 + NT * sl + t) * 64 + L.lane] : zero4;
+        // this wave's group of the tile, split once for all eight readers
+        f32x2 bh[NT], bl[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const f32x4& b = bt[t];
             _Float16 h[4], l[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -259,9 +263,9 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int sl, con
         {
             const int pr = L.wave >> 1, e = L.wave & 1;
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                sB2[(((pr * 2 + t) * 2 + 0) * 64 + L.lane) * 2 + e] = bh[t];
-                sB2[(((pr * 2 + t) * 2 + 1) * 64 + L.lane) * 2 + e] = bl[t];
+            for (int t = 0; t < NT; ++t) {
+                sB2[(((pr * NT + t) * 2 + 0) * 64 + L.lane) * 2 + e] = bh[t];
+                sB2[(((pr * NT + t) * 2 + 1) * 64 + L.lane) * 2 + e] = bl[t];
             }
         }
         __syncthreads();
@@ -275,9 +279,9 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int sl, con
                 a_load(g + 2);                             // the next pair (zeros beyond the chunk)
                 const f32x4* sB4 = reinterpret_cast<const f32x4*>(sRed);
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const f16x8 fbh = __builtin_bit_cast(f16x8, sB4[((pr * 2 + t) * 2 + 0) * 64 + L.lane]);
-                    const f16x8 fbl = __builtin_bit_cast(f16x8, sB4[((pr * 2 + t) * 2 + 1) * 64 + L.lane]);
+                for (int t = 0; t < NT; ++t) {
+                    const f16x8 fbh = __builtin_bit_cast(f16x8, sB4[((pr * NT + t) * 2 + 0) * 64 + L.lane]);
+                    const f16x8 fbl = __builtin_bit_cast(f16x8, sB4[((pr * NT + t) * 2 + 1) * 64 + L.lane]);
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
                         acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[u], fbh, acc[u][t], 0, 0, 0);
@@ -293,11 +297,12 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int sl, con
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[u][t][j] *= un;
     }
 #else
+    static_assert(NT == 2, "the exact-fp32 engine keeps 32-column slices");
     constexpr int DEPTH = 2;
     f32x4 fa0[DEPTH], fa1[DEPTH];
     auto a_load = [&](long g, int slot) {
@@ -349,10 +354,10 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int sl, con
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    sW2e[(16 * (2 * L.wave + u) + 4 * L.rg + j) * H + 32 * sl + 16 * t + L.c] = acc[u][t][j];
+                    sW2e[(16 * (2 * L.wave + u) + 4 * L.rg + j) * H + 16 * NT * sl + 16 * t + L.c] = acc[u][t][j];
     }
 #endif
     __syncthreads();                                      // the staging corners of the thin part alias the B tile
@@ -384,10 +389,10 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int sl, con
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    sW2[(16 * (2 * L.wave + u) + 4 * L.rg + j) * H + 32 * sl + 16 * t + L.c] = acc[u][t][j];
+                    sW2[(16 * (2 * L.wave + u) + 4 * L.rg + j) * H + 16 * NT * sl + 16 * t + L.c] = acc[u][t][j];
     }
 #endif
     if constexpr (ROLE == 1) return;                      // (the thin entries of the slab belong to the ROLE 2 workgroup of this slice)
@@ -456,6 +461,18 @@ __device__ __forceinline__ void wgrad_map(int b, int nch, int& chunk, int& sl) {
     }
 }
 
+// the same for the 64-column slices (four workgroups per chunk)
+__device__ __forceinline__ void wgrad_map4(int b, int nch, int& chunk, int& sl) {
+    if ((nch & 7) == 0) {
+        const int xcd = b & 7, k = b >> 3;
+        chunk = xcd + 8 * (k >> 2);
+        sl = k & 3;
+    } else {
+        chunk = b >> 2;
+        sl = b & 3;
+    }
+}
+
 // Chunking of a network's weight-gradient job: every chunk is 8 workgroups (one per 32-column slice) that leave one slab of
 // partial sums for the reduction.  16 chunks per network: the bench step's three jobs are then 384 workgroups, all resident at
 // once (512 slots), and 13 MB of slabs.  Measured on the bench step (tools/ab_repeat.sh, k_wgrad_multi / whole step):
@@ -471,7 +488,14 @@ __device__ __forceinline__ void wgrad_map(int b, int nch, int& chunk, int& sl) {
 #ifndef MPG_WGRAD_MAX_CHUNKS_SINGLE
 #define MPG_WGRAD_MAX_CHUNKS_SINGLE 64
 #endif
+#ifndef MPG_WGRAD_MAX_CHUNKS_W2
+#define MPG_WGRAD_MAX_CHUNKS_W2 128      // the dW2-only launch with 64-column slices: 4 workgroups per chunk, 512 in all
+#endif
 constexpr int WGRAD_MAX_CHUNKS = MPG_WGRAD_MAX_CHUNKS, WGRAD_MAX_CHUNKS_SINGLE = MPG_WGRAD_MAX_CHUNKS_SINGLE;
+inline int wgrad_groups_per_chunk_w2(long ngroups) {
+    long gp = (ngroups + MPG_WGRAD_MAX_CHUNKS_W2 - 1) / MPG_WGRAD_MAX_CHUNKS_W2;
+    return (int)(gp < 1 ? 1 : gp);
+}
 inline int wgrad_groups_per_chunk(long ngroups, bool single_job = false) {
     const long mc = single_job ? WGRAD_MAX_CHUNKS_SINGLE : WGRAD_MAX_CHUNKS;
     long gp = (ngroups + mc - 1) / mc;
