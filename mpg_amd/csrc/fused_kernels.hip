@@ -749,14 +749,18 @@ __global__ void __launch_bounds__(NTHREAD, MPG_WGM_WAVES) k_wgrad_multi(const Wg
     constexpr int NQA = wgrad_nq<IA, OA>(), NQB = wgrad_nq<IB, OB>();
     __shared__ __attribute__((aligned(16))) float sRed[NWAVE * (NQA > NQB ? NQA : NQB) * 64];
     int gchunk, sl;
-#ifndef MPG_WG_ROLES            // every workgroup does both, the thin pieces as a tail behind the matrix loop
+#if defined(MPG_SPLIT) && !defined(MPG_AB_WG_ONE_ROLE)
+    // Two kinds of workgroup (round 4): the first third of the grid takes dW2 in 64-COLUMN slices (four workgroups per chunk re-read
+    // the chunk's H1 through L2 instead of eight: mlp_wgrad.h NT = 4), the other two thirds the thin pieces of the (chunk, 32-column
+    // slice) pairs - a chain of load round trips that used to run as a tail behind every matrix loop.  12 workgroups per chunk,
+    // 576 for the bench step's three jobs on 512 resident slots; the matrix ones are dispatched first.
+    const int nch = gridDim.x / 12;
+    const int role = (int)blockIdx.x < 4 * nch ? 1 : 2;
+    if (role == 1) wgrad_map4(blockIdx.x, nch, gchunk, sl);
+    else wgrad_map((int)blockIdx.x - 4 * nch, nch, gchunk, sl);
+#else       // every workgroup does both, the thin pieces as a tail behind the matrix loop (the exact-fp32 engine; rounds 2 - 3)
     const int role = 0;
     wgrad_map(blockIdx.x, gridDim.x >> 3, gchunk, sl);
-#else
-    // experiment (mlp_wgrad.h): the first half of the grid takes the dW2 slices, the second half the thin pieces of the same (chunk, slice) pairs
-    const int nb = gridDim.x >> 1;
-    const int role = (int)blockIdx.x < nb ? 1 : 2;
-    wgrad_map((int)blockIdx.x - (role == 2 ? nb : 0), nb >> 3, gchunk, sl);
 #endif
     gchunk += m.chunk0;
     int j = 0;
@@ -764,19 +768,19 @@ __global__ void __launch_bounds__(NTHREAD, MPG_WGM_WAVES) k_wgrad_multi(const Wg
     const int chunk = gchunk - m.chunk_off[j];
     MPG_TL_DECL
     MPG_TL(0);
-#ifndef MPG_WG_ROLES
-    if (role == 0) {
-        if (m.type[j] == 0) wgrad_body<IA, OA, 0>(m.a[j], sl, chunk, sRed);
-        else wgrad_body<IB, OB, 0>(m.a[j], sl, chunk, sRed);
-    } else
-#endif
+#if defined(MPG_SPLIT) && !defined(MPG_AB_WG_ONE_ROLE)
     if (role == 1) {
-        if (m.type[j] == 0) wgrad_body<IA, OA, 1>(m.a[j], sl, chunk, sRed);
-        else wgrad_body<IB, OB, 1>(m.a[j], sl, chunk, sRed);
+        if (m.type[j] == 0) wgrad_body<IA, OA, 1, 4>(m.a[j], sl, chunk, sRed);
+        else wgrad_body<IB, OB, 1, 4>(m.a[j], sl, chunk, sRed);
     } else {
         if (m.type[j] == 0) wgrad_body<IA, OA, 2>(m.a[j], sl, chunk, sRed);
         else wgrad_body<IB, OB, 2>(m.a[j], sl, chunk, sRed);
     }
+#else
+    if (m.type[j] == 0) wgrad_body<IA, OA, 0>(m.a[j], sl, chunk, sRed);
+    else wgrad_body<IB, OB, 0>(m.a[j], sl, chunk, sRed);
+    (void)role;
+#endif
     MPG_TL(7);
 #ifdef MPG_TIMELINE
     __syncthreads();
@@ -1067,13 +1071,13 @@ int launch_wgrad_multi(const mpg_cfg_t* cfg, const WgradJob* jobs, int n_jobs, c
     m.chunk0 = chunk0;
     if (phases & 1) {
     mpg_prof_begin(mpg_prof_of(cfg), 5, s);
-#ifndef MPG_WG_ROLES
-    const int wg_per_slice = 1;
+#if defined(MPG_SPLIT) && !defined(MPG_AB_WG_ONE_ROLE)
+    const int wg_per_chunk = 12;          // 4 matrix (64-column slices) + 8 thin (32-column slices)
 #else
-    const int wg_per_slice = 2;
+    const int wg_per_chunk = 8;
 #endif
-    if (!pendulum) hipLaunchKernelGGL((k_wgrad_multi<8, 1, 6, 2>), dim3(wg_per_slice * 8 * (off - chunk0)), dim3(NTHREAD), 0, s, m);
-    else hipLaunchKernelGGL((k_wgrad_multi<5, 1, 4, 1>), dim3(wg_per_slice * 8 * (off - chunk0)), dim3(NTHREAD), 0, s, m);
+    if (!pendulum) hipLaunchKernelGGL((k_wgrad_multi<8, 1, 6, 2>), dim3(wg_per_chunk * (off - chunk0)), dim3(NTHREAD), 0, s, m);
+    else hipLaunchKernelGGL((k_wgrad_multi<5, 1, 4, 1>), dim3(wg_per_chunk * (off - chunk0)), dim3(NTHREAD), 0, s, m);
     mpg_prof_end(mpg_prof_of(cfg), 5, s);
     }
 #ifdef MPG_TIMELINE

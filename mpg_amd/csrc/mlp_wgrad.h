@@ -25,8 +25,7 @@ constexpr int wgrad_nq() { return 2 * IN + 4 + 2 * OU + OU; }      // thin quant
 // sl: column slice (hidden columns [32 sl, 32 sl + 32)); chunk: which run of row groups; sRed: NWAVE*NQ*64 floats of LDS
 // ROLE 0: the workgroup computes its 256 x 32 slice of dW2 AND the thin pieces of its 32 columns; 1: dW2 only; 2: the thin pieces only.
 // The thin pieces are a chain of load round trips that runs as a tail behind the matrix loop (~5 us of the bench step's k_wgrad_multi,
-// tools/ab_wg_nothin.sh).  -DMPG_WG_ROLES deals the two to different workgroups of k_wgrad_multi (round-4 experiment, tools/ab_wg_roles.sh):
-// 768 workgroups for 512 resident slots, kernel 26.5 -> 25.4 us, step within the noise - not the default.
+// tools/ab_wg_nothin.sh); k_wgrad_multi deals the two roles to different workgroups, the matrix ones with 64-column slices (NT = 4).
 // NT: 16-column tiles of DZ2 per workgroup (2: a 32-column slice, 8 workgroups per chunk; 4: a 64-column slice, 4 per chunk - the dW2-only
 // role of the launches that carry no thin pieces: every workgroup of a chunk re-reads the chunk's H1 through L2, and halving that traffic
 // is worth 18 - 23 % of the kernel, tools/ab_wg_half_a.sh)
