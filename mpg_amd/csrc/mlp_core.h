@@ -359,13 +359,31 @@ __device__ __forceinline__ void load_w2_bwd(const float* __restrict__ W2, const 
                 if (r == 3) __builtin_amdgcn_sched_barrier(0);
             }
 }
+// Position (in 1 KiB blocks of 64 lanes x 16 bytes) of wave `wave`'s v-th block in a packed image: one contiguous 32 KB run per wave.
+// Every workgroup of a launch loads the same 256 KB image at the same time (~9 k cycles, ~45 % of what the L2 could deliver).  Round 4
+// tried the eight waves' blocks INTERLEAVED (v * 8 + wave: the eight streams of a CU then read consecutive blocks instead of sitting
+// 32 KB apart) - it is SLOWER: bench step 0.2305 -> 0.2423 ms, the worker launch 21.4 -> 30.4 us (tools/ab_img.sh, -DMPG_IMG_INTERLEAVE).
+__host__ __device__ constexpr int img_slot(int wave, int v) {
+#ifdef MPG_IMG_INTERLEAVE
+    return v * 8 + wave;
+#else
+    return wave * 32 + v;
+#endif
+}
+__host__ __device__ inline void img_unslot(int slot, int& wave, int& v) {
+#ifdef MPG_IMG_INTERLEAVE
+    v = slot >> 3; wave = slot & 7;
+#else
+    wave = slot >> 5; v = slot & 31;
+#endif
+}
 // Same register images from the pre-packed copy kept by the weight cache (weight_cache.hip): 16-byte word index
-// (wave*32 + v)*64 + lane holds w[4v .. 4v+3] -> 32 fully coalesced 1 KiB loads per wave.
+// img_slot(wave, v)*64 + lane holds w[4v .. 4v+3] -> 32 fully coalesced 1 KiB loads per wave.
 __device__ __forceinline__ void load_w2_packed(const float* __restrict__ pack, const Lane& L, float (&w)[128]) {
-    const f32x4* p = reinterpret_cast<const f32x4*>(pack) + (L.wave * 32) * 64 + L.lane;
+    const f32x4* p = reinterpret_cast<const f32x4*>(pack) + L.lane;
 #pragma unroll
     for (int v = 0; v < 32; ++v) {
-        const f32x4 q = p[v * 64];
+        const f32x4 q = p[img_slot(L.wave, v) * 64];
 #pragma unroll
         for (int e = 0; e < 4; ++e) w[4 * v + e] = q[e];
     }

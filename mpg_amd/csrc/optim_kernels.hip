@@ -27,7 +27,8 @@ constexpr int HH = MPG_HIDDEN * MPG_HIDDEN;
 // where contraction index k owns the lane group and register, output index n the lane column.  Writes both halves.
 __device__ __forceinline__ void pack_store(float* __restrict__ image, int k, int n, float w) {
     const int wave = n >> 5, t = (n >> 4) & 1, c = n & 15, kb = k >> 5, rg = (k >> 3) & 3, r = (k >> 1) & 3, e = k & 1;
-    const int word = (((wave * 32 + (kb * 2 + t) * 2) * 64 + rg * 16 + c) << 2) + r;      // hi word; the lo word is 256 further
+    const int v = (kb * 2 + t) * 2;                                                       // hi block; the lo block is v + 1
+    const int word = ((mlp::img_slot(wave, v) * 64 + rg * 16 + c) << 2) + r, word_lo = ((mlp::img_slot(wave, v + 1) * 64 + rg * 16 + c) << 2) + r;
     // a parameter beyond the engine's envelope (|w| >= 1023.5, include/mpg_hip.h) enters the image clamped, never as an fp16
     // infinity; the caller of pack_store reports it (range_check)
     const float ws = fminf(fmaxf(w * mlp::W_SCALE, -65504.f), 65504.f);
@@ -35,7 +36,7 @@ __device__ __forceinline__ void pack_store(float* __restrict__ image, int k, int
     const _Float16 lo = (_Float16)(ws - (float)hi);
     _Float16* p = reinterpret_cast<_Float16*>(image);
     p[2 * word + e] = hi;
-    p[2 * (word + 256) + e] = lo;
+    p[2 * word_lo + e] = lo;
 }
 #else
 // position of W2[row][col] in the packed image where `col`-like index n owns the lane and `row`-like index k the step

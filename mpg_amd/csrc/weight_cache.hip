@@ -33,9 +33,11 @@ __global__ void k_pack(const PackArgs a) {
     if (dir == 0 && idx < a.w3_n[net] && a.status && !(fabsf(W2[mlp::H * mlp::H + mlp::H + idx]) < mlp::P_LIMIT))
         atomicOr(a.status, MPG_STATUS_PARAMETER_RANGE);
 #ifdef MPG_SPLIT
-    // word ((wave*32 + v)*64 + lane)*4 + r, v = (kb*2 + t)*2 + part: the packed pair (k0, k0 + 1), k0 = 32 kb + 8 (lane>>4) + 2 r,
+    // word (img_slot(wave, v)*64 + lane)*4 + r, v = (kb*2 + t)*2 + part: the packed pair (k0, k0 + 1), k0 = 32 kb + 8 (lane>>4) + 2 r,
     // of output column n = 32 wave + 16 t + (lane&15); part 0 = hi halves, 1 = lo halves of W * W_SCALE (mlp_core.h)
-    const int r = idx & 3, lane = (idx >> 2) & 63, v = (idx >> 8) & 31, wave = idx >> 13;
+    const int r = idx & 3, lane = (idx >> 2) & 63;
+    int wave, v;
+    mlp::img_unslot(idx >> 8, wave, v);                          // (the 1 KiB blocks of the eight waves are interleaved: mlp_core.h img_slot)
     const int part = v & 1, t = (v >> 1) & 1, kb = v >> 2;
     const int k0 = 32 * kb + 8 * (lane >> 4) + 2 * r, n = 32 * wave + 16 * t + (lane & 15);
     // a hidden-kernel entry beyond the envelope (|w| >= 1023.5, include/mpg_hip.h) enters clamped and is reported
