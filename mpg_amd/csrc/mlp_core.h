@@ -362,17 +362,43 @@ __device__ __forceinline__ void load_w2_bwd(const float* __restrict__ W2, const 
 // Position (in 1 KiB blocks of 64 lanes x 16 bytes) of wave `wave`'s v-th block in a packed image: one contiguous 32 KB run per wave.
 // Every workgroup of a launch loads the same 256 KB image at the same time (~9 k cycles, ~45 % of what the L2 could deliver).  Round 4
 // tried the eight waves' blocks INTERLEAVED (v * 8 + wave: the eight streams of a CU then read consecutive blocks instead of sitting
-// 32 KB apart) - it is SLOWER: bench step 0.2305 -> 0.2423 ms, the worker launch 21.4 -> 30.4 us (tools/ab_img.sh, -DMPG_IMG_INTERLEAVE).
-__host__ __device__ constexpr int img_slot(int wave, int v) {
+// 32 KB apart) - it is SLOWER: bench step 0.2305 -> 0.2423 ms, the worker launch 21.4 -> 30.4 us; runs of 2 / 4 KB and a per-wave phase
+// shift: within the noise; runs of 8 KB: forward sweep -0.9 us three times out of three, the step within the noise (tools/ab_img.sh).
+#ifndef MPG_IMG_LAYOUT
 #ifdef MPG_IMG_INTERLEAVE
+#define MPG_IMG_LAYOUT 1
+#else
+#define MPG_IMG_LAYOUT 0
+#endif
+#endif
+// MPG_IMG_LAYOUT (experiments, tools/ab_img.sh): 0 one 32 KB run per wave (shipped); 1 blocks of the eight waves interleaved (1 KB runs);
+// 2 / 3 / 4: 2 / 4 / 8 KB runs; 5: 32 KB runs, every wave starting 4 KB further into its run (v ^ 4 wave)
+__host__ __device__ constexpr int img_slot(int wave, int v) {
+#if MPG_IMG_LAYOUT == 1
     return v * 8 + wave;
+#elif MPG_IMG_LAYOUT == 2
+    return (v >> 1) * 16 + wave * 2 + (v & 1);
+#elif MPG_IMG_LAYOUT == 3
+    return (v >> 2) * 32 + wave * 4 + (v & 3);
+#elif MPG_IMG_LAYOUT == 4
+    return (v >> 3) * 64 + wave * 8 + (v & 7);
+#elif MPG_IMG_LAYOUT == 5
+    return wave * 32 + (v ^ ((wave * 4) & 31));
 #else
     return wave * 32 + v;
 #endif
 }
 __host__ __device__ inline void img_unslot(int slot, int& wave, int& v) {
-#ifdef MPG_IMG_INTERLEAVE
+#if MPG_IMG_LAYOUT == 1
     v = slot >> 3; wave = slot & 7;
+#elif MPG_IMG_LAYOUT == 2
+    v = (slot >> 4) * 2 + (slot & 1); wave = (slot >> 1) & 7;
+#elif MPG_IMG_LAYOUT == 3
+    v = (slot >> 5) * 4 + (slot & 3); wave = (slot >> 2) & 7;
+#elif MPG_IMG_LAYOUT == 4
+    v = (slot >> 6) * 8 + (slot & 7); wave = (slot >> 3) & 7;
+#elif MPG_IMG_LAYOUT == 5
+    wave = slot >> 5; v = (slot & 31) ^ ((wave * 4) & 31);
 #else
     wave = slot >> 5; v = slot & 31;
 #endif

@@ -2,7 +2,8 @@
 # img_slot) against one contiguous 32 KB run per wave (default).  Round 4: interleaved is slower (0.2305 -> 0.2423 ms).
 cd $GRAFT_REPO_ROOT
 export MPG_BENCH_NO_F32=1
-for V in "" "-DMPG_IMG_INTERLEAVE" "" "-DMPG_IMG_INTERLEAVE"; do
+for V in ${VARIANTS:-"" "-DMPG_IMG_LAYOUT=5" "-DMPG_IMG_LAYOUT=4" "-DMPG_IMG_LAYOUT=3" "-DMPG_IMG_LAYOUT=2" "-DMPG_IMG_LAYOUT=1" ""}; do
+  [ "$V" = "-" ] && V=""
   echo "== [$V]"; MPG_EXTRA_CFLAGS="$V" python3 -m mpg_amd.build --split-only > /tmp/b.log 2>&1 || tail -3 /tmp/b.log
   python bench.py --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys
