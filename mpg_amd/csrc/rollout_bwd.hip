@@ -15,7 +15,9 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_bwd(const RollBwdArgs a)
     constexpr int NIN = WIDE ? 16 : OBS, XSW = xs_of<NIN>();
     // per-lane running sums of the thin gradients, in LDS (registers: none to spare): [quad][thread] float4, slot order
     // gb1[2] gb2[2] gW3[2][ACT] gW1[2][OBS] (+ padding); the own lanes' db3 in sB3; the step's scaled network inputs of the 16
-    // rows in sXin, double-buffered by step parity (written at the top of a step, read behind its last barrier)
+    // rows in sXin, double-buffered by the parity of a RUNNING step count (written at the top of a step, read behind its last
+    // barrier; the count runs across the groups of a workgroup: with `t & 1` and an even horizon the first step of the next
+    // group (t = n) wrote the buffer the slower waves were still reading for step 0 of the previous one - ADVICE r4)
     constexpr int NACC = 4 + 2 * ACT + 2 * OBS, TQ = (NACC + 3) / 4;
     __shared__ __attribute__((aligned(16))) float sThin[THIN ? TQ * NTHREAD * 4 : 4];
     __shared__ __attribute__((aligned(16))) float sXin[THIN ? 2 * GROUP * 8 : 4];
@@ -63,6 +65,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_bwd(const RollBwdArgs a)
         g_st_prev[tid >> 6] = __builtin_amdgcn_s_memtime();
     }
 #endif
+    int xpar = 0;                              // THIN: which half of sXin this step uses (flips once per processed step)
     for (long g = blockIdx.x; g < ngroups; g += gridDim.x) {
         const long tr = g * GROUP + tid;
         const bool own = tid < GROUP, live = own && tr < R;
@@ -141,7 +144,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_bwd(const RollBwdArgs a)
                 }
                 if constexpr (THIN) {       // this step's network input of the row, as the forward sweep published it (obs * scale)
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) sXin[(t & 1) * GROUP * 8 + tid * 8 + i] = i < OBS ? o[i] * a.obs_scale[i] : 0.f;
+                    for (int i = 0; i < 8; ++i) sXin[xpar * GROUP * 8 + tid * 8 + i] = i < OBS ? o[i] * a.obs_scale[i] : 0.f;
                 }
             }
             float dz1[2][4], dz2[2][4];
@@ -238,7 +241,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_bwd(const RollBwdArgs a)
                 for (int e = 0; e < 2 * OBS; ++e) gw1[e / OBS][e % OBS] = sThin[((BASE + e) / 4 * NTHREAD + tid) * 4 + (BASE + e) % 4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float* xr = sXin + (t & 1) * GROUP * 8 + L.row(j) * 8;
+                    const float* xr = sXin + xpar * GROUP * 8 + L.row(j) * 8;
                     const f32x4 x0 = *reinterpret_cast<const f32x4*>(xr), x1 = *reinterpret_cast<const f32x4*>(xr + 4);
 #pragma unroll
                     for (int i = 0; i < OBS; ++i) {
@@ -254,6 +257,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_bwd(const RollBwdArgs a)
             for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) h2_cur[tt][j] = h2_pre[tt][j];
+            xpar ^= 1;
             MPG_STAMP_AT(7);
             // next iteration: sD3 is rewritten by wave 0 only after it has passed backward_group's final barrier,
             // and read by the others only after the __syncthreads above -> no extra barrier needed.

@@ -449,3 +449,60 @@ def test_cart_pole_env_restatement_is_self_consistent():
     s, r, d, _ = env.step(np.array([3.5, -0.2]))              # action clipped to +-3 by ctrlrange
     assert d[0] and not d[1]
     np.testing.assert_allclose(r, -(0.01 * s[:, 0] ** 2 + s[:, 1] ** 2) - 0.1 * (s[:, 2] ** 2 + s[:, 3] ** 2))
+
+
+def test_philox_restatements_of_the_device_noise_streams_have_the_stated_laws():
+    """The host-side restatements of the device's counter-based draws (oracle.model_noise_philox & co.; the GPU tests pin the
+    kernels to them, tests/test_noise_gpu.py).  Here, without a GPU: the in-kernel model noise is a standard normal - mean,
+    variance, third and fourth moment of 10^6 draws, no correlation between consecutive steps of a trajectory (lag-1 in t),
+    between neighbouring trajectories (cross-row), between the Q-target and the policy rollout of one iteration (counters 2k,
+    2k+1) nor between iterations - which is what path_tracking_env.py:119 / inverted_pendulum_model.py:61 (tfd.Normal.sample())
+    ask for; the replay indices are uniform on [0, n); the cart-pole reset is U(-0.01, 0.01)^4."""
+    n, R = 25, 40000
+    z = O.model_noise_philox(n, R, 12345, 2 * 77).astype(np.float64)            # 10^6 draws
+    N = z.size
+    assert abs(z.mean()) < 4 / np.sqrt(N) and abs(z.var() - 1) < 4 * np.sqrt(2 / N)
+    assert abs((z ** 3).mean()) < 4 * np.sqrt(15 / N) and abs((z ** 4).mean() - 3) < 4 * np.sqrt(96 / N)
+    corr = lambda a, b: float(np.corrcoef(a.ravel(), b.ravel())[0, 1])
+    assert abs(corr(z[:-1], z[1:])) < 4 / np.sqrt(N)                              # lag 1 along a trajectory
+    assert abs(corr(z[:, :-1], z[:, 1:])) < 4 / np.sqrt(N)                        # neighbouring trajectories
+    z2 = O.model_noise_philox(n, R, 12345, 2 * 77 + 1).astype(np.float64)         # the policy rollout of the same iteration
+    z3 = O.model_noise_philox(n, R, 12345, 2 * 78).astype(np.float64)             # the next iteration
+    z4 = O.model_noise_philox(n, R, 12346, 2 * 77).astype(np.float64)             # another seed
+    assert max(abs(corr(z, z2)), abs(corr(z, z3)), abs(corr(z, z4))) < 4 / np.sqrt(N)
+    assert abs(z).max() < 5.9                                                     # 24-bit uniforms: |z| <= sqrt(2 ln 2^25)
+    # the per-trajectory sum over the horizon (what a 25-step random walk of the pendulum's p sees): variance n
+    assert abs(z.sum(0).var() / n - 1) < 4 * np.sqrt(2 / R)
+    zz = O.normal_fill_philox(1000001, 3, 9).astype(np.float64)
+    assert zz.shape == (1000001,) and abs(zz.mean()) < 4e-3 and abs(zz.var() - 1) < 6e-3
+    assert abs(corr(zz[0:-1:2], zz[1::2])) < 6e-3                                  # the cos / sin pair of one Box-Muller draw
+    idx = O.uniform_indices_philox(3072, 1 << 18, 5, 1)
+    assert idx.min() == 0 and idx.max() == 3071
+    cnt = np.bincount(idx, minlength=3072)
+    assert abs(cnt.mean() - (1 << 18) / 3072) < 1e-9 and cnt.std() < 1.15 * np.sqrt((1 << 18) / 3072)
+    assert not np.array_equal(idx[:64], O.uniform_indices_philox(3072, 64, 5, 2))
+    s = O.cart_pole_reset_philox(100000, 1, 4)
+    assert s.dtype == np.float32 and s.shape == (100000, 4) and np.abs(s).max() < 0.01
+    assert np.abs(s.mean(0)).max() < 1e-4 and np.abs(s.var(0) - 0.02 ** 2 / 12).max() < 1e-6
+    e = O.explore_noise_philox(200000, 2, 0.1, 7, 3)
+    assert abs(e.std() - 0.1) < 1e-3 and abs(corr(e[:, 0], e[:, 1])) < 1e-2
+
+
+def test_oracle_config3_loop_is_deterministic_and_follows_the_optimizer_order():
+    """tests/c3_loop.py (the oracle side of the whole-loop test of config 3): two runs from the same weights and seed are
+    bit-identical, another seed differs, the ring fills to replay_starts first (optimizer.py:310-313) and a sample is taken every
+    `sampling_interval` iterations (optimizer.py:332-337)."""
+    from tests.c3_loop import OracleConfig3Loop
+    from tests.golden_inputs import mlp_weights_flat
+    rng = np.random.Generator(np.random.PCG64(0))
+    q, p = mlp_weights_flat(rng, 5, 1), mlp_weights_flat(rng, 4, 2)
+    kw = dict(num_agent=16, batch_size=64, replay_batch_size=32, replay_starts=100, sampling_interval=2)
+    a, b, c = OracleConfig3Loop(q, p, seed=1, **kw), OracleConfig3Loop(q, p, seed=1, **kw), OracleConfig3Loop(q, p, seed=2, **kw)
+    assert a.size == 128 and a.env_ctr == 1 + 8                 # two samples of 4 env steps each, one reset draw per step + the first
+    for _ in range(3):
+        a.step(); b.step(); c.step()
+    assert a.size == 128 + 2 * 64 and a.replay_times == 3 and a.counter == 3
+    np.testing.assert_array_equal(a.flat()[0], b.flat()[0])
+    np.testing.assert_array_equal(a.ring_obs[:a.size], b.ring_obs[:b.size])
+    assert not np.array_equal(a.flat()[0], c.flat()[0])
+    assert np.isfinite(a.stats['targets']).all() and a.stats['targets'].shape == (32,)
