@@ -63,6 +63,9 @@ HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 # launch of the timed region: an event record is a stream packet of its own (~4-5 us between two otherwise back-to-back
 # kernels; 8 of them per step with every launch timed = 6 % of a 0.5 ms step - profiles/README.md has the trace).
 PROF_EVERY = 16
+N_REGIONS = 5          # timed regions of K steps each; value = the median region
+ENV_SAT_AGENTS = 1 << 20      # agents per launch of the stand-alone env-kernel measurement at a saturating size
+ENV_FLOP_PER_STEP = 2300.0    # ~2.3 kflop per env-step (20 sub-steps x ~115, transcendentals counted as 1)
 
 
 def build_stack(dev, seed):
@@ -83,9 +86,15 @@ def build_stack(dev, seed):
 
 
 # ---- CPU baseline: the oracle, the way the reference scales (1 thread per process x P processes) -------------------
-def _cpu_worker(budget_s, seed, q):
+CPU_ROWS = 1024            # rows (agents / replay rows) per CPU step: a bounded sample of the 4096-row step (the unit, env-steps/s, scales)
+CPU_LEGS = (64, 128, 256)  # processes side by side: per-core regime ... memory-bound regime of a 2-socket host
+
+
+def _cpu_worker(budget_s, min_timed, seed, q, go):
     """One reference-style actor: torch pinned to ONE thread (the reference pins TF the same way, mpg_learner.py:27-28),
-    steps of [4096-agent worker.sample + MPG-v2 compute_gradient at B = 4096] of the torch-CPU/numpy oracle."""
+    steps of [CPU_ROWS-agent worker.sample + MPG-v2 compute_gradient at B = CPU_ROWS] of the torch-CPU/numpy oracle.  The FIRST step
+    (allocator warm-up, first-call costs: BASELINE.md section 2 excludes it too) is not timed; then at least `min_timed` steps and
+    as many more as fit into `budget_s`."""
     import numpy as np
     import torch
     torch.set_num_threads(1)
@@ -94,20 +103,26 @@ def _cpu_worker(budget_s, seed, q):
     rng = np.random.Generator(np.random.PCG64(seed))
     cfg = O.Cfg()
     flat = {'policy': mlp_weights_flat(rng, 6, 4), 'Q1': mlp_weights_flat(rng, 8, 1), 'Q2': mlp_weights_flat(rng, 8, 1)}
-    env = O.PathTrackingEnvOracle(B_PER_GPU)
+    env = O.PathTrackingEnvOracle(CPU_ROWS)
     env.reset(rng=rng)
-    n_done, t0 = 0, time.perf_counter()
-    while True:
+
+    def step(k):
         nets = O.Nets(cfg, flat, target_scale=1.0)
         tr = O.worker_sample(cfg, nets, env, rng, 1)[0]
         batch = [tr[0], tr[1], tr[2], tr[3], tr[4].astype(np.float32)]
-        eps = rng.standard_normal((N_STEP, B_PER_GPU)).astype(np.float32)
-        O.mpg_compute_gradient(cfg, nets, batch, eps, 100 + n_done, 'MPG-v2')
+        eps = rng.standard_normal((N_STEP, CPU_ROWS)).astype(np.float32)
+        O.mpg_compute_gradient(cfg, nets, batch, eps, 100 + k, 'MPG-v2')
+    q.put(('ready', seed))
+    go.wait()                   # every process of the leg starts its steps together (imports are not part of the sample)
+    step(0)                     # excluded
+    n_done, t0 = 0, time.perf_counter()
+    while True:
+        step(1 + n_done)
         n_done += 1
         el = time.perf_counter() - t0
-        if el > budget_s or n_done >= 200:
+        if n_done >= min_timed and (el > budget_s or n_done >= 200):
             break
-    q.put((n_done, el))
+    q.put(('done', n_done, el))
 
 
 def _cpu_model():
@@ -120,11 +135,7 @@ def _cpu_model():
     return 'unknown'
 
 
-def cpu_baseline(budget_s=12.0, max_procs=256):
-    """`kind: port` - the oracle timed on the host cores on a bounded sample of the SAME workload, shaped like the
-    reference's own scaling: P single-threaded processes side by side.  P = min(host cores, max_procs,
-    what the free memory allows at ~1.5 GB per process: `import torch` alone is 0.6 GB of private pages)."""
-    import multiprocessing as mp
+def _host_limits(max_procs):
     try:
         host = len(os.sched_getaffinity(0))
     except AttributeError:
@@ -134,37 +145,85 @@ def cpu_baseline(budget_s=12.0, max_procs=256):
         mem_cap = max(1, int(psutil.virtual_memory().available * 0.5 / 1.5e9))
     except Exception:
         mem_cap = 8
-    procs = max(1, min(host, max_procs, mem_cap))
+    return host, mem_cap, max(1, min(host, max_procs, mem_cap))
+
+
+def _run_leg(target, args_of, procs, timeout_s):
+    """`procs` spawned single-threaded processes side by side; returns their ('done', units, seconds) results and the wall time"""
+    import multiprocessing as mp
+    ctx = mp.get_context('spawn')          # fresh interpreters: nothing of this process' GPU state is inherited
+    q, go = ctx.Queue(), ctx.Event()
+    ps = [ctx.Process(target=target, args=args_of(i) + (q, go)) for i in range(procs)]
+    t0 = time.perf_counter()
+    for p in ps:
+        p.start()
+    ready, res = 0, []
+    try:
+        while ready < procs:
+            q.get(timeout=300)
+            ready += 1
+        go.set()
+        for _ in ps:
+            res.append(q.get(timeout=timeout_s)[1:])
+    except Exception:              # noqa: BLE001 - a process that died or stalled: report what arrived
+        go.set()
+    for p in ps:
+        p.join(timeout=10)
+        if p.is_alive():
+            p.kill()
+    return res, time.perf_counter() - t0
+
+
+def cpu_baseline(budget_s=8.0, min_timed=3, max_procs=256):
+    """`kind: port` - the oracle timed on the host cores on a bounded sample of the SAME workload, shaped like the
+    reference's own scaling: P single-threaded processes side by side, for P = 64 / 128 / 256 (capped by
+    the host's cores and by what the free memory allows at ~1.5 GB per process: `import torch` alone is 0.6 GB of private
+    pages), so that the per-core regime (few processes) and the memory-bound regime (every hardware thread busy) are both in
+    the line.  Every process: one untimed step, then >= 3 timed steps of CPU_ROWS rows.  `value` = the best leg."""
+    host, mem_cap, cap = _host_limits(max_procs)
     # one thread per process means ONE: without these every child would start an OpenMP/MKL pool as wide as the host
     # (256 threads each on the MI355X box) before torch.set_num_threads(1) is reached
     for k in ('OMP_NUM_THREADS', 'MKL_NUM_THREADS', 'OPENBLAS_NUM_THREADS', 'NUMEXPR_NUM_THREADS'):
         os.environ[k] = '1'
     os.environ['HIP_VISIBLE_DEVICES'] = ''      # the CPU actors never touch the GPU
-    ctx = mp.get_context('spawn')          # fresh interpreters: nothing of this process' GPU state is inherited
-    q = ctx.Queue()
-    ps = [ctx.Process(target=_cpu_worker, args=(budget_s, 1000 + i, q)) for i in range(procs)]
-    t0 = time.perf_counter()
-    for p in ps:
-        p.start()
-    res = []
-    for _ in ps:
-        try:
-            res.append(q.get(timeout=budget_s * 6 + 120))
-        except Exception:
-            break
-    for p in ps:
-        p.join(timeout=10)
-        if p.is_alive():
-            p.kill()
-    wall = time.perf_counter() - t0
-    steps_per_s = sum(n / el for n, el in res)
-    return {'value': steps_per_s * B_PER_GPU, 'unit': 'env-steps/s', 'cores': len(res), 'kind': 'port',
-            'grad_steps_per_sec': steps_per_s, 'host_cores': host, 'cpu_model': _cpu_model(),
-            'per_process_grad_steps_per_sec': steps_per_s / max(1, len(res)),
-            'sample': '%d single-threaded processes side by side, each %.0f s of steps of [4096-agent worker.sample + MPG-v2 '
-                      'compute_gradient B=4096] of the torch-CPU oracle (%d steps in total, %.0f s wall incl. start-up); process '
-                      'count = min(host cores %d, %d, free-memory cap %d)'
-                      % (len(res), budget_s, sum(n for n, _ in res), wall, host, max_procs, mem_cap)}
+    legs = []
+    for want in sorted(set(min(p, cap) for p in CPU_LEGS)):
+        res, wall = _run_leg(_cpu_worker, lambda i: (budget_s, min_timed, 1000 + i), want, budget_s * 20 + 300)
+        if not res:
+            continue
+        sps = sum(n / el for n, el in res)
+        legs.append({'processes': len(res), 'env_steps_per_sec': sps * CPU_ROWS, 'steps_per_sec_per_process': sps / len(res),
+                     'seconds_per_step': len(res) / sps, 'timed_steps': sum(n for n, _ in res), 'wall_s': round(wall, 1)})
+    best = max(legs, key=lambda g: g['env_steps_per_sec'])
+    return {'value': best['env_steps_per_sec'], 'unit': 'env-steps/s', 'cores': best['processes'], 'kind': 'port',
+            'grad_steps_per_sec': best['env_steps_per_sec'] / B_PER_GPU, 'host_cores': host, 'cpu_model': _cpu_model(),
+            'rows_per_cpu_step': CPU_ROWS, 'legs': legs,
+            'sample': 'P single-threaded processes side by side, P = %s (host cores %d, free-memory cap %d); each process: one '
+                      'untimed step, then >= %d timed steps (%.0f s budget) of [%d-agent worker.sample + MPG-v2 compute_gradient '
+                      'B=%d] of the torch-CPU oracle - a quarter of the 4096-row step per CPU step, env-steps/s scales with the rows; '
+                      'value = the best leg (%d processes); grad_steps_per_sec = value / 4096'
+                      % ('/'.join(str(g['processes']) for g in legs), host, mem_cap, min_timed, budget_s, CPU_ROWS, CPU_ROWS, best['processes'])}
+
+
+def _under_profiler():
+    """rocprofv3 (or any rocprofiler-sdk tool) preloads its library into this process AND into every child: the children's kernels
+    would be averaged into the profile of this run under the same names"""
+    if 'rocprof' in os.environ.get('LD_PRELOAD', '').lower():
+        return True
+    return any(k.startswith(('ROCPROF', 'ROCP_TOOL')) for k in os.environ)
+
+
+def _env_sat(sat):
+    out = {'agents_per_launch': ENV_SAT_AGENTS, 'algorithmic_bytes_per_env_step': 85, 'algorithmic_flop_per_env_step': ENV_FLOP_PER_STEP,
+           'timed_with': 'one HIP event pair around 10 back-to-back launches after the timed region (3 untimed first)'}
+    for name, ms in sat.items():
+        rate = ENV_SAT_AGENTS / (ms * 1e-3)
+        f_hbm, f_valu = 85 * rate / 1e9 / HBM_PEAK_GBS, ENV_FLOP_PER_STEP * rate / 1e12 / FP32_MFMA_PEAK_TFLOPS
+        out[name] = {'kernel': 'k_step (mpg_env_step)' if name == 'step_only' else 'k_step_store_reset (mpg_env_step_store_reset)',
+                     'avg_ms': ms, 'env_steps_per_sec': rate, 'achieved_GBs': 85 * rate / 1e9, 'frac_hbm': f_hbm,
+                     'achieved_valu_tflops': ENV_FLOP_PER_STEP * rate / 1e12, 'peak_valu_tflops': FP32_MFMA_PEAK_TFLOPS, 'frac_valu': f_valu,
+                     'binding': 'valu' if f_valu >= f_hbm else 'hbm'}
+    return out
 
 
 def _free_port():
@@ -218,16 +277,15 @@ SIDE = {
 }
 
 
-def _cpu_side_worker(budget_s, seed, q, config):
+def _cpu_side_worker(budget_s, seed, config, q, go):
     """one single-threaded actor running the oracle's gradient step of the side configuration on a REDUCED batch (the unit is
-    rows / s, so the sample scales): NADP 512 rows, TD3 4096 rows"""
+    rows / s, so the sample scales): NADP 512 rows, TD3 4096 rows; first step untimed"""
     import numpy as np
     import torch
     torch.set_num_threads(1)
     from oracle import mpg_oracle as O
     from tests.golden_inputs import mlp_weights_flat, reset_law_obs
     rng = np.random.Generator(np.random.PCG64(seed))
-    n_done, t0 = 0, time.perf_counter()
     if config == 'c3':
         rows = 512
         cfg = O.Cfg(env='InvertedPendulumConti-v0', select=[25], delay_update=1)
@@ -240,55 +298,38 @@ def _cpu_side_worker(budget_s, seed, q, config):
         flat = {'policy': mlp_weights_flat(rng, 6, 4), 'Q1': mlp_weights_flat(rng, 8, 1), 'Q2': mlp_weights_flat(rng, 8, 1)}
         batch = [reset_law_obs(rng, rows), rng.uniform(-1, 1, (rows, 2)).astype(np.float32), rng.uniform(-30, 0, rows).astype(np.float32),
                  reset_law_obs(rng, rows), np.ones(rows, np.float32)]
-    while True:
+
+    def step():
         nets = O.Nets(cfg, flat, target_scale=1.0)
         if config == 'c3':
             O.nadp_compute_gradient(cfg, nets, [obs, act], rng.standard_normal((25, rows)).astype(np.float32),
                                     rng.standard_normal((25, rows)).astype(np.float32))
         else:
             O.td3_compute_gradient(cfg, nets, batch, rng.standard_normal((rows, 2)).astype(np.float32))
+    q.put(('ready', seed))
+    go.wait()
+    step()
+    n_done, t0 = 0, time.perf_counter()
+    while True:
+        step()
         n_done += 1
         el = time.perf_counter() - t0
-        if el > budget_s or n_done >= 500:
+        if n_done >= 3 and (el > budget_s or n_done >= 500):
             break
-    q.put((n_done * rows, el))
+    q.put(('done', n_done * rows, el))
 
 
-def cpu_side_baseline(config, budget_s=10.0, max_procs=256):
-    import multiprocessing as mp
-    try:
-        host = len(os.sched_getaffinity(0))
-    except AttributeError:
-        host = os.cpu_count() or 1
-    try:
-        import psutil
-        mem_cap = max(1, int(psutil.virtual_memory().available * 0.5 / 1.5e9))
-    except Exception:
-        mem_cap = 8
-    procs = max(1, min(host, max_procs, mem_cap))
+def cpu_side_baseline(config, budget_s=8.0, max_procs=256):
+    host, mem_cap, procs = _host_limits(max_procs)
     for k in ('OMP_NUM_THREADS', 'MKL_NUM_THREADS', 'OPENBLAS_NUM_THREADS', 'NUMEXPR_NUM_THREADS'):
         os.environ[k] = '1'
     os.environ['HIP_VISIBLE_DEVICES'] = ''
-    ctx = mp.get_context('spawn')
-    q = ctx.Queue()
-    ps = [ctx.Process(target=_cpu_side_worker, args=(budget_s, 2000 + i, q, config)) for i in range(procs)]
-    for p in ps:
-        p.start()
-    res = []
-    for _ in ps:
-        try:
-            res.append(q.get(timeout=budget_s * 6 + 120))
-        except Exception:
-            break
-    for p in ps:
-        p.join(timeout=10)
-        if p.is_alive():
-            p.kill()
+    res, _ = _run_leg(_cpu_side_worker, lambda i: (budget_s, 2000 + i, config), procs, budget_s * 20 + 300)
     rows_per_s = sum(n / el for n, el in res)
     return {'value': rows_per_s, 'unit': 'rows/s', 'cores': len(res), 'kind': 'port', 'host_cores': host, 'cpu_model': _cpu_model(),
-            'sample': '%d single-threaded processes side by side, each %.0f s of the oracle\'s %s gradient step on %d-row batches '
-                      '(rows/s scales with the batch); process count = min(host cores %d, %d, free-memory cap %d)'
-                      % (len(res), budget_s, SIDE[config]['alg'], 512 if config == 'c3' else 4096, host, max_procs, mem_cap)}
+            'sample': '%d single-threaded processes side by side, each one untimed step and then >= 3 timed steps (%.0f s budget) of the '
+                      'oracle\'s %s gradient step on %d-row batches (rows/s scales with the batch); process count = min(host cores %d, '
+                      '%d, free-memory cap %d)' % (len(res), budget_s, SIDE[config]['alg'], 512 if config == 'c3' else 4096, host, max_procs, mem_cap)}
 
 
 def side_config(a):
@@ -346,17 +387,19 @@ def side_config(a):
     quiesce_gc()
     for _ in range(max(a.warmup, 5)):
         step()
-    D.barrier()
-    torch.cuda.synchronize()
     gc.disable()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    D.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    regions = []
+    for _ in range(N_REGIONS):              # like the main line: value from the median of N_REGIONS regions of K steps
+        D.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            step()
+        D.barrier()
+        torch.cuda.synchronize()
+        regions.append(D.max_over_ranks(time.perf_counter() - t0))
     gc.enable()
-    dt = D.max_over_ranks(dt)
+    dt = sorted(regions)[len(regions) // 2]
     # kernel groups: a second, short pass with EVERY launch of the library's timer slots bracketed by HIP events (the records
     # cost ~4-5 us each, which is why this pass is not the timed one)
     nprof = min(a.steps, 10)
@@ -390,7 +433,8 @@ def side_config(a):
     out = {
         'metric': c['metric'], 'value': world * B * a.steps / dt, 'unit': 'rows/s', 'grad_steps_per_sec': a.steps / dt,
         'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak',
-        'vs_baseline': None, 'dtype': 'f32-via-split-f16', 'data': 'synthetic', 'schema': 3,
+        'timed_regions': N_REGIONS, 'region_ms_per_step': [1e3 * r / a.steps for r in regions],
+        'vs_baseline': None, 'dtype': 'f32-via-split-f16', 'data': 'synthetic', 'schema': 4,
         'config': {'workload': c['workload'], 'global_batch': world * B, 'parallelism': 'dp%d' % world, 'dist_backend': D.backend()},
         'device': _device_info(),
         # whole-step matrix view (the step is a chain of weight-stationary launches, all on the f16 pipe).  `achieved` / `frac`
@@ -422,6 +466,7 @@ def main():
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-side-configs', action='store_true', help='do not run --config c3 / c4 as child processes after the timed region')
     ap.add_argument('--config', default='c2', choices=['c2', 'c3', 'c4'],
                     help='c2 (default): the BASELINE metric - PathTracking MPG n=25 batch 4096; c3: NADP on the pendulum model, batch '
                          '8192; c4: TD3 + prioritized replay, batch 65536 (BASELINE.json configs[2], [3]: side lines, same JSON shape)')
@@ -450,7 +495,7 @@ def main():
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
     args, worker, learner, rb, opt = build_stack(dev, seed=rank)
-    n_samples = (max(a.steps, 1) + PROF_EVERY - 1) // PROF_EVERY + 1
+    n_samples = (N_REGIONS * max(a.steps, 1) + PROF_EVERY - 1) // PROF_EVERY + 1
     prof = ops.Profiler(max_samples=n_samples)      # every HIP event exists from here on
     opt.set_profiler(prof)
     quiesce_gc()                                     # gc.collect() + gc.freeze(): see the module docstring
@@ -459,18 +504,23 @@ def main():
         opt.step()
     for _ in range(a.warmup):
         opt.step()
-    D.barrier()
-    torch.cuda.synchronize()
     prof.start(PROF_EVERY)                           # clears the samples; no event is created
     gc.disable()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        opt.step()
-    D.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    # N_REGIONS consecutive timed regions of EXACTLY K steps each, every one bracketed by barrier + synchronize on both sides and
+    # reduced with MAX over the ranks; `value` comes from the MEDIAN region (one 4.7 ms region is at the mercy of
+    # a single host stall - profiles/r04_final_bench_driver_form_outlier.json - so the line lists all of them)
+    regions = []
+    for _ in range(N_REGIONS):
+        D.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            opt.step()
+        D.barrier()
+        torch.cuda.synchronize()
+        regions.append(D.max_over_ranks(time.perf_counter() - t0))
     gc.enable()
-    dt = D.max_over_ranks(dt)
+    dt = sorted(regions)[len(regions) // 2]
 
     fwd_ms, fwd_n = prof.read(0)
     bwd_ms, bwd_n = prof.read(1)
@@ -482,7 +532,7 @@ def main():
     xch_ms, xch_n = prof.read(8)                     # the gradient exchange (None on one GPU: there is none)
     adam_ms, adam_n = prof.read(9)
     prof.stop()
-    n_sampled = (a.steps + PROF_EVERY - 1) // PROF_EVERY
+    n_sampled = (N_REGIONS * a.steps + PROF_EVERY - 1) // PROF_EVERY
     assert fwd_n == n_sampled and bwd_n == n_sampled, (fwd_n, bwd_n, n_sampled)
     # per-step distribution: a second pass of the same K steps, one HIP event per step (not part of `value`)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
@@ -534,6 +584,39 @@ def main():
     es[1].record()
     torch.cuda.synchronize()
     step_store_reset_ms = es[0].elapsed_time(es[1]) / 64
+    # ... and the env kernel at a SATURATING size (SURVEY section 8d K1 prices it as a scan: 85 B per env-step against the HBM roof,
+    # with the VALU fraction beside it - 4096 agents are 64 waves on 256 CUs, which measures launch latency and the 20-sub-step
+    # dependency chain, not the kernel): ENV_SAT_AGENTS agents per launch, reset law for the states, U(-1, 1) actions
+    ns = ENV_SAT_AGENTS
+    from mpg_amd.envs import PathTrackingEnv
+    big = PathTrackingEnv(num_agent=ns, device=dev, seed=11)
+    big.reset()
+    b_act = torch.rand(ns, 2, device=dev) * 2 - 1
+    b_obs, b_rew = torch.empty(ns, 6, device=dev), torch.empty(ns, device=dev)
+    b_done, b_di = torch.empty(ns, dtype=torch.uint8, device=dev), torch.empty(ns, dtype=torch.uint8, device=dev)
+    b_robs, b_robs2 = torch.empty(ns, 6, device=dev), torch.empty(ns, 6, device=dev)
+    b_ract, b_rrew, b_rdone = torch.empty(ns, 2, device=dev), torch.empty(ns, device=dev), torch.empty(ns, dtype=torch.uint8, device=dev)
+
+    def big_step(k):
+        for _ in range(k):
+            L.call('mpg_env_step', L.c_int(0), L.c_int(ns), L.c_int(6), L.ptr(big._state), L.ptr(b_act), L.ptr(b_obs), L.ptr(b_rew),
+                   L.ptr(b_done), L.ptr(b_di), L.stream())
+
+    def big_step_store_reset(k):
+        for j in range(k):
+            L.call('mpg_env_step_store_reset', L.c_int(0), L.c_int(ns), L.c_int(6), L.ptr(big._state), L.ptr(b_act), L.c_int(ns), L.c_int(0),
+                   L.ptr(b_robs), L.ptr(b_ract), L.ptr(b_rrew), L.ptr(b_robs2), L.ptr(b_rdone), L.c_u64(7), L.c_u64(j), L.ptr(b_obs),
+                   L.ptr(b_done), L.stream())
+    sat = {}
+    for name, fn in (('step_only', big_step), ('step_store_reset', big_step_store_reset)):
+        fn(3)
+        torch.cuda.synchronize()
+        es[0].record()
+        fn(10)
+        es[1].record()
+        torch.cuda.synchronize()
+        sat[name] = es[0].elapsed_time(es[1]) / 10
+    del big, b_act, b_obs, b_rew, b_done, b_di, b_robs, b_robs2, b_ract, b_rrew, b_rdone
     finite = bool(torch.isfinite(worker.policy_with_value.params).all().item())
     assert finite and int(worker.policy_with_value.nonfinite.sum().item()) == 0, 'non-finite parameters after the timed region'
     worker.policy_with_value.check_status()          # raises if the split-fp16 engine left its numerical envelope anywhere
@@ -553,20 +636,38 @@ def main():
     # anywhere), measured NOW: a child process (a fresh interpreter that selects the other shared object before its first GPU
     # call; this process only waits) runs the same K / W after this run's timed region
     exact = {'ms_per_step': None, 'from': None}
-    if a.engine == 'split' and world == 1 and not os.environ.get('MPG_BENCH_NO_F32'):
-        cmd = [sys.executable, os.path.abspath(__file__), '--gpus', '1', '--steps', str(a.steps), '--warmup', str(a.warmup),
-               '--engine', 'f32', '--no-cpu-baseline']
+    profiled = _under_profiler()
+    children = a.engine == 'split' and world == 1 and not os.environ.get('MPG_BENCH_NO_F32') and not profiled
+
+    def child(extra, timeout=900):
+        cmd = [sys.executable, os.path.abspath(__file__), '--gpus', '1', '--steps', str(a.steps), '--warmup', str(a.warmup), '--no-cpu-baseline'] + extra
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+        if r.returncode == 0 and line:
+            return json.loads(line[-1]), ' '.join(cmd[1:])
+        raise RuntimeError('rc %d: %s' % (r.returncode, r.stderr[-300:]))
+    if children:
         try:
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
-            line = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
-            if r.returncode == 0 and line:
-                d32 = json.loads(line[-1])
-                exact = {'ms_per_step': d32['ms_per_step'], 'from': 'this run: child process `%s` after the timed region' % ' '.join(cmd[1:]),
-                         'rollout_kernels_ms': [d32['roofline']['avg_ms'], d32['roofline_other_rollout_kernel']['avg_ms']]}
-            else:
-                exact['from'] = 'child failed (rc %d): %s' % (r.returncode, r.stderr[-300:])
+            d32, how = child(['--engine', 'f32', '--no-side-configs'])
+            exact = {'ms_per_step': d32['ms_per_step'], 'from': 'this run: child process `%s` after the timed region' % how,
+                     'rollout_kernels_ms': [d32['roofline']['avg_ms'], d32['roofline_other_rollout_kernel']['avg_ms']]}
         except Exception as e:                       # noqa: BLE001 - a side measurement must not take the line down
             exact['from'] = 'child failed: %r' % (e,)
+    elif profiled:
+        exact['from'] = 'skipped: this process runs under a profiler (the child would inherit its preload and be counted into its output)'
+    # BASELINE.json configs[2] / [3] (C3: NADP on the pendulum model, B = 8192; C4: TD3 + prioritized replay, B = 65 536) as
+    # child processes after the timed region, like the exact-fp32 engine: parity-test configurations, NOT the bench line - here so
+    # that the driver's record carries them
+    side = {}
+    if children and not a.no_side_configs:
+        for cname in ('c3', 'c4'):
+            try:
+                d, how = child(['--config', cname])
+                side[cname] = {k: d.get(k) for k in ('metric', 'value', 'unit', 'ms_per_step', 'grad_steps_per_sec', 'steps', 'timed_regions',
+                                                     'region_ms_per_step', 'roofline', 'per', 'kernel_groups_ms_per_step')}
+                side[cname]['from'] = 'child process `%s` after the timed region' % how
+            except Exception as e:                   # noqa: BLE001
+                side[cname] = {'error': repr(e)}
 
     def roof(kernel, nbytes, flop, ms, n):
         """Both roofs of a rollout sweep.  With the split-fp16 engine the sweeps sit closer to the HBM roof (the activation
@@ -598,13 +699,17 @@ def main():
         'grad_steps_per_sec': a.steps / dt,
         'model_steps_per_sec': world * B_PER_GPU * N_STEP * a.steps / dt,
         'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': 1e3 * dt / a.steps,
+        # value / ms_per_step / grad_steps_per_sec come from the MEDIAN of `timed_regions` consecutive regions of exactly `steps`
+        # steps each (barrier + synchronize on both sides of every region, MAX over ranks per region); all regions listed in order
+        'timed_regions': N_REGIONS, 'region_ms_per_step': [1e3 * r / a.steps for r in regions],
         'burn_in_steps': BURN_IN_STEPS,
         'gc': 'gc.collect()+gc.freeze() before the burn-in, gc.disable() inside the timed region',
         'step_ms_median': per_step[len(per_step) // 2], 'step_ms_min': per_step[0], 'step_ms_max': per_step[-1],
         'step_ms_from': 'second pass of the same %d steps, one HIP event per step (not part of value)' % a.steps,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f32-via-split-f16' if a.engine == 'split' else 'f32', 'data': 'synthetic',
-        'schema': 3,     # 3: roofline.frac = HBM view (round 1: fp32-MFMA view), frac_hbm / frac_f16_mfma under stable keys, exact_fp32_*
+        'schema': 4,     # 4: value from the median of 5 timed regions, env_step_kernel at a saturating size, side_configs, cpu_baseline legs
+                         # 3: roofline.frac = HBM view (round 1: fp32-MFMA view), frac_hbm / frac_f16_mfma under stable keys, exact_fp32_*
         'exact_fp32_ms_per_step': exact.get('ms_per_step'),
         'exact_fp32_from': exact.get('from'),
         'exact_fp32_rollout_kernels_ms': exact.get('rollout_kernels_ms'),
@@ -621,8 +726,10 @@ def main():
         'roofline_other_rollout_kernel': other,
         'other_kernels_avg_ms': {'k_target_fused': tgt_ms, 'k_critic_fused': crit_ms, 'k_wgrad_multi': wg_ms,
                                  # (one launch when the native driver runs the path-tracking worker: policy pass + env step)
-                                 'k_forward (worker policy)': pol_ms,
-                                 ('k_policy_step_store_reset (worker policy + env)' if not pol_ms else 'k_step_store_reset (env)'): env_ms,
+                                 # stable keys (the A/B scripts under tools/ read them): with the fused worker launch the policy pass
+                                 # has no launch of its own (0.0) and the env entry is the whole worker launch - see `worker_launch`
+                                 'k_forward (worker policy)': pol_ms or 0.0,
+                                 'k_step_store_reset (env)': env_ms,
                                  'k_clip_adam_polyak': adam_ms},
         # the ONE exchange step per gradient step (all-reduce of the flat [gradients | statistics] buffer), HIP events on the
         # launch stream around every PROF_EVERY-th exchange of the timed region on rank 0; null on one GPU (none is enqueued)
@@ -631,6 +738,10 @@ def main():
                             'env_steps_per_sec_kernel_only': B_PER_GPU / (step_store_reset_ms * 1e-3),
                             'algorithmic_bytes_per_env_step': 85,
                             'timed_with': 'like env_step_only_kernel (stand-alone; inside the training step the env rides in the worker launch)'},
+        # SURVEY section 8d K1 at a saturating size: 85 algorithmic bytes and ~2.3 kflop per env-step; the binding roof is the larger
+        # fraction (the kernel is a 20-sub-step dependency chain of sin / cos / atan / divisions per agent: VALU work, not a scan)
+        'env_step_kernel_saturating': _env_sat(sat),
+        'side_configs': side,
         'worker_launch': {'kernel': 'k_policy_step_store_reset' if not pol_ms else 'k_step_store_reset', 'avg_ms': env_ms, 'launches': env_n},
         # both env rates of SURVEY section 8d under stable keys (kernel-only, 4096 agents per launch)
         'env_steps_per_sec_step_only': B_PER_GPU / (step_only_ms * 1e-3),

@@ -54,7 +54,11 @@ __device__ __forceinline__ void pack_store(float* __restrict__ image, int k, int
 // every hidden-kernel (W2) and output-kernel (W3) entry the update writes is checked against the envelope of the split engine
 // (one compare in a memory-bound kernel).  `e` = index relative to the network's W2 (-1: no weight cache bound): W2 is [0, HH),
 // b2 [HH, HH + 256), W3 and b3 follow.  The first layer and the hidden biases have no fp16 envelope (they are float32 operands of
-// the fp32 MFMA / the accumulator) and are not flagged; a NaN anywhere still is (the comparison is false).
+// the fp32 MFMA / the accumulator) and are not flagged; a NaN anywhere still is (the comparison is false).  The out_dim entries
+// of b3 behind W3 are held to W3's limit as well (this check does not know out_dim; an output bias beyond 1023.5 is reported
+// although the engine could carry it - stricter than necessary, never laxer).  e = -1 (no usable weight cache bound): only NaN
+// is looked for - the callers pass a null status word in exactly that case (adam_args: status_w / status_t come from the
+// cache descriptors), so nothing could be reported anyway; the envelope is then checked when a cache is next packed.
 __device__ __forceinline__ void range_check(int* status, float w, int e) {
     const bool enveloped = (e >= 0 && e < HH) || e >= HH + MPG_HIDDEN;
     if (status && (enveloped ? !(fabsf(w) < mlp::P_LIMIT) : w != w)) atomicOr(status, MPG_STATUS_PARAMETER_RANGE);

@@ -43,16 +43,23 @@ class _HostShm(object):
       * `handles[g & 1][r]` - the interprocess-event handles (4 x 64 bytes) of rank r's generation g."""
     HB = 64                                        # sizeof(hipIpcEventHandle_t)
 
+    TIMEOUT_S = 120.0                              # wall-clock bound on any hand-shake wait (a dead peer is reported, not spun on)
+
     def __init__(self, world, rank, tag):
         import numpy as np
+        import uuid
         self.world, self.rank = world, rank
-        path = '/dev/shm/mpg_oneshot_%s_%s' % (os.environ.get('MASTER_PORT', '0'), tag)
         n_i64 = 16 * world
         nbytes = 8 * n_i64 + 2 * world * 4 * self.HB
+        # a name nobody else can hold: rank 0 picks it (pid + uuid) and creates the file exclusively, the others learn it through
+        # the process group (two jobs on one node, or a stale file of another user, can no longer collide - ADVICE r4)
+        name = ['/dev/shm/mpg_oneshot_%d_%s_%s' % (os.getpid(), uuid.uuid4().hex, tag) if rank == 0 else None]
         if rank == 0:
-            with open(path, 'wb') as fh:
+            fd = os.open(name[0], os.O_CREAT | os.O_EXCL | os.O_RDWR, 0o600)
+            with os.fdopen(fd, 'wb') as fh:
                 fh.write(b'\0' * nbytes)
-        dist.barrier()
+        dist.broadcast_object_list(name, src=0)
+        path = name[0]
         self.raw = np.memmap(path, dtype=np.uint8, mode='r+', shape=(nbytes,))
         self.a = self.raw[:8 * n_i64].view(np.int64)
         self.h = self.raw[8 * n_i64:].reshape(2, world, 4, self.HB)
@@ -64,11 +71,19 @@ class _HostShm(object):
         self.a[16 * self.rank] = v
 
     def _spin(self, i, v, what):
-        a, spins = self.a, 0
+        """waits until counter i reaches v: a short pure spin (the common case - the peers' hosts run ahead of their GPUs - is
+        settled within it), then yielding the core between polls (ranks that time-share a few cores must not starve the peer they
+        wait for), bounded by the wall clock"""
+        import time
+        a = self.a
+        for _ in range(2000):
+            if a[i] >= v:
+                return
+        deadline = time.monotonic() + self.TIMEOUT_S
         while a[i] < v:
-            spins += 1
-            if spins > 200000000:
-                raise RuntimeError('one-shot all-reduce: %s %d never reached' % (what, v))
+            os.sched_yield()
+            if time.monotonic() > deadline:
+                raise RuntimeError('one-shot all-reduce: %s %d not reached within %.0f s (a peer died or stalled)' % (what, v, self.TIMEOUT_S))
 
     def wait(self, p, v):
         self._spin(16 * p, v, 'rank %d, exchange' % p)

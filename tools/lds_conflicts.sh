@@ -1,4 +1,5 @@
 #!/bin/bash
+export MPG_BENCH_NO_F32=1   # no child processes under the profiler (their kernels would be averaged into this profile; bench.py also detects the preload itself)
 # Attribution of SQ_LDS_BANK_CONFLICT in the network kernels (run through gpurun):  bash tools/lds_conflicts.sh
 # Two builds - shipped, and -DMPG_AB_NO_IMGWRITE (the split-fp16 image stores of store_c_to_a dropped; results are garbage, only
 # the counters matter) - each profiled with one rocprofv3 --pmc pass (no tracing) over a short bench run; prints per kernel

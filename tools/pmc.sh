@@ -1,4 +1,5 @@
 #!/bin/bash
+export MPG_BENCH_NO_F32=1   # no child processes under the profiler (their kernels would be averaged into this profile; bench.py also detects the preload itself)
 # PMC passes of the bench workload on the GPU box (run through gpurun):  bash tools/pmc.sh <outdir-under-gpurun_out>
 # Counters are collected in their own rocprofv3 runs (no tracing options), FETCH_SIZE and WRITE_SIZE in separate passes
 # (TCC slots), as MI355X_MICROARCH.md prescribes.  Writes <outdir>/pmc_summary.csv (per-kernel averages per dispatch) and
