@@ -580,24 +580,42 @@ extern "C" int mpg_mpg_gradients(const mpg_cfg_t* cfg, int n_q, const float* par
         sums[ns].src = ret_part + (size_t)k * ngroups * 2; sums[ns].n = ngroups; sums[ns].stride = 2; sums[ns].dst = stats + 2 + k; ++ns;
         sums[ns].src = ret_part + (size_t)k * ngroups * 2 + 1; sums[ns].n = ngroups; sums[ns].stride = 2; sums[ns].dst = stats + 2 + n_select + k; ++ns;
     }
-    // -DMPG_AB_WGRAD_EARLY (A/B build, tools/ab_early.sh; slower): the critics' chunk products right behind the critic
-    // launch, while their stashes are still in the caches, the policy's behind the reverse sweep, one reduction at the end
+    // Scheduling options (mpg_cfg_t.grad_opts, round 5):
+    //   critics_ready_event - the critics' gradient is FINISHED (chunk products, slab sums, loss sums) right behind the critic launch and
+    //                         the event recorded there, so that a caller can exchange it between GPUs under the reverse sweep; the
+    //                         policy's follows the sweep as a second weight-gradient + reduction pair (one launch more; the critics'
+    //                         chunk products ahead of the sweep cost ~9 us on one GPU, EXPERIMENTS.md "Why nothing overlaps the exchange");
+    //   defer_reduce        - the final slab reduction is not launched but described to the caller (mpg_reduce_clip_adam_polyak).
+    // -DMPG_AB_WGRAD_EARLY (A/B build, tools/ab_early.sh): the early chunk products with ONE reduction at the end.
+    const mpg_grad_opts_t* opts = cfg->grad_opts;
+    hipEvent_t critics_ready = opts ? reinterpret_cast<hipEvent_t>(opts->critics_ready_event) : nullptr;
 #ifdef MPG_AB_WGRAD_EARLY
     constexpr bool early = true;
 #else
     constexpr bool early = false;
 #endif
-    if (early) {
+    if (critics_ready) {
+        // the loss sums are the first n_q scalar jobs; no clip partials: an exchanged gradient gets them afterwards (mpg_sq_partials)
+        rc = launch_wgrad_multi(cfg, jobs, n_q, sums, n_q, nullptr, s);
+        if (rc) return rc;
+        if (hipEventRecord(critics_ready, s) != hipSuccess) { mpg_set_error("mpg_mpg_gradients: hipEventRecord(critics_ready_event) failed"); return MPG_EINVAL; }
+    } else if (early) {
         rc = launch_wgrad_multi(cfg, jobs, n_q, nullptr, 0, nullptr, s, 1, 0);
         if (rc) return rc;
     }
     // 5. reverse sweep
     rc = run_rollout_bwd(cfg, policy, rows, 1, n, select, n_select, cf.rho, H1, H2, SA, GXQ, 0, DZ1, DZ2, DZ3, s);
     if (rc) return rc;
+    if (critics_ready) return launch_wgrad_multi(cfg, jobs + n_q, 1, sums + n_q, ns - n_q, nullptr, s);
     if (early) {
         rc = launch_wgrad_multi(cfg, jobs, n_q + 1, nullptr, 0, nullptr, s, 1, n_q);
         if (rc) return rc;
         return launch_wgrad_multi(cfg, jobs, n_q + 1, sums, ns, sq_part, s, 2, 0);
+    }
+    if (opts && opts->defer_reduce) {      // chunk products only; the sums ride in the optimizer launch
+        rc = launch_wgrad_multi(cfg, jobs, n_q + 1, nullptr, 0, nullptr, s, 1, 0);
+        if (rc) return rc;
+        return describe_wgrad_reduction(jobs, n_q + 1, sums, ns, opts->defer_reduce);
     }
     return launch_wgrad_multi(cfg, jobs, n_q + 1, sums, ns, sq_part, s);
 }

@@ -7,7 +7,7 @@ import torch
 import torch.distributed as dist
 
 
-_oneshot = None          # OneShotAllReduce of this process (MPG_DIST_BACKEND=oneshot), built at the first exchange
+_oneshot = {}            # OneShotAllReduce objects of this process by buffer length (MPG_DIST_BACKEND=oneshot), built at the first exchange
 _exchange = 'collective'  # 'collective': dist.all_reduce of the process group's backend; 'oneshot': the IPC one-shot form below
 
 
@@ -40,8 +40,10 @@ class _HostShm(object):
         before "I issue my wait" (a wait captures the event's latest record at the time of the call - a fact about the peers'
         host threads, not about the GPU, so it is settled host to host without draining any stream);
       * `gen[r]`     - the newest event GENERATION whose handles rank r has published;
-      * `handles[g & 1][r]` - the interprocess-event handles (4 x 64 bytes) of rank r's generation g."""
+      * `handles[g & 1][r]` - the interprocess-event handles (NEV x 64 bytes) of rank r's generation g;
+      * `calls2[r]`  - the same kind of counter for the second phase of the two-shot form (the all-gather's records)."""
     HB = 64                                        # sizeof(hipIpcEventHandle_t)
+    NEV = 6                                        # events per generation: W0 W1 S0 S1 (one-shot) + G0 G1 (two-shot)
 
     TIMEOUT_S = 120.0                              # wall-clock bound on any hand-shake wait (a dead peer is reported, not spun on)
 
@@ -50,7 +52,7 @@ class _HostShm(object):
         import uuid
         self.world, self.rank = world, rank
         n_i64 = 16 * world
-        nbytes = 8 * n_i64 + 2 * world * 4 * self.HB
+        nbytes = 8 * n_i64 + 2 * world * self.NEV * self.HB
         # a name nobody else can hold: rank 0 picks it (pid + uuid) and creates the file exclusively, the others learn it through
         # the process group (two jobs on one node, or a stale file of another user, can no longer collide - ADVICE r4)
         name = ['/dev/shm/mpg_oneshot_%d_%s_%s' % (os.getpid(), uuid.uuid4().hex, tag) if rank == 0 else None]
@@ -62,7 +64,7 @@ class _HostShm(object):
         path = name[0]
         self.raw = np.memmap(path, dtype=np.uint8, mode='r+', shape=(nbytes,))
         self.a = self.raw[:8 * n_i64].view(np.int64)
-        self.h = self.raw[8 * n_i64:].reshape(2, world, 4, self.HB)
+        self.h = self.raw[8 * n_i64:].reshape(2, world, self.NEV, self.HB)
         dist.barrier()
         if rank == 0:
             os.unlink(path)              # the mappings keep it alive; nothing is left behind if a rank dies
@@ -88,6 +90,12 @@ class _HostShm(object):
     def wait(self, p, v):
         self._spin(16 * p, v, 'rank %d, exchange' % p)
 
+    def publish2(self, v):
+        self.a[16 * self.rank + 1] = v
+
+    def wait2(self, p, v):
+        self._spin(16 * p + 1, v, 'rank %d, all-gather of exchange' % p)
+
     def publish_handles(self, g, handles):
         import numpy as np
         for k, hb in enumerate(handles):
@@ -96,7 +104,7 @@ class _HostShm(object):
 
     def peer_handles(self, p, g):
         self._spin(16 * p + 8, g + 1, 'rank %d, event generation' % p)
-        return [bytes(self.h[g & 1, p, k, :]) for k in range(4)]
+        return [bytes(self.h[g & 1, p, k, :]) for k in range(self.NEV)]
 
 
 class OneShotAllReduce(object):
@@ -128,11 +136,20 @@ class OneShotAllReduce(object):
     tens of microseconds every GEN_LEN steps, off the GPU's critical path.
     `sync='host'` (MPG_ONESHOT_SYNC=host): the round-3 form - stream.synchronize() + dist.barrier() - kept as the control.
 
+    TWO-SHOT form (`mode='twoshot'`, MPG_ONESHOT_MODE=twoshot; round 5 - the reduce-scatter + all-gather SURVEY f4 names): the
+    buffer is cut into `world` slices.  (A) rank r writes slice p of its buffer into slot r of peer p's staging array - 1/world of
+    the bytes per link; (B) behind every peer's writes rank r sums the `world` copies of ITS slice in rank order (the same
+    association as the one-shot sum, computed once instead of `world` times: bit-identical results, identical on every replica by
+    construction) and writes the reduced slice into every rank's gather array [2 parities][n]; behind every peer's slice the
+    gather array is the result.  Two dependent hops and two event hand-shakes instead of one, for 2/world of the one-shot's bytes
+    per link: at 8 ranks and 821 KB, 2 x 103 KB per link against 821 KB.  `mode='auto'` (MPG_ONESHOT_MODE=auto) takes the
+    two-shot form from 4 ranks and 512 KiB on - an untested guess at the cross-over, which is why the default stays 'oneshot'.
+
     Validated for correctness only - 2, 4 and 8 processes time-sharing one GPU (tests/test_dist_gpu.py); no multi-GPU number is
     claimed."""
     GEN_LEN = 40          # exchanges per event generation: 20 records per event (+ 1 at creation), under the limit of 32
 
-    def __init__(self, n, device, sync=None):
+    def __init__(self, n, device, sync=None, mode=None):
         from torch.multiprocessing.reductions import reduce_tensor
         from . import _lib as L
         self.L = L
@@ -140,24 +157,44 @@ class OneShotAllReduce(object):
         self.n = int(n)
         self.sync = sync or os.environ.get('MPG_ONESHOT_SYNC', 'event')
         assert self.sync in ('event', 'host')
+        mode = mode or os.environ.get('MPG_ONESHOT_MODE', 'oneshot')
+        assert mode in ('oneshot', 'twoshot', 'auto')
+        if mode == 'auto':
+            mode = 'twoshot' if (self.world >= 4 and 4 * self.n >= (512 << 10)) else 'oneshot'
+        self.mode = mode
+        # slice r of the two-shot form: [r * chunk, min(n, (r + 1) * chunk)), chunk a multiple of 64 floats
+        self.chunk = (((self.n + self.world - 1) // self.world) + 63) // 64 * 64
         self.dev = torch.device(device) if not isinstance(device, torch.device) else device
-        self.stage = torch.zeros(2, self.world, self.n, dtype=torch.float32, device=device)
+        # ONE IPC-mapped allocation per rank: [2 parities][world slots + 1][n] - the staging slots and, behind them, the gather
+        # array of the two-shot form
+        self.block = torch.zeros(2, self.world + 1, self.n, dtype=torch.float32, device=device)
+        self.stage = self.block[:, :self.world]
+        self.gath = self.block[:, self.world]
         torch.cuda.synchronize()
         handles = [None] * self.world
-        dist.all_gather_object(handles, reduce_tensor(self.stage))
-        self.peers = []
+        dist.all_gather_object(handles, reduce_tensor(self.block))
+        self.peer_blocks = []
         for r in range(self.world):
             if r == self.rank:
-                self.peers.append(self.stage)
+                self.peer_blocks.append(self.block)
             else:
-                f, a = handles[r]
-                self.peers.append(f(*a))           # rebuild_cuda_tensor: opens the peer's allocation
+                try:
+                    f, a = handles[r]
+                    self.peer_blocks.append(f(*a))           # rebuild_cuda_tensor: opens the peer's allocation
+                except Exception as e:          # noqa: BLE001 - reported with what a first multi-GPU run needs to know
+                    raise RuntimeError('one-shot all-reduce: rank %d cannot open the IPC handle of rank %d\'s staging array (%r). '
+                                       'HSA_ENABLE_IPC_MODE_LEGACY=0 must be set in every rank\'s environment (dmabuf IPC), all ranks '
+                                       'must see the peer GPU (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES not restricting it), and the '
+                                       'GPUs must be peer-accessible; MPG_DIST_BACKEND=nccl selects the RCCL all-reduce instead.'
+                                       % (self.rank, r, e)) from e
+        self.peers = [b[:, :self.world] for b in self.peer_blocks]
+        self.peer_gath = [b[:, self.world] for b in self.peer_blocks]
         self.calls = 0
         if self.sync == 'event':
             global _oneshot_tag
             _oneshot_tag += 1
             self.shm = _HostShm(self.world, self.rank, '%d_%d' % (self.n, _oneshot_tag))
-            self.mine, self.theirs = {}, {}        # generation -> [W0, W1, S0, S1] / {peer: [W0, W1, S0, S1]}
+            self.mine, self.theirs = {}, {}        # generation -> [W0, W1, S0, S1, G0, G1] / {peer: [...]}
             self._make_generation(0)
             self._make_generation(1)
             self._open_generation(0)
@@ -165,7 +202,7 @@ class OneShotAllReduce(object):
 
     # ---- event generations ----
     def _make_generation(self, g):
-        ev = [torch.cuda.Event(enable_timing=False, interprocess=True) for _ in range(4)]
+        ev = [torch.cuda.Event(enable_timing=False, interprocess=True) for _ in range(_HostShm.NEV)]
         for e in ev:
             e.record()                   # an interprocess event gets its handle once it has been recorded
         self.mine[g] = ev
@@ -181,7 +218,33 @@ class OneShotAllReduce(object):
         self.calls += 1
         L = self.L
         st = torch.cuda.current_stream()
+        two = self.mode == 'twoshot'
+        ch, me = self.chunk, self.rank
+        lo, hi = min(self.n, me * ch), min(self.n, (me + 1) * ch)
+
+        def scatter():                                  # two-shot (A): slice p of my buffer into slot `rank` of rank p's array
+            for p in range(self.world):
+                a, b = min(self.n, p * ch), min(self.n, (p + 1) * ch)
+                if b > a:
+                    self.peers[p][par, me, a:b].copy_(flat[a:b], non_blocking=True)
+
+        def reduce_and_gather():                        # two-shot (B): the rank-order sum of MY slice, then into every rank's gather array
+            if hi > lo:
+                L.call('mpg_sum_slots_strided', L.ptr(self.stage[par, 0, lo:hi]), L.c_int(self.world), L.c_size_t(self.n), L.c_int(hi - lo),
+                       L.ptr(self.gath[par, lo:hi]), L.stream())
+                for p in range(self.world):
+                    if p != me:
+                        self.peer_gath[p][par, lo:hi].copy_(self.gath[par, lo:hi], non_blocking=True)
         if self.sync == 'host':
+            if two:
+                scatter()
+                st.synchronize()
+                dist.barrier()
+                reduce_and_gather()
+                st.synchronize()
+                dist.barrier()
+                flat.copy_(self.gath[par], non_blocking=True)
+                return flat
             for r in range(self.world):                 # 1. my buffer into slot `rank` of every rank's array
                 self.peers[r][par, self.rank].copy_(flat, non_blocking=True)
             st.synchronize()                            # 2. my writes have landed ...
@@ -201,15 +264,27 @@ class OneShotAllReduce(object):
             g2 = (it - 3) // self.GEN_LEN
             for p, ev in self.theirs[g2].items():
                 st.wait_event(ev[2 + par])
-        for r in range(self.world):                     # 1. my buffer into slot `rank` of every rank's array
-            self.peers[r][par, self.rank].copy_(flat, non_blocking=True)
+        if two:
+            scatter()
+        else:
+            for r in range(self.world):                 # 1. my buffer into slot `rank` of every rank's array
+                self.peers[r][par, self.rank].copy_(flat, non_blocking=True)
         self.mine[g][par].record(st)                    # W[par]
         self.shm.publish(it)                            # host: "my record of exchange `it` has been issued"
         for p, ev in self.theirs[g].items():            # 2. behind every peer's writes - a stream wait, not a host wait
             self.shm.wait(p, it)
             st.wait_event(ev[par])
-        L.call('mpg_sum_slots', L.ptr(self.stage[par]), L.c_int(self.world), L.c_int(self.n), L.ptr(flat), L.stream())   # 3.
-        self.mine[g][2 + par].record(st)                # S[par]
+        if two:
+            reduce_and_gather()                         # 3. my slice, reduced, into every rank's gather array
+            self.mine[g][4 + par].record(st)            # G[par]
+            self.shm.publish2(it)
+            for p, ev in self.theirs[g].items():        # 4. behind every peer's slice
+                self.shm.wait2(p, it)
+                st.wait_event(ev[4 + par])
+            flat.copy_(self.gath[par], non_blocking=True)
+        else:
+            L.call('mpg_sum_slots', L.ptr(self.stage[par]), L.c_int(self.world), L.c_int(self.n), L.ptr(flat), L.stream())   # 3.
+        self.mine[g][2 + par].record(st)                # S[par]: my reads of this parity's slots (and gather array) are done
         return flat
 
 
@@ -229,12 +304,12 @@ def world_size():
 def all_reduce_sum_(flat, force=False):
     """In-place sum over ranks of one flat float32 buffer (no-op on a single process unless `force`: a one-rank group
     still runs the collective - the way the RCCL path is exercised on a 1-GPU box)."""
-    global _oneshot
     if dist.is_initialized() and (dist.get_world_size() > 1 or force):
         if _exchange == 'oneshot':
-            if _oneshot is None or _oneshot.n != flat.numel():
-                _oneshot = OneShotAllReduce(flat.numel(), flat.device)
-            _oneshot.all_reduce_sum_(flat)
+            ex = _oneshot.get(flat.numel())
+            if ex is None:         # (a collective construction: every rank reaches it at the same exchange of the same length)
+                ex = _oneshot[flat.numel()] = OneShotAllReduce(flat.numel(), flat.device)
+            ex.all_reduce_sum_(flat)
         else:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     return flat

@@ -22,7 +22,8 @@ class CfgStruct(ctypes.Structure):
                 ('action_range', ctypes.c_float), ('obs_scale', ctypes.c_float * 16),
                 ('rew_scale', ctypes.c_float), ('rew_shift', ctypes.c_float), ('gamma', ctypes.c_float),
                 ('env_kind', ctypes.c_int),
-                ('wcache', ctypes.POINTER(WCacheStruct) * 2), ('prof', ctypes.c_void_p), ('status', ctypes.c_void_p)]
+                ('wcache', ctypes.POINTER(WCacheStruct) * 2), ('prof', ctypes.c_void_p), ('status', ctypes.c_void_p),
+                ('grad_opts', ctypes.c_void_p)]      # mpg_grad_opts_t*: set by the native step driver only (NULL here)
 
 
 class WeightCache(object):

@@ -134,18 +134,44 @@ def test_native_step_driver_keeps_two_replicas_bit_identical(exchange):
     assert not np.array_equal(out[0][2], out[1][2])               # the ranks really saw different data
 
 
-@pytest.mark.timeout(600)
+@pytest.mark.timeout(900)
 @pytest.mark.parametrize('backend', ['gloo', 'oneshot'])
 def test_native_step_driver_keeps_four_replicas_bit_identical(backend, monkeypatch):
     """The same with FOUR ranks time-sharing the one GPU (nothing had run with more than two ranks, so rank-count
-    dependent state - slot indexing, the two staging parities, the per-peer events - was untested beyond 2)."""
+    dependent state - slot indexing, the two staging parities, the per-peer events - was untested beyond 2).  Round 5: the one-shot
+    backend runs in both forms - one-shot and TWO-SHOT (reduce-scatter + all-gather) - and, because both take the rank-order sum,
+    20 native steps must leave the SAME bits in both."""
     monkeypatch.setenv('MPG_DIST_BACKEND', backend)
     monkeypatch.setenv('MPG_ONESHOT_SYNC', 'event')
-    out = _run(_driver_worker, world=4)
-    for r in range(1, 4):
-        assert np.array_equal(out[0][1], out[r][1]), r
-        assert not np.array_equal(out[0][2], out[r][2])
-    assert np.isfinite(out[0][1]).all()
+    runs = []
+    for mode in (['oneshot', 'twoshot'] if backend == 'oneshot' else ['oneshot']):
+        monkeypatch.setenv('MPG_ONESHOT_MODE', mode)
+        out = _run(_driver_worker, world=4)
+        for r in range(1, 4):
+            assert np.array_equal(out[0][1], out[r][1]), (mode, r)
+            assert not np.array_equal(out[0][2], out[r][2])
+        assert np.isfinite(out[0][1]).all()
+        runs.append(out[0][1])
+    if len(runs) == 2:
+        assert np.array_equal(runs[0], runs[1])
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize('backend', ['gloo', 'oneshot'])
+def test_critics_exchange_under_the_reverse_sweep_leaves_the_same_bits(backend, monkeypatch):
+    """SURVEY f4 "overlap with the Q-grad kernel" (off by default, MPG_OVERLAP_EXCHANGE=1): the library finishes the critics' gradient
+    ahead of the reverse sweep and records the caller's event there (mpg_grad_opts_t.critics_ready_event); the driver exchanges
+    the critics' slice on a second stream under the sweep and the policy's slice + statistics behind it.  Two exchanges instead of
+    one, the same sums in the same order: 20 native steps on two ranks must leave the same bits as the single exchange."""
+    monkeypatch.setenv('MPG_DIST_BACKEND', backend)
+    monkeypatch.setenv('MPG_ONESHOT_SYNC', 'event')
+    runs = []
+    for ov in ('0', '1'):
+        monkeypatch.setenv('MPG_OVERLAP_EXCHANGE', ov)
+        out = _run(_driver_worker)
+        assert np.array_equal(out[0][1], out[1][1]) and np.isfinite(out[0][1]).all()
+        runs.append(out[0][1])
+    assert np.array_equal(runs[0], runs[1])
 
 
 def _oneshot_sum_worker(rank, world, port, q):
@@ -155,10 +181,12 @@ def _oneshot_sum_worker(rank, world, port, q):
     mine = (torch.randn(n, generator=g) * torch.logspace(-6, 2, n)).float()
     flat = mine.cuda()
     outs = []
-    for k in range(6):                                    # both staging parities, each re-used twice
-        buf = flat * float(k + 1)
+    n_ex = int(os.environ.get('MPG_TEST_EXCHANGES', '6'))
+    for k in range(n_ex):                                 # both staging parities, each re-used (6: twice; 90: across two event generations)
+        buf = flat * float(k % 7 + 1)
         D.all_reduce_sum_(buf)
-        outs.append(buf.cpu().numpy())
+        if k < 6 or k >= n_ex - 2:
+            outs.append((k, buf.cpu().numpy()))
     torch.cuda.synchronize()
     D.barrier()
     q.put((rank, mine.numpy(), outs))
@@ -166,22 +194,30 @@ def _oneshot_sum_worker(rank, world, port, q):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize('world,sync', [(2, 'event'), (2, 'host'), (8, 'event')])
-def test_oneshot_all_reduce_is_the_in_rank_order_sum_bit_for_bit(monkeypatch, world, sync):
-    """OneShotAllReduce on its own: six exchanges of a 205 334-float buffer with entries over eight orders of magnitude (both
-    staging parities, each re-used twice: the slot-reuse waits of the event form are exercised).  Every rank must hold exactly
-    fl(..fl(x_0 + x_1) + .. + x_{world-1}) - the rank-order float32 sum - each time; 2 ranks in both synchronisation forms and
-    8 ranks (all time-sharing the one GPU of the test box) in the event form."""
+@pytest.mark.parametrize('world,sync,mode,n_ex', [(2, 'event', 'oneshot', 6), (2, 'host', 'oneshot', 6), (8, 'event', 'oneshot', 6),
+                                                  (2, 'event', 'twoshot', 90), (2, 'host', 'twoshot', 6), (4, 'event', 'twoshot', 6),
+                                                  (8, 'event', 'twoshot', 6), (3, 'event', 'twoshot', 6)])
+def test_oneshot_all_reduce_is_the_in_rank_order_sum_bit_for_bit(monkeypatch, world, sync, mode, n_ex):
+    """OneShotAllReduce on its own: exchanges of a 205 334-float buffer with entries over eight orders of magnitude (both
+    staging parities re-used: the slot-reuse waits of the event form are exercised; 90 exchanges cross two event generations).
+    Every rank must hold exactly fl(..fl(x_0 + x_1) + .. + x_{world-1}) - the rank-order float32 sum - each time; 2 ranks in
+    both synchronisation forms and 8 ranks (all time-sharing the one GPU of the test box) in the event form.
+    Round 5: the same for the TWO-SHOT form (reduce-scatter + all-gather) with 2, 3 (slices of unequal length), 4 and 8
+    ranks - its slice sums take the same rank order, so the result must be the same bits."""
     monkeypatch.setenv('MPG_DIST_BACKEND', 'oneshot')
     monkeypatch.setenv('MPG_ONESHOT_SYNC', sync)
+    monkeypatch.setenv('MPG_ONESHOT_MODE', mode)
+    monkeypatch.setenv('MPG_TEST_EXCHANGES', str(n_ex))
     out = _run(_oneshot_sum_worker, world=world)
     xs = [out[r][1] for r in range(world)]
-    for k in range(6):
-        ref = xs[0] * np.float32(k + 1)
+    assert len(out[0][2]) == min(n_ex, 8)
+    for k, _ in out[0][2]:
+        ref = xs[0] * np.float32(k % 7 + 1)
         for r in range(1, world):
-            ref = ref + xs[r] * np.float32(k + 1)                       # float32 arithmetic, rank order
+            ref = ref + xs[r] * np.float32(k % 7 + 1)                       # float32 arithmetic, rank order
         for r in range(world):
-            assert np.array_equal(out[r][2][k], ref), (k, r)
+            got = dict(out[r][2])[k]
+            assert np.array_equal(got, ref), (k, r)
 
 
 def _rccl_worker(rank, world, port, q):
