@@ -617,6 +617,35 @@ def main():
         torch.cuda.synchronize()
         sat[name] = es[0].elapsed_time(es[1]) / 10
     del big, b_act, b_obs, b_rew, b_done, b_di, b_robs, b_robs2, b_ract, b_rrew, b_rdone
+    # N > 1: the exchange on its own in every form this process group can run (RCCL when the group is an nccl group; the one-shot and
+    # the two-shot IPC forms of mpg_amd/dist.py), 50 exchanges of a scratch buffer of the gradient's length each, HIP events on the
+    # launch stream of rank 0.  A form that cannot be set up (no peer access, IPC refused) is reported as its error text on EVERY rank
+    # (the constructor fails collectively) - the line still prints; nothing here is part of `value`.
+    exchange_forms = None
+    if world > 1:
+        import torch.distributed as tdist
+        exchange_forms = {}
+        scratch_buf = torch.zeros_like(learner.flat)
+
+        def time_form(fn):
+            for _ in range(5):
+                fn(scratch_buf)
+            D.barrier()
+            torch.cuda.synchronize()
+            es[0].record()
+            for _ in range(50):
+                fn(scratch_buf)
+            es[1].record()
+            torch.cuda.synchronize()
+            return es[0].elapsed_time(es[1]) / 50
+        if tdist.get_backend() == 'nccl':
+            exchange_forms['nccl'] = time_form(lambda b: tdist.all_reduce(b, op=tdist.ReduceOp.SUM))
+        for form in ('oneshot', 'twoshot'):
+            try:
+                ex = D.OneShotAllReduce(scratch_buf.numel(), dev, mode=form)
+                exchange_forms[form] = time_form(ex.all_reduce_sum_)
+            except Exception as e:               # noqa: BLE001
+                exchange_forms[form] = 'unavailable: %s' % (str(e)[:300],)
     finite = bool(torch.isfinite(worker.policy_with_value.params).all().item())
     assert finite and int(worker.policy_with_value.nonfinite.sum().item()) == 0, 'non-finite parameters after the timed region'
     worker.policy_with_value.check_status()          # raises if the split-fp16 engine left its numerical envelope anywhere
@@ -734,6 +763,8 @@ def main():
         # the ONE exchange step per gradient step (all-reduce of the flat [gradients | statistics] buffer), HIP events on the
         # launch stream around every PROF_EVERY-th exchange of the timed region on rank 0; null on one GPU (none is enqueued)
         'exchange_ms': xch_ms, 'exchange_launches': xch_n,
+        # the exchange alone, per form (ms per exchange of the flat buffer; stand-alone, after the timed region; null on one GPU)
+        'exchange_forms_ms': exchange_forms,
         'env_step_kernel': {'kernel': 'k_step_store_reset (mpg_env_step_store_reset)', 'avg_ms': step_store_reset_ms, 'launches': 64,
                             'env_steps_per_sec_kernel_only': B_PER_GPU / (step_store_reset_ms * 1e-3),
                             'algorithmic_bytes_per_env_step': 85,

@@ -348,11 +348,14 @@ __global__ void __launch_bounds__(256) k_reduce_clip_adam_polyak(const Segs sg, 
     const float sq = mpg_block_sum256(fmaf(tot, tot, 0.f), red);
     // ---- grid barrier ----
     if (threadIdx.x == 0) {
+        // NO release / acquire fences: at agent scope a release is a write-back of the XCD's whole L2 (tens of MB of slabs and
+        // stashes the previous launches left dirty there: measured 52 us per launch) and an acquire an invalidation of it.  The only
+        // data that crosses the barrier are the partials, and every access to them is an agent-scope atomic (performed at the
+        // coherence point, not in the XCD's L2); the store is complete (vmcnt) before this block's arrival is counted.
         if ((int)blockIdx.x < CLIP_PARTS) __hip_atomic_store(&part[k * CLIP_PARTS + blockIdx.x], sq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_fetch_add(sync, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        while (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < sync_target) __builtin_amdgcn_s_sleep(2);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        while (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < sync_target) __builtin_amdgcn_s_sleep(1);
     }
     __syncthreads();
     // ---- phase 2: the norms from everybody's partials (agent-scope loads: they were written by other CUs during this launch) ----

@@ -173,20 +173,24 @@ class OneShotAllReduce(object):
         torch.cuda.synchronize()
         handles = [None] * self.world
         dist.all_gather_object(handles, reduce_tensor(self.block))
-        self.peer_blocks = []
+        self.peer_blocks, failure = [], None
         for r in range(self.world):
             if r == self.rank:
                 self.peer_blocks.append(self.block)
-            else:
-                try:
-                    f, a = handles[r]
-                    self.peer_blocks.append(f(*a))           # rebuild_cuda_tensor: opens the peer's allocation
-                except Exception as e:          # noqa: BLE001 - reported with what a first multi-GPU run needs to know
-                    raise RuntimeError('one-shot all-reduce: rank %d cannot open the IPC handle of rank %d\'s staging array (%r). '
-                                       'HSA_ENABLE_IPC_MODE_LEGACY=0 must be set in every rank\'s environment (dmabuf IPC), all ranks '
-                                       'must see the peer GPU (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES not restricting it), and the '
-                                       'GPUs must be peer-accessible; MPG_DIST_BACKEND=nccl selects the RCCL all-reduce instead.'
-                                       % (self.rank, r, e)) from e
+                continue
+            try:
+                f, a = handles[r]
+                self.peer_blocks.append(f(*a))           # rebuild_cuda_tensor: opens the peer's allocation
+            except Exception as e:          # noqa: BLE001 - reported below, on EVERY rank (a one-sided raise would leave the others in a barrier)
+                failure = 'rank %d cannot open the IPC handle of rank %d\'s staging array (%r)' % (self.rank, r, e)
+                break
+        failures = [None] * self.world
+        dist.all_gather_object(failures, failure)
+        if any(failures):
+            raise RuntimeError('one-shot all-reduce: ' + '; '.join(f for f in failures if f) + '. HSA_ENABLE_IPC_MODE_LEGACY=0 must be set '
+                               'in every rank\'s environment (dmabuf IPC), every rank must see the peer GPUs (HIP_VISIBLE_DEVICES / '
+                               'ROCR_VISIBLE_DEVICES not hiding them) and the GPUs must be peer-accessible; MPG_DIST_BACKEND=nccl selects '
+                               'the RCCL all-reduce instead.')
         self.peers = [b[:, :self.world] for b in self.peer_blocks]
         self.peer_gath = [b[:, self.world] for b in self.peer_blocks]
         self.calls = 0

@@ -163,6 +163,8 @@ def test_config3_whole_loop_follows_the_oracle_loop_on_identical_random_inputs()
     from mpg_amd.worker import OffPolicyWorker
     from tests.c3_loop import OracleConfig3Loop
     seed = 2
+    nthreads = torch.get_num_threads()
+    torch.set_num_threads(8)                    # the oracle's 512-row matmuls: a 256-thread pool is slower than 8 threads
     args = default_args('NADP', num_agent=64, batch_size=512, replay_batch_size=512, replay_starts=3000, seed=seed, init_seed=seed,
                         nan_check_interval=10 ** 9)
     worker = OffPolicyWorker(PolicyWithQs, args.env_id, args, 0)
@@ -200,4 +202,5 @@ def test_config3_whole_loop_follows_the_oracle_loop_on_identical_random_inputs()
               (it + 10, e_p, e_t, e_u, tg.max(), ot.max(), tg.mean(), ot.mean()))
         assert e_p <= 1e-4 and e_t <= 1e-4 and e_u <= 2e-2, (it, e_p, e_t, e_u)
         assert abs(tg.max() - ot.max()) <= 2e-3 and abs(tg.mean() - ot.mean()) <= 2e-3
+    torch.set_num_threads(nthreads)
     print('config-3 whole loop, 120 iterations: parameters %.1e, update %.1e, minibatch targets %.1e abs' % (worst_p, worst_u, worst_t))
