@@ -182,32 +182,14 @@ int mpg_sum_slots_strided(const float* slots, int n_slots, size_t slot_stride, i
  * Networks (K3), critic targets, losses and gradients (K5, K6)
  * ---------------------------------------------------------------------------------------------- */
 
-/* Slab reduction left pending by mpg_mpg_gradients (round 5, ABI 9).  The weight-gradient launch leaves one partial gradient
- * ("slab") per chunk of rows and network; their fixed-order sum is normally a launch of its own (k_reduce_multi).  With
- * mpg_grad_opts_t.defer_reduce set, mpg_mpg_gradients skips that launch and describes it here (HOST struct, device pointers into
- * the caller's workspace and gradient buffer - valid until the workspace is reused); mpg_reduce_clip_adam_polyak then takes the
- * sums inside the optimizer launch: same association, same partial sums of squares, bit-identical parameters, one launch less.
- * Single-GPU path only: an exchange needs the summed gradient between the two. */
-typedef struct {
-    int n_jobs;                 /* networks, in the order of the caller's flat gradient buffer (<= 3) */
-    const float* slabs[3];      /* device: nslab[k] slabs of n[k] floats each */
-    int nslab[3], n[3];
-    float* out[3];              /* device: where the summed gradient of network k belongs (grad + offset) */
-    int n_sums;                 /* scalar statistics: dst[j] = sum over i < sum_n[j] of src[j][i * stride[j]] (<= 8) */
-    const float* sum_src[8];
-    int sum_n[8], sum_stride[8];
-    float* sum_dst[8];
-} mpg_pending_reduce_t;
-
 /* Per-call options of the gradient entry points, reached through mpg_cfg_t.grad_opts (NULL: none).  HOST memory, read at
- * call time.  No reference counterpart: both fields only change HOW the same numbers are scheduled. */
+ * call time.  No reference counterpart: it only changes HOW the same numbers are scheduled. */
 typedef struct {
     void* critics_ready_event;           /* hipEvent_t, nullable.  mpg_mpg_gradients then finishes the critics' gradient (chunk
                                             products + slab sums + loss sums) BEFORE the reverse sweep and records this event behind
                                             it on the launch stream: a caller that exchanges gradients between GPUs can start the
                                             critics' part of the exchange on a second stream under the reverse sweep
                                             (optimizer.py:60-94, payload mpg_learner.py:448-455).  Costs one launch more. */
-    mpg_pending_reduce_t* defer_reduce;  /* nullable, see mpg_pending_reduce_t (ignored when critics_ready_event is set) */
 } mpg_grad_opts_t;
 
 /* Hyper-parameters of one config (host memory, read at call time). */
@@ -433,19 +415,6 @@ int mpg_clip_adam_polyak(float* w, float* m, float* v, float* target, float* gra
                          const mpg_wcache_t* wc_w /* nullable: packed images of w, kept current */,
                          const mpg_wcache_t* wc_target /* nullable: same for target */, mpg_stream_t stream);
 
-/* mpg_clip_adam_polyak with the slab sums of a pending reduction (mpg_pending_reduce_t: network k of `pending` is segment k,
- * pending->out[k] == grad + offset of segment k) taken INSIDE the launch: every thread first sums its element's slabs (the
- * association of the separate reduction launch), the blocks leave their partial sums of squares in sq_part, meet at a grid-wide
- * barrier (all of the launch's 272 x n_seg blocks are resident at once; an agent-scope counter in `grid_sync`, which the caller
- * zero-initialises once and never touches again; `grid_arrivals` = the sum of MPG_CLIP_PARTS * n_seg over all earlier calls made
- * on this counter, i.e. the value it holds when this launch starts) and continue as mpg_clip_adam_polyak.  Bit-identical to the
- * reduction launch followed by mpg_clip_adam_polyak. */
-int mpg_reduce_clip_adam_polyak(const mpg_pending_reduce_t* pending, unsigned long long* grid_sync, unsigned long long grid_arrivals,
-                                float* w, float* m, float* v, float* target, float* grad, float* sq_part,
-                                const int* seg_sizes, int n_seg, float clip, const float* lr_t, const int* do_adam,
-                                const int* do_polyak, float tau, float* norms, int* nonfinite_flags,
-                                const mpg_wcache_t* wc_w, const mpg_wcache_t* wc_target, mpg_stream_t stream);
-
 /* PolicyWithQs.apply_gradients + update_*_target  - policy.py:123-171.  For every network k (HOST arrays):
  * do_adam[k]: one Keras Adam step (beta .9/.999, eps 1e-7 outside the sqrt, TF ApplyAdam form) with the
  * bias-corrected rate lr_t[k] = lr(step)*sqrt(1-b2^t)/(1-b1^t) computed by the caller from ITS per-optimizer
@@ -585,12 +554,8 @@ typedef struct {
     float* b_weights;                 /* [batch] IS weights of the draw (buffer.py:146-160; the TD3 loss does not use them) */
     float* scratch;                   /* max(batch * (act_dim + 3), 2 * num_agent) floats: smoothing noise | y1 | td | priority errors
                                          (and the index / priority pairs of a ring add) */
-    /* scheduling options (round 5, ABI 9; MPG-v2 only, all optional) */
-    unsigned long long* grid_sync;    /* device, nullable, zero-initialised by the caller: with it (and no exchange) the slab sums of
-                                         the weight gradients ride in the optimizer launch (mpg_reduce_clip_adam_polyak) */
-    unsigned long long grid_arrivals; /* what grid_sync holds before the next call (advanced by mpg_step_end) */
+    /* scheduling option (round 5, ABI 9; MPG only, optional) */
     void* critics_ready_event;        /* hipEvent_t, nullable: see mpg_grad_opts_t (the caller overlaps the critics' exchange) */
-    mpg_pending_reduce_t pending;     /* filled by mpg_step_begin, consumed by mpg_step_end */
     mpg_grad_opts_t grad_opts;        /* storage for cfg.grad_opts during mpg_step_begin */
 } mpg_train_ctx_t;
 

@@ -1030,27 +1030,6 @@ int launch_critic_fused(const mpg_cfg_t* cfg, const float* const* q_params, int 
     return MPG_OK;
 }
 
-int describe_wgrad_reduction(const WgradJob* jobs, int n_jobs, const SumJob* sums, int n_sums, mpg_pending_reduce_t* out) {
-    MPG_REQUIRE(jobs && out && n_jobs >= 1 && n_jobs <= 3 && n_sums >= 0 && n_sums <= 8, "describe_wgrad_reduction: bad argument");
-    out->n_jobs = n_jobs;
-    for (int j = 0; j < 3; ++j) {
-        if (j < n_jobs) {
-            const WgradJob& jb = jobs[j];
-            const long ngroups = (jb.rows + GROUP - 1) / GROUP;
-            const int gpc = wgrad_groups_per_chunk(ngroups);                 // (the chunking of launch_wgrad_multi)
-            out->slabs[j] = jb.slabs; out->nslab[j] = (int)((ngroups + gpc - 1) / gpc);
-            out->n[j] = net_size(jb.in_dim, jb.out_dim); out->out[j] = jb.grad;
-        } else { out->slabs[j] = nullptr; out->nslab[j] = out->n[j] = 0; out->out[j] = nullptr; }
-    }
-    out->n_sums = n_sums;
-    for (int k = 0; k < 8; ++k) {
-        const bool on = k < n_sums;
-        out->sum_src[k] = on ? sums[k].src : nullptr; out->sum_n[k] = on ? sums[k].n : 0;
-        out->sum_stride[k] = on ? sums[k].stride : 1; out->sum_dst[k] = on ? sums[k].dst : nullptr;
-    }
-    return MPG_OK;
-}
-
 // phases: 1 = the chunk products of jobs[first_job .. n_jobs) only, 2 = the slab reduction (+ sums) of jobs[0 .. n_jobs) only,
 // 3 = both (one weight-gradient launch over all jobs, then the reduction)
 int launch_wgrad_multi(const mpg_cfg_t* cfg, const WgradJob* jobs, int n_jobs, const SumJob* sums, int n_sums, float* sq_part, hipStream_t s,

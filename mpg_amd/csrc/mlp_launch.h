@@ -130,9 +130,6 @@ struct SumJob {
 };
 int launch_wgrad_multi(const mpg_cfg_t* cfg, const WgradJob* jobs, int n_jobs, const SumJob* sums, int n_sums, float* sq_part, hipStream_t s,
                        int phases = 3, int first_job = 0);
-// what phase 2 of launch_wgrad_multi (the slab reduction + scalar sums) WOULD do, as a host-side description for
-// mpg_reduce_clip_adam_polyak (include/mpg_hip.h, mpg_pending_reduce_t)
-int describe_wgrad_reduction(const WgradJob* jobs, int n_jobs, const SumJob* sums, int n_sums, mpg_pending_reduce_t* out);
 // critic losses + critic at the two selected slices in one launch (launch_qloss_fused + launch_qslice_fused with n_sel == 2)
 int launch_critic_fused(const mpg_cfg_t* cfg, const float* const* q_params, int n_q, int rows, const float* obs,
                         const float* act, const float* y, float inv_b, const CriticStash* st, float* loss_part, const float* xq,

@@ -11,7 +11,7 @@
                             // 5: status words (mpg_cfg_t.status, mpg_wcache_t.status), step entry points for TD3 / NADP
                             // 6: mpg_cfg_t.obs_scale has 16 entries (observations with look-ahead entries: obs_dim up to 14)
                             // 8: mpg_worker_step
-                            // 9: mpg_sum_slots_strided (two-shot exchange), deferred slab reduction in the optimizer launch
+                            // 9: mpg_sum_slots_strided (two-shot exchange), mpg_cfg_t.grad_opts (critics_ready_event)
                             // 7: MPG_PROF_SLOTS 10 (gradient exchange, k_clip_adam_polyak), mpg_prof_region_begin / _end
 
 void mpg_set_error(const char* fmt, ...);

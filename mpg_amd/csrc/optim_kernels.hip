@@ -217,8 +217,7 @@ __global__ void k_adam_polyak(const Segs sg, float* __restrict__ w, float* __res
     }
 }
 
-// second half of the clip + Adam + Polyak for one element (shared by k_clip_adam_polyak and k_reduce_clip_adam_polyak: the same
-// instructions on the same operands, so that the two forms are bit-identical)
+// second half of the clip + Adam + Polyak for one element
 __device__ __forceinline__ void clip_adam_polyak_element(const Segs& sg, int k, int i, int j, bool adam, bool polyak, float g_in, float wj,
                                                          float mj, float vj, float t_in, float nrm, bool bad, float clip, float tau,
                                                          float* __restrict__ w, float* __restrict__ m, float* __restrict__ v,
@@ -281,107 +280,6 @@ __global__ void __launch_bounds__(256) k_clip_adam_polyak(const Segs sg, float* 
     }
     if (!live) return;
     clip_adam_polyak_element(sg, k, i, j, adam, polyak, g_in, wj, mj, vj, t_in, nrm, bad, clip, tau, w, m, v, target, grad);
-}
-
-// The slab sums of the weight gradients (k_reduce_multi, fused_kernels.hip), the clip, Adam and Polyak in ONE launch
-// (mpg_reduce_clip_adam_polyak; round 5).  Phase 1 = k_reduce_multi's arithmetic: the element's slabs summed with four
-// accumulators in the same association, the block's sum of squares into part[k][block] (mpg_block_sum256: the same partials);
-// the blocks of row n_seg take the scalar statistics.  GRID BARRIER: every block of rows 0 .. n_seg - 1 publishes its partial
-// (release fence at agent scope: the XCDs' L2s are not coherent with each other by themselves), adds one to the caller's
-// counter and waits until all of this launch have (the launch is 272 x n_seg blocks of 256 threads with < 64 registers: a
-// fraction of what the chip holds at once, so every block is resident and the wait cannot deadlock).  Phase 2 = the second half
-// of k_clip_adam_polyak, on the sums held in registers.  The element's parameter / moment / target loads are issued BEFORE the
-// barrier and arrive under it.
-struct PendingDev {
-    const float* slabs[3];
-    int nslab[3];
-    int n_sums;
-    const float* sum_src[8];
-    int sum_n[8], sum_stride[8];
-    float* sum_dst[8];
-};
-
-__global__ void __launch_bounds__(256) k_reduce_clip_adam_polyak(const Segs sg, const PendingDev pd, unsigned long long* __restrict__ sync,
-                                                                 unsigned long long sync_target, float* __restrict__ w,
-                                                                 float* __restrict__ m, float* __restrict__ v, float* __restrict__ target,
-                                                                 float* __restrict__ grad, float* __restrict__ part, float clip, float tau,
-                                                                 float* __restrict__ norms, int* __restrict__ nonfinite) {
-    __shared__ float red[256];
-    __shared__ float s_norm[MAXSEG];
-    const int k = blockIdx.y;
-    if (k == sg.n_seg) {                 // scalar statistics (loss / return sums): one block each, outside the barrier
-        if ((int)blockIdx.x < pd.n_sums) {
-            const float* src = pd.sum_src[blockIdx.x];
-            const int n = pd.sum_n[blockIdx.x], stride = pd.sum_stride[blockIdx.x];
-            float s = 0.f;
-            for (int i = threadIdx.x; i < n; i += 256) s += src[(size_t)i * stride];
-            const float t = mpg_block_sum256(s, red);
-            if (threadIdx.x == 0) pd.sum_dst[blockIdx.x][0] = t;
-        }
-        return;
-    }
-    const int wave = threadIdx.x >> 6;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int n = sg.n[k];
-    const bool live = i < n;
-    const int j = sg.off[k] + (live ? i : 0);
-    const bool adam = sg.do_adam[k] != 0, polyak = sg.do_polyak[k] && target;
-    // ---- phase 1: this element's slab sum (the association of k_reduce_multi) ----
-    float tot = 0.f;
-    if (live) {
-        const float* sl = pd.slabs[k];
-        const int ns = pd.nslab[k];
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        int q = 0;
-        for (; q + 3 < ns; q += 4) {
-            acc[0] += sl[(size_t)q * n + i];
-            acc[1] += sl[(size_t)(q + 1) * n + i];
-            acc[2] += sl[(size_t)(q + 2) * n + i];
-            acc[3] += sl[(size_t)(q + 3) * n + i];
-        }
-        for (; q < ns; ++q) acc[0] += sl[(size_t)q * n + i];
-        tot = (acc[0] + acc[1]) + (acc[2] + acc[3]);
-    }
-    float wj = live ? w[j] : 0.f;
-    float mj = (live && adam) ? m[j] : 0.f, vj = (live && adam) ? v[j] : 0.f;
-    const float t_in = (live && polyak) ? target[j] : 0.f;
-    const float sq = mpg_block_sum256(fmaf(tot, tot, 0.f), red);
-    // ---- grid barrier ----
-    if (threadIdx.x == 0) {
-        // NO release / acquire fences: at agent scope a release is a write-back of the XCD's whole L2 (tens of MB of slabs and
-        // stashes the previous launches left dirty there: measured 52 us per launch) and an acquire an invalidation of it.  The only
-        // data that crosses the barrier are the partials, and every access to them is an agent-scope atomic (performed at the
-        // coherence point, not in the XCD's L2); the store is complete (vmcnt) before this block's arrival is counted.
-        if ((int)blockIdx.x < CLIP_PARTS) __hip_atomic_store(&part[k * CLIP_PARTS + blockIdx.x], sq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_fetch_add(sync, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        while (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < sync_target) __builtin_amdgcn_s_sleep(1);
-    }
-    __syncthreads();
-    // ---- phase 2: the norms from everybody's partials (agent-scope loads: they were written by other CUs during this launch) ----
-    for (int q = wave; q < sg.n_seg; q += 4) {
-        const int lane = threadIdx.x & 63;
-        float a = 0.f;
-#pragma unroll
-        for (int u = 0; u < (CLIP_PARTS + 63) / 64; ++u) {
-            const int b = lane + 64 * u;
-            a += b < CLIP_PARTS ? __hip_atomic_load(&part[q * CLIP_PARTS + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
-        }
-#pragma unroll
-        for (int mk = 32; mk > 0; mk >>= 1) a += __shfl_xor(a, mk, 64);       // (seg_sumsq's association)
-        const float nrm = sqrtf(a);
-        if (lane == 0) s_norm[q] = nrm;
-    }
-    __syncthreads();
-    bool bad = false;                                         // optimizer.py:357-361
-    for (int q = 0; q < sg.n_seg; ++q) bad |= !isfinite(s_norm[q]);
-    const float nrm = s_norm[k];
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        norms[k] = nrm;
-        if (nonfinite) nonfinite[k] = isfinite(nrm) ? 0 : 1;
-    }
-    if (!live) return;
-    clip_adam_polyak_element(sg, k, i, j, adam, polyak, tot, wj, mj, vj, t_in, nrm, bad, clip, tau, w, m, v, target, grad);
 }
 
 int fill(Segs& sg, int n_seg, const int* seg_sizes) {
@@ -486,41 +384,6 @@ extern "C" int mpg_clip_adam_polyak(float* w, float* m, float* v, float* target,
     hipLaunchKernelGGL(k_clip_adam_polyak, dim3((maxn + 255) / 256, n_seg), dim3(256), 0, mpg_stream(stream), sg, w, m, v,
                        target, grad, sq_part, clip, tau, norms, nonfinite_flags);
     MPG_CHECK_LAUNCH("k_clip_adam_polyak");
-    return MPG_OK;
-}
-
-extern "C" int mpg_reduce_clip_adam_polyak(const mpg_pending_reduce_t* pending, unsigned long long* grid_sync, unsigned long long grid_arrivals,
-                                           float* w, float* m, float* v, float* target, float* grad, float* sq_part,
-                                           const int* seg_sizes, int n_seg, float clip, const float* lr_t, const int* do_adam,
-                                           const int* do_polyak, float tau, float* norms, int* nonfinite_flags,
-                                           const mpg_wcache_t* wc_w, const mpg_wcache_t* wc_target, mpg_stream_t stream) {
-    Segs sg;
-    int maxn = 0;
-    MPG_REQUIRE(pending && grid_sync && w && m && v && grad && sq_part && norms && lr_t && do_adam && do_polyak && clip > 0.f &&
-                    fill_adam(sg, n_seg, seg_sizes, w, target, lr_t, do_adam, do_polyak, wc_w, wc_target, &maxn) == 0,
-                "mpg_reduce_clip_adam_polyak: bad argument");
-    MPG_REQUIRE(pending->n_jobs == n_seg && n_seg <= 3 && pending->n_sums >= 0 && pending->n_sums <= 8 && maxn <= CLIP_PARTS * 256,
-                "mpg_reduce_clip_adam_polyak: the pending reduction does not describe these %d networks", n_seg);
-    PendingDev pd;
-    for (int k = 0; k < 3; ++k) {
-        pd.slabs[k] = k < n_seg ? pending->slabs[k] : nullptr;
-        pd.nslab[k] = k < n_seg ? pending->nslab[k] : 0;
-        if (k < n_seg)
-            MPG_REQUIRE(pending->n[k] == sg.n[k] && pending->out[k] == grad + sg.off[k] && pending->slabs[k] && pending->nslab[k] > 0,
-                        "mpg_reduce_clip_adam_polyak: network %d of the pending reduction is not segment %d of grad", k, k);
-    }
-    pd.n_sums = pending->n_sums;
-    for (int q = 0; q < 8; ++q) {
-        const bool on = q < pending->n_sums;
-        pd.sum_src[q] = on ? pending->sum_src[q] : nullptr; pd.sum_n[q] = on ? pending->sum_n[q] : 0;
-        pd.sum_stride[q] = on ? pending->sum_stride[q] : 1; pd.sum_dst[q] = on ? pending->sum_dst[q] : nullptr;
-    }
-    // every network takes the full row of CLIP_PARTS blocks (unused partial slots must be written - as zeros - for the norm's
-    // fixed-order sum, exactly like the reduction launch), + one row for the scalar statistics
-    const unsigned long long blocks = (unsigned long long)CLIP_PARTS * n_seg;
-    hipLaunchKernelGGL(k_reduce_clip_adam_polyak, dim3(CLIP_PARTS, n_seg + (pd.n_sums ? 1 : 0)), dim3(256), 0, mpg_stream(stream), sg, pd,
-                       grid_sync, grid_arrivals + blocks, w, m, v, target, grad, sq_part, clip, tau, norms, nonfinite_flags);
-    MPG_CHECK_LAUNCH("k_reduce_clip_adam_polyak");
     return MPG_OK;
 }
 

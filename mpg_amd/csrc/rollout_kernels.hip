@@ -580,12 +580,11 @@ extern "C" int mpg_mpg_gradients(const mpg_cfg_t* cfg, int n_q, const float* par
         sums[ns].src = ret_part + (size_t)k * ngroups * 2; sums[ns].n = ngroups; sums[ns].stride = 2; sums[ns].dst = stats + 2 + k; ++ns;
         sums[ns].src = ret_part + (size_t)k * ngroups * 2 + 1; sums[ns].n = ngroups; sums[ns].stride = 2; sums[ns].dst = stats + 2 + n_select + k; ++ns;
     }
-    // Scheduling options (mpg_cfg_t.grad_opts, round 5):
+    // Scheduling option (mpg_cfg_t.grad_opts, round 5):
     //   critics_ready_event - the critics' gradient is FINISHED (chunk products, slab sums, loss sums) right behind the critic launch and
     //                         the event recorded there, so that a caller can exchange it between GPUs under the reverse sweep; the
     //                         policy's follows the sweep as a second weight-gradient + reduction pair (one launch more; the critics'
     //                         chunk products ahead of the sweep cost ~9 us on one GPU, EXPERIMENTS.md "Why nothing overlaps the exchange");
-    //   defer_reduce        - the final slab reduction is not launched but described to the caller (mpg_reduce_clip_adam_polyak).
     // -DMPG_AB_WGRAD_EARLY (A/B build, tools/ab_early.sh): the early chunk products with ONE reduction at the end.
     const mpg_grad_opts_t* opts = cfg->grad_opts;
     hipEvent_t critics_ready = opts ? reinterpret_cast<hipEvent_t>(opts->critics_ready_event) : nullptr;
@@ -611,11 +610,6 @@ extern "C" int mpg_mpg_gradients(const mpg_cfg_t* cfg, int n_q, const float* par
         rc = launch_wgrad_multi(cfg, jobs, n_q + 1, nullptr, 0, nullptr, s, 1, n_q);
         if (rc) return rc;
         return launch_wgrad_multi(cfg, jobs, n_q + 1, sums, ns, sq_part, s, 2, 0);
-    }
-    if (opts && opts->defer_reduce) {      // chunk products only; the sums ride in the optimizer launch
-        rc = launch_wgrad_multi(cfg, jobs, n_q + 1, nullptr, 0, nullptr, s, 1, 0);
-        if (rc) return rc;
-        return describe_wgrad_reduction(jobs, n_q + 1, sums, ns, opts->defer_reduce);
     }
     return launch_wgrad_multi(cfg, jobs, n_q + 1, sums, ns, sq_part, s);
 }

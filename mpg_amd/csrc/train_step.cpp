@@ -284,12 +284,9 @@ extern "C" int mpg_step_begin(mpg_train_ctx_t* c, int iteration, mpg_stream_t s)
     // MPG-v2 with num_batch_reuse > 1 keeps the targets of the batch they were computed for (mpg_learner.py:402-403)
     const bool fresh = (c->learner_counter - 1) % c->num_batch_reuse == 0;
     const float* y_in = (c->learner_version == 2 && fresh) ? nullptr : c->b_targets;
-    // scheduling options (include/mpg_hip.h, mpg_grad_opts_t): with an exchange and the caller's event, the critics' gradient is
-    // finished ahead of the reverse sweep; without an exchange and with the caller's barrier counter, the slab sums are left to
-    // the optimizer launch of mpg_step_end (mpg_reduce_clip_adam_polyak)
+    // scheduling option (include/mpg_hip.h, mpg_grad_opts_t): with an exchange and the caller's event, the critics' gradient is finished
+    // ahead of the reverse sweep
     c->grad_opts.critics_ready_event = exchanged(c) ? c->critics_ready_event : nullptr;
-    c->pending.n_jobs = 0;
-    c->grad_opts.defer_reduce = (!exchanged(c) && c->grid_sync) ? &c->pending : nullptr;
     c->cfg.grad_opts = &c->grad_opts;
     const int rc = mpg_mpg_gradients(&c->cfg, l.n_nets - 1, c->params, c->targets, c->batch, c->b_obs, c->b_act, c->b_rew, c->b_obs2, y_in,
                                      c->M, c->n, c->select, c->n_select, w, nullptr, c->learner_seed, c->learner_counter, inv_b, c->grad,
@@ -321,16 +318,8 @@ extern "C" int mpg_step_end(mpg_train_ctx_t* c, int iteration, mpg_stream_t s) {
         if (upd) c->opt_steps[k] = t;
     }
     mpg_prof_begin(c->cfg.prof, 9, mpg_stream(s));
-    int rc;
-    if (is_mpg(c) && !exchanged(c) && c->pending.n_jobs == l.n_nets) {      // mpg_step_begin left the slab sums to this launch
-        rc = mpg_reduce_clip_adam_polyak(&c->pending, c->grid_sync, c->grid_arrivals, c->params, c->adam_m, c->adam_v, c->targets, c->grad,
-                                         c->clip_scratch, l.sizes, l.n_nets, c->clip, lr_t, do_adam, do_polyak, c->tau, c->norms,
-                                         c->nonfinite, c->cfg.wcache[0], c->cfg.wcache[1], s);
-        c->grid_arrivals += (unsigned long long)MPG_CLIP_PARTS * l.n_nets;
-        c->pending.n_jobs = 0;
-    } else
-    rc = mpg_clip_adam_polyak(c->params, c->adam_m, c->adam_v, c->targets, c->grad, c->clip_scratch, l.sizes, l.n_nets, c->clip,
-                              lr_t, do_adam, do_polyak, c->tau, c->norms, c->nonfinite, c->cfg.wcache[0], c->cfg.wcache[1], s);
+    const int rc = mpg_clip_adam_polyak(c->params, c->adam_m, c->adam_v, c->targets, c->grad, c->clip_scratch, l.sizes, l.n_nets, c->clip,
+                                        lr_t, do_adam, do_polyak, c->tau, c->norms, c->nonfinite, c->cfg.wcache[0], c->cfg.wcache[1], s);
     mpg_prof_end(c->cfg.prof, 9, mpg_stream(s));
     return rc;
 }

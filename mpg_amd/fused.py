@@ -13,16 +13,9 @@ from .ops import CfgStruct
 _P = ctypes.c_void_p
 
 
-class PendingReduce(ctypes.Structure):
-    """mpg_pending_reduce_t (include/mpg_hip.h): filled and consumed inside the library"""
-    _fields_ = [('n_jobs', ctypes.c_int), ('slabs', _P * 3), ('nslab', ctypes.c_int * 3), ('n', ctypes.c_int * 3), ('out', _P * 3),
-                ('n_sums', ctypes.c_int), ('sum_src', _P * 8), ('sum_n', ctypes.c_int * 8), ('sum_stride', ctypes.c_int * 8),
-                ('sum_dst', _P * 8)]
-
-
 class GradOpts(ctypes.Structure):
     """mpg_grad_opts_t"""
-    _fields_ = [('critics_ready_event', _P), ('defer_reduce', _P)]
+    _fields_ = [('critics_ready_event', _P)]
 
 
 class TrainCtx(ctypes.Structure):
@@ -49,8 +42,7 @@ class TrainCtx(ctypes.Structure):
         ('per_sum', _P), ('per_min', _P), ('per_stamp', _P), ('per_capacity', ctypes.c_int), ('per_max_priority', _P),
         ('per_alpha', ctypes.c_double), ('per_beta', ctypes.c_double), ('per_eps', ctypes.c_double),
         ('b_weights', _P), ('scratch', _P),
-        ('grid_sync', _P), ('grid_arrivals', ctypes.c_ulonglong), ('critics_ready_event', _P), ('pending', PendingReduce),
-        ('grad_opts', GradOpts)]
+        ('critics_ready_event', _P), ('grad_opts', GradOpts)]
 
 
 class FusedMPGStep(object):
@@ -127,17 +119,12 @@ class FusedMPGStep(object):
                 c.per_sum, c.per_min, c.per_stamp = L.ptr(rb._it_sum), L.ptr(rb._it_min), L.ptr(rb._stamp)
                 c.per_capacity, c.per_max_priority = rb._cap, L.ptr(rb._max_priority)
                 c.per_alpha, c.per_beta, c.per_eps = rb._alpha, rb._beta, rb._eps
-        # scheduling options of the MPG step (include/mpg_hip.h, mpg_grad_opts_t; both leave every number unchanged):
-        #  * one GPU: the slab sums of the weight gradients ride in the optimizer launch (mpg_reduce_clip_adam_polyak: a grid barrier
-        #    instead of a launch boundary) - MPG_NO_FUSED_REDUCE=1 keeps the separate reduction launch (A/B);
-        #  * with an exchange, MPG_OVERLAP_EXCHANGE=1 (off by default): the critics' gradient is finished ahead of the reverse sweep
-        #    and exchanged on a second stream under it (costs ~9 us on one GPU, where there is nothing to hide)
+        # scheduling option of the MPG step (include/mpg_hip.h, mpg_grad_opts_t; leaves every number unchanged): with an exchange,
+        # MPG_OVERLAP_EXCHANGE=1 (off by default): the critics' gradient is finished ahead of the reverse sweep and exchanged on a
+        # second stream under it (costs ~9 us on one GPU, where there is nothing to hide)
         import os
         self.overlap = None
         if c.learner_version in (1, 2):
-            if not c.grads_exchanged and not os.environ.get('MPG_NO_FUSED_REDUCE'):
-                self.grid_sync = torch.zeros(2, dtype=torch.int64, device=dev)
-                c.grid_sync, c.grid_arrivals = L.ptr(self.grid_sync), 0
             if c.grads_exchanged and os.environ.get('MPG_OVERLAP_EXCHANGE') == '1':
                 side = torch.cuda.Stream(device=dev)
                 e1, e2 = torch.cuda.Event(), torch.cuda.Event()

@@ -503,44 +503,6 @@ def test_native_step_driver_equals_method_by_method_path(alg):
     assert ((g1 - g2).norm() / g2.norm()).item() < 1e-5
 
 
-@pytest.mark.parametrize('alg,B', [('MPG-v2', 4096), ('MPG-v2', 96), ('MPG-v1', 128)])
-def test_slab_sums_inside_the_optimizer_launch_are_bit_identical(alg, B, monkeypatch):
-    """Round 5: on one GPU the native step driver leaves the fixed-order sum of the weight-gradient slabs (k_reduce_multi) to the
-    optimizer launch - mpg_reduce_clip_adam_polyak: slab sums, per-block sums of squares, a grid-wide barrier, clip + Adam + Polyak
-    in ONE launch.  Same association, same partials: after 12 iterations parameters, targets, Adam moments, the clipped gradient,
-    the norms and the statistics must be the same BITS as with the separate reduction launch (MPG_NO_FUSED_REDUCE=1)."""
-    from mpg_amd.buffer import ReplayBuffer
-    from mpg_amd.config import default_args
-    from mpg_amd.learners import MPGLearner
-    from mpg_amd.optimizer import SingleProcessOffPolicyOptimizer
-    from mpg_amd.policy import PolicyWithQs
-    from mpg_amd.worker import OffPolicyWorker
-
-    def run(separate):
-        if separate:
-            monkeypatch.setenv('MPG_NO_FUSED_REDUCE', '1')
-        else:
-            monkeypatch.delenv('MPG_NO_FUSED_REDUCE', raising=False)
-        args = default_args(alg, num_agent=min(B, 512), batch_size=min(B, 512), replay_batch_size=B, replay_starts=2 * B, max_buffer_size=8 * B,
-                            num_batch_reuse=2 if alg == 'MPG-v1' else 1)
-        worker = OffPolicyWorker(PolicyWithQs, args.env_id, args, 0)
-        learner = MPGLearner(PolicyWithQs, args)
-        opt = SingleProcessOffPolicyOptimizer(worker, learner, ReplayBuffer(args, 0), None, args, sampling_interval=2)
-        assert opt._fused is not None and (opt._fused.c.grid_sync is None) == separate
-        for _ in range(12):
-            opt.step()
-        pw = worker.policy_with_value
-        torch.cuda.synchronize()
-        if not separate:
-            assert opt._fused.c.grid_arrivals == 12 * 272 * len(pw.names) and int(opt._fused.grid_sync[0].item()) == opt._fused.c.grid_arrivals
-        return [pw.params.clone(), pw.targets.clone(), pw.m.clone(), pw.v.clone(), learner.flat.clone(), learner.norms.clone(),
-                pw.wc_params.packed.clone()]
-    a, b = run(False), run(True)
-    for x, y in zip(a, b):
-        assert torch.equal(x, y)
-    assert torch.isfinite(a[0]).all()
-
-
 def test_stock_methods_interleaved_with_native_steps():
     """The stock worker / buffer methods may be called between native steps (mpg_amd/fused.py: sync_in / push): a run that
     interleaves `worker.sample()` + `rb.add_batch()` with fused steps ends in the same ring, counters and parameters as
