@@ -211,6 +211,35 @@ def test_nstep_target_vs_golden(golden):
     Y.check_values(y, g['it100_targets'], g['it100_targets_f64'], what='n-step targets')
 
 
+@pytest.mark.parametrize('shapes', [[(8, 1), (8, 1), (6, 4)], [(5, 1), (4, 2)]])
+def test_optimizer_launch_keeps_both_packed_images_current(shapes):
+    """mpg_clip_adam_polyak rewrites the packed register images of the hidden kernels it updates (parameters AND targets, forward and
+    transposed image each).  After an update both images of both buffers must equal a fresh mpg_weight_cache_pack of the updated
+    buffers, bit for bit, and the update itself must equal the launch without cache descriptors."""
+    from mpg_amd import ops
+    from tests.golden_inputs import mlp_weights_flat
+    rng = np.random.Generator(np.random.PCG64(23))
+    sizes = [ops.net_size(i, o) for i, o in shapes]
+    n, k = sum(sizes), len(shapes)
+    flat = dev(np.concatenate([mlp_weights_flat(rng, i, o) for i, o in shapes]))
+    tgt = (flat * 0.9).contiguous()
+    m, v = dev(rng.standard_normal(n) * 0.01), dev(rng.random(n) * 1e-3)
+    g = dev(rng.standard_normal(n) * 0.02)
+    wc, wct = ops.WeightCache(flat, shapes), ops.WeightCache(tgt, shapes)
+    plain = [t.clone() for t in (flat, m, v, tgt, g)]
+    norms, norms2 = torch.zeros(k, device=DEV), torch.zeros(k, device=DEV)
+    lr, da, dp = [1e-2] * k, [1] * k, [1] * (k - 1) + [0]
+    ops.clip_adam_polyak(flat, m, v, tgt, g, ops.sq_partials(g, sizes), sizes, 3.0, lr, da, dp, 0.005, norms, wc_w=wc, wc_target=wct)
+    ops.clip_adam_polyak(plain[0], plain[1], plain[2], plain[3], plain[4], ops.sq_partials(plain[4], sizes), sizes, 3.0, lr, da, dp, 0.005, norms2)
+    for x, y in zip((flat, m, v, tgt, g, norms), plain + [norms2]):
+        assert torch.equal(x, y)
+    for c in (wc, wct):
+        got = c.packed.clone()
+        c.packed.zero_()
+        c.pack()
+        assert torch.equal(got, c.packed)
+
+
 def test_weight_cache_is_bit_identical_to_the_strided_path():
     """mpg_wcache_t: packed register images are an acceleration only - forward, backward and rollout results are
     bit-identical with and without a descriptor in the cfg, and stay so after mpg_adam_polyak (which is handed the
