@@ -486,6 +486,14 @@ int mpg_per_add(double* sum_tree, double* min_tree, int* stamp, int capacity, in
 int mpg_per_sample(const double* sum_tree, const double* min_tree, int capacity, int n_storage, int n,
                    const double* u, uint64_t seed, uint64_t ctr, double beta, int* idx, float* is_weight,
                    mpg_stream_t stream);
+/* The same draw with the gather of the sampled transitions in the same launch: PrioritizedReplayBuffer.sample, buffer.py:161-164
+ * (_sample_proportional + IS weights + _encode_sample).  Results identical to mpg_per_sample followed by mpg_replay_gather.
+ * o_done (nullable): the dones as float, like mpg_replay_gather. */
+int mpg_per_sample_gather(const double* sum_tree, const double* min_tree, int capacity, int n_storage, int n,
+                          const double* u, uint64_t seed, uint64_t ctr, double beta, int* idx, float* is_weight,
+                          int obs_dim, int act_dim, const float* ring_obs, const float* ring_act, const float* ring_rew,
+                          const float* ring_obs2, const uint8_t* ring_done, float* o_obs, float* o_act, float* o_rew,
+                          float* o_obs2, float* o_done, mpg_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Native step driver  - SingleProcessOffPolicyOptimizer.step, optimizer.py:330-362

@@ -118,9 +118,20 @@ class PrioritizedReplayBuffer(ReplayBuffer):
         return idx
 
     def sample(self, batch_size):
-        """[obs, act, rew, obs', done, weights, idx] (buffer.py:146-164)."""
-        idx = self.sample_idxes(batch_size)
-        return list(self._encode_sample(idx)) + [self._last_weights, idx]
+        """[obs, act, rew, obs', done, weights, idx] (buffer.py:146-164): the proportional draw, the IS weights and the gather of the
+        drawn rows in ONE launch (mpg_per_sample_gather; the same results as sample_idxes + _encode_sample)."""
+        n = batch_size
+        f = dict(dtype=torch.float32, device=self.device)
+        idx = torch.empty(n, dtype=torch.int32, device=self.device)
+        w = torch.empty(n, **f)
+        o, o2 = torch.empty(n, self.obs_dim, **f), torch.empty(n, self.obs_dim, **f)
+        a, r, d = torch.empty(n, self.act_dim, **f), torch.empty(n, **f), torch.empty(n, **f)
+        L.call('mpg_per_sample_gather', L.ptr(self._it_sum), L.ptr(self._it_min), L.c_int(self._cap), L.c_int(self._size), L.c_int(n),
+               L.ptr(None), L.c_u64(self.seed), L.c_u64(self.replay_times), L.c_double(self._beta), L.ptr(idx), L.ptr(w),
+               L.c_int(self.obs_dim), L.c_int(self.act_dim), L.ptr(self.obs), L.ptr(self.act), L.ptr(self.rew), L.ptr(self.obs2),
+               L.ptr(self.done), L.ptr(o), L.ptr(a), L.ptr(r), L.ptr(o2), L.ptr(d), L.stream())
+        self._last_weights = w
+        return [o, a, r, o2, d, w, idx]
 
     def update_priorities(self, idxes, priorities):
         """buffer.py:166-189; priorities may be signed td errors (|.| + eps is taken on the device)."""

@@ -403,9 +403,8 @@ extern "C" int mpg_q_loss_grad(const mpg_cfg_t* cfg, const float* q_params, int 
     rc = launch_backward(cfg, q_params, in, 1, 1, rows, dz3, 1, nullptr, 0, 0, 1.f, h1, h2, thin ? nullptr : dz1, dz2, nullptr, nullptr, 0, s,
                          thin ? &xq : nullptr, thin ? dz1 : nullptr);
     if (rc) return rc;
-    rc = launch_wgrad(cfg, in, 1, 1, rows, xq, h1, h2, dz1, dz2, dz3, inv_b_global, grad, slabs, s, thin);
-    if (rc || !thin) return rc;
-    return launch_thin_reduce(dz1, backward_thin_parts(rows), in, 1, grad, s);
+    return launch_wgrad(cfg, in, 1, 1, rows, xq, h1, h2, dz1, dz2, dz3, inv_b_global, grad, slabs, s, thin, thin ? dz1 : nullptr,
+                        thin ? backward_thin_parts(rows) : 0);
 }
 
 extern "C" size_t mpg_td3_policy_grad_workspace_bytes(const mpg_cfg_t* cfg, int rows) {
@@ -463,7 +462,6 @@ extern "C" int mpg_td3_policy_grad(const mpg_cfg_t* cfg, const float* policy_par
     rc = launch_backward(cfg, policy_params, od, 2 * ad, ad, rows, ga, ad, a, ad, po.out_tanh, po.out_scale, hp1, hp2, thin ? nullptr : dz1,
                          dz2, dz3, nullptr, 0, s, thin ? &xp : nullptr, thin ? dz1 : nullptr);
     if (rc) return rc;
-    rc = launch_wgrad(cfg, od, 2 * ad, ad, rows, xp, hp1, hp2, dz1, dz2, dz3, inv_b_global, grad, slabs, s, thin);
-    if (rc || !thin) return rc;
-    return launch_thin_reduce(dz1, backward_thin_parts(rows), od, 2 * ad, grad, s);
+    return launch_wgrad(cfg, od, 2 * ad, ad, rows, xp, hp1, hp2, dz1, dz2, dz3, inv_b_global, grad, slabs, s, thin, thin ? dz1 : nullptr,
+                        thin ? backward_thin_parts(rows) : 0);
 }

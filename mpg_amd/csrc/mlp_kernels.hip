@@ -333,6 +333,54 @@ __global__ void __launch_bounds__(256) k_sum_parts(const float* __restrict__ par
     }
 }
 
+// one output of k_sum_parts (device function form: the same association)
+template <int SL>
+__device__ __forceinline__ void sum_parts_block(const float* __restrict__ part, int n_part, int n, int block, float (*sR)[256 / SL + 1], int& i,
+                                                float& sum, bool& writer) {
+    constexpr int NO = 256 / SL;
+    const int o = threadIdx.x % NO, sl = threadIdx.x / NO;
+    i = block * NO + o;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (i < n) {
+        int k = sl;
+        for (; k + 3 * SL < n_part; k += 4 * SL) {
+            acc[0] += part[(size_t)k * n + i];
+            acc[1] += part[(size_t)(k + SL) * n + i];
+            acc[2] += part[(size_t)(k + 2 * SL) * n + i];
+            acc[3] += part[(size_t)(k + 3 * SL) * n + i];
+        }
+        for (; k < n_part; k += SL) acc[0] += part[(size_t)k * n + i];
+    }
+    sR[sl][o] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    __syncthreads();
+    sum = 0.f;
+    writer = sl == 0 && i < n;
+    if (writer) {
+#pragma unroll
+        for (int q = 0; q < SL; ++q) sum += sR[q][o];
+    }
+}
+// The two sums behind a weight-gradient launch whose thin pieces live in per-workgroup partials (k_sum_parts<4> over the chunk slabs,
+// k_sum_parts<16> over the thin partials) in ONE launch (round 5: two dependent 5 - 10 us launches per network gradient at large
+// batches).  Blocks [0, nb_slab): the hidden kernel's entries from the slabs (the slabs' thin positions are not read); the rest: the
+// thin positions from the partials.  The same association per output as the two launches: bit-identical gradients.
+__global__ void __launch_bounds__(256) k_sum_slabs_thin(const float* __restrict__ slabs, int n_slab, int n, int w2_off, int nb_slab,
+                                                        const float* __restrict__ thin, int n_thin_part, int n_thin, float* __restrict__ out) {
+    __shared__ float sR4[4][65];
+    __shared__ float sR16[16][17];
+    int i;
+    float sum;
+    bool writer;
+    if ((int)blockIdx.x < nb_slab) {
+        // (slab column = position in the flat network: the W2 block starts at w2_off)
+        sum_parts_block<4>(slabs + w2_off, n_slab, n, blockIdx.x, sR4, i, sum, writer);
+        if (writer && i < H * H) out[w2_off + i] = sum;
+    } else {
+        sum_parts_block<16>(thin, n_thin_part, n_thin, (int)blockIdx.x - nb_slab, sR16, i, sum, writer);
+        if (writer) out[i < w2_off ? i : i + H * H] = sum;
+    }
+}
+
 int launch_thin_reduce(const float* part, int n_part, int in_dim, int out_dim, float* grad, hipStream_t s) {
     const int n_thin = thin_floats(in_dim, out_dim);
     // thin positions of the flat gradient: W1 | b1 in front of W2, b2 | W3 | b3 behind it
@@ -436,7 +484,8 @@ size_t wgrad_workspace_floats(int rows, int in_dim, int out_dim) {
 }
 
 int launch_wgrad(const mpg_cfg_t* cfg, int in_dim, int out_dim, int ou, int rows, const XSpec& x, const float* h1, const float* h2,
-                 const float* dz1, const float* dz2, const float* dz3, float inv_b, float* grad, float* ws, hipStream_t s, bool no_thin) {
+                 const float* dz1, const float* dz2, const float* dz3, float inv_b, float* grad, float* ws, hipStream_t s, bool no_thin,
+                 const float* thin_part, int n_thin_part) {
     MPG_REQUIRE(rows > 0 && h1 && h2 && (dz1 || no_thin) && dz2 && dz3 && grad && ws, "launch_wgrad: bad argument");
     WgradArgs a;
     a.no_thin = no_thin ? 1 : 0;
@@ -466,6 +515,13 @@ int launch_wgrad(const mpg_cfg_t* cfg, int in_dim, int out_dim, int ou, int rows
     mpg_prof_end(mpg_prof_of(cfg), 5, s);
     MPG_CHECK_LAUNCH("k_wgrad");
     const int n = net_size(in_dim, out_dim);
+    if (no_thin && thin_part) {        // the chunk slabs (hidden kernel) and the thin partials of the backward launch / reverse sweep in one launch
+        const int n_thin = thin_floats(in_dim, out_dim), nb_slab = H * H / 64;
+        hipLaunchKernelGGL(k_sum_slabs_thin, dim3(nb_slab + (n_thin + 15) / 16), dim3(256), 0, s, ws, nch, n, in_dim * H + H, nb_slab, thin_part,
+                           n_thin_part, n_thin, grad);
+        MPG_CHECK_LAUNCH("k_sum_slabs_thin");
+        return MPG_OK;
+    }
     hipLaunchKernelGGL((k_sum_parts<4>), dim3((n + 63) / 64), dim3(256), 0, s, ws, nch, n, n, 0, grad);     // the chunk slabs
     MPG_CHECK_LAUNCH("k_sum_parts (slabs)");
     return MPG_OK;

@@ -80,7 +80,9 @@ size_t wgrad_workspace_floats(int rows, int in_dim, int out_dim);
 // no_thin: only dW2 is computed (the thin parts of `grad` are left ZERO: the caller adds them - rollout_common.h thin_floats)
 int launch_wgrad(const mpg_cfg_t* cfg, int in_dim, int out_dim, int ou, int rows, const XSpec& x, const float* h1, const float* h2,
                  const float* dz1, const float* dz2, const float* dz3, float inv_b, float* grad, float* ws, hipStream_t s,
-                 bool no_thin = false);
+                 bool no_thin = false, const float* thin_part = nullptr, int n_thin_part = 0);
+// (no_thin with thin_part: the thin partials of the backward launch / reverse sweep are summed in the same launch as the chunk slabs -
+// no launch_thin_reduce afterwards)
 
 // ---- fused critic-side kernels (one 16-row group per workgroup; callers fall back to the unfused launchers when a
 // configuration is not covered) ----------------------------------------------------------------------------------

@@ -7,7 +7,7 @@
 // Batched update = (1) set the leaves, last occurrence of a duplicate index wins like the sequential python loop,
 // (2) rebuild the internal nodes: bottom 10 levels per 1024-leaf subtree inside one workgroup, top levels by one
 // workgroup.  No float atomics.
-#include "mpg_common.h"
+#include "replay_common.h"
 
 namespace {
 
@@ -82,9 +82,18 @@ __global__ void __launch_bounds__(1024) k_update_paths(int capacity, int n, cons
     }
 }
 
+// GATHER: the sampled transition is also copied out of the ring by the thread that found it (ReplayBuffer._encode_sample,
+// buffer.py:57-68, 161-164): one launch instead of k_sample + k_gather (11 + 11 us at 65 536 rows; the row's random reads are
+// issued right behind the descent instead of in a launch of their own)
+struct GatherOut {
+    Ring ring;
+    int od, ad;
+    float *obs, *act, *rew, *obs2, *done;
+};
+template <bool GATHER>
 __global__ void k_sample(int capacity, int n_storage, int n, const double* __restrict__ sum_tree,
                          const double* __restrict__ min_tree, const double* __restrict__ u, uint32_t k0, uint32_t k1,
-                         uint32_t c1, uint32_t c2, double beta, int* __restrict__ idx, float* __restrict__ is_w) {
+                         uint32_t c1, uint32_t c2, double beta, int* __restrict__ idx, float* __restrict__ is_w, GatherOut go) {
     // the top levels of the sum tree (nodes 1 .. 2047: 16 KB) are staged in LDS once per workgroup: the first 10 of the 19 dependent
     // reads of a descent at capacity 2^19 then cost an LDS access instead of an L2 round trip (round 3: 41 us for sample + gather at
     // B = 65 536).  Same values, same comparisons: the indices are bit-identical.
@@ -125,6 +134,7 @@ __global__ void k_sample(int capacity, int n_storage, int n, const double* __res
     }
     const int leaf = node - capacity;
     idx[i] = leaf;
+    if constexpr (GATHER) gather_row(go.ring, leaf, i, go.od, go.ad, go.obs, go.act, go.rew, go.obs2, go.done);
     if (is_w) {                                          // buffer.py:146-158
         const double p_min = min_tree[1] / total;
         const double max_w = pow(p_min * (double)n_storage, -beta);
@@ -199,10 +209,31 @@ extern "C" int mpg_per_sample(const double* sum_tree, const double* min_tree, in
                               mpg_stream_t stream) {
     MPG_REQUIRE(sum_tree && min_tree && idx && pow2(capacity) && n > 0 && n_storage > 0 && n_storage <= capacity,
                 "mpg_per_sample: bad argument");
-    hipLaunchKernelGGL(k_sample, dim3((n + 255) / 256), dim3(256), 0, mpg_stream(stream), capacity, n_storage, n, sum_tree,
+    hipLaunchKernelGGL(k_sample<false>, dim3((n + 255) / 256), dim3(256), 0, mpg_stream(stream), capacity, n_storage, n, sum_tree,
                        min_tree, u, (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)ctr, (uint32_t)(ctr >> 32), beta,
-                       idx, is_weight);
+                       idx, is_weight, GatherOut{});
     MPG_CHECK_LAUNCH("k_sample");
+    return MPG_OK;
+}
+
+extern "C" int mpg_per_sample_gather(const double* sum_tree, const double* min_tree, int capacity, int n_storage, int n,
+                                     const double* u, uint64_t seed, uint64_t ctr, double beta, int* idx, float* is_weight,
+                                     int obs_dim, int act_dim, const float* ring_obs, const float* ring_act, const float* ring_rew,
+                                     const float* ring_obs2, const uint8_t* ring_done, float* o_obs, float* o_act, float* o_rew,
+                                     float* o_obs2, float* o_done, mpg_stream_t stream) {
+    MPG_REQUIRE(sum_tree && min_tree && idx && pow2(capacity) && n > 0 && n_storage > 0 && n_storage <= capacity,
+                "mpg_per_sample_gather: bad argument");
+    MPG_REQUIRE(ring_obs && ring_act && ring_rew && ring_obs2 && ring_done && o_obs && o_act && o_rew && o_obs2 && obs_dim > 0 &&
+                    obs_dim <= MAXOD && act_dim > 0 && act_dim <= MAXAD,
+                "mpg_per_sample_gather: bad ring / output argument");
+    GatherOut go;
+    go.ring = Ring{const_cast<float*>(ring_obs), const_cast<float*>(ring_act), const_cast<float*>(ring_rew), const_cast<float*>(ring_obs2),
+                   const_cast<uint8_t*>(ring_done)};
+    go.od = obs_dim; go.ad = act_dim; go.obs = o_obs; go.act = o_act; go.rew = o_rew; go.obs2 = o_obs2; go.done = o_done;
+    hipLaunchKernelGGL(k_sample<true>, dim3((n + 255) / 256), dim3(256), 0, mpg_stream(stream), capacity, n_storage, n, sum_tree,
+                       min_tree, u, (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)ctr, (uint32_t)(ctr >> 32), beta,
+                       idx, is_weight, go);
+    MPG_CHECK_LAUNCH("k_sample (gather)");
     return MPG_OK;
 }
 

@@ -303,13 +303,10 @@ extern "C" int mpg_rollout_pg(const mpg_cfg_t* cfg, const float* policy_params, 
         MPG_CHECK_LAUNCH("k_wide_inputs");
         xs = xspec(XW, od, nullptr, 0, cfg->obs_scale, od);
     }
-    rc = launch_wgrad(cfg, od, 2 * ad, ad, (int)(T * R), xs, H1, H2, DZ1, DZ2, DZ3, inv_b_global / (float)M, grad, slabs, s,
-                      thin_part != nullptr);
-    if (rc || !thin_part) return rc;
-    // dW2 came from the launch above (its thin parts are zeros); the thin parts are the sum of the sweep's per-workgroup partials
+    // (with thin_part: dW2 from the chunk slabs, the thin parts from the sweep's per-workgroup partials, summed in one launch)
     const int n_part = (int)std::min<long>(256, (R + GROUP - 1) / GROUP);
-    return launch_thin_reduce(thin_part, n_part, od, 2 * ad, grad, s);
-    return MPG_OK;
+    return launch_wgrad(cfg, od, 2 * ad, ad, (int)(T * R), xs, H1, H2, DZ1, DZ2, DZ3, inv_b_global / (float)M, grad, slabs, s,
+                        thin_part != nullptr, thin_part, thin_part ? n_part : 0);
 }
 
 extern "C" size_t mpg_rollout_q_target_workspace_bytes(const mpg_cfg_t* cfg, int rows) {

@@ -182,10 +182,9 @@ extern "C" int mpg_step_begin(mpg_train_ctx_t* c, int iteration, mpg_stream_t s)
         MPG_REQUIRE(c->ring_size > 0, "mpg_step_begin: empty replay ring");
         c->replay_times++;
         if (c->learner_version == 4 && c->prioritized) {
-            TRY(mpg_per_sample(c->per_sum, c->per_min, c->per_capacity, c->ring_size, c->batch, nullptr, c->replay_seed, c->replay_times,
-                               c->per_beta, c->idx, c->b_weights, s));
-            TRY(mpg_replay_gather(c->batch, c->idx, od, ad, c->ring_obs, c->ring_act, c->ring_rew, c->ring_obs2, c->ring_done, c->b_obs,
-                                  c->b_act, c->b_rew, c->b_obs2, c->b_done, s));
+            TRY(mpg_per_sample_gather(c->per_sum, c->per_min, c->per_capacity, c->ring_size, c->batch, nullptr, c->replay_seed,
+                                      c->replay_times, c->per_beta, c->idx, c->b_weights, od, ad, c->ring_obs, c->ring_act, c->ring_rew,
+                                      c->ring_obs2, c->ring_done, c->b_obs, c->b_act, c->b_rew, c->b_obs2, c->b_done, s));
         } else {
             TRY(mpg_replay_sample_uniform(c->ring_size, c->batch, c->replay_seed, c->replay_times, od, ad, c->ring_obs, c->ring_act,
                                           c->ring_rew, c->ring_obs2, c->ring_done, c->idx, c->b_obs, c->b_act, c->b_rew, c->b_obs2,

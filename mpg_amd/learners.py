@@ -345,8 +345,8 @@ class TD3Learner(_LearnerBase):
             pending = nm == 'Q1' and getattr(self, '_y1', None) is not None
             td = ops.q_loss_grad(self.cfg, pw.net(nm), b['batch_obs'], b['batch_actions'], b['batch_targets'], inv_b_global=inv_b,
                                  grad_out=self.grad(nm), loss_out=stats[i:i + 1], want_td=pending)[2]
-            if pending:        # td = Q1(s, a) - y  =>  y1 - Q1(s, a) = (y1 - y) - td
-                self.info_for_buffer['td_error'] = (self._y1 - b['batch_targets']) - td
+            if pending:        # td = Q1(s, a) - y  =>  y1 - Q1(s, a) = (y1 - y) - td  (one launch, like the native step driver)
+                self.info_for_buffer['td_error'] = ops.td3_priority_errors(self._y1, b['batch_targets'], td)
                 self._y1 = None
         ops.td3_policy_grad(self.cfg, pw.net('policy'), pw.net('Q1'), pw.net('Q2'), b['batch_obs'], inv_b_global=inv_b,
                             grad_out=self.grad('policy'), stats_out=stats[2:4])

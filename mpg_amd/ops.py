@@ -223,6 +223,13 @@ def normal_fill(n, seed, ctr, device):
     return out
 
 
+def td3_priority_errors(y1, y, td):
+    """(y1 - y) - td  = y1 - Q1(s, a), the priorities' td error of TD3 (td3.py:83-92) from the critic pass's own td output"""
+    out = torch.empty_like(td)
+    L.call('mpg_td3_priority_errors', L.c_int(td.numel()), L.ptr(_f32(y1)), L.ptr(_f32(y)), L.ptr(_f32(td)), L.ptr(out), L.stream())
+    return out
+
+
 def nstep_targets(cfg, policy_t, q1t, rewards, last_obs):
     n, rows = rewards.shape
     y = torch.empty(rows, dtype=torch.float32, device=last_obs.device)

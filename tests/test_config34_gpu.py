@@ -268,6 +268,28 @@ def test_prioritized_replay_at_config4_sizes():
     np.testing.assert_array_equal(s[0].cpu().numpy(), batch[0][s[-1].long()].cpu().numpy())
 
 
+def test_prioritized_sample_in_one_launch_equals_sample_plus_gather():
+    """Round 5: PrioritizedReplayBuffer.sample draws, weighs and gathers in ONE launch (mpg_per_sample_gather).  Same Philox stream,
+    same descent, same copies: indices, IS weights and all five gathered arrays must equal mpg_per_sample + mpg_replay_gather."""
+    from mpg_amd.buffer import PrioritizedReplayBuffer
+    from mpg_amd.config import default_args
+    rng = np.random.Generator(np.random.PCG64(9))
+    N, B = 5000, 4096
+    args = default_args('TD3', replay_batch_size=B, buffer_type='priority', replay_starts=N, max_buffer_size=8192)
+    rb = PrioritizedReplayBuffer(args, 3)
+    rb.add_batch((dev(rng.standard_normal((N, 6))), dev(rng.uniform(-1, 1, (N, 2))), dev(rng.standard_normal(N)),
+                  dev(rng.standard_normal((N, 6))), torch.as_tensor(rng.integers(0, 2, N).astype(np.uint8)).to(DEV)))
+    rb.update_priorities(torch.arange(N, dtype=torch.int32, device=DEV), dev(np.abs(rng.standard_normal(N)) + 1e-3))
+    rb.replay_times = 7
+    one = rb.sample(B)
+    idx = rb.sample_idxes(B)
+    two = list(rb._encode_sample(idx)) + [rb._last_weights, idx]
+    assert len(one) == len(two) == 7
+    for a, b in zip(one, two):
+        assert torch.equal(a, b)
+    assert one[4].dtype == torch.float32 and set(one[4].unique().tolist()) <= {0.0, 1.0}
+
+
 def test_config3_end_to_end_worker_ring_nadp_adam():
     """Config 3 end to end on the device (SURVEY.md section 8 f3): OffPolicyWorker on the analytic cart-pole (64 pendulums per launch;
     the reference steps ONE MuJoCo pendulum behind DummyVecEnv, train_script4mujoco.py:328, with explore_sigma None) -> replay
