@@ -267,7 +267,7 @@ SIDE = {
     'c3': dict(B=8192, alg='NADP', flop_per_row=14.8e6, hidden_flop_per_row=110 * 2 * 256 * 256,
                metric='grad-steps/sec, InvertedPendulumConti model NADP n=25 batch=8192',
                workload='InvertedPendulumConti (inverted_pendulum_model.py), NADP learner, n=25, replay batch 8192 per GPU; step = '
-                        'compute_gradient (Q-target rollout + Q loss/grad + policy rollout with all-step parameter gradients) + '
+                        'replay (uniform draw + gather) + compute_gradient (Q-target rollout + Q loss/grad + policy rollout with all-step parameter gradients) + '
                         '(all-reduce) + apply_gradients'),
     'c4': dict(B=65536, alg='TD3', flop_per_row=2.17e6, hidden_flop_per_row=16 * 2 * 256 * 256,
                metric='replay-rows/sec + grad-steps/sec, PathTrackingEnv TD3 + prioritized replay batch=65536',
@@ -349,41 +349,41 @@ def side_config(a):
     c = SIDE[a.config]
     B = c['B']
     rng = np.random.Generator(np.random.PCG64(rank))
+    from mpg_amd.optimizer import SingleProcessOffPolicyOptimizer
+    from mpg_amd.worker import OffPolicyWorker
+    # the stock stack in SingleProcessOffPolicyOptimizer's order; `--side-driver native` (default): enqueued by the native step driver
+    # (mpg_step_begin / _end, learner_version 3 / 4), `method`: method by method from Python (rounds 2 - 4).  The worker's sampling
+    # (every 10th iteration of 512 env steps in the reference, optimizer.py:331) is NOT part of these side lines' step: the interval is
+    # set beyond the run, the replay is filled up front.
+    never = 1 << 30
     if a.config == 'c3':
+        from mpg_amd.buffer import ReplayBuffer
         from mpg_amd.learners import NADPLearner
-        learner = NADPLearner(PolicyWithQs, default_args('NADP', replay_batch_size=B), device=dev)
-        obs = torch.as_tensor((rng.standard_normal((B, 4)) * np.array([0.5, 0.1, 0.5, 0.5])).astype(np.float32)).to(dev)
-        act = torch.as_tensor(rng.uniform(-3, 3, (B, 1)).astype(np.float32)).to(dev)
-        batch = [obs, act, torch.zeros(B, device=dev), obs, torch.zeros(B, device=dev)]
-        rb = None
+        args = default_args('NADP', replay_batch_size=B, num_agent=512, batch_size=512, replay_starts=2 * B, seed=rank)
+        worker = OffPolicyWorker(PolicyWithQs, args.env_id, args, rank, device=dev)
+        learner = NADPLearner(PolicyWithQs, args, device=dev)
+        rb = ReplayBuffer(args, rank, device=dev)
     else:
         from mpg_amd.buffer import PrioritizedReplayBuffer
         from mpg_amd.learners import TD3Learner
         from tests.golden_inputs import reset_law_obs
         N = 500000
-        args = default_args('TD3', replay_batch_size=B, buffer_type='priority', replay_starts=N)
+        args = default_args('TD3', replay_batch_size=B, buffer_type='priority', replay_starts=N, num_agent=512, batch_size=512, seed=rank)
+        worker = OffPolicyWorker(PolicyWithQs, args.env_id, args, rank, device=dev)
         learner = TD3Learner(PolicyWithQs, args, device=dev)
         rb = PrioritizedReplayBuffer(args, rank, device=dev)
         for _ in range(N // 50000):
             rb.add_batch((torch.as_tensor(reset_law_obs(rng, 50000)).to(dev), torch.as_tensor(rng.uniform(-1, 1, (50000, 2)), dtype=torch.float32).to(dev),
                           torch.as_tensor(rng.standard_normal(50000), dtype=torch.float32).to(dev),
                           torch.as_tensor(reset_law_obs(rng, 50000)).to(dev), torch.ones(50000, dtype=torch.uint8, device=dev)))
-    pw = learner.policy_with_value
+    opt = SingleProcessOffPolicyOptimizer(worker, learner, rb, None, args, sampling_interval=never, fused=a.side_driver == 'native')
+    opt.iteration = 1                       # (iteration 0 would sample: 0 % interval == 0)
+    assert (opt._fused is not None) == (a.side_driver == 'native')
+    pw = worker.policy_with_value
     pw.sync_from_rank0()
     prof = ops.Profiler(max_samples=4096)
-    prof.attach(pw.cfg)
-    it = [0]
-
-    def step():
-        if rb is None:
-            learner.compute_gradient(batch, None, None, it[0])
-        else:
-            smp = rb.replay()
-            learner.compute_gradient(smp[:5], rb, smp[-1], it[0])
-            info = learner.get_info_for_buffer()
-            info['rb'].update_priorities(info['indexes'], info['td_error'])
-        pw.apply_gradients(it[0], learner.flat_grad)
-        it[0] += 1
+    opt.set_profiler(prof)
+    step = opt.step
     quiesce_gc()
     for _ in range(max(a.warmup, 5)):
         step()
@@ -414,7 +414,7 @@ def side_config(a):
             slots[ctypes_name(k)] = {'avg_ms': ms, 'launches_per_step': n / nprof, 'ms_per_step': ms * n / nprof}
     prof.stop()
     t_per = None
-    if rb is not None:      # the sampling + gather alone, timed with device events on the launch stream
+    if a.config == 'c4':    # the sampling + gather alone, timed with device events on the launch stream
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(20):
@@ -435,7 +435,8 @@ def side_config(a):
         'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak',
         'timed_regions': N_REGIONS, 'region_ms_per_step': [1e3 * r / a.steps for r in regions],
         'vs_baseline': None, 'dtype': 'f32-via-split-f16', 'data': 'synthetic', 'schema': 4,
-        'config': {'workload': c['workload'], 'global_batch': world * B, 'parallelism': 'dp%d' % world, 'dist_backend': D.backend()},
+        'config': {'workload': c['workload'], 'global_batch': world * B, 'parallelism': 'dp%d' % world, 'dist_backend': D.backend(),
+                   'driver': 'native step driver (mpg_step_begin / _end)' if a.side_driver == 'native' else 'method by method from Python'},
         'device': _device_info(),
         # whole-step matrix view (the step is a chain of weight-stationary launches, all on the f16 pipe).  `achieved` / `frac`
         # count ALGORITHMIC flop (the 3x of the split-fp16 emulation is overhead, not work); the executed view (the
@@ -466,6 +467,8 @@ def main():
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--side-driver', default='native', choices=['native', 'method'],
+                    help='--config c3 / c4: the native step driver (default) or the method-by-method path of rounds 2 - 4')
     ap.add_argument('--no-side-configs', action='store_true', help='do not run --config c3 / c4 as child processes after the timed region')
     ap.add_argument('--config', default='c2', choices=['c2', 'c3', 'c4'],
                     help='c2 (default): the BASELINE metric - PathTracking MPG n=25 batch 4096; c3: NADP on the pendulum model, batch '

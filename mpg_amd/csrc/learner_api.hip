@@ -37,6 +37,16 @@ __global__ void k_smooth(int n, float* __restrict__ a, const float* __restrict__
     a[i] += fminf(fmaxf(sigma * eps[i], -c), c);
 }
 
+// the two above in one launch (mpg_td3_targets: the plain Q1 target of the priorities, then the smoothing of the action for the
+// clipped double-Q target - two dependent ~5 us launches at any batch size)
+__global__ void k_combine_and_smooth(int rows, int ad, const float* __restrict__ rew, const float* __restrict__ q1, float shift, float scale,
+                                     float gamma, float* __restrict__ y1, float* __restrict__ a, const float* __restrict__ eps, float sigma,
+                                     float c) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < rows) y1[i] = (rew[i] + shift) * scale + gamma * q1[i];
+    if (i < rows * ad) a[i] += fminf(fmaxf(sigma * eps[i], -c), c);
+}
+
 // y = sum_t gamma^t (r_t + shift) * scale + gamma^n q          (mpg_learner.py:165-168)
 __global__ void k_nstep(int rows, int n, const float* __restrict__ rewards, const float* __restrict__ q, float shift,
                         float scale, float gamma, float* __restrict__ y) {
@@ -303,15 +313,17 @@ extern "C" int mpg_td3_targets(const mpg_cfg_t* cfg, const float* policy_t, cons
     const XSpec xq = xspec(obs_tp1, od, a, ad, cfg->obs_scale, od);
     rc = launch_forward(cfg, q1t, od + ad, 1, 1, rows, xq, linear_out(), q1, 1, nullptr, nullptr, s);      // Q1t(s~', pi_t(s~')): y1
     if (rc) return rc;
-    hipLaunchKernelGGL(k_combine_target, dim3((rows + 255) / 256), dim3(256), 0, s, rows, rew, q1, (const float*)nullptr, cfg->rew_shift,
-                       cfg->rew_scale, cfg->gamma, y1);
-    MPG_CHECK_LAUNCH("k_combine_target");
     if (smooth_eps) {
         const int n = rows * ad;
-        hipLaunchKernelGGL(k_smooth, dim3((n + 255) / 256), dim3(256), 0, s, n, a, smooth_eps, smooth_sigma, smooth_clip);
-        MPG_CHECK_LAUNCH("k_smooth");
+        hipLaunchKernelGGL(k_combine_and_smooth, dim3((n + 255) / 256), dim3(256), 0, s, rows, ad, rew, q1, cfg->rew_shift, cfg->rew_scale,
+                           cfg->gamma, y1, a, smooth_eps, smooth_sigma, smooth_clip);
+        MPG_CHECK_LAUNCH("k_combine_and_smooth");
         rc = launch_forward(cfg, q1t, od + ad, 1, 1, rows, xq, linear_out(), q1, 1, nullptr, nullptr, s);
         if (rc) return rc;
+    } else {
+        hipLaunchKernelGGL(k_combine_target, dim3((rows + 255) / 256), dim3(256), 0, s, rows, rew, q1, (const float*)nullptr, cfg->rew_shift,
+                           cfg->rew_scale, cfg->gamma, y1);
+        MPG_CHECK_LAUNCH("k_combine_target");
     }
     rc = launch_forward(cfg, q2t, od + ad, 1, 1, rows, xq, linear_out(), q2, 1, nullptr, nullptr, s);
     if (rc) return rc;
@@ -391,20 +403,24 @@ extern "C" int mpg_q_loss_grad(const mpg_cfg_t* cfg, const float* q_params, int 
     const XSpec xq = xspec(obs, od, act, ad, cfg->obs_scale, od);
     int rc = launch_forward(cfg, q_params, in, 1, 1, rows, xq, linear_out(), q, 1, h1, h2, s);
     if (rc) return rc;
-    if (rows >= ERR_MB_MIN_ROWS) {
-        hipLaunchKernelGGL(k_q_err_mb, dim3(ERR_PARTS), dim3(1024), 0, s, rows, q, y, inv_b_global, dz3, td, parts);
-        hipLaunchKernelGGL(k_finish_parts, dim3(1), dim3(128), 0, s, ERR_PARTS, parts, 0.5f * inv_b_global, 0.f, loss_sum, (float*)nullptr);
-    } else
-    hipLaunchKernelGGL(k_q_err, dim3(1), dim3(1024), 0, s, rows, q, y, inv_b_global, dz3, td, loss_sum);
-    MPG_CHECK_LAUNCH("k_q_err");
     // the thin parameter gradients ride in the backward launch (mlp_launch.h): its per-workgroup partials live where the dz1 stash
     // would (never larger), the weight-gradient launch reads h1 and dz2 only
     const bool thin = backward_takes_thin(in, 1);
+    // large batches: the loss partials of the 64-block error kernel are added up by one extra block of the gradient's summation launch
+    // (round 5; k_finish_parts' arithmetic) when that launch exists (thin), by k_finish_parts otherwise
+    FinishJob fin{parts, ERR_PARTS, ERR_PARTS, 0.5f * inv_b_global, 0.f, loss_sum, nullptr};
+    const bool mb = rows >= ERR_MB_MIN_ROWS;
+    if (mb) {
+        hipLaunchKernelGGL(k_q_err_mb, dim3(ERR_PARTS), dim3(1024), 0, s, rows, q, y, inv_b_global, dz3, td, parts);
+        if (!thin) hipLaunchKernelGGL(k_finish_parts, dim3(1), dim3(128), 0, s, ERR_PARTS, parts, 0.5f * inv_b_global, 0.f, loss_sum, (float*)nullptr);
+    } else
+    hipLaunchKernelGGL(k_q_err, dim3(1), dim3(1024), 0, s, rows, q, y, inv_b_global, dz3, td, loss_sum);
+    MPG_CHECK_LAUNCH("k_q_err");
     rc = launch_backward(cfg, q_params, in, 1, 1, rows, dz3, 1, nullptr, 0, 0, 1.f, h1, h2, thin ? nullptr : dz1, dz2, nullptr, nullptr, 0, s,
                          thin ? &xq : nullptr, thin ? dz1 : nullptr);
     if (rc) return rc;
     return launch_wgrad(cfg, in, 1, 1, rows, xq, h1, h2, dz1, dz2, dz3, inv_b_global, grad, slabs, s, thin, thin ? dz1 : nullptr,
-                        thin ? backward_thin_parts(rows) : 0);
+                        thin ? backward_thin_parts(rows) : 0, (mb && thin) ? &fin : nullptr);
 }
 
 extern "C" size_t mpg_td3_policy_grad_workspace_bytes(const mpg_cfg_t* cfg, int rows) {
@@ -446,9 +462,12 @@ extern "C" int mpg_td3_policy_grad(const mpg_cfg_t* cfg, const float* policy_par
     if (rc) return rc;
     rc = launch_forward(cfg, q2, qin, 1, 1, rows, xq, linear_out(), qv2, 1, h21, h22, s);                  // :125
     if (rc) return rc;
-    if (rows >= ERR_MB_MIN_ROWS) {
+    const bool thin = backward_takes_thin(od, ad);        // (see mpg_q_loss_grad)
+    FinishJob fin{parts, ERR_PARTS, ERR_PARTS, 1.f, 1.f, qmin_sum, qmin_sqsum};
+    const bool mb = rows >= ERR_MB_MIN_ROWS;
+    if (mb) {
         hipLaunchKernelGGL(k_td3_dy_mb, dim3(ERR_PARTS), dim3(1024), 0, s, rows, qv1, qv2, inv_b_global, dy1, dy2, parts);
-        hipLaunchKernelGGL(k_finish_parts, dim3(1), dim3(128), 0, s, ERR_PARTS, parts, 1.f, 1.f, qmin_sum, qmin_sqsum);
+        if (!thin) hipLaunchKernelGGL(k_finish_parts, dim3(1), dim3(128), 0, s, ERR_PARTS, parts, 1.f, 1.f, qmin_sum, qmin_sqsum);
     } else
     hipLaunchKernelGGL(k_td3_dy, dim3(1), dim3(1024), 0, s, rows, qv1, qv2, inv_b_global, dy1, dy2, qmin_sum, qmin_sqsum);
     MPG_CHECK_LAUNCH("k_td3_dy");
@@ -458,10 +477,9 @@ extern "C" int mpg_td3_policy_grad(const mpg_cfg_t* cfg, const float* policy_par
     if (rc) return rc;
     hipLaunchKernelGGL(k_sum_action_grad, dim3((rows * ad + 255) / 256), dim3(256), 0, s, rows, od, ad, dx1, dx2, ga);
     MPG_CHECK_LAUNCH("k_sum_action_grad");
-    const bool thin = backward_takes_thin(od, ad);        // (see mpg_q_loss_grad)
     rc = launch_backward(cfg, policy_params, od, 2 * ad, ad, rows, ga, ad, a, ad, po.out_tanh, po.out_scale, hp1, hp2, thin ? nullptr : dz1,
                          dz2, dz3, nullptr, 0, s, thin ? &xp : nullptr, thin ? dz1 : nullptr);
     if (rc) return rc;
     return launch_wgrad(cfg, od, 2 * ad, ad, rows, xp, hp1, hp2, dz1, dz2, dz3, inv_b_global, grad, slabs, s, thin, thin ? dz1 : nullptr,
-                        thin ? backward_thin_parts(rows) : 0);
+                        thin ? backward_thin_parts(rows) : 0, (mb && thin) ? &fin : nullptr);
 }

@@ -365,12 +365,25 @@ __device__ __forceinline__ void sum_parts_block(const float* __restrict__ part, 
 // batches).  Blocks [0, nb_slab): the hidden kernel's entries from the slabs (the slabs' thin positions are not read); the rest: the
 // thin positions from the partials.  The same association per output as the two launches: bit-identical gradients.
 __global__ void __launch_bounds__(256) k_sum_slabs_thin(const float* __restrict__ slabs, int n_slab, int n, int w2_off, int nb_slab,
-                                                        const float* __restrict__ thin, int n_thin_part, int n_thin, float* __restrict__ out) {
+                                                        const float* __restrict__ thin, int n_thin_part, int n_thin, float* __restrict__ out,
+                                                        const FinishJob fin, int nb_all) {
     __shared__ float sR4[4][65];
     __shared__ float sR16[16][17];
     int i;
     float sum;
     bool writer;
+    if ((int)blockIdx.x == nb_all) {          // the extra block: a pending scalar reduction (k_finish_parts' arithmetic, block order)
+        if (threadIdx.x == 0) {
+            float sacc = 0.f;
+            for (int b = 0; b < fin.n_part; ++b) sacc += fin.part[b];
+            fin.out0[0] = fin.scale0 * sacc;
+        } else if (threadIdx.x == 64 && fin.out1) {
+            float sacc = 0.f;
+            for (int b = 0; b < fin.n_part; ++b) sacc += fin.part[fin.stride1 + b];
+            fin.out1[0] = fin.scale1 * sacc;
+        }
+        return;
+    }
     if ((int)blockIdx.x < nb_slab) {
         // (slab column = position in the flat network: the W2 block starts at w2_off)
         sum_parts_block<4>(slabs + w2_off, n_slab, n, blockIdx.x, sR4, i, sum, writer);
@@ -485,7 +498,7 @@ size_t wgrad_workspace_floats(int rows, int in_dim, int out_dim) {
 
 int launch_wgrad(const mpg_cfg_t* cfg, int in_dim, int out_dim, int ou, int rows, const XSpec& x, const float* h1, const float* h2,
                  const float* dz1, const float* dz2, const float* dz3, float inv_b, float* grad, float* ws, hipStream_t s, bool no_thin,
-                 const float* thin_part, int n_thin_part) {
+                 const float* thin_part, int n_thin_part, const FinishJob* fin) {
     MPG_REQUIRE(rows > 0 && h1 && h2 && (dz1 || no_thin) && dz2 && dz3 && grad && ws, "launch_wgrad: bad argument");
     WgradArgs a;
     a.no_thin = no_thin ? 1 : 0;
@@ -516,12 +529,13 @@ int launch_wgrad(const mpg_cfg_t* cfg, int in_dim, int out_dim, int ou, int rows
     MPG_CHECK_LAUNCH("k_wgrad");
     const int n = net_size(in_dim, out_dim);
     if (no_thin && thin_part) {        // the chunk slabs (hidden kernel) and the thin partials of the backward launch / reverse sweep in one launch
-        const int n_thin = thin_floats(in_dim, out_dim), nb_slab = H * H / 64;
-        hipLaunchKernelGGL(k_sum_slabs_thin, dim3(nb_slab + (n_thin + 15) / 16), dim3(256), 0, s, ws, nch, n, in_dim * H + H, nb_slab, thin_part,
-                           n_thin_part, n_thin, grad);
+        const int n_thin = thin_floats(in_dim, out_dim), nb_slab = H * H / 64, nb_all = nb_slab + (n_thin + 15) / 16;
+        hipLaunchKernelGGL(k_sum_slabs_thin, dim3(nb_all + (fin ? 1 : 0)), dim3(256), 0, s, ws, nch, n, in_dim * H + H, nb_slab, thin_part,
+                           n_thin_part, n_thin, grad, fin ? *fin : FinishJob{}, nb_all);
         MPG_CHECK_LAUNCH("k_sum_slabs_thin");
         return MPG_OK;
     }
+    MPG_REQUIRE(!fin, "launch_wgrad: a pending scalar reduction needs the merged summation launch");
     hipLaunchKernelGGL((k_sum_parts<4>), dim3((n + 63) / 64), dim3(256), 0, s, ws, nch, n, n, 0, grad);     // the chunk slabs
     MPG_CHECK_LAUNCH("k_sum_parts (slabs)");
     return MPG_OK;

@@ -78,9 +78,17 @@ size_t wgrad_workspace_floats(int rows, int in_dim, int out_dim);
 // inv_b: the scale the upstream gradients carry (1/B_global, / M for tiled rollouts); informational - the fp16 split operands are
 // centred per chunk from the data itself (mlp_wgrad.h)
 // no_thin: only dW2 is computed (the thin parts of `grad` are left ZERO: the caller adds them - rollout_common.h thin_floats)
+// a pending scalar reduction that rides in the weight-gradient launch's summation kernel (one block more) instead of a launch of its
+// own: out0 = scale0 * sum_b part[b], out1 (nullable) = scale1 * sum_b part[stride1 + b], b < n_part, in block order
+struct FinishJob {
+    const float* part;
+    int n_part, stride1;
+    float scale0, scale1;
+    float *out0, *out1;
+};
 int launch_wgrad(const mpg_cfg_t* cfg, int in_dim, int out_dim, int ou, int rows, const XSpec& x, const float* h1, const float* h2,
                  const float* dz1, const float* dz2, const float* dz3, float inv_b, float* grad, float* ws, hipStream_t s,
-                 bool no_thin = false, const float* thin_part = nullptr, int n_thin_part = 0);
+                 bool no_thin = false, const float* thin_part = nullptr, int n_thin_part = 0, const struct FinishJob* fin = nullptr);
 // (no_thin with thin_part: the thin partials of the backward launch / reverse sweep are summed in the same launch as the chunk slabs -
 // no launch_thin_reduce afterwards)
 

@@ -31,6 +31,27 @@ __global__ void k_set_leaves(int n, int capacity, const int* __restrict__ idx, c
     min_tree[capacity + leaf] = v;
     if (max_prio) atomicMax(reinterpret_cast<unsigned int*>(max_prio), __float_as_uint((float)p));   // p > 0: bit order == value order
 }
+// the same with ONE atomic per wave for the running maximum (65 536 atomics on one address were 12 of the kernel's 17.6 us at TD3's batch):
+// every lane takes part in the wave's maximum (lanes without a leaf of their own contribute 0: every p is > 0)
+__global__ void __launch_bounds__(256) k_set_leaves_wmax(int n, int capacity, const int* __restrict__ idx, const float* __restrict__ prio,
+                                                         double alpha, double eps, const int* __restrict__ stamp, double* __restrict__ sum_tree,
+                                                         double* __restrict__ min_tree, float* __restrict__ max_prio) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    float mine = 0.f;
+    if (i < n) {
+        const int leaf = idx[i];
+        if (stamp[leaf] == i) {                          // (a later entry of the batch overrides the others)
+            const double p = fabs((double)prio[i]) + eps;
+            const double v = pow(p, alpha);
+            sum_tree[capacity + leaf] = v;
+            min_tree[capacity + leaf] = v;
+            mine = (float)p;
+        }
+    }
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) mine = fmaxf(mine, __shfl_xor(mine, m, 64));
+    if ((threadIdx.x & 63) == 0 && mine > 0.f) atomicMax(reinterpret_cast<unsigned int*>(max_prio), __float_as_uint(mine));
+}
 
 __global__ void k_unstamp(int n, const int* __restrict__ idx, int* __restrict__ stamp) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -38,7 +59,11 @@ __global__ void k_unstamp(int n, const int* __restrict__ idx, int* __restrict__ 
 }
 
 // rebuild nodes of one 1024-leaf subtree (levels below the subtree root), SegmentTree.__setitem__ :90-97 semantics
-__global__ void __launch_bounds__(512) k_rebuild_bottom(int capacity, double* __restrict__ sum_tree, double* __restrict__ min_tree) {
+// n_unstamp > 0: the batch's stamps are also cleared here (k_unstamp's work, one launch less: the stamps are only read by
+// k_set_leaves, which has finished)
+__global__ void __launch_bounds__(512) k_rebuild_bottom(int capacity, double* __restrict__ sum_tree, double* __restrict__ min_tree, int n_unstamp,
+                                                        const int* __restrict__ idx, int* __restrict__ stamp) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_unstamp; i += gridDim.x * blockDim.x) stamp[idx[i]] = -1;
     const int nsub_leaves = capacity < SUB ? capacity : SUB;
     const int sub = blockIdx.x;                         // subtree index
     // node ids of level with `w` nodes inside this subtree: first = (capacity / nsub_leaves * w') ... compute per level
@@ -152,9 +177,9 @@ __global__ void k_tree_init(int capacity, double* __restrict__ sum_tree, double*
     if (i < capacity) stamp[i] = -1;
 }
 
-int rebuild(int capacity, double* sum_tree, double* min_tree, hipStream_t s) {
+int rebuild(int capacity, double* sum_tree, double* min_tree, hipStream_t s, int n_unstamp = 0, const int* idx = nullptr, int* stamp = nullptr) {
     const int nsub = capacity < SUB ? 1 : capacity / SUB;
-    hipLaunchKernelGGL(k_rebuild_bottom, dim3(nsub), dim3(512), 0, s, capacity, sum_tree, min_tree);
+    hipLaunchKernelGGL(k_rebuild_bottom, dim3(nsub), dim3(512), 0, s, capacity, sum_tree, min_tree, n_unstamp, idx, stamp);
     MPG_CHECK_LAUNCH("k_rebuild_bottom");
     if (nsub > 1) {
         hipLaunchKernelGGL(k_rebuild_top, dim3(1), dim3(512), 0, s, nsub, sum_tree, min_tree);
@@ -189,19 +214,20 @@ extern "C" int mpg_per_update(double* sum_tree, double* min_tree, int* stamp, in
     MPG_REQUIRE(sum_tree && min_tree && stamp && idx && prio && pow2(capacity) && n > 0, "mpg_per_update: bad argument");
     hipStream_t s = mpg_stream(stream);
     const dim3 g((n + 255) / 256), b(256);
+    const bool paths = (long)n * 64 <= (long)capacity;
     hipLaunchKernelGGL(k_stamp, g, b, 0, s, n, idx, stamp);
-    hipLaunchKernelGGL(k_set_leaves, g, b, 0, s, n, capacity, idx, prio, alpha, eps, stamp, sum_tree, min_tree,
-                       max_priority);
-    hipLaunchKernelGGL(k_unstamp, g, b, 0, s, n, idx, stamp);
+    if (max_priority) hipLaunchKernelGGL(k_set_leaves_wmax, g, b, 0, s, n, capacity, idx, prio, alpha, eps, stamp, sum_tree, min_tree, max_priority);
+    else hipLaunchKernelGGL(k_set_leaves, g, b, 0, s, n, capacity, idx, prio, alpha, eps, stamp, sum_tree, min_tree, max_priority);
+    if (paths) hipLaunchKernelGGL(k_unstamp, g, b, 0, s, n, idx, stamp);
     MPG_CHECK_LAUNCH("mpg_per_update");
     // n log2(capacity) node updates by one workgroup against 2 * capacity by the whole chip: the paths win for small batches (B = 256
     // into 2^19 leaves: 19 levels of 256 nodes)
-    if ((long)n * 64 <= (long)capacity) {
+    if (paths) {
         hipLaunchKernelGGL(k_update_paths, dim3(1), dim3(1024), 0, s, capacity, n, idx, sum_tree, min_tree);
         MPG_CHECK_LAUNCH("k_update_paths");
         return MPG_OK;
     }
-    return rebuild(capacity, sum_tree, min_tree, s);
+    return rebuild(capacity, sum_tree, min_tree, s, n, idx, stamp);        // (clears the stamps on its way)
 }
 
 extern "C" int mpg_per_sample(const double* sum_tree, const double* min_tree, int capacity, int n_storage, int n,
