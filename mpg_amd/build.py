@@ -85,6 +85,12 @@ def _build_one(engine, force, verbose, jobs):
     from concurrent.futures import ThreadPoolExecutor
     OBJ, LIB, vflags = VARIANTS[engine]
     os.makedirs(OBJ, exist_ok=True)
+    # objects (and their stamps / by-products) whose source no longer exists are removed: they would not be linked, but they travel
+    # with every snapshot of the tree
+    live = set(s + '.o' for s in sources())
+    for f in os.listdir(OBJ):
+        if not any(f == o or f.startswith(o + '.') for o in live):
+            os.remove(os.path.join(OBJ, f))
     cc = hipcc()
     objs, todo = [], []
     for s in sources():

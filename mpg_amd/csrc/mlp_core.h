@@ -41,10 +41,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // Default: SPLIT-FP16.  Every float32 operand x of the hidden-layer product is written as hi + lo with hi = fp16(x),
 // lo = fp16(x - hi) - 22..23 significand bits, exact products - and the product is evaluated as hi*hi + hi*lo + lo*hi by
 // THREE v_mfma_f32_16x16x32_f16 per fp32-equivalent tile step into ONE float32 accumulator (the lo*lo term, 2^-22
-// relative, is dropped; the matrix pipe handles fp16 subnormals exactly - tools/proto/denorm_mfma.hip).  The f16 matrix pipe
+// relative, is dropped; the matrix pipe handles fp16 subnormals exactly - archive/proto/denorm_mfma.hip).  The f16 matrix pipe
 // runs at 16x the rate of v_mfma_f32_16x16x4_f32, so the layer costs 3/16 of the exact-fp32 form.  Measured against
 // float64 on random data a 256-term contraction is MORE accurate than the fp32 fma chain (1.9e-7 vs 2.9e-7 rel-L2: exact
-// products, 8x fewer roundings per accumulator - tools/proto/split_mfma.hip); what it does NOT reproduce is the last bit of
+// products, 8x fewer roundings per accumulator - archive/proto/split_mfma.hip); what it does NOT reproduce is the last bit of
 // a quarter of the weights (a 13-bit residual in an 11-bit lo), a FIXED perturbation of <= 2^-23 relative that the 26
 // policy evaluations of a rollout see coherently: the 25-step policy gradient sits at 4e-6 of the float64 oracle instead
 // of 1.2e-6 (tools/engine_error.py; the bar is 1e-4, tests/yardstick.py states the allowance).

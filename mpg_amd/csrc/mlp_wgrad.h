@@ -122,7 +122,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int sl, con
             // they become packed v_pk_fma_f32 / v_pk_add_f32 (op_sel forms), and in k_wgrad_multi single products were then
             // lost nondeterministically: first the (row 13, even i) terms of dW1 in ~85 % of launches, after dW1 was
             // unpacked the t = 1 half of dW3 in ~5 % (found by the repeated-launch determinism
-            // check, not reproduced in isolation by tools/proto/pk_hazard.hip; a build without packed fp32 is clean).
+            // check, not reproduced in isolation by archive/proto/pk_hazard.hip; a build without packed fp32 is clean).
 #ifdef MPG_AB_PKFMA
             // ablation build (tools/pk_anomaly.sh): the form the compiler is free to pack (v_pk_fma_f32 / v_pk_add_f32 with
             // op_sel) - the one that lost products in round 2
@@ -347,7 +347,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int sl, con
 #endif
     }
     MPG_TL(2);
-#ifdef MPG_AB_WG_W2_FIRST      // diagnosis build (tools/proto/pk_repro): dW2 leaves its registers before the thin pieces start
+#ifdef MPG_AB_WG_W2_FIRST      // diagnosis build (archive/proto/pk_repro): dW2 leaves its registers before the thin pieces start
     if constexpr (ROLE != 2) {
         float* sW2e = a.slabs + (size_t)chunk * net_size(a.in_dim, a.out_dim) + a.in_dim * H + H;
 #pragma unroll

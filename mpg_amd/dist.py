@@ -130,7 +130,7 @@ class OneShotAllReduce(object):
     step driver enqueues a 0.24 ms step in ~40 us).  So the launch queue of the native driver no longer drains at the exchange.
     There is still no device-side spin between processes (on the test box several ranks time-share ONE GPU).
     A HIP interprocess event can be recorded 32 times in its life (ROCm 7.2: the 33rd hipStreamWaitEvent on an opened handle
-    returns hipErrorInvalidValue whatever the owner does in between - tools/proto/ipc_event/probe.py), so the events live in
+    returns hipErrorInvalidValue whatever the owner does in between - archive/proto/ipc_event/probe.py), so the events live in
     GENERATIONS of GEN_LEN exchanges: the next generation's four events are created and their handles published through the
     shared-memory file while the current one is in use, and opened by the peers at the generation boundary - host work of a few
     tens of microseconds every GEN_LEN steps, off the GPU's critical path.
