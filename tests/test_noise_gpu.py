@@ -152,9 +152,9 @@ def test_config3_whole_loop_follows_the_oracle_loop_on_identical_random_inputs()
     every 10 iterations: ring contents, parameters, targets of the online and target networks, and the statistics the judge
     compared last round (target max / mean over the minibatch).
 
-    Bars: the parameter UPDATE (parameters minus initial parameters) within 2 % relative L2 of the oracle's and the parameters
-    themselves within 1e-4 (float32 rounding through Adam's normalisation: measured below); ring observations within 1e-4 abs;
-    target_max / target_mean within 2e-3."""
+    Bars: the parameter UPDATE (parameters minus initial parameters) within 1e-3 relative L2 of the oracle's (measured: 2.1e-5) and
+    the parameters themselves within 1e-5 (measured 1.1e-6: float32 rounding through Adam's normalisation); ring observations within
+    1e-3; target_max / target_mean within 2e-3."""
     from mpg_amd.buffer import ReplayBuffer
     from mpg_amd.config import default_args
     from mpg_amd.learners import NADPLearner
@@ -200,7 +200,69 @@ def test_config3_whole_loop_follows_the_oracle_loop_on_identical_random_inputs()
         worst_p, worst_u, worst_t = max(worst_p, e_p, e_t), max(worst_u, e_u), max(worst_t, float(np.abs(tg - ot).max()))
         print('iteration %3d: parameters %.1e (targets %.1e), update %.1e; target max %.4f / %.4f mean %.4f / %.4f' %
               (it + 10, e_p, e_t, e_u, tg.max(), ot.max(), tg.mean(), ot.mean()))
-        assert e_p <= 1e-4 and e_t <= 1e-4 and e_u <= 2e-2, (it, e_p, e_t, e_u)
+        assert e_p <= 1e-5 and e_t <= 1e-5 and e_u <= 1e-3, (it, e_p, e_t, e_u)
         assert abs(tg.max() - ot.max()) <= 2e-3 and abs(tg.mean() - ot.mean()) <= 2e-3
     torch.set_num_threads(nthreads)
     print('config-3 whole loop, 120 iterations: parameters %.1e, update %.1e, minibatch targets %.1e abs' % (worst_p, worst_u, worst_t))
+
+
+def test_bench_workload_whole_loop_follows_the_oracle_loop_on_identical_random_inputs():
+    """The BENCH workload's own loop (configs 1 / 2: OffPolicyWorker on PathTrackingEnv with exploration noise -> ring -> uniform draw ->
+    MPG-v2 gradients with in-kernel model noise -> clip -> Adam -> Polyak with delayed policy updates; the native step driver's eight
+    launches per iteration) against tests/c2_loop.py: the oracle's loop (worker.py:91-119, optimizer.py:330-362, mpg_learner.py:401-455,
+    policy.py:123-171 restated; the oracle's environment) fed the SAME Philox draws (reset law after every step, exploration noise,
+    replay indices, model noise) from the device's initial weights.  60 iterations, checked every 10.
+
+    Bars: parameter update within 1e-3 relative L2 of the oracle's (measured: 1.4e-6), parameters within 1e-5 (1.5e-8); the replay indices
+    bit-exact; ring contents within 1e-3 (the exploration noise comes from the hardware log2 / cos on the device, numpy's on the
+    host; the 20-sub-step environment amplifies ulps); critic losses within 1e-3 relative."""
+    from mpg_amd import ops
+    from mpg_amd.buffer import ReplayBuffer
+    from mpg_amd.config import default_args
+    from mpg_amd.learners import MPGLearner
+    from mpg_amd.optimizer import SingleProcessOffPolicyOptimizer
+    from mpg_amd.policy import PolicyWithQs
+    from mpg_amd.worker import OffPolicyWorker
+    from tests.c2_loop import OracleConfig2Loop
+    seed = 3
+    nthreads = torch.get_num_threads()
+    torch.set_num_threads(8)
+    args = default_args('MPG-v2', num_agent=64, batch_size=64, replay_batch_size=256, replay_starts=512, seed=seed, init_seed=seed,
+                        nan_check_interval=10 ** 9)
+    worker = OffPolicyWorker(PolicyWithQs, args.env_id, args, 0)
+    learner = MPGLearner(PolicyWithQs, args)
+    rb = ReplayBuffer(args, 0)
+    pw = worker.policy_with_value
+    init = pw.params.cpu().numpy().copy()
+    off = np.cumsum([0] + list(pw.sizes))
+    loop = OracleConfig2Loop({n: init[off[i]:off[i + 1]] for i, n in enumerate(pw.names)}, seed=seed)
+    opt = SingleProcessOffPolicyOptimizer(worker, learner, rb, None, args, sampling_interval=1)
+    assert opt._fused is not None and opt._fused.c.learner_version == 2
+    assert len(rb) == loop.size == 512
+    np.testing.assert_allclose(rb.obs[:512].cpu().numpy(), loop.ring['obs'][:512], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(rb.act[:512].cpu().numpy(), loop.ring['act'][:512], rtol=1e-4, atol=1e-5)
+    worst_p = worst_u = 0.0
+    for it in range(0, 60, 10):
+        for _ in range(10):
+            opt.step()
+            loop.step()
+        torch.cuda.synchronize()
+        n = loop.size
+        assert len(rb) == n and opt._fused.c.replay_times == loop.replay_times and opt._fused.c.learner_counter == loop.counter
+        assert worker._noise_ctr == loop.noise_ctr and worker.env._ctr == loop.env_ctr
+        np.testing.assert_array_equal(opt._fused.t['idx'].cpu().numpy(), loop.idx)
+        for k, tol in (('obs', 1e-3), ('act', 1e-3), ('obs2', 1e-3)):
+            np.testing.assert_allclose(getattr(rb, k)[:n].cpu().numpy(), loop.ring[k][:n], rtol=tol, atol=tol, err_msg=k)
+        np.testing.assert_allclose(rb.rew[:n].cpu().numpy(), loop.ring['rew'][:n], rtol=1e-3, atol=1e-3)
+        got, gott = pw.params.cpu().numpy(), pw.targets.cpu().numpy()
+        ref, reft = loop.flat()
+        e_p, e_t, e_u = rel_l2(got, ref), rel_l2(gott, reft), rel_l2(got - init, ref - init)
+        worst_p, worst_u = max(worst_p, e_p, e_t), max(worst_u, e_u)
+        st = learner.get_stats()
+        print('iteration %2d: parameters %.1e (targets %.1e), update %.1e; q_loss1 %.5f / %.5f value_mean %.5f / %.5f' %
+              (it + 10, e_p, e_t, e_u, float(st['q_loss1']), float(loop.stats['q_loss1']), float(st['value_mean']), float(loop.stats['value_mean'])))
+        assert e_p <= 1e-5 and e_t <= 1e-5 and e_u <= 1e-3, (it, e_p, e_t, e_u)
+        assert abs(float(st['q_loss1']) - float(loop.stats['q_loss1'])) <= 1e-3 * abs(float(loop.stats['q_loss1'])) + 1e-7
+        assert pw.opt_steps['Q1'] == it + 10 and pw.opt_steps['policy'] == (it + 10) // 2            # delay_update 2 (policy.py:127-153)
+    torch.set_num_threads(nthreads)
+    print('bench workload whole loop, 60 iterations: parameters %.1e, update %.1e' % (worst_p, worst_u))
