@@ -18,8 +18,10 @@ from oracle import mpg_oracle as O
 
 class OracleConfig2Loop(object):
     def __init__(self, flat_by_name, seed=0, num_agent=64, batch_size=64, replay_batch_size=256, replay_starts=512, capacity=500000,
-                 sampling_interval=1, explore_sigma=0.1, dtype=torch.float32):
-        self.cfg = O.Cfg()                                # PathTracking-v0, MPG-v2 defaults (select [0, 25], delay_update 2, ...)
+                 sampling_interval=1, explore_sigma=0.1, dtype=torch.float32, alg='MPG-v2'):
+        assert alg in ('MPG-v2', 'TD3')                   # TD3 (learners/td3.py:150-188, uniform replay): the same loop, another learner
+        self.alg = alg
+        self.cfg = O.Cfg()                                # PathTracking-v0 defaults (select [0, 25], delay_update 2, smoothing .2 / .5, ...)
         self.names = ['Q1', 'Q2', 'policy']
         self.w = {k: np.array(flat_by_name[k], np.float32) for k in self.names}
         self.tgt = {k: v.copy() for k, v in self.w.items()}
@@ -83,10 +85,14 @@ class OracleConfig2Loop(object):
         self.replay_times += 1
         idx = self.idx = O.uniform_indices_philox(self.size, self.B, self.rb_seed, self.replay_times)
         self.counter += 1
-        eps = O.model_noise_philox(self.cfg.n, self.B, self.l_seed, self.counter)
         r = self.ring
         batch = [r['obs'][idx], r['act'][idx], r['rew'][idx], r['obs2'][idx], r['done'][idx]]
-        grads, st = O.mpg_compute_gradient(self.cfg, self.nets(), batch, eps, it, 'MPG-v2')
+        if self.alg == 'TD3':       # target-policy smoothing noise (td3.py:74): mpg_normal_fill(learner seed, call counter)
+            eps = O.normal_fill_philox(self.B * 2, self.l_seed, self.counter).reshape(self.B, 2)
+            grads, st = O.td3_compute_gradient(self.cfg, self.nets(), batch, eps)
+        else:
+            eps = O.model_noise_philox(self.cfg.n, self.B, self.l_seed, self.counter)
+            grads, st = O.mpg_compute_gradient(self.cfg, self.nets(), batch, eps, it, 'MPG-v2')
         g, o = {}, 0
         for k in self.names:
             g[k] = np.concatenate([x.ravel() for x in grads[o:o + 6]]).astype(np.float32)

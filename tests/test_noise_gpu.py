@@ -206,8 +206,12 @@ def test_config3_whole_loop_follows_the_oracle_loop_on_identical_random_inputs()
     print('config-3 whole loop, 120 iterations: parameters %.1e, update %.1e, minibatch targets %.1e abs' % (worst_p, worst_u, worst_t))
 
 
-def test_bench_workload_whole_loop_follows_the_oracle_loop_on_identical_random_inputs():
-    """The BENCH workload's own loop (configs 1 / 2: OffPolicyWorker on PathTrackingEnv with exploration noise -> ring -> uniform draw ->
+@pytest.mark.parametrize('alg', ['MPG-v2', 'TD3'])
+def test_bench_workload_whole_loop_follows_the_oracle_loop_on_identical_random_inputs(alg):
+    """[TD3: the same loop with TD3Learner and uniform replay (learners/td3.py:150-188; smoothing noise = mpg_normal_fill's Philox
+    stream) through the native driver's learner_version 4.  With PRIORITIZED replay the loop is not comparable draw for draw: a 1e-6
+    relative difference in a float32 priority moves the float64 prefix sums enough to flip ~1 of 256 sampled indices per step.]
+    The BENCH workload's own loop (configs 1 / 2: OffPolicyWorker on PathTrackingEnv with exploration noise -> ring -> uniform draw ->
     MPG-v2 gradients with in-kernel model noise -> clip -> Adam -> Polyak with delayed policy updates; the native step driver's eight
     launches per iteration) against tests/c2_loop.py: the oracle's loop (worker.py:91-119, optimizer.py:330-362, mpg_learner.py:401-455,
     policy.py:123-171 restated; the oracle's environment) fed the SAME Philox draws (reset law after every step, exploration noise,
@@ -219,7 +223,7 @@ def test_bench_workload_whole_loop_follows_the_oracle_loop_on_identical_random_i
     from mpg_amd import ops
     from mpg_amd.buffer import ReplayBuffer
     from mpg_amd.config import default_args
-    from mpg_amd.learners import MPGLearner
+    from mpg_amd.learners import MPGLearner, TD3Learner
     from mpg_amd.optimizer import SingleProcessOffPolicyOptimizer
     from mpg_amd.policy import PolicyWithQs
     from mpg_amd.worker import OffPolicyWorker
@@ -227,17 +231,17 @@ def test_bench_workload_whole_loop_follows_the_oracle_loop_on_identical_random_i
     seed = 3
     nthreads = torch.get_num_threads()
     torch.set_num_threads(8)
-    args = default_args('MPG-v2', num_agent=64, batch_size=64, replay_batch_size=256, replay_starts=512, seed=seed, init_seed=seed,
+    args = default_args(alg, num_agent=64, batch_size=64, replay_batch_size=256, replay_starts=512, seed=seed, init_seed=seed,
                         nan_check_interval=10 ** 9)
     worker = OffPolicyWorker(PolicyWithQs, args.env_id, args, 0)
-    learner = MPGLearner(PolicyWithQs, args)
+    learner = (MPGLearner if alg == 'MPG-v2' else TD3Learner)(PolicyWithQs, args)
     rb = ReplayBuffer(args, 0)
     pw = worker.policy_with_value
     init = pw.params.cpu().numpy().copy()
     off = np.cumsum([0] + list(pw.sizes))
-    loop = OracleConfig2Loop({n: init[off[i]:off[i + 1]] for i, n in enumerate(pw.names)}, seed=seed)
+    loop = OracleConfig2Loop({n: init[off[i]:off[i + 1]] for i, n in enumerate(pw.names)}, seed=seed, alg=alg)
     opt = SingleProcessOffPolicyOptimizer(worker, learner, rb, None, args, sampling_interval=1)
-    assert opt._fused is not None and opt._fused.c.learner_version == 2
+    assert opt._fused is not None and opt._fused.c.learner_version == (2 if alg == 'MPG-v2' else 4)
     assert len(rb) == loop.size == 512
     np.testing.assert_allclose(rb.obs[:512].cpu().numpy(), loop.ring['obs'][:512], rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(rb.act[:512].cpu().numpy(), loop.ring['act'][:512], rtol=1e-4, atol=1e-5)
