@@ -305,3 +305,8 @@ def test_bench_in_the_drivers_multi_rank_form(backend, nproc):
     np.testing.assert_allclose(d['value'], nproc * 4096 / (d['ms_per_step'] * 1e-3), rtol=1e-6)
     assert 'roofline' in d and d['vs_baseline'] is None
     assert d['exchange_ms'] is not None and d['exchange_ms'] > 0 and d['exchange_launches'] > 0
+    # round 5: the median of five timed regions, and the exchange alone in every form this group can run (both IPC forms here)
+    assert d['timed_regions'] == 5 and len(d['region_ms_per_step']) == 5
+    assert abs(d['ms_per_step'] - sorted(d['region_ms_per_step'])[2]) <= 1e-9 * d['ms_per_step']
+    forms = d['exchange_forms_ms']
+    assert set(forms) >= {'oneshot', 'twoshot'} and all(isinstance(forms[k], float) and forms[k] > 0 for k in ('oneshot', 'twoshot')), forms
