@@ -624,8 +624,9 @@ def main():
     # the two-shot IPC forms of mpg_amd/dist.py), 50 exchanges of a scratch buffer of the gradient's length each, HIP events on the
     # launch stream of rank 0.  A form that cannot be set up (no peer access, IPC refused) is reported as its error text on EVERY rank
     # (the constructor fails collectively) - the line still prints; nothing here is part of `value`.
-    exchange_forms = None
+    exchange_forms, side_hung = None, False
     if world > 1:
+        import threading
         import torch.distributed as tdist
         exchange_forms = {}
         scratch_buf = torch.zeros_like(learner.flat)
@@ -641,14 +642,39 @@ def main():
             es[1].record()
             torch.cuda.synchronize()
             return es[0].elapsed_time(es[1]) / 50
-        if tdist.get_backend() == 'nccl':
-            exchange_forms['nccl'] = time_form(lambda b: tdist.all_reduce(b, op=tdist.ReduceOp.SUM))
+
+        def guarded(fn, seconds=90.0):
+            """a SIDE measurement must never take the line down: it runs in a daemon thread with a deadline (a collective that a
+            peer never joins cannot be cancelled, but it can be abandoned - the process then leaves through os._exit below)"""
+            box = {}
+
+            def run():
+                try:
+                    torch.cuda.set_device(dev)
+                    box['v'] = fn()
+                except Exception as e:           # noqa: BLE001
+                    box['e'] = e
+            th = threading.Thread(target=run, daemon=True)
+            th.start()
+            th.join(seconds)
+            if th.is_alive():
+                return 'timeout', None
+            return ('error', box['e']) if 'e' in box else ('ok', box['v'])
+        forms = [('nccl', lambda: time_form(lambda b: tdist.all_reduce(b, op=tdist.ReduceOp.SUM)))] if tdist.get_backend() == 'nccl' else []
         for form in ('oneshot', 'twoshot'):
-            try:
-                ex = D.OneShotAllReduce(scratch_buf.numel(), dev, mode=form)
-                exchange_forms[form] = time_form(ex.all_reduce_sum_)
-            except Exception as e:               # noqa: BLE001
-                exchange_forms[form] = 'unavailable: %s' % (str(e)[:300],)
+            forms.append((form, lambda form=form: time_form(D.OneShotAllReduce(scratch_buf.numel(), dev, mode=form).all_reduce_sum_)))
+        for name, fn in forms:
+            status, v = guarded(fn)
+            if status == 'ok':
+                exchange_forms[name] = v
+            elif status == 'error':
+                exchange_forms[name] = 'unavailable: %s' % (str(v)[:300],)
+            else:
+                exchange_forms[name] = 'abandoned after 90 s (a rank did not join); later forms not attempted'
+                side_hung = True
+                break
+        if side_hung and rank != 0:
+            os._exit(0)                          # this rank's part of the line (the timed regions) is done
     finite = bool(torch.isfinite(worker.policy_with_value.params).all().item())
     assert finite and int(worker.policy_with_value.nonfinite.sum().item()) == 0, 'non-finite parameters after the timed region'
     worker.policy_with_value.check_status()          # raises if the split-fp16 engine left its numerical envelope anywhere
@@ -787,6 +813,9 @@ def main():
     if world == 1 and not a.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline()
     print(json.dumps(out), flush=True)
+    if side_hung:                                # an abandoned collective would block the interpreter's shutdown
+        sys.stdout.flush()
+        os._exit(0)
 
 
 if __name__ == '__main__':
