@@ -42,6 +42,9 @@ EXTRA = {'env_path_tracking.hip': ['-ffp-contract=off'] + os.environ.get('MPG_EN
          'rollout_fwd.hip': os.environ.get('MPG_FWD_CFLAGS', '-mllvm -amdgpu-sched-strategy=iterative-ilp').split(),
          # experiments only (tools/ab_flags.sh): per-file flags of the other two engine translation units
          'fused_kernels.hip': os.environ.get('MPG_FUSED_CFLAGS', '').split(),
+         # (-DMPG_TR_IMAGE here - the transposed activation image for k_forward / k_backward only - measured k_forward -3.5 %, the TD3 step
+         # at B = 65 536 0.896 -> 0.881 ms, null on the bench step (tools/ab_tr_files.sh, round 5); NOT shipped: its v_fma_mixhi_f16 forms
+         # carry a low op_sel bit, which the containment rule of tests/test_abi.py keeps out of the shipped ISA altogether)
          'mlp_kernels.hip': os.environ.get('MPG_MLP_CFLAGS', '').split(),
          # reverse sweep: the same strategy measures 1.7 us faster than the default; without the SLP vectorizer (which turns the
          # model adjoint on the serial chain into v_pk_*_f32 plus the register moves that assemble their operand pairs) it
