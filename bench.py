@@ -68,7 +68,7 @@ ENV_SAT_AGENTS = 1 << 20      # agents per launch of the stand-alone env-kernel 
 ENV_FLOP_PER_STEP = 2300.0    # ~2.3 kflop per env-step (20 sub-steps x ~115, transcendentals counted as 1)
 
 
-def build_stack(dev, seed):
+def build_stack(dev, seed, always_exchange=False):
     from mpg_amd.buffer import ReplayBuffer
     from mpg_amd.config import default_args
     from mpg_amd.learners import MPGLearner
@@ -80,7 +80,7 @@ def build_stack(dev, seed):
     worker = OffPolicyWorker(PolicyWithQs, args.env_id, args, worker_id=seed, device=dev)
     learner = MPGLearner(PolicyWithQs, args, device=dev)
     rb = ReplayBuffer(args, seed, device=dev)
-    opt = SingleProcessOffPolicyOptimizer(worker, learner, rb, None, args, sampling_interval=1)
+    opt = SingleProcessOffPolicyOptimizer(worker, learner, rb, None, args, sampling_interval=1, always_exchange=always_exchange)
     worker.policy_with_value.sync_from_rank0()      # replicas start (and, with identical updates, stay) identical
     return args, worker, learner, rb, opt
 
@@ -203,6 +203,16 @@ def cpu_baseline(budget_s=8.0, min_timed=3, max_procs=256):
                       'B=%d] of the torch-CPU oracle - a quarter of the 4096-row step per CPU step, env-steps/s scales with the rows; '
                       'value = the best leg (%d processes); grad_steps_per_sec = value / 4096'
                       % ('/'.join(str(g['processes']) for g in legs), host, mem_cap, min_timed, budget_s, CPU_ROWS, CPU_ROWS, best['processes'])}
+
+
+def _flush_c_stdio():
+    """RCCL prints a version banner through C stdio, which a pipe buffers until exit - i.e. BEHIND the JSON line.  Flushing it first
+    keeps the JSON line the last line of stdout."""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:                # noqa: BLE001
+        pass
 
 
 def _under_profiler():
@@ -469,6 +479,10 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--side-driver', default='native', choices=['native', 'method'],
                     help='--config c3 / c4: the native step driver (default) or the method-by-method path of rounds 2 - 4')
+    ap.add_argument('--always-exchange', action='store_true',
+                    help='diagnostic, one GPU: run the exchange path in a ONE-rank RCCL group (the collective between mpg_step_begin and '
+                         'mpg_step_end, the clip partials from the exchanged buffer; with MPG_OVERLAP_EXCHANGE=1 also the critics\' early '
+                         'gradient + second stream) - what the multi-GPU step costs on one GPU beyond the bytes on the wire')
     ap.add_argument('--no-side-configs', action='store_true', help='do not run --config c3 / c4 as child processes after the timed region')
     ap.add_argument('--config', default='c2', choices=['c2', 'c3', 'c4'],
                     help='c2 (default): the BASELINE metric - PathTracking MPG n=25 batch 4096; c3: NADP on the pendulum model, batch '
@@ -488,7 +502,10 @@ def main():
     from mpg_amd import dist as D
     from mpg_amd import ops
     from mpg_amd.optimizer import quiesce_gc
-    rank, world, local = D.init_from_env()
+    if a.always_exchange and a.gpus == 1 and 'WORLD_SIZE' not in os.environ:
+        os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()))
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    rank, world, local = D.init_from_env(backend='nccl' if a.always_exchange and a.gpus == 1 else None)
     assert world == a.gpus, '--gpus %d but WORLD_SIZE=%d' % (a.gpus, world)
     assert torch.cuda.is_available(), 'bench.py needs a GPU: the product path has no CPU fallback'
     ndev = torch.cuda.device_count()
@@ -497,7 +514,7 @@ def main():
         local = local % ndev
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
-    args, worker, learner, rb, opt = build_stack(dev, seed=rank)
+    args, worker, learner, rb, opt = build_stack(dev, seed=rank, always_exchange=a.always_exchange)
     n_samples = (N_REGIONS * max(a.steps, 1) + PROF_EVERY - 1) // PROF_EVERY + 1
     prof = ops.Profiler(max_samples=n_samples)      # every HIP event exists from here on
     opt.set_profiler(prof)
@@ -778,7 +795,8 @@ def main():
                                '(all-reduce) + apply_gradients',
                    'global_batch': world * B_PER_GPU, 'parallelism': 'dp%d' % world,
                    'grad_allreduce_floats': int(learner.flat.numel()), 'native_step_driver': opt._fused is not None,
-                   'dist_backend': D.backend()},
+                   'dist_backend': D.backend(), 'always_exchange': bool(a.always_exchange),
+                   'overlap_exchange': os.environ.get('MPG_OVERLAP_EXCHANGE') == '1'},
         'device': _device_info(),
         'roofline': dominant,
         'roofline_other_rollout_kernel': other,
@@ -812,6 +830,7 @@ def main():
     }
     if world == 1 and not a.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline()
+    _flush_c_stdio()
     print(json.dumps(out), flush=True)
     if side_hung:                                # an abandoned collective would block the interpreter's shutdown
         sys.stdout.flush()
