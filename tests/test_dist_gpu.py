@@ -135,16 +135,16 @@ def test_native_step_driver_keeps_two_replicas_bit_identical(exchange):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize('backend', ['gloo', 'oneshot'])
-def test_native_step_driver_keeps_four_replicas_bit_identical(backend, monkeypatch):
+def test_native_step_driver_keeps_four_replicas_bit_identical(monkeypatch):
     """The same with FOUR ranks time-sharing the one GPU (nothing had run with more than two ranks, so rank-count
-    dependent state - slot indexing, the two staging parities, the per-peer events - was untested beyond 2).  Round 5: the one-shot
-    backend runs in both forms - one-shot and TWO-SHOT (reduce-scatter + all-gather) - and, because both take the rank-order sum,
-    20 native steps must leave the SAME bits in both."""
-    monkeypatch.setenv('MPG_DIST_BACKEND', backend)
+    dependent state - slot indexing, the two staging parities, the per-peer events - was untested beyond 2).  Round 5: both IPC forms -
+    one-shot and TWO-SHOT (reduce-scatter + all-gather) - and, because both take the rank-order sum, 20 native steps must leave the
+    SAME bits in both.  (gloo with four ranks was dropped in round 5 to keep the suite's run time: nothing in that path depends on
+    the rank count beyond what the two-rank test and the 8-rank bench dry run exercise.)"""
+    monkeypatch.setenv('MPG_DIST_BACKEND', 'oneshot')
     monkeypatch.setenv('MPG_ONESHOT_SYNC', 'event')
     runs = []
-    for mode in (['oneshot', 'twoshot'] if backend == 'oneshot' else ['oneshot']):
+    for mode in ('oneshot', 'twoshot'):
         monkeypatch.setenv('MPG_ONESHOT_MODE', mode)
         out = _run(_driver_worker, world=4)
         for r in range(1, 4):
@@ -152,8 +152,7 @@ def test_native_step_driver_keeps_four_replicas_bit_identical(backend, monkeypat
             assert not np.array_equal(out[0][2], out[r][2])
         assert np.isfinite(out[0][1]).all()
         runs.append(out[0][1])
-    if len(runs) == 2:
-        assert np.array_equal(runs[0], runs[1])
+    assert np.array_equal(runs[0], runs[1])
 
 
 @pytest.mark.timeout(900)
@@ -195,15 +194,15 @@ def _oneshot_sum_worker(rank, world, port, q):
 
 @pytest.mark.timeout(600)
 @pytest.mark.parametrize('world,sync,mode,n_ex', [(2, 'event', 'oneshot', 6), (2, 'host', 'oneshot', 6), (8, 'event', 'oneshot', 6),
-                                                  (2, 'event', 'twoshot', 90), (2, 'host', 'twoshot', 6), (4, 'event', 'twoshot', 6),
-                                                  (8, 'event', 'twoshot', 6), (3, 'event', 'twoshot', 6)])
+                                                  (2, 'event', 'twoshot', 90), (2, 'host', 'twoshot', 6), (8, 'event', 'twoshot', 6),
+                                                  (3, 'event', 'twoshot', 6)])
 def test_oneshot_all_reduce_is_the_in_rank_order_sum_bit_for_bit(monkeypatch, world, sync, mode, n_ex):
     """OneShotAllReduce on its own: exchanges of a 205 334-float buffer with entries over eight orders of magnitude (both
     staging parities re-used: the slot-reuse waits of the event form are exercised; 90 exchanges cross two event generations).
     Every rank must hold exactly fl(..fl(x_0 + x_1) + .. + x_{world-1}) - the rank-order float32 sum - each time; 2 ranks in
     both synchronisation forms and 8 ranks (all time-sharing the one GPU of the test box) in the event form.
-    Round 5: the same for the TWO-SHOT form (reduce-scatter + all-gather) with 2, 3 (slices of unequal length), 4 and 8
-    ranks - its slice sums take the same rank order, so the result must be the same bits."""
+    Round 5: the same for the TWO-SHOT form (reduce-scatter + all-gather) with 2, 3 (slices of unequal length) and 8
+    ranks (4 ranks: the native-driver test above) - its slice sums take the same rank order, so the result must be the same bits."""
     monkeypatch.setenv('MPG_DIST_BACKEND', 'oneshot')
     monkeypatch.setenv('MPG_ONESHOT_SYNC', sync)
     monkeypatch.setenv('MPG_ONESHOT_MODE', mode)
