@@ -116,7 +116,7 @@ def _driver_worker(rank, world, port, q):
     opt = SingleProcessOffPolicyOptimizer(worker, MPGLearner(PolicyWithQs, args), ReplayBuffer(args, 0), None, args,
                                           sampling_interval=1)
     assert opt._fused is not None and opt._fused.c.world_size == world
-    for _ in range(20):
+    for _ in range(int(os.environ.get('MPG_TEST_STEPS', '20'))):
         opt.step()
     pw = worker.policy_with_value
     torch.cuda.synchronize()
@@ -138,11 +138,12 @@ def test_native_step_driver_keeps_two_replicas_bit_identical(exchange):
 def test_native_step_driver_keeps_four_replicas_bit_identical(monkeypatch):
     """The same with FOUR ranks time-sharing the one GPU (nothing had run with more than two ranks, so rank-count
     dependent state - slot indexing, the two staging parities, the per-peer events - was untested beyond 2).  Round 5: both IPC forms -
-    one-shot and TWO-SHOT (reduce-scatter + all-gather) - and, because both take the rank-order sum, 20 native steps must leave the
+    one-shot and TWO-SHOT (reduce-scatter + all-gather) - and, because both take the rank-order sum, 10 native steps must leave the
     SAME bits in both.  (gloo with four ranks was dropped in round 5 to keep the suite's run time: nothing in that path depends on
     the rank count beyond what the two-rank test and the 8-rank bench dry run exercise.)"""
     monkeypatch.setenv('MPG_DIST_BACKEND', 'oneshot')
     monkeypatch.setenv('MPG_ONESHOT_SYNC', 'event')
+    monkeypatch.setenv('MPG_TEST_STEPS', '10')          # (four processes time-slicing one GPU: ~3 s per step; both parities re-used 5 times)
     runs = []
     for mode in ('oneshot', 'twoshot'):
         monkeypatch.setenv('MPG_ONESHOT_MODE', mode)
