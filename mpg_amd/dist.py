@@ -34,6 +34,13 @@ def init_from_env(backend=None):
     return rank, world, local
 
 
+def twoshot_slices(n, world):
+    """[(lo, hi)] per rank: slice r of a buffer of n floats in the two-shot form - contiguous, disjoint, covering [0, n); every slice but
+    the last starts and ends on a multiple of 64 floats (256-byte aligned copies); trailing ranks may get empty slices"""
+    chunk = (((n + world - 1) // world) + 63) // 64 * 64
+    return [(min(n, r * chunk), min(n, (r + 1) * chunk)) for r in range(world)]
+
+
 class _HostShm(object):
     """A POSIX shared-memory file the ranks of one node use for HOST-to-host hand-shakes of the one-shot exchange:
       * `calls[r]`   - int64 counter per rank (a cache line each): publish(v) / wait(p, v) order "peer issued its event record"
@@ -162,8 +169,7 @@ class OneShotAllReduce(object):
         if mode == 'auto':
             mode = 'twoshot' if (self.world >= 4 and 4 * self.n >= (512 << 10)) else 'oneshot'
         self.mode = mode
-        # slice r of the two-shot form: [r * chunk, min(n, (r + 1) * chunk)), chunk a multiple of 64 floats
-        self.chunk = (((self.n + self.world - 1) // self.world) + 63) // 64 * 64
+        self.slices = twoshot_slices(self.n, self.world)
         self.dev = torch.device(device) if not isinstance(device, torch.device) else device
         # ONE IPC-mapped allocation per rank: [2 parities][world slots + 1][n] - the staging slots and, behind them, the gather
         # array of the two-shot form
@@ -223,12 +229,12 @@ class OneShotAllReduce(object):
         L = self.L
         st = torch.cuda.current_stream()
         two = self.mode == 'twoshot'
-        ch, me = self.chunk, self.rank
-        lo, hi = min(self.n, me * ch), min(self.n, (me + 1) * ch)
+        me = self.rank
+        lo, hi = self.slices[me]
 
         def scatter():                                  # two-shot (A): slice p of my buffer into slot `rank` of rank p's array
             for p in range(self.world):
-                a, b = min(self.n, p * ch), min(self.n, (p + 1) * ch)
+                a, b = self.slices[p]
                 if b > a:
                     self.peers[p][par, me, a:b].copy_(flat[a:b], non_blocking=True)
 

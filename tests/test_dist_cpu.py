@@ -104,3 +104,19 @@ def test_single_process_dist_helpers_are_noops():
     t = torch.arange(4, dtype=torch.float32)
     assert D.world_size() == 1 and torch.equal(D.all_reduce_sum_(t.clone()), t) and D.max_over_ranks(3.5) == 3.5
     D.barrier()
+
+
+def test_twoshot_slices_partition_the_buffer():
+    """mpg_amd.dist.twoshot_slices: the reduce-scatter / all-gather slices of the two-shot exchange are contiguous, disjoint,
+    cover the buffer exactly and are 64-float aligned - for the gradient buffers of all four learners, ragged lengths and every world
+    size up to 8 (trailing slices may be empty: more ranks than 64-float chunks)."""
+    from mpg_amd.dist import twoshot_slices
+    for n in (205318 + 16, 136965 + 16, 1, 63, 64, 65, 127, 4097, 1 << 20):
+        for world in range(1, 9):
+            sl = twoshot_slices(n, world)
+            assert len(sl) == world and sl[0][0] == 0 and sl[-1][1] == n
+            for r, (lo, hi) in enumerate(sl):
+                assert 0 <= lo <= hi <= n and lo % 64 == 0 or lo == n
+                if r:
+                    assert lo == sl[r - 1][1]
+            assert sum(hi - lo for lo, hi in sl) == n
