@@ -19,10 +19,14 @@ from oracle import mpg_oracle as O
 class OracleConfig2Loop(object):
     def __init__(self, flat_by_name, seed=0, num_agent=64, batch_size=64, replay_batch_size=256, replay_starts=512, capacity=500000,
                  sampling_interval=1, explore_sigma=0.1, dtype=torch.float32, alg='MPG-v2'):
-        assert alg in ('MPG-v2', 'TD3')                   # TD3 (learners/td3.py:150-188, uniform replay): the same loop, another learner
+        # TD3 (learners/td3.py:150-188, uniform replay): the same loop, another learner.  MPG-v1 (networks [Q1 | policy]): the critic's
+        # target is the 25-step REAL-env return from (s, a_replay) (mpg_learner.py:109-124,146-169), recomputed with a new minibatch every
+        # num_batch_reuse = 10 gradient calls and kept in between (mpg_learner.py:402-403; train_script.py's default for v1)
+        assert alg in ('MPG-v2', 'TD3', 'MPG-v1')
         self.alg = alg
+        self.reuse = 10 if alg == 'MPG-v1' else 1
         self.cfg = O.Cfg()                                # PathTracking-v0 defaults (select [0, 25], delay_update 2, smoothing .2 / .5, ...)
-        self.names = ['Q1', 'Q2', 'policy']
+        self.names = ['Q1', 'policy'] if alg == 'MPG-v1' else ['Q1', 'Q2', 'policy']
         self.w = {k: np.array(flat_by_name[k], np.float32) for k in self.names}
         self.tgt = {k: v.copy() for k, v in self.w.items()}
         self.opt = {k: O.AdamState(v.size) for k, v in self.w.items()}
@@ -82,17 +86,25 @@ class OracleConfig2Loop(object):
         it = self.iteration
         if it % self.sampling_interval == 0:
             self.sample()
-        self.replay_times += 1
-        idx = self.idx = O.uniform_indices_philox(self.size, self.B, self.rb_seed, self.replay_times)
-        self.counter += 1
+        self.replay_times += 1                            # replay() is called every iteration (optimizer.py:340-341) ...
         r = self.ring
-        batch = [r['obs'][idx], r['act'][idx], r['rew'][idx], r['obs2'][idx], r['done'][idx]]
+        nets = self.nets()
+        if self.counter % self.reuse == 0:                # ... but the learner takes a new minibatch only every `reuse` calls
+            idx = self.idx = O.uniform_indices_philox(self.size, self.B, self.rb_seed, self.replay_times)
+            self.batch = [r['obs'][idx], r['act'][idx], r['rew'][idx], r['obs2'][idx], r['done'][idx]]
+            if self.alg == 'MPG-v1':
+                self.targets = O.n_step_target(self.cfg, nets, self.batch[0], self.batch[1])
+        self.counter += 1
+        batch = self.batch
         if self.alg == 'TD3':       # target-policy smoothing noise (td3.py:74): mpg_normal_fill(learner seed, call counter)
             eps = O.normal_fill_philox(self.B * 2, self.l_seed, self.counter).reshape(self.B, 2)
-            grads, st = O.td3_compute_gradient(self.cfg, self.nets(), batch, eps)
+            grads, st = O.td3_compute_gradient(self.cfg, nets, batch, eps)
+        elif self.alg == 'MPG-v1':
+            eps = O.model_noise_philox(self.cfg.n, self.B, self.l_seed, self.counter)
+            grads, st = self._v1_gradient(nets, batch, self.targets, eps, it)
         else:
             eps = O.model_noise_philox(self.cfg.n, self.B, self.l_seed, self.counter)
-            grads, st = O.mpg_compute_gradient(self.cfg, self.nets(), batch, eps, it, 'MPG-v2')
+            grads, st = O.mpg_compute_gradient(self.cfg, nets, batch, eps, it, 'MPG-v2')
         g, o = {}, 0
         for k in self.names:
             g[k] = np.concatenate([x.ravel() for x in grads[o:o + 6]]).astype(np.float32)
@@ -100,6 +112,20 @@ class OracleConfig2Loop(object):
         O.apply_gradients(self.cfg, self.w, self.tgt, self.opt, g, it, self.names)
         self.stats = st
         self.iteration += 1
+
+    def _v1_gradient(self, nets, batch, targets, eps, iteration):
+        """MPGLearner.compute_gradient for MPG-v1 with the CACHED n-step targets (mpg_learner.py:401-455): O.mpg_compute_gradient with the
+        target taken from the caller instead of being recomputed"""
+        cfg, dt = self.cfg, nets.dtype
+        obs, act = [torch.as_tensor(np.asarray(b, np.float32)).to(dt) for b in batch[:2]]
+        q_losses, q_grads = O.q_forward_and_backward(cfg, nets, obs, act, torch.as_tensor(targets).to(dt), ['Q1'])
+        qg, qn = O.clip_by_global_norm(q_grads[0], cfg.clip)
+        reduced, _, _ = O.model_rollout_for_policy_update(cfg, nets, obs, torch.as_tensor(eps).to(dt))
+        ws = O.rule_based_weights(iteration, cfg.total_ite, cfg.eta, cfg.select, dt)
+        total_loss = torch.sum(ws.detach() * torch.stack([-reduced[k] for k in cfg.select]))
+        pg, pn = O.clip_by_global_norm(list(torch.autograd.grad(total_loss, nets.w['policy'])), cfg.clip)
+        st = dict(q_loss1=q_losses[0].numpy(), value_mean=reduced[0].detach().numpy(), targets=np.asarray(targets))
+        return [g.detach().numpy() for g in qg + pg], st
 
     def flat(self):
         return np.concatenate([self.w[k] for k in self.names]), np.concatenate([self.tgt[k] for k in self.names])

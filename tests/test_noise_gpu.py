@@ -206,10 +206,13 @@ def test_config3_whole_loop_follows_the_oracle_loop_on_identical_random_inputs()
     print('config-3 whole loop, 120 iterations: parameters %.1e, update %.1e, minibatch targets %.1e abs' % (worst_p, worst_u, worst_t))
 
 
-@pytest.mark.parametrize('alg', ['MPG-v2', 'TD3'])
+@pytest.mark.parametrize('alg', ['MPG-v2', 'TD3', 'MPG-v1'])
 def test_bench_workload_whole_loop_follows_the_oracle_loop_on_identical_random_inputs(alg):
     """[TD3: the same loop with TD3Learner and uniform replay (learners/td3.py:150-188; smoothing noise = mpg_normal_fill's Philox
-    stream) through the native driver's learner_version 4.  With PRIORITIZED replay the loop is not comparable draw for draw: a 1e-6
+    stream) through the native driver's learner_version 4.  MPG-v1: networks [Q1 | policy], the critic's target = the 25-step REAL-env
+    return of 25 env launches on the learner's own env (mpg_learner.py:109-124,146-169), recomputed with a new minibatch every 10th
+    call and cached in between (learner_version 1; measured: update 1.7e-6).
+    With PRIORITIZED replay the loop is not comparable draw for draw: a 1e-6
     relative difference in a float32 priority moves the float64 prefix sums enough to flip ~1 of 256 sampled indices per step.]
     The BENCH workload's own loop (configs 1 / 2: OffPolicyWorker on PathTrackingEnv with exploration noise -> ring -> uniform draw ->
     MPG-v2 gradients with in-kernel model noise -> clip -> Adam -> Polyak with delayed policy updates; the native step driver's eight
@@ -234,14 +237,14 @@ def test_bench_workload_whole_loop_follows_the_oracle_loop_on_identical_random_i
     args = default_args(alg, num_agent=64, batch_size=64, replay_batch_size=256, replay_starts=512, seed=seed, init_seed=seed,
                         nan_check_interval=10 ** 9)
     worker = OffPolicyWorker(PolicyWithQs, args.env_id, args, 0)
-    learner = (MPGLearner if alg == 'MPG-v2' else TD3Learner)(PolicyWithQs, args)
+    learner = (TD3Learner if alg == 'TD3' else MPGLearner)(PolicyWithQs, args)
     rb = ReplayBuffer(args, 0)
     pw = worker.policy_with_value
     init = pw.params.cpu().numpy().copy()
     off = np.cumsum([0] + list(pw.sizes))
     loop = OracleConfig2Loop({n: init[off[i]:off[i + 1]] for i, n in enumerate(pw.names)}, seed=seed, alg=alg)
     opt = SingleProcessOffPolicyOptimizer(worker, learner, rb, None, args, sampling_interval=1)
-    assert opt._fused is not None and opt._fused.c.learner_version == (2 if alg == 'MPG-v2' else 4)
+    assert opt._fused is not None and opt._fused.c.learner_version == {'MPG-v2': 2, 'TD3': 4, 'MPG-v1': 1}[alg]
     assert len(rb) == loop.size == 512
     np.testing.assert_allclose(rb.obs[:512].cpu().numpy(), loop.ring['obs'][:512], rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(rb.act[:512].cpu().numpy(), loop.ring['act'][:512], rtol=1e-4, atol=1e-5)
