@@ -35,4 +35,4 @@ cat $OUT/pmc_traffic.json | head -20
 for f in $OUT/bench_*.json; do python3 -c "
 import json,sys
 d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
-print(sys.argv[1].split('/')[-1], 'ms/step %.4f median %.4f max %.4f' % (d['ms_per_step'], d['step_ms_median'], d['step_ms_max']), d['roofline']['kernel'], 'avg_ms %.4f frac %.3f' % (d['roofline']['avg_ms'], d['roofline']['frac']), d.get('cpu_baseline', {}).get('value'), d.get('cpu_baseline', {}).get('cores'))" $f; done
+print(sys.argv[1].split('/')[-1], 'ms/step %.4f' % d['ms_per_step'], 'regions', ['%.4f' % x for x in d.get('region_ms_per_step', [])], d['roofline']['kernel'][:60], 'frac %.3f' % d['roofline']['frac'], d.get('cpu_baseline', {}).get('value'), d.get('cpu_baseline', {}).get('cores'))" $f; done
