@@ -206,9 +206,11 @@ def test_config3_whole_loop_follows_the_oracle_loop_on_identical_random_inputs()
     print('config-3 whole loop, 120 iterations: parameters %.1e, update %.1e, minibatch targets %.1e abs' % (worst_p, worst_u, worst_t))
 
 
-@pytest.mark.parametrize('alg', ['MPG-v2', 'TD3', 'MPG-v1'])
-def test_bench_workload_whole_loop_follows_the_oracle_loop_on_identical_random_inputs(alg):
-    """[TD3: the same loop with TD3Learner and uniform replay (learners/td3.py:150-188; smoothing noise = mpg_normal_fill's Philox
+@pytest.mark.parametrize('alg,size', [('MPG-v2', 'small'), ('TD3', 'small'), ('MPG-v1', 'small'), ('MPG-v2', 'bench')])
+def test_bench_workload_whole_loop_follows_the_oracle_loop_on_identical_random_inputs(alg, size):
+    """[size 'bench': the loop AT THE BENCH'S OWN SIZE - 4096 agents, replay batch 4096: only there do the launches the bench times engage
+    (the split target launch, k_critic_fused4, the fused worker launch with the pre-gathered draw, two-role weight gradients) - for 8
+    iterations, checked at 4 and 8.  TD3: the same loop with TD3Learner and uniform replay (learners/td3.py:150-188; smoothing noise = mpg_normal_fill's Philox
     stream) through the native driver's learner_version 4.  MPG-v1: networks [Q1 | policy], the critic's target = the 25-step REAL-env
     return of 25 env launches on the learner's own env (mpg_learner.py:109-124,146-169), recomputed with a new minibatch every 10th
     call and cached in between (learner_version 1; measured: update 1.7e-6).
@@ -234,7 +236,9 @@ def test_bench_workload_whole_loop_follows_the_oracle_loop_on_identical_random_i
     seed = 3
     nthreads = torch.get_num_threads()
     torch.set_num_threads(8)
-    args = default_args(alg, num_agent=64, batch_size=64, replay_batch_size=256, replay_starts=512, seed=seed, init_seed=seed,
+    big = size == 'bench'
+    NA, B, RS, every, total = (4096, 4096, 8192, 4, 8) if big else (64, 256, 512, 10, 60)
+    args = default_args(alg, num_agent=NA, batch_size=NA, replay_batch_size=B, replay_starts=RS, seed=seed, init_seed=seed,
                         nan_check_interval=10 ** 9)
     worker = OffPolicyWorker(PolicyWithQs, args.env_id, args, 0)
     learner = (TD3Learner if alg == 'TD3' else MPGLearner)(PolicyWithQs, args)
@@ -242,15 +246,16 @@ def test_bench_workload_whole_loop_follows_the_oracle_loop_on_identical_random_i
     pw = worker.policy_with_value
     init = pw.params.cpu().numpy().copy()
     off = np.cumsum([0] + list(pw.sizes))
-    loop = OracleConfig2Loop({n: init[off[i]:off[i + 1]] for i, n in enumerate(pw.names)}, seed=seed, alg=alg)
+    loop = OracleConfig2Loop({n: init[off[i]:off[i + 1]] for i, n in enumerate(pw.names)}, seed=seed, alg=alg, num_agent=NA, batch_size=NA,
+                             replay_batch_size=B, replay_starts=RS)
     opt = SingleProcessOffPolicyOptimizer(worker, learner, rb, None, args, sampling_interval=1)
     assert opt._fused is not None and opt._fused.c.learner_version == {'MPG-v2': 2, 'TD3': 4, 'MPG-v1': 1}[alg]
-    assert len(rb) == loop.size == 512
-    np.testing.assert_allclose(rb.obs[:512].cpu().numpy(), loop.ring['obs'][:512], rtol=1e-4, atol=1e-4)
-    np.testing.assert_allclose(rb.act[:512].cpu().numpy(), loop.ring['act'][:512], rtol=1e-4, atol=1e-5)
+    assert len(rb) == loop.size == RS
+    np.testing.assert_allclose(rb.obs[:RS].cpu().numpy(), loop.ring['obs'][:RS], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(rb.act[:RS].cpu().numpy(), loop.ring['act'][:RS], rtol=1e-4, atol=1e-5)
     worst_p = worst_u = 0.0
-    for it in range(0, 60, 10):
-        for _ in range(10):
+    for it in range(0, total, every):
+        for _ in range(every):
             opt.step()
             loop.step()
         torch.cuda.synchronize()
@@ -267,9 +272,9 @@ def test_bench_workload_whole_loop_follows_the_oracle_loop_on_identical_random_i
         worst_p, worst_u = max(worst_p, e_p, e_t), max(worst_u, e_u)
         st = learner.get_stats()
         print('iteration %2d: parameters %.1e (targets %.1e), update %.1e; q_loss1 %.5f / %.5f value_mean %.5f / %.5f' %
-              (it + 10, e_p, e_t, e_u, float(st['q_loss1']), float(loop.stats['q_loss1']), float(st['value_mean']), float(loop.stats['value_mean'])))
+              (it + every, e_p, e_t, e_u, float(st['q_loss1']), float(loop.stats['q_loss1']), float(st['value_mean']), float(loop.stats['value_mean'])))
         assert e_p <= 1e-5 and e_t <= 1e-5 and e_u <= 1e-3, (it, e_p, e_t, e_u)
         assert abs(float(st['q_loss1']) - float(loop.stats['q_loss1'])) <= 1e-3 * abs(float(loop.stats['q_loss1'])) + 1e-7
-        assert pw.opt_steps['Q1'] == it + 10 and pw.opt_steps['policy'] == (it + 10) // 2            # delay_update 2 (policy.py:127-153)
+        assert pw.opt_steps['Q1'] == it + every and pw.opt_steps['policy'] == (it + every) // 2            # delay_update 2 (policy.py:127-153)
     torch.set_num_threads(nthreads)
-    print('bench workload whole loop, 60 iterations: parameters %.1e, update %.1e' % (worst_p, worst_u))
+    print('%s whole loop (%s), %d iterations: parameters %.1e, update %.1e' % (alg, size, total, worst_p, worst_u))
