@@ -209,11 +209,12 @@ def test_config3_whole_loop_follows_the_oracle_loop_on_identical_random_inputs(B
     print('config-3 whole loop (B = %d), %d iterations: parameters %.1e, update %.1e, minibatch targets %.1e abs' % (B, total, worst_p, worst_u, worst_t))
 
 
-@pytest.mark.parametrize('alg,size', [('MPG-v2', 'small'), ('TD3', 'small'), ('MPG-v1', 'small'), ('MPG-v2', 'bench')])
+@pytest.mark.parametrize('alg,size', [('MPG-v2', 'small'), ('TD3', 'small'), ('MPG-v1', 'small'), ('MPG-v2', 'bench'), ('TD3', 'c4')])
 def test_bench_workload_whole_loop_follows_the_oracle_loop_on_identical_random_inputs(alg, size):
     """[size 'bench': the loop AT THE BENCH'S OWN SIZE - 4096 agents, replay batch 4096: only there do the launches the bench times engage
     (the split target launch, k_critic_fused4, the fused worker launch with the pre-gathered draw, two-role weight gradients) - for 8
-    iterations, checked at 4 and 8.  TD3: the same loop with TD3Learner and uniform replay (learners/td3.py:150-188; smoothing noise = mpg_normal_fill's Philox
+    iterations, checked at 4 and 8.  size 'c4': TD3 at config 4's batch size (65 536 rows drawn uniformly: the launch-per-stage passes over
+    4096 row groups, the 64-block error kernels) for 2 iterations.  TD3: the same loop with TD3Learner and uniform replay (learners/td3.py:150-188; smoothing noise = mpg_normal_fill's Philox
     stream) through the native driver's learner_version 4.  MPG-v1: networks [Q1 | policy], the critic's target = the 25-step REAL-env
     return of 25 env launches on the learner's own env (mpg_learner.py:109-124,146-169), recomputed with a new minibatch every 10th
     call and cached in between (learner_version 1; measured: update 1.7e-6).
@@ -240,7 +241,7 @@ def test_bench_workload_whole_loop_follows_the_oracle_loop_on_identical_random_i
     nthreads = torch.get_num_threads()
     torch.set_num_threads(8)
     big = size == 'bench'
-    NA, B, RS, every, total = (4096, 4096, 8192, 4, 8) if big else (64, 256, 512, 10, 60)
+    NA, B, RS, every, total = {'bench': (4096, 4096, 8192, 4, 8), 'c4': (512, 65536, 4096, 1, 2), 'small': (64, 256, 512, 10, 60)}[size]
     args = default_args(alg, num_agent=NA, batch_size=NA, replay_batch_size=B, replay_starts=RS, seed=seed, init_seed=seed,
                         nan_check_interval=10 ** 9)
     worker = OffPolicyWorker(PolicyWithQs, args.env_id, args, 0)
@@ -278,6 +279,6 @@ def test_bench_workload_whole_loop_follows_the_oracle_loop_on_identical_random_i
               (it + every, e_p, e_t, e_u, float(st['q_loss1']), float(loop.stats['q_loss1']), float(st['value_mean']), float(loop.stats['value_mean'])))
         assert e_p <= 1e-5 and e_t <= 1e-5 and e_u <= 1e-3, (it, e_p, e_t, e_u)
         assert abs(float(st['q_loss1']) - float(loop.stats['q_loss1'])) <= 1e-3 * abs(float(loop.stats['q_loss1'])) + 1e-7
-        assert pw.opt_steps['Q1'] == it + every and pw.opt_steps['policy'] == (it + every) // 2            # delay_update 2 (policy.py:127-153)
+        assert pw.opt_steps['Q1'] == it + every and pw.opt_steps['policy'] == (it + every + 1) // 2      # delay_update 2: iterations 0, 2, 4, ... (policy.py:127-153)
     torch.set_num_threads(nthreads)
     print('%s whole loop (%s), %d iterations: parameters %.1e, update %.1e' % (alg, size, total, worst_p, worst_u))
