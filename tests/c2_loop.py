@@ -113,6 +113,19 @@ class OracleConfig2Loop(object):
         self.stats = st
         self.iteration += 1
 
+    # ---- data-parallel form: R replicas with their own worker / replay / noise streams and SHARED parameters ----
+    def draw(self):
+        """this rank's part of an iteration up to the gradient: sample (every sampling_interval-th iteration), replay, model noise"""
+        assert self.alg == 'MPG-v2'
+        if self.iteration % self.sampling_interval == 0:
+            self.sample()
+        self.replay_times += 1
+        idx = self.idx = O.uniform_indices_philox(self.size, self.B, self.rb_seed, self.replay_times)
+        self.counter += 1
+        r = self.ring
+        return [r['obs'][idx], r['act'][idx], r['rew'][idx], r['obs2'][idx], r['done'][idx]], \
+            O.model_noise_philox(self.cfg.n, self.B, self.l_seed, self.counter)
+
     def _v1_gradient(self, nets, batch, targets, eps, iteration):
         """MPGLearner.compute_gradient for MPG-v1 with the CACHED n-step targets (mpg_learner.py:401-455): O.mpg_compute_gradient with the
         target taken from the caller instead of being recomputed"""
@@ -129,3 +142,26 @@ class OracleConfig2Loop(object):
 
     def flat(self):
         return np.concatenate([self.w[k] for k in self.names]), np.concatenate([self.tgt[k] for k in self.names])
+
+
+def data_parallel_step(loops):
+    """One iteration of R replicas (OracleConfig2Loop objects built from the SAME weights with seeds 0 .. R-1): the gradient the ranks
+    exchange is the sum of their 1 / B_global-scaled partials = the gradient of the concatenated minibatch (every loss is a mean over
+    the batch); the clip runs on that sum, Adam / Polyak identically on every replica (the reference's own multi-learner
+    form applies stale gradients one at a time, optimizer.py:60-94 - this is the synchronous statement of it)."""
+    lead = loops[0]
+    it = lead.iteration
+    for lp in loops[1:]:                                   # replicas share ONE set of parameters, targets and optimizer states
+        lp.w, lp.tgt, lp.opt = lead.w, lead.tgt, lead.opt
+    parts = [lp.draw() for lp in loops]
+    batch = [np.concatenate([p[0][k] for p in parts], 0) for k in range(5)]
+    eps = np.concatenate([p[1] for p in parts], 1)
+    grads, st = O.mpg_compute_gradient(lead.cfg, lead.nets(), batch, eps, it, 'MPG-v2')
+    g, o = {}, 0
+    for k in lead.names:
+        g[k] = np.concatenate([x.ravel() for x in grads[o:o + 6]]).astype(np.float32)
+        o += 6
+    O.apply_gradients(lead.cfg, lead.w, lead.tgt, lead.opt, g, it, lead.names)
+    for lp in loops:
+        lp.stats = st
+        lp.iteration += 1

@@ -134,6 +134,38 @@ def test_native_step_driver_keeps_two_replicas_bit_identical(exchange):
     assert not np.array_equal(out[0][2], out[1][2])               # the ranks really saw different data
 
 
+@pytest.mark.timeout(600)
+def test_two_rank_training_loop_follows_the_data_parallel_oracle_loop(monkeypatch):
+    """Config 5's semantics in closed loop, two ranks on the one GPU: each rank runs its own worker / replay / model-noise
+    streams (seed = rank) through the native step driver, the flat gradient is exchanged (gloo) between mpg_step_begin and
+    mpg_step_end, clip + Adam + Polyak run on every replica.  Against tests/c2_loop.data_parallel_step: the oracle's loop with two
+    replicas' Philox inputs, the gradient of the CONCATENATED minibatch (every loss is a mean over the global batch), one shared set of
+    parameters.  20 iterations from the same initial weights: parameter update within 1e-3 relative L2 (measured: printed)."""
+    import torch as T
+    from mpg_amd.policy import init_mlp_flat
+    from tests.c2_loop import OracleConfig2Loop, data_parallel_step
+    monkeypatch.setenv('MPG_DIST_BACKEND', 'gloo')
+    out = _run(_driver_worker)                               # 20 native steps per rank, replicas bit-identical
+    assert np.array_equal(out[0][1], out[1][1])
+    gen = T.Generator().manual_seed(0)                       # PolicyWithQs' initialisation for init_seed = 0 (mpg_amd/policy.py)
+    dims = {'Q1': (8, 1), 'Q2': (8, 1), 'policy': (6, 4)}
+    w = {n: init_mlp_flat(gen, *dims[n]).numpy() for n in ('Q1', 'Q2', 'policy')}
+    init = np.concatenate([w[n] for n in ('Q1', 'Q2', 'policy')])
+    nthreads = T.get_num_threads()
+    T.set_num_threads(8)
+    loops = [OracleConfig2Loop(w, seed=r, num_agent=64, batch_size=64, replay_batch_size=64, replay_starts=128, capacity=4096) for r in range(2)]
+    for _ in range(20):
+        data_parallel_step(loops)
+    T.set_num_threads(nthreads)
+    ref, reft = loops[0].flat()
+    n = ref.size
+    got, gott = out[0][1][:n], out[0][1][n:2 * n]
+    rel = lambda a, b: float(np.linalg.norm(a.astype(np.float64) - b) / np.linalg.norm(b.astype(np.float64)))
+    e_u, e_p, e_t = rel(got - init, ref - init), rel(got, ref), rel(gott, reft)
+    print('two-rank loop vs data-parallel oracle loop, 20 iterations: update %.1e, parameters %.1e, targets %.1e' % (e_u, e_p, e_t))
+    assert e_u <= 1e-3 and e_p <= 1e-5 and e_t <= 1e-5, (e_u, e_p, e_t)
+
+
 @pytest.mark.timeout(900)
 def test_native_step_driver_keeps_four_replicas_bit_identical(monkeypatch):
     """The same with FOUR ranks time-sharing the one GPU (nothing had run with more than two ranks, so rank-count
