@@ -637,6 +637,10 @@ def main():
         torch.cuda.synchronize()
         sat[name] = es[0].elapsed_time(es[1]) / 10
     del big, b_act, b_obs, b_rew, b_done, b_di, b_robs, b_robs2, b_ract, b_rrew, b_rdone
+    finite = bool(torch.isfinite(worker.policy_with_value.params).all().item())
+    assert finite and int(worker.policy_with_value.nonfinite.sum().item()) == 0, 'non-finite parameters after the timed region'
+    worker.policy_with_value.check_status()          # raises if the split-fp16 engine left its numerical envelope anywhere
+    # (checked HERE, before the side measurement below: an abandoned collective may leave the stream blocked for good)
     # N > 1: the exchange on its own in every form this process group can run (RCCL when the group is an nccl group; the one-shot and
     # the two-shot IPC forms of mpg_amd/dist.py), 50 exchanges of a scratch buffer of the gradient's length each, HIP events on the
     # launch stream of rank 0.  A form that cannot be set up (no peer access, IPC refused) is reported as its error text on EVERY rank
@@ -692,10 +696,6 @@ def main():
                 break
         if side_hung and rank != 0:
             os._exit(0)                          # this rank's part of the line (the timed regions) is done
-    finite = bool(torch.isfinite(worker.policy_with_value.params).all().item())
-    assert finite and int(worker.policy_with_value.nonfinite.sum().item()) == 0, 'non-finite parameters after the timed region'
-    worker.policy_with_value.check_status()          # raises if the split-fp16 engine left its numerical envelope anywhere
-
     if rank != 0:
         return
     # HBM bytes per launch from the PMC counters (FETCH_SIZE/WRITE_SIZE, separate rocprofv3 --pmc passes, gfx950
