@@ -943,28 +943,40 @@ __device__ __forceinline__ void backward_group2(const float* sD3a, const float* 
 }
 
 // all XS partial sums of one row: ds_read_b128 pairs in two batches of four waves (32 VGPRs in flight; all sixteen
-// reads at once cost 64 VGPRs at a point where the reverse sweep has none to spare)
-template <int XSW = XS>
+// reads at once cost 64 VGPRs at a point where the reverse sweep has none to spare).
+// NEED: how many of the XSW entries the caller uses (the observation width).  Every read fetches exactly the entries that are
+// used - b128 / b64 / none for the upper four of a block of eight: with a b128 whose upper half is dead the register allocator
+// overlaps that dead half with the next read's destination, and the write-after-write hazard puts an `s_waitcnt lgkmcnt(0)`
+// between the reads - eight serialised LDS round trips on the reverse sweep's serial chain (found in the ISA, round 5).
+template <int XSW = XS, int NEED = XSW>
 __device__ __forceinline__ void dx_reduce_row(const float* sPartX, int row, float (&out)[XSW]) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
     for (int i = 0; i < XSW; ++i) out[i] = 0.f;
 #pragma unroll
-    for (int half = 0; half < XSW / 8; ++half)
+    for (int half = 0; half < XSW / 8; ++half) {
+        constexpr int NL_ALL = NEED >= XSW ? 8 : NEED;          // (only the one-block form, XSW == 8, is ever asked for fewer)
+        const int nl = XSW == 8 ? NL_ALL : 8;                   // entries used in this block of eight
 #pragma unroll
         for (int b = 0; b < NWAVE; b += 4) {
             f32x4 lo[4], hi[4];
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
-                const f32x4* p = reinterpret_cast<const f32x4*>(sPartX + ((b + w) * GROUP + row) * XSW + 8 * half);
-                lo[w] = p[0];
-                hi[w] = p[1];
+                const float* p = sPartX + ((b + w) * GROUP + row) * XSW + 8 * half;
+                lo[w] = *reinterpret_cast<const f32x4*>(p);
+                if (nl > 6) hi[w] = *reinterpret_cast<const f32x4*>(p + 4);
+                else if (nl > 4) {
+                    const f32x2 h2 = *reinterpret_cast<const f32x2*>(p + 4);
+                    hi[w] = f32x4{h2[0], h2[1], 0.f, 0.f};
+                } else hi[w] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 out[8 * half + i] += (lo[0][i] + lo[1][i]) + (lo[2][i] + lo[3][i]);
-                out[8 * half + 4 + i] += (hi[0][i] + hi[1][i]) + (hi[2][i] + hi[3][i]);
+                if (4 + i < nl) out[8 * half + 4 + i] += (hi[0][i] + hi[1][i]) + (hi[2][i] + hi[3][i]);
             }
         }
+    }
 }
 
 template <int XSW = XS>

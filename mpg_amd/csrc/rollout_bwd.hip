@@ -212,7 +212,11 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_bwd(const RollBwdArgs a)
             if (own) {
                 if (t > 0) {
                     float dxr[XSW];
+                    #ifdef MPG_AB_DXROW_FULL    // A/B: full-width reads, as before round 5
                     dx_reduce_row<XSW>(sPartX, tid, dxr);
+#else
+                    dx_reduce_row<XSW, WIDE ? XSW : OBS>(sPartX, tid, dxr);
+#endif
 #pragma unroll
                     for (int i = 0; i < OBS; ++i) lam[i] += dxr[i] * a.obs_scale[i];
                     if constexpr (WIDE) {       // t > 0 here: the observation of this step came out of the model
