@@ -135,6 +135,13 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_fwd(const RollArgs a) {
             }
         };
         if (chain) publish(o, true);
+#ifndef MPG_AB_B3R_PENDING
+        // The output bias was requested in the prologue; consumed HERE once, it is not a pending load anywhere in the step loop.
+        // Left pending across the loop header, the wait-count bookkeeping re-waits for it in every step - `s_waitcnt vmcnt(4)` in the
+        // middle of the serial chain, which in fact waits for the stash stores of the step before (the counter retires in order).
+#pragma unroll
+        for (int k = 0; k < ACT; ++k) asm volatile("" ::"v"(b3r[k]));
+#endif
         for (int t = 0; t <= a.n; ++t) {
             lds_barrier();
             MPG_STAMP_AT(0);
