@@ -26,6 +26,10 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_fwd(const RollArgs a) {
     const int tid = threadIdx.x;
     prefer_young_waves();
     if (tid <= a.n) sGp[tid] = powf(a.gamma, (float)tid);     // tf.pow(gamma, ri) in float32, mpg_learner.py:245
+    unsigned selmask = 0;                      // bit t: step t is a selected slice
+#pragma unroll
+    for (int ks = 0; ks < MAXSEL; ++ks)
+        if (ks < a.n_sel) selmask |= 1u << a.sel[ks];
     const Net net = make_net(a.policy, OD, 2 * ACT);
     float w2[128];
     SmallRegs<NIN, ACT> r;
@@ -113,7 +117,11 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_fwd(const RollArgs a) {
                     for (int k = 0; k < ACT; ++k) rec[k] = act[k];
                 }
                 // constant indices only: a dynamically indexed kernel-argument array is re-read from memory by a scalar load
-                // (+ wait) on every use - ~200 cycles each
+                // (+ wait) on every use - ~200 cycles each.  The slice search runs only on the steps a bit mask marks (two of 26):
+                // the book lanes' work behind the second barrier is as long as the chain lanes' - every step waits for it too.
+#ifndef MPG_AB_FWD_NOSELMASK
+                if ((selmask >> tb) & 1u)
+#endif
 #pragma unroll
                 for (int ks = 0; ks < MAXSEL; ++ks)
                     if (ks < a.n_sel && a.sel[ks] == tb) {
@@ -206,6 +214,9 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_fwd(const RollArgs a) {
 #pragma unroll
                         for (int i = 0; i < OBS; ++i) rec[i] = o[i];
                     }
+#ifndef MPG_AB_FWD_NOSELMASK
+                    if ((selmask >> t) & 1u)
+#endif
 #pragma unroll
                     for (int ks = 0; ks < MAXSEL; ++ks)
                         if (ks < a.n_sel && a.sel[ks] == t) {
