@@ -88,6 +88,21 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_bwd(const RollBwdArgs a)
         stash_load(a.H2, (long)a.n * ngroups + g, L, h2_cur);
         for (int t = a.n; t >= 0; --t) {
             float h1[2][4];
+#if !defined(MPG_AB_H1_LATE) && !defined(MPG_AB_NO_H1)
+            // h1 of this step is requested at the TOP of the step: nothing older is pending here (the step before consumed its
+            // prefetches when it copied them), nothing before the matrix block waits on the vector-memory counter, and the seven
+            // waves that would only wait for the chain lanes at the first barrier put the request ~2 k cycles further ahead of
+            // its use behind the matrix block - where the ISA showed a drained counter (vmcnt(0)) in every step.
+            stash_load(a.H1, (long)t * ngroups + g, L, h1);
+            // ... and with it the record of step t - 1 (used at the end of this step): requested behind the dz2 phase it was two more
+            // loads in flight at the drain in the matrix block
+            if (t > 0 && live) {
+                const f32x4* rp = reinterpret_cast<const f32x4*>(a.SA + ((long)(t - 1) * R + tr) * SAW);
+                const f32x4 r0 = rp[0], r1 = rp[1];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { rec_pre[i] = r0[i]; rec_pre[4 + i] = r1[i]; }
+            }
+#endif
             if (own) {
                 float ga[2] = {0.f, 0.f};
 #pragma unroll
@@ -188,16 +203,18 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_bwd(const RollBwdArgs a)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) h1[tt][j] = h2_cur[tt][j];
             }
-#else
+#elif defined(MPG_AB_H1_LATE)      // A/B: requested behind the dz2 phase, as before round 5
             stash_load(a.H1, (long)t * ngroups + g, L, h1);
 #endif
             if (t > 0) {
+#if defined(MPG_AB_H1_LATE) || defined(MPG_AB_NO_H1)
                 if (live) {
                     const f32x4* rp = reinterpret_cast<const f32x4*>(a.SA + ((long)(t - 1) * R + tr) * SAW);
                     const f32x4 r0 = rp[0], r1 = rp[1];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) { rec_pre[i] = r0[i]; rec_pre[4 + i] = r1[i]; }
                 }
+#endif
                 stash_load(a.H2, (long)(t - 1) * ngroups + g, L, h2_pre);
             }
             if (t > 0)
