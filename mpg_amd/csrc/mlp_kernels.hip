@@ -39,6 +39,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_forward(const FwdArgs a) {
     const long nunits = (ngroups + G2 - 1) / G2;                // units of G2 consecutive groups
     // the first unit's inputs are requested BEFORE the small pieces and the 256 KB image and consumed after them: loads
     // retire in order, so layer 1 and its barrier then run while the image is still streaming in
+#ifdef MPG_AB_FWD_NOPREFETCH
     auto x_value = [&](long u) {
         float v = 0.f;
         if (threadIdx.x < G2 * GROUP * XSW) {
@@ -49,17 +50,57 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_forward(const FwdArgs a) {
         return v;
     };
     float xv = x_value(blockIdx.x);
+#else
+    // Several units per workgroup (one workgroup per CU: nothing else covers a load's way to memory and back): the NEXT unit's inputs
+    // are requested at the top of a unit, stay in flight across its passes and go into the other half of a double-buffered input
+    // block BEFORE the unit's stash stores are issued - the vector-memory counter retires in order and the wait-count bookkeeping
+    // drains it at a loop-carried value, so a register carried across the back edge would wait for those stores.  RAW values are
+    // requested: a thread's input column, and with it its scale, is the same for every unit; the product is taken on arrival.
+    __shared__ __attribute__((aligned(16))) float sX2[2][G2 * GROUP * XSW];
+    float xsc = 1.f;
+    if (threadIdx.x < G2 * GROUP * XSW) {
+        const int i = threadIdx.x % XSW;
+        if (i < a.in_dim && i < a.x.d0) xsc = a.x.scale[i];
+    }
+    auto x_value = [&](long u) {
+        float v = 0.f;
+        if (threadIdx.x < G2 * GROUP * XSW) {
+            const int g2 = threadIdx.x / (GROUP * XSW), e = threadIdx.x % (GROUP * XSW), row = e / XSW, i = e % XSW;
+            const long gr = (u * G2 + g2) * GROUP + row;
+            if (gr < a.rows && i < a.in_dim) v = i < a.x.d0 ? a.x.x0[gr * a.x.ld0 + i] : a.x.x1[gr * a.x.ld1 + (i - a.x.d0)];
+        }
+        return v;
+    };
+    float xv = x_value(blockIdx.x);
+    int cur = 0;
+#endif
     float b3v = 0.f;             // this output thread's bias, requested up front (at its point of use it is a memory round trip)
     if (threadIdx.x < G2 * GROUP * OU) b3v = net.b3[threadIdx.x % OU];
     float zmax = 0.f;
     bool saw_nan = false;                       // worker.py:95-107 judge_is_nan, on the device: inputs and outputs of the pass
     load_small<IN, OU>(net, L, r);
     if constexpr (PK) load_w2_packed(a.pack, L, w2); else load_w2_fwd(net.W2, L, w2);
+#ifndef MPG_AB_FWD_NOPREFETCH
+    xv *= xsc;                                   // (x * 1.f is x: unscaled columns keep their bits)
+    saw_nan |= xv != xv;
+    if (threadIdx.x < G2 * GROUP * XSW) sX2[0][threadIdx.x] = xv;
+    // the image is consumed ONCE here: left pending across the loop header, the wait-count bookkeeping drains the counter (vmcnt(0)) in
+    // every unit's matrix block - and with it the input request issued just before.  (What a first unit loses - its layer 1 under the
+    // image request - measured nothing: EXPERIMENTS.md section 5.7.)
+#pragma unroll
+    for (int v = 0; v < 32; ++v) asm volatile("" ::"v"(w2[4 * v]), "v"(w2[4 * v + 1]), "v"(w2[4 * v + 2]), "v"(w2[4 * v + 3]));
+#endif
     for (long u = blockIdx.x; u < nunits; u += gridDim.x) {
+#ifdef MPG_AB_FWD_NOPREFETCH
         if (u != (long)blockIdx.x) xv = x_value(u);
         saw_nan |= xv != xv;
         if (threadIdx.x < G2 * GROUP * XSW) sX[threadIdx.x] = xv;
         lds_barrier();
+#else
+        lds_barrier();
+        sX = sX2[cur];
+        xv = u + gridDim.x < nunits ? x_value(u + gridDim.x) : 0.f;
+#endif
         // a NaN among a row's inputs stays a NaN in its outputs (row_poison, mlp_core.h): read here, while the block is this
         // unit's - the next unit's inputs are stored in front of the barrier above
         float pz = 0.f;
@@ -70,6 +111,15 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_forward(const FwdArgs a) {
                                    h2[1], &zmax);
         else
             forward_group<IN, OU>(sX, sA, sPart, L, w2, r, h1[0], h2[0], nullptr, 0, nullptr, &zmax);
+#ifndef MPG_AB_FWD_NOPREFETCH
+        // the next unit's inputs, ahead of this unit's stores (ordered by the barrier at the top).  Unconditional - behind the last
+        // unit it stores a zero nobody reads: as a second `if (more)` the consumption could be skipped on a path on which the request
+        // was made, as far as the wait-count bookkeeping can tell, and the counter was drained at the top of every unit
+        xv *= xsc;
+        saw_nan |= xv != xv;
+        if (threadIdx.x < G2 * GROUP * XSW) sX2[cur ^ 1][threadIdx.x] = xv;
+        cur ^= 1;
+#endif
 #pragma unroll
         for (int g2 = 0; g2 < G2; ++g2) {
             const long g = u * G2 + g2;
