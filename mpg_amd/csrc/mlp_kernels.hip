@@ -251,6 +251,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_backward(const BwdArgs a) {
         for (int i = 0; i < IN; ++i) gw1[t][i] = 0.f;
     }
     int par = 0;
+#ifdef MPG_AB_BWD_NOPREFETCH
     for (long g = blockIdx.x; g < ngroups; g += gridDim.x, par ^= 1) {
         if (tid < GROUP * OU) {
             const int row = tid / OU, o = tid % OU;
@@ -274,6 +275,77 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_backward(const BwdArgs a) {
         stash_load(a.h1, g, L, h1);
         stash_load(a.h2, g, L, h2);
         lds_barrier();
+#else
+    // Software pipeline over the row groups (one workgroup per CU: nothing else covers a load's way to memory and back): the loads of
+    // group g + 1 - two stash fragments each of h1 and h2, the output gradient, the THIN input row - are requested at the top of
+    // group g, stay in flight across its pass and are consumed behind it, AHEAD of the group's own stash stores (the vector-memory
+    // counter retires in order, and the wait-count bookkeeping drains it at a loop-carried value).  Requested at the top of their own
+    // group they were a memory round trip in front of every group's first barrier: 16 per launch at B = 65 536.
+    struct Req {
+        float h1[2][4], h2[2][4], dy, yo, x;
+    };
+    float xsc = 1.f;
+    if constexpr (THIN) {
+        if (tid < GROUP * XSW && tid % XSW < a.x.d0) xsc = a.x.scale[tid % XSW];
+    }
+    auto request = [&](long g, Req& q) {
+        stash_load(a.h1, g, L, q.h1);
+        stash_load(a.h2, g, L, q.h2);
+        q.dy = q.yo = q.x = 0.f;
+        if (tid < GROUP * OU) {
+            const long gr = g * GROUP + tid / OU;
+            if (gr < a.rows) {
+                q.dy = a.dy[gr * a.lddy + tid % OU];
+                if (a.out_tanh) q.yo = a.yout[gr * a.ldyo + tid % OU];
+            }
+        }
+        if constexpr (THIN) {
+            if (tid < GROUP * XSW) {
+                const int i = tid % XSW;
+                const long gr = g * GROUP + tid / XSW;
+                if (gr < a.rows && i < a.x.d0 + a.x.d1) q.x = i < a.x.d0 ? a.x.x0[gr * a.x.ld0 + i] : a.x.x1[gr * a.x.ld1 + (i - a.x.d0)];
+            }
+        }
+    };
+    // the output gradient of group g into sD3 (and the caller's dz3), the THIN input row into the parity's block
+    auto publish = [&](long g, const Req& q, int parity) {
+        if (tid < GROUP * OU) {
+            const int row = tid / OU, o = tid % OU;
+            const long gr = g * GROUP + row;
+            float d = 0.f;
+            if (gr < a.rows) {
+                d = q.dy;
+                if (a.out_tanh) {   // a = S*tanh(z): da/dz = S*(1 - (a/S)^2)
+                    const float t = q.yo / a.out_scale;
+                    d *= a.out_scale * (1.f - t * t);
+                }
+                if (a.dz3) a.dz3[gr * OU + o] = d;
+            }
+            sD3[d3_index(row, o)] = d;
+            if constexpr (THIN) gb3 += d;
+        }
+        if constexpr (THIN) {
+            if (tid < GROUP * XSW) sXt[parity * GROUP * XSW + tid] = q.x * xsc;        // (x * 1.f is x)
+        }
+    };
+    Req nx;
+    float h1[2][4], h2[2][4], dz1[2][4], dz2[2][4];
+    if ((long)blockIdx.x < ngroups) {
+        request(blockIdx.x, nx);
+        publish(blockIdx.x, nx, 0);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { h1[t][j] = nx.h1[t][j]; h2[t][j] = nx.h2[t][j]; }
+    }
+    // (the transposed image is consumed once, ahead of the loop: see k_forward)
+#pragma unroll
+    for (int v = 0; v < 32; ++v) asm volatile("" ::"v"(w2t[4 * v]), "v"(w2t[4 * v + 1]), "v"(w2t[4 * v + 2]), "v"(w2t[4 * v + 3]));
+    for (long g = blockIdx.x; g < ngroups; g += gridDim.x, par ^= 1) {
+        lds_barrier();                           // sD3 / the THIN input block of this group are in place
+        const long gn = g + gridDim.x < ngroups ? g + gridDim.x : g;      // (behind the last group: its own, again - nobody reads it)
+        request(gn, nx);
+#endif
         if constexpr (THIN) {           // dW3 += h2 dz3^T (sD3 is stable until backward_group's last barrier)
 #pragma unroll
             for (int k = 0; k < OU; ++k) {
@@ -286,6 +358,15 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_backward(const BwdArgs a) {
             }
         }
         backward_group<IN, OU, WANT_DX>(sD3, sA, sA1, sPartX, L, w2t, r, h1, h2, dz1, dz2);
+#ifndef MPG_AB_BWD_NOPREFETCH
+        // the next group's requests, consumed ahead of this group's stores (sD3 was last read in front of backward_group's final
+        // barrier; the input block of the other parity two groups ago)
+        if (g + gridDim.x < ngroups) publish(g + gridDim.x, nx, par ^ 1);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { h1[t][j] = nx.h1[t][j]; h2[t][j] = nx.h2[t][j]; }
+#endif
         if (!THIN && a.dz1) stash_store(a.dz1, g, L, dz1);
         if (a.dz2) stash_store(a.dz2, g, L, dz2);
         if constexpr (THIN) {           // db2 += dz2, db1 += dz1, dW1 += x^T dz1
