@@ -37,6 +37,35 @@ __global__ void __launch_bounds__(1024) k_returns(int rows, int M, int n_sel, co
     const long R = (long)rows * M;
     for (int k = 0; k < n_sel; ++k) {
         float s = 0.f, s2 = 0.f;
+#ifdef MPG_AB_RETURNS_SERIAL
+        if (false) {
+#else
+        if (M == 1) {
+#endif
+            // eight row blocks of a thread at a time: their sixteen loads are requested together (unconditional, from clamped rows) and
+            // then summed in the order of the plain loop - one memory round trip where the plain loop makes eight, one after the other
+            for (int b0 = threadIdx.x; b0 < rows; b0 += 8 * 1024) {
+                float gk[8], qv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int b = b0 + j * 1024 < rows ? b0 + j * 1024 : b0;
+                    gk[j] = GK[k * R + b];
+                    qv[j] = Q[k * R + b];
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int b = b0 + j * 1024;
+                    if (b < rows) {
+                        float m = 0.f;
+                        m += gk[j] + rc.gpow[k] * qv[j];
+                        m /= 1.f;
+                        s += m;
+                        s2 += m * m;
+                        dyq[k * R + b] = rc.coef[k];
+                    }
+                }
+            }
+        } else
         for (int b = threadIdx.x; b < rows; b += 1024) {
             float m = 0.f;
             for (int mm = 0; mm < M; ++mm) {
