@@ -950,7 +950,6 @@ __device__ __forceinline__ void backward_group2(const float* sD3a, const float* 
 // between the reads - eight serialised LDS round trips on the reverse sweep's serial chain (found in the ISA, round 5).
 template <int XSW = XS, int NEED = XSW>
 __device__ __forceinline__ void dx_reduce_row(const float* sPartX, int row, float (&out)[XSW]) {
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
     for (int i = 0; i < XSW; ++i) out[i] = 0.f;
 #pragma unroll
@@ -966,8 +965,11 @@ __device__ __forceinline__ void dx_reduce_row(const float* sPartX, int row, floa
                 lo[w] = *reinterpret_cast<const f32x4*>(p);
                 if (nl > 6) hi[w] = *reinterpret_cast<const f32x4*>(p + 4);
                 else if (nl > 4) {
-                    const f32x2 h2 = *reinterpret_cast<const f32x2*>(p + 4);
-                    hi[w] = f32x4{h2[0], h2[1], 0.f, 0.f};
+                    // (as ONE 64-bit integer, taken apart by shifts: read as a two-float vector, the sums below are re-formed into
+                    // v_pk_add_f32 by the vector combiner - packed fp32 arithmetic beside matrix instructions is what the containment
+                    // rule of DESIGN.md section 4.2 / tests/test_abi.py keeps out of the shipped ISA)
+                    const unsigned long long u = *reinterpret_cast<const unsigned long long*>(p + 4);
+                    hi[w] = f32x4{__uint_as_float((unsigned)u), __uint_as_float((unsigned)(u >> 32)), 0.f, 0.f};
                 } else hi[w] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
 #pragma unroll
