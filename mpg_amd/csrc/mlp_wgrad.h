@@ -491,8 +491,15 @@ __device__ __forceinline__ void wgrad_map4(int b, int nch, int& chunk, int& sl) 
 #define MPG_WGRAD_MAX_CHUNKS_W2 128      // the dW2-only launch with 64-column slices: 4 workgroups per chunk, 512 in all
 #endif
 constexpr int WGRAD_MAX_CHUNKS = MPG_WGRAD_MAX_CHUNKS, WGRAD_MAX_CHUNKS_SINGLE = MPG_WGRAD_MAX_CHUNKS_SINGLE;
+// (jobs of 4096 row groups and more - TD3 at B = 65 536 - take at least MPG_WGRAD_W2_MIN_GROUPS groups per chunk: 64 chunks there
+// instead of 128 halve the 32 MB of slabs the summation launch reads; C4 0.838 -> 0.830 ms, tools/ab_side.sh.  Smaller jobs keep up
+// to 128 chunks: they need the workgroups.)
+#ifndef MPG_WGRAD_W2_MIN_GROUPS
+#define MPG_WGRAD_W2_MIN_GROUPS 64
+#endif
 inline int wgrad_groups_per_chunk_w2(long ngroups) {
     long gp = (ngroups + MPG_WGRAD_MAX_CHUNKS_W2 - 1) / MPG_WGRAD_MAX_CHUNKS_W2;
+    if (ngroups >= 4096 && gp < MPG_WGRAD_W2_MIN_GROUPS) gp = MPG_WGRAD_W2_MIN_GROUPS;
     return (int)(gp < 1 ? 1 : gp);
 }
 inline int wgrad_groups_per_chunk(long ngroups, bool single_job = false) {
