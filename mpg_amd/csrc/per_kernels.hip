@@ -40,8 +40,9 @@ __global__ void __launch_bounds__(256) k_set_leaves_wmax(int n, int capacity, co
     float mine = 0.f;
     if (i < n) {
         const int leaf = idx[i];
+        const float pr = prio[i];                        // (requested with the index: behind the stamp test it was a third round trip)
         if (stamp[leaf] == i) {                          // (a later entry of the batch overrides the others)
-            const double p = fabs((double)prio[i]) + eps;
+            const double p = fabs((double)pr) + eps;
             const double v = pow(p, alpha);
             sum_tree[capacity + leaf] = v;
             min_tree[capacity + leaf] = v;
@@ -50,7 +51,10 @@ __global__ void __launch_bounds__(256) k_set_leaves_wmax(int n, int capacity, co
     }
 #pragma unroll
     for (int m = 32; m > 0; m >>= 1) mine = fmaxf(mine, __shfl_xor(mine, m, 64));
-    if ((threadIdx.x & 63) == 0 && mine > 0.f) atomicMax(reinterpret_cast<unsigned int*>(max_prio), __float_as_uint(mine));
+    // (the running maximum only grows: a wave whose maximum does not exceed what it reads there has nothing to add - a stale read costs
+    // one redundant atomic, never a lost one; 1024 atomics on one address are ~35 ns each)
+    if ((threadIdx.x & 63) == 0 && mine > 0.f && mine > *reinterpret_cast<volatile float*>(max_prio))
+        atomicMax(reinterpret_cast<unsigned int*>(max_prio), __float_as_uint(mine));
 }
 
 __global__ void k_unstamp(int n, const int* __restrict__ idx, int* __restrict__ stamp) {
