@@ -53,8 +53,9 @@ EXTRA = {'env_path_tracking.hip': ['-ffp-contract=off'] + os.environ.get('MPG_EN
          # for max-memory-clause, 80 default, 94 max-ilp; iterative-minreg / -maxocc: 2x slower or worse)
          'rollout_bwd.hip': os.environ.get('MPG_BWD_CFLAGS', '-mllvm -amdgpu-sched-strategy=iterative-ilp').split(),
          # the pendulum instantiations (NADP, config 3) measure 10 us slower under those and keep max-memory-clause with SLP
-         'rollout_bwd_pendulum.hip': ['-mllvm', '-amdgpu-sched-strategy=max-memory-clause'],
-         'rollout_fwd_pendulum.hip': ['-mllvm', '-amdgpu-sched-strategy=max-memory-clause']}
+         # (MPG_BWDP_CFLAGS / MPG_FWDP_CFLAGS: experiments, tools/ab_side.sh)
+         'rollout_bwd_pendulum.hip': os.environ.get('MPG_BWDP_CFLAGS', '-mllvm -amdgpu-sched-strategy=max-memory-clause').split(),
+         'rollout_fwd_pendulum.hip': os.environ.get('MPG_FWDP_CFLAGS', '-mllvm -amdgpu-sched-strategy=max-memory-clause').split()}
 
 
 def hipcc():
