@@ -47,10 +47,22 @@ void rule_based_weights(int ite, int total_ite, float eta, const int* select, in
     for (int k = 0; k < ns; ++k) w[k] /= sum;
 }
 
-double polynomial_decay(const float* sched, long long step) {       // policy.py:54,62
-    const double lr0 = sched[0], S = sched[1], lr_end = sched[2];
-    const double s = std::min((double)step, S);
-    return (lr0 - lr_end) * (1.0 - s / S) + lr_end;
+// PolynomialDecay (policy.py:54,62) and the ApplyAdam step size AS TENSORFLOW FORMS THEM: every operand a float32 tensor
+// (schedule in the dtype of the initial rate; beta^t = pow of the float32 hyper-parameter; alpha = lr sqrt(1 - b2^t) / (1 - b1^t)
+// in float32).  float32(0.999) is 1.3e-8 above 0.999, which puts alpha 6.7e-6 below the real-number formula for the first
+// thousands of steps - found in round 6 when the reference's own PolicyWithQs.apply_gradients first ran against this path.
+// beta^t: double-precision pow of the float32 operand rounded once = the correctly rounded powf.
+float polynomial_decay(const float* sched, long long step) {
+    const float lr0 = sched[0], S = sched[1], lr_end = sched[2];
+    const float p = std::min((float)step, S) / S;
+    return (lr0 - lr_end) * (1.f - p) + lr_end;
+}
+
+float adam_step_size(const float* sched, long long steps_done) {
+    const float lr = polynomial_decay(sched, steps_done);
+    const double t = (double)(steps_done + 1);
+    const float b1p = (float)std::pow((double)0.9f, t), b2p = (float)std::pow((double)0.999f, t);
+    return lr * std::sqrt(1.f - b2p) / (1.f - b1p);
 }
 
 #define TRY(call)            \
@@ -310,8 +322,7 @@ extern "C" int mpg_step_end(mpg_train_ctx_t* c, int iteration, mpg_stream_t s) {
         const bool is_policy = k == l.n_nets - 1;
         const bool upd = !is_policy || delayed;
         const long long t = c->opt_steps[k] + 1;
-        const double lr = polynomial_decay(is_policy ? c->policy_lr : c->value_lr, c->opt_steps[k]);
-        lr_t[k] = (float)(lr * std::sqrt(1.0 - std::pow(0.999, (double)t)) / (1.0 - std::pow(0.9, (double)t)));
+        lr_t[k] = adam_step_size(is_policy ? c->policy_lr : c->value_lr, c->opt_steps[k]);
         do_adam[k] = upd ? 1 : 0;
         do_polyak[k] = delayed ? 1 : 0;
         if (upd) c->opt_steps[k] = t;

@@ -37,10 +37,23 @@ def mlp_shapes(in_dim, out_dim, hidden=256):
 
 
 def polynomial_decay(sched, step):
-    """tf.keras.optimizers.schedules.PolynomialDecay(lr0, decay_steps, lr_end) (policy.py:54,62)."""
-    lr0, S, lr_end = sched
-    s = min(step, S)
-    return (lr0 - lr_end) * (1 - s / S) + lr_end
+    """tf.keras.optimizers.schedules.PolynomialDecay(lr0, decay_steps, lr_end) (policy.py:54,62), evaluated like TensorFlow does:
+    in float32, p = min(step, S) / S; lr = (lr0 - lr_end) * (1 - p) + lr_end."""
+    f = np.float32
+    lr0, S, lr_end = f(sched[0]), f(sched[1]), f(sched[2])
+    p = min(f(step), S) / S
+    return (lr0 - lr_end) * (f(1) - p) + lr_end
+
+
+def adam_step_size(sched, steps_done):
+    """ApplyAdam's alpha = lr * sqrt(1 - beta_2^t) / (1 - beta_1^t), t = steps_done + 1, with every operand a float32 like in Keras
+    (`_prepare_local`: the betas are float32 hyper-parameters, beta^t a float32 pow).  float32(0.999) > 0.999 puts this 6.7e-6 below the
+    real-number formula during the first thousands of steps.  The same code as train_step.cpp:adam_step_size."""
+    f = np.float32
+    lr = polynomial_decay(sched, steps_done)
+    t = steps_done + 1
+    b1p, b2p = f(float(f(0.9)) ** t), f(float(f(0.999)) ** t)      # correctly rounded float32 powers
+    return float(f(lr * np.sqrt(f(1) - b2p) / (f(1) - b1p)))
 
 
 class PolicyWithQs(object):
@@ -195,8 +208,7 @@ class PolicyWithQs(object):
         for n in self.names:
             upd = (n != 'policy') or delayed
             t = self.opt_steps[n] + 1
-            lr = polynomial_decay(self.schedules[n], self.opt_steps[n])
-            lr_t.append(lr * math.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t))
+            lr_t.append(adam_step_size(self.schedules[n], self.opt_steps[n]))
             do_adam.append(int(upd))
             do_polyak.append(int(delayed))
             if upd:

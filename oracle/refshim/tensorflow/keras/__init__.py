@@ -124,19 +124,67 @@ class Model(object):
 
 
 class PolynomialDecay(object):
-    def __init__(self, initial_learning_rate, decay_steps, end_learning_rate=0.0001, power=1.0):
-        self.args = (initial_learning_rate, decay_steps, end_learning_rate, power)
+    """tf.keras.optimizers.schedules.PolynomialDecay (cycle=False) as TensorFlow evaluates it: every operand is cast to the dtype of
+    `initial_learning_rate` (float32; the float64 yard-stick run uses float64 throughout),
+        step' = min(step, decay_steps);  p = step' / decay_steps;  lr = (lr0 - lr_end) * (1 - p) ** power + lr_end.
+    Call site: policy.py:54,62 (`PolynomialDecay(*policy_lr_schedule)` = (lr0, decay_steps, lr_end))."""
+
+    def __init__(self, initial_learning_rate, decay_steps, end_learning_rate=0.0001, power=1.0, cycle=False, name=None):
+        assert not cycle
+        self.initial_learning_rate, self.decay_steps = initial_learning_rate, decay_steps
+        self.end_learning_rate, self.power = end_learning_rate, power
+
+    def __call__(self, step):
+        dt = tf.REF_DTYPE
+        c = lambda x: torch.as_tensor(float(x), dtype=dt)
+        lr0, lr_end, power, S = c(self.initial_learning_rate), c(self.end_learning_rate), c(self.power), c(self.decay_steps)
+        p = torch.minimum(c(int(step)), S) / S
+        return (lr0 - lr_end) * torch.pow(c(1.0) - p, power) + lr_end
 
 
 class Adam(object):
-    """Not exercised by any golden (a20 is restated from the published TF formulae)."""
+    """tf.keras.optimizers.Adam (OptimizerV2, amsgrad=False) restated from its published update - the `ApplyAdam` kernel the dense
+    path calls (`training_ops.resource_apply_adam`), all in the variable's dtype:
+        lr_t    = learning_rate(iterations)                       (the schedule sees the count BEFORE this call's increment)
+        t       = iterations + 1;  b1p = beta_1 ** t;  b2p = beta_2 ** t
+        alpha   = lr_t * sqrt(1 - b2p) / (1 - b1p)
+        m      += (g - m) * (1 - beta_1);   v += (g * g - v) * (1 - beta_2);   var -= (m * alpha) / (sqrt(v) + epsilon)
+    `epsilon` (1e-7) sits OUTSIDE the bias-corrected root; `iterations` is per optimizer object and moves once per
+    `apply_gradients` call.  TensorFlow itself is absent from this image, so the ARITHMETIC is this restatement (stated as such in
+    DESIGN.md section 2); what the stand-in buys is that the reference's own control flow around it (policy.py:123-171: which
+    optimizer steps when, per-optimizer counters, delayed policy / target updates) executes unmodified."""
 
-    def __init__(self, learning_rate=0.001, name='Adam', **kw):
-        self.learning_rate = learning_rate
+    def __init__(self, learning_rate=0.001, beta_1=0.9, beta_2=0.999, epsilon=1e-7, amsgrad=False, name='Adam', **kw):
+        assert not amsgrad
+        self.learning_rate, self.beta_1, self.beta_2, self.epsilon = learning_rate, beta_1, beta_2, epsilon
         self._name = name
+        self.iterations = 0
+        self._slots = {}                                   # id(variable) -> (m, v)
 
-    def apply_gradients(self, grads_and_vars):
-        raise NotImplementedError('Keras Adam is not reproduced by the stand-in')
+    def get_slot(self, var, name):
+        return self._slots[id(var)][0 if name == 'm' else 1]
+
+    def apply_gradients(self, grads_and_vars, name=None):
+        with torch.no_grad():
+            for g, var in grads_and_vars:
+                dt = var.dtype
+                c = lambda x, dt=dt: torch.as_tensor(float(x), dtype=dt)
+                lr = self.learning_rate(self.iterations) if callable(self.learning_rate) else self.learning_rate
+                lr_t = torch.as_tensor(lr).to(dt)
+                t = c(self.iterations + 1)
+                b1, b2, eps = c(self.beta_1), c(self.beta_2), c(self.epsilon)
+                b1p, b2p = torch.pow(b1, t), torch.pow(b2, t)
+                alpha = lr_t * torch.sqrt(c(1.0) - b2p) / (c(1.0) - b1p)
+                if id(var) not in self._slots:
+                    z = torch.Tensor.detach(var).as_subclass(torch.Tensor)
+                    self._slots[id(var)] = (torch.zeros_like(z), torch.zeros_like(z))
+                m, v = self._slots[id(var)]
+                g = torch.as_tensor(np.asarray(g)) if not isinstance(g, torch.Tensor) else g
+                g = g.detach().as_subclass(torch.Tensor).to(dt)
+                m += (g - m) * (c(1.0) - b1)
+                v += (g * g - v) * (c(1.0) - b2)
+                var.as_subclass(torch.Tensor).sub_((m * alpha) / (torch.sqrt(v) + eps))
+        self.iterations += 1
 
 
 layers = _ns('layers', Dense=Dense)

@@ -32,6 +32,7 @@ same float32-rounded inputs - the error yard-stick of SURVEY.md §8c):
 import argparse
 import os
 import sys
+import tempfile
 
 import numpy as np
 
@@ -44,6 +45,9 @@ np.int = int                                            # path_tracking_env.py:3
 
 import torch                                            # noqa: E402
 import tensorflow as tf                                 # noqa: E402  (the stand-in)
+
+sys.path.insert(0, ROOT)
+from oracle import mpg_oracle as O                      # noqa: E402  (only the Philox restatements of the device's random streams + the cart-pole stand-in of round 6)
 
 OBS_SCALE_PT = [1., 1., 2., 1., 2.4, 1 / 1200]
 OBS_SCALE_PD = [0.001, 1 / 3, 0.1, 0.5]
@@ -620,12 +624,288 @@ def fx_q_estimation(H=256, B=64, seed=70):
     np.savez_compressed(os.path.join(HERE, 'q_estimation_ref.npz'), **out)
 
 
+# ------------------------------------------------------------------------------------------------
+# round 6: the reference's OWN loop code, unmodified - PolicyWithQs.apply_gradients (policy.py:123-171), OffPolicyWorker.sample
+# (worker.py:91-119), SingleProcessOffPolicyOptimizer.step (optimizer.py:330-362) - on random streams that are the oracle's
+# restatements of the DEVICE's Philox draws, so that tests/c2_loop.py / tests/c3_loop.py (CPU) and the device loops (GPU) can be
+# compared with what the reference's control flow produced, iteration for iteration.
+# ------------------------------------------------------------------------------------------------
+sys.path.insert(0, ROOT)
+from golden_inputs import LOOP_SEED, NET_DIMS, apply_case_grads, loop_case_weights, split_keras      # noqa: E402
+
+
+def loop_args(case, **kw):
+    """train_script.py:built_MPG_parser / train_script4mujoco.py:built_NADP_parser defaults for the single-process optimizer"""
+    if case == 'nadp':
+        args = mpg_args('NADP', 256, 256, env='InvertedPendulumConti-v0')
+        args.num_rollout_list_for_policy_update, args.num_rollout_list_for_q_estimation = [25], [25]
+        args.delay_update, args.num_agent, args.explore_sigma = 1, 1, None
+    else:
+        args = mpg_args('MPG-' + case, 256, 256)
+        if case == 'v1':
+            args.num_batch_reuse = 10
+    d = tempfile.mkdtemp(prefix='mpg_golden_')
+    args.log_dir, args.model_dir = d + '/logs', d + '/models'
+    args.worker_log_interval, args.buffer_log_interval = 10 ** 9, 10 ** 9
+    args.obs_ptype, args.rew_ptype = 'scale', 'scale'
+    for k, v in kw.items():
+        setattr(args, k, v)
+    return args
+
+
+def keras_nets(case, flat_by_name):
+    return {name: split_keras(flat_by_name[name], din, dout) for name, din, dout in NET_DIMS[case]}
+
+
+def set_online_and_targets(pwq, case, flat_by_name):
+    """online networks AND targets = the given weights (PolicyWithQs.__init__ copies online -> target, policy.py:60,68)"""
+    nets = keras_nets(case, flat_by_name)
+    for k in list(nets):
+        nets[k + '_target'] = nets[k]
+    set_policy_weights(pwq, nets)
+
+
+def flat_models(pwq):
+    return (np.concatenate([flat(m.get_weights()) for m in pwq.models]),
+            np.concatenate([flat(m.get_weights()) for m in pwq.target_models]))
+
+
+class DeviceStreams(object):
+    """Every random draw of a reference loop run, replaced IN THE GENERATOR PROCESS by the oracle's restatement of the device's
+    counter-based Philox stream for the same event (oracle/mpg_oracle.py; keys as mpg_amd derives them from args.seed):
+      np.random.uniform / normal   the env's reset law (path_tracking_env.py:426-437: six calls per reset, O.reset_law_draws with
+                                   the reset counter) and the worker's exploration noise (worker.py:98, O.explore_noise_philox with
+                                   the policy-call counter)
+      random.randint               ReplayBuffer.sample_idxes (buffer.py:70-71): O.uniform_indices_philox(len, B, seed, replay_times)
+      tf noise source              the model's in-graph noise (path_tracking_env.py:119, inverted_pendulum_model.py:61): row t of
+                                   O.model_noise_philox(n, B, seed, counter); TD3's smoothing noise (td3.py:74): O.normal_fill_philox
+    `install()` patches the three entry points, `remove()` restores them.  No reference file is edited."""
+
+    def __init__(self, seed, num_agent, sigma, B, n=25, noise_counters=lambda k: [k], smoothing=False):
+        self.w_seed, self.rb_seed, self.l_seed = seed * 1000003, seed * 7919, seed + 12345
+        self.num_agent, self.sigma, self.B, self.n = num_agent, sigma, B, n
+        self.env_ctr = self.noise_ctr = self.randint_calls = self.model_draws = 0
+        self.noise_counters, self.smoothing = noise_counters, smoothing
+        self.draw = self.idx = self.eps = None
+        self.idx_log = []
+
+    # -- numpy --
+    def np_uniform(self, low=0.0, high=1.0, size=None):
+        n = int(np.prod(size))
+        assert n == self.num_agent, (low, high, size)
+        if (low, high) == (0, 600):
+            self.draw = O.reset_law_draws(n, self.w_seed, self.env_ctr)
+            self.env_ctr += 1
+            return self.draw['x'].copy()
+        assert (low, high) == (15, 25), (low, high)
+        return self.draw['vx'].copy()
+
+    def np_normal(self, loc=0.0, scale=1.0, size=None):
+        size = tuple(np.atleast_1d(size))
+        if len(size) == 2:                                  # worker.py:98
+            assert loc == 0 and scale == self.sigma and size[0] == self.num_agent
+            z = O.explore_noise_philox(size[0], size[1], self.sigma, self.w_seed, self.noise_ctr)
+            self.noise_ctr += 1
+            return z
+        assert loc == 0 and size == (self.num_agent,)
+        key = {1: 'dy', np.pi / 9: 'dphi', 0.15: 'beta', 0.3: 'r'}[scale]
+        return self.draw[key].copy()
+
+    # -- stdlib random (buffer.py:71) --
+    def randint(self, a, b):
+        k = self.randint_calls % self.B
+        if k == 0:
+            self.idx = O.uniform_indices_philox(b + 1, self.B, self.rb_seed, self.randint_calls // self.B + 1)
+            self.idx_log.append(self.idx.copy())
+        assert a == 0
+        self.randint_calls += 1
+        return int(self.idx[k])
+
+    # -- tf.random.normal / tfd.Normal.sample --
+    def tf_noise(self, shape):
+        if self.smoothing:                                  # one [B, act] draw per compute_gradient (td3.py:74)
+            self.model_draws += 1
+            return O.normal_fill_philox(int(np.prod(shape)), self.l_seed, self.model_draws).reshape(shape)
+        t = self.model_draws % self.n
+        call = self.model_draws // self.n                   # rollouts so far: per_call rollouts per compute_gradient
+        per_call = len(self.noise_counters(1))
+        if t == 0:
+            ctr = self.noise_counters(call // per_call + 1)[call % per_call]
+            self.eps = O.model_noise_philox(self.n, int(np.prod(shape)), self.l_seed, ctr)
+        self.model_draws += 1
+        return self.eps[t].reshape(shape)
+
+    def install(self):
+        import random
+        self._saved = (np.random.uniform, np.random.normal, random.randint)
+        np.random.uniform, np.random.normal, random.randint = self.np_uniform, self.np_normal, self.randint
+        tf.set_noise_source(self.tf_noise)
+
+    def remove(self):
+        import random
+        np.random.uniform, np.random.normal, random.randint = self._saved
+        tf.set_noise_source(None)
+
+
+def fx_apply_gradients(n_iter=6):
+    """PolicyWithQs.apply_gradients (policy.py:123-171) x n_iter on given gradient lists: which optimizer steps when (delay_update 2:
+    the policy and ALL targets move at iterations 0, 2, 4; delay 1: every iteration), the per-optimizer `iterations`, the learning
+    rates the PolynomialDecay schedules hand out (policy.py:54-70), the Polyak mix.  Cases: v2 (double_Q, Q1 / Q2 / policy), v1
+    (Q1 / policy, delay 2), nadp (pendulum widths, delay 1).  Per iteration: every 64th parameter and target entry; at the end: all (v2) or
+    every 4th (v1, nadp); from the float64 run the parameter and target UPDATES, every 4th entry."""
+    from policy import PolicyWithQs
+    out = dict(n_iter=n_iter)
+    for case in ('v2', 'v1', 'nadp'):
+        w0, gl = loop_case_weights(case), apply_case_grads(case, n_iter)
+        for tag, dt in (('', torch.float32), ('_f64', torch.float64)):
+            tf.set_ref_dtype(dt)
+            pwq = PolicyWithQs(**vars(loop_args(case)))
+            set_online_and_targets(pwq, case, w0)
+            snaps, snaps_t, iters = [], [], []
+            w0_flat = np.concatenate([w0[name] for name, _, _ in NET_DIMS[case]]).astype(np.float64)
+            for it in range(n_iter):
+                grads = [a for name, din, dout in NET_DIMS[case] for a in split_keras(gl[it][name], din, dout)]
+                pwq.apply_gradients(tf.constant(it, dtype=tf.int32), grads)
+                p, t = flat_models(pwq)
+                snaps.append(p[::64]), snaps_t.append(t[::64])
+                iters.append([o.iterations for o in pwq.optimizers])
+            if tag == '':
+                every = 1 if case == 'v2' else 4
+                out[case + '_params_sub'], out[case + '_targets_sub'] = np.stack(snaps), np.stack(snaps_t)
+                out[case + '_opt_iterations'] = np.array(iters)
+                out[case + '_params'], out[case + '_targets'], out[case + '_every'] = p[::every], t[::every], every
+            else:       # the float64 run is the error yard-stick: its parameter UPDATE (every 4th entry), as float32
+                out[case + '_update_f64'] = (p.astype(np.float64) - w0_flat)[::4].astype(np.float32)
+                out[case + '_target_update_f64'] = (t.astype(np.float64) - w0_flat)[::4].astype(np.float32)
+    tf.set_ref_dtype(torch.float32)
+    np.savez_compressed(os.path.join(HERE, 'apply_gradients_ref.npz'), **out)
+
+
+def fx_worker_sample(num_agent=8, batch_size=64, calls=2):
+    """OffPolicyWorker.sample (worker.py:91-119) x `calls` on the reference's PathTrackingEnv: policy -> + exploration noise -> env.step
+    -> 5-tuples -> env.reset() of every agent (done is always true).  Random inputs: DeviceStreams (seed LOOP_SEED)."""
+    from policy import PolicyWithQs
+    from worker import OffPolicyWorker
+    out = dict(num_agent=num_agent, batch_size=batch_size, calls=calls, seed=LOOP_SEED)
+    w0 = loop_case_weights('v2')
+    for tag, dt in (('', torch.float32), ('_f64', torch.float64)):
+        tf.set_ref_dtype(dt)
+        args = loop_args('v2', num_agent=num_agent, batch_size=batch_size)
+        st = DeviceStreams(LOOP_SEED, num_agent, args.explore_sigma, args.replay_batch_size)
+        st.install()
+        try:
+            worker = OffPolicyWorker(PolicyWithQs, args.env_id, args, 0)
+            set_online_and_targets(worker.policy_with_value, 'v2', w0)
+            data = []
+            for _ in range(calls):
+                batch, count = worker.sample_with_count()
+                assert count == batch_size
+                data += batch
+        finally:
+            st.remove()
+        for k, name in enumerate(('obs', 'act', 'rew', 'obs2', 'done')):
+            out[name + tag] = np.stack([np.asarray(t[k]) for t in data]).astype(np.float32 if name != 'done' else np.uint8)
+        out['final_obs' + tag] = np.asarray(worker.obs, np.float32)
+        out['counters' + tag] = np.array([st.env_ctr, st.noise_ctr])
+    tf.set_ref_dtype(torch.float32)
+    np.savez_compressed(os.path.join(HERE, 'worker_sample_ref.npz'), **out)
+
+
+def _register_cart_pole(seed):
+    """InvertedPendulumConti-v0 is a MuJoCo environment (inverted_pendulum_conti.py; MuJoCo is absent): the loop fixture steps the
+    oracle's closed-form cart-pole instead (oracle.InvertedPendulumContiOracle - parity of THAT env is unpinned)
+    behind the reference's own DummyVecEnv (utils/dummy_vec_env.py).  Reset draw k = the device's Philox stream with counter = env
+    steps taken so far (the device re-draws after every step and keeps the draw only where done)."""
+    import gym
+
+    class CartPole(gym.Env):
+        def __init__(self):
+            self.sim, self.n_steps = O.InvertedPendulumContiOracle(1, dtype=np.float32), 0
+
+        def reset(self):
+            return self.sim.reset(init_obs=O.cart_pole_reset_philox(1, seed * 1000003, self.n_steps))[0]
+
+        def step(self, a):
+            obs, rew, done, info = self.sim.step(np.asarray(a, np.float32).reshape(1, 1))
+            self.n_steps += 1
+            return obs[0], rew[0], bool(done[0]), info
+    gym.register('InvertedPendulumConti-v0', CartPole)
+
+
+def fx_loop(case, n_iter=20):
+    """SingleProcessOffPolicyOptimizer (optimizer.py:286-397) at the reference's defaults - OffPolicyWorker (8 agents, 512 transitions
+    per sample) / ReplayBuffer (replay_starts 3000, batch 256) / MPGLearner MPG-v2 (case 'v2') or NADPLearner on the pendulum model
+    (case 'nadp': 1 agent behind DummyVecEnv) / PolicyWithQs - constructed (fills the ring) and stepped n_iter times (sampling at
+    iterations 0 and 10).  All reference classes unmodified; random inputs: DeviceStreams(LOOP_SEED); initial weights:
+    golden_inputs.loop_case_weights.  Per iteration: replay indices, learner statistics, per-optimizer counters, per-network update
+    norms, every 64th parameter; at the end: all parameters and targets, the ring."""
+    from buffer import ReplayBuffer
+    from optimizer import SingleProcessOffPolicyOptimizer
+    from policy import PolicyWithQs
+    from worker import OffPolicyWorker
+    if case == 'nadp':
+        from learners.nadp import NADPLearner as Learner
+        _register_cart_pole(LOOP_SEED)
+        keys = ('q_loss', 'policy_loss', 'value_mean', 'q_gradient_norm', 'policy_gradient_norm')
+        counters = lambda k: [2 * k, 2 * k + 1]             # Q-target rollout, then the policy rollout (nadp.py:175,188)
+    else:
+        from learners.mpg_learner import MPGLearner as Learner
+        keys = ('q_loss1', 'q_loss2', 'value_mean', 'policy_total_loss', 'q_gradient_norm1', 'q_gradient_norm2', 'policy_gradient_norm')
+        counters = lambda k: [k]
+    w0 = loop_case_weights(case)
+    w0_flat = np.concatenate([w0[name] for name, _, _ in NET_DIMS[case]])
+    out = dict(n_iter=n_iter, seed=LOOP_SEED)
+    for tag, dt in (('', torch.float32), ('_f64', torch.float64)):
+        tf.set_ref_dtype(dt)
+        args = loop_args(case)
+        st = DeviceStreams(LOOP_SEED, args.num_agent, args.explore_sigma, args.replay_batch_size, noise_counters=counters)
+        st.install()
+        try:
+            worker = OffPolicyWorker(PolicyWithQs, args.env_id, args, 0)
+            set_online_and_targets(worker.policy_with_value, case, w0)
+            learner = Learner(PolicyWithQs, args)
+            rb = ReplayBuffer(args, 0)
+            opt = SingleProcessOffPolicyOptimizer(worker, learner, rb, None, args)
+            fill = len(rb)
+            stats, iters, upd, sub = [], [], [], []
+            for it in range(n_iter):
+                opt.step()
+                s = learner.get_stats()
+                stats.append([float(np.asarray(s[k])) for k in keys])
+                pwq = worker.policy_with_value
+                iters.append([o.iterations for o in pwq.optimizers])
+                p, t = flat_models(pwq)
+                o, row = 0, []
+                for name, _, _ in NET_DIMS[case]:
+                    n = w0[name].size
+                    row.append(float(np.linalg.norm(p[o:o + n].astype(np.float64) - w0[name])))
+                    o += n
+                upd.append(row), sub.append(p[::64])
+        finally:
+            st.remove()
+        out['stats' + tag], out['update_norms' + tag] = np.array(stats), np.array(upd)
+        if tag == '':
+            out.update(stat_keys=np.array(keys), fill=fill, opt_iterations=np.array(iters), idx=np.stack(st.idx_log).astype(np.int32),
+                       params=p, targets=t, params_sub=np.stack(sub), ring_len=len(rb), ring_next=rb._next_idx,
+                       num_sampled_steps=opt.num_sampled_steps, replay_times=rb.replay_times, learner_counter=learner.counter,
+                       counters=np.array([st.env_ctr, st.noise_ctr, st.randint_calls, st.model_draws]))
+            for k, name in enumerate(('obs', 'act', 'rew', 'obs2', 'done')):
+                out['ring_' + name] = np.stack([np.asarray(x[k]) for x in rb._storage]).astype(np.float32)
+        else:
+            out['update_f64'] = (p.astype(np.float64) - w0_flat)[::4].astype(np.float32)       # yard-stick: the float64 run's parameter update
+            out['target_update_f64'] = (t.astype(np.float64) - w0_flat)[::4].astype(np.float32)
+    tf.set_ref_dtype(torch.float32)
+    np.savez_compressed(os.path.join(HERE, 'loop_%s_ref.npz' % case), **out)
+
+
 ROUND2 = {'replay_buffer': fx_replay_buffer, 'evaluator': fx_evaluator, 'env_future': fx_env_future,
           'q_estimation': fx_q_estimation}
 ROUND2.update({n: (lambda n=n: fx_bench_case(n)) for n in BENCH_CASES})
 ROUND2['trained_c2'] = lambda: fx_bench_case('c2_mpg_v2_B4096', trained=True)      # round 3
 ROUND2['mpg_future'] = lambda: fx_mpg('MPG-v2', 256, 64, seed=12, K=3)               # round 3: num_future_data = 3
 ROUND2['mpg_future10'] = lambda: fx_mpg('MPG-v2', 256, 64, seed=13, K=10)           # round 4: num_future_data = 10 (obs_dim 16, critics 18 wide)
+ROUND2.update(apply_gradients=fx_apply_gradients, worker_sample=fx_worker_sample,           # round 6: the reference's own loop code
+              loop_v2=lambda: fx_loop('v2'), loop_nadp=lambda: fx_loop('nadp'))
 
 
 def main():

@@ -76,3 +76,45 @@ def bench_case_inputs(name):
     else:
         d['smooth_eps'] = rng.standard_normal((B, 2)).astype(np.float32)
     return d
+
+
+# ---- round 6: the reference's OWN loop code (policy.py:123-171, worker.py:91-119, optimizer.py:330-362) run unmodified ----
+# Initial weights and gradient lists are seeded draws regenerated on both sides; the fixtures hold what the reference computed.
+LOOP_SEED = 3                 # `args.seed` of the loop cases: worker / env stream 3 * 1000003, replay stream 3 * 7919, learner stream 3 + 12345
+NET_DIMS = {                  # case -> ordered (name, in, out) like PolicyWithQs.models (policy.py:72-86)
+    'v2': [('Q1', 8, 1), ('Q2', 8, 1), ('policy', 6, 4)],
+    'v1': [('Q1', 8, 1), ('policy', 6, 4)],
+    'nadp': [('Q1', 5, 1), ('policy', 4, 2)],
+}
+
+
+def loop_case_weights(case, seed=600):
+    """Initial ONLINE networks of a loop / apply_gradients case as {name: flat float32}: Orthogonal(sqrt 2 / 1) kernels, ZERO biases
+    (model.py:23-36 - what the reference and the device both start from)."""
+    rng = np.random.Generator(np.random.PCG64(seed + sorted(NET_DIMS).index(case)))
+    return {name: mlp_weights_flat(rng, din, dout, bias_jitter=0.0) for name, din, dout in NET_DIMS[case]}
+
+
+def apply_case_grads(case, n_iter=6, seed=610):
+    """n_iter gradient lists for PolicyWithQs.apply_gradients: per network a flat float32 vector; magnitudes spread over four
+    decades so that Adam's normalisation meets small and large second moments."""
+    rng = np.random.Generator(np.random.PCG64(seed + sorted(NET_DIMS).index(case)))
+    out = []
+    for _ in range(n_iter):
+        g = {}
+        for name, din, dout in NET_DIMS[case]:
+            n = (din + 1) * 256 + 257 * 256 + 257 * dout
+            g[name] = (rng.standard_normal(n) * 10.0 ** rng.uniform(-5, -1, n)).astype(np.float32)
+        out.append(g)
+    return out
+
+
+def split_keras(flat, din, dout, H=256):
+    """flat float32 -> Keras-shaped list [W1, b1, W2, b2, W3, b3]"""
+    out, o = [], 0
+    for shp in [(din, H), (H,), (H, H), (H,), (H, dout), (dout,)]:
+        n = int(np.prod(shp))
+        out.append(np.asarray(flat[o:o + n], np.float32).reshape(shp))
+        o += n
+    assert o == len(flat)
+    return out

@@ -253,7 +253,12 @@ def test_adam_restatement_cross_checked_against_an_independent_adam():
     # 0.001 by 4.7e-5 relative - inherent in the form being restated, not an error of the restatement
     np.testing.assert_allclose(opt.v, ref.state[p]['exp_avg_sq'].numpy(), rtol=1e-4, atol=1e-7)
     # PolynomialDecay(lr0, S, lr_end), power 1: documented closed form
-    assert abs(O.polynomial_decay(sched, 50000) - (8e-5 - 8e-6) * 0.5 - 8e-6) < 1e-12 and O.polynomial_decay(sched, 10 ** 7) == 8e-6
+    # (evaluated in float32 like TensorFlow does: within float32 rounding of the real-number value)
+    assert abs(O.polynomial_decay(sched, 50000) - (8e-5 - 8e-6) * 0.5 - 8e-6) < 1e-11 and O.polynomial_decay(sched, 10 ** 7) == np.float32(8e-6)
+    # ApplyAdam's step size from float32 operands: 6.7e-6 below the real-number formula at t = 1 (float32(0.999) > 0.999)
+    import math
+    a = O.adam_step_size(sched, 0) / (8e-5 * math.sqrt(1 - 0.999) / (1 - 0.9)) - 1
+    assert -7.5e-6 < a < -6e-6, a
 
 
 # ---- round 2: bench-size cases, the reference's own buffer / evaluator, future-data obs, Q-estimation rollout ---------
