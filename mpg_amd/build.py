@@ -93,8 +93,12 @@ def _build_one(engine, force, verbose, jobs):
     # with every snapshot of the tree
     live = set(s + '.o' for s in sources())
     for f in os.listdir(OBJ):
-        if not any(f == o or f.startswith(o + '.') for o in live):
-            os.remove(os.path.join(OBJ, f))
+        path = os.path.join(OBJ, f)
+        if os.path.isfile(path) and (f.endswith('.o') or f.endswith('.o.stamp')) and not any(f == o or f.startswith(o + '.') for o in live):
+            try:
+                os.remove(path)
+            except OSError:
+                pass              # a concurrent build got there first
     cc = hipcc()
     objs, todo = [], []
     for s in sources():

@@ -138,7 +138,9 @@ __global__ void k_sample(int capacity, int n_storage, int n, const double* __res
         ui = u[i];
     } else {
         const Philox4 p = philox4x32_10((uint32_t)i, c1, c2, 0x9e4u, k0, k1);
-        ui = ((double)(((uint64_t)p.v[0] << 21) ^ (uint64_t)(p.v[1] >> 11)) + 0.5) * (1.0 / 9007199254740992.0);   // 53-bit uniform in (0,1)
+        // 52 random bits + 0.5: exactly representable, so ui lies STRICTLY inside (0, 1) (with 53 bits the largest value + 0.5 rounds to
+        // 2^53: ui == 1, prefix == total, and the descent ends in the rightmost - unfilled - leaf)
+        ui = ((double)(((uint64_t)p.v[0] << 20) ^ (uint64_t)(p.v[1] >> 12)) + 0.5) * (1.0 / 4503599627370496.0);
     }
     const double total = sTop[1];                        // == sum(0, len(storage)) bit for bit (unfilled leaves are exact zeros)
     double prefix = ui * total;                          // buffer.py:141
@@ -161,7 +163,10 @@ __global__ void k_sample(int capacity, int n_storage, int n, const double* __res
             node = 2 * node + 1;
         }
     }
-    const int leaf = node - capacity;
+    // A caller-supplied u keeps find_prefixsum_idx's own answer (u = 1 -> the rightmost leaf, segment_tree.py:133-140: the reference
+    // would then fail on its storage list).  The library's own draws and every gathering launch never leave the filled slots:
+    // ui * total can still round up to `total` once in 2^52 draws.
+    const int leaf = (u && !GATHER) ? node - capacity : min(node - capacity, n_storage - 1);
     idx[i] = leaf;
     if constexpr (GATHER) gather_row(go.ring, leaf, i, go.od, go.ad, go.obs, go.act, go.rew, go.obs2, go.done);
     if (is_w) {                                          // buffer.py:146-158

@@ -485,6 +485,10 @@ extern "C" int mpg_mpg_gradients(const mpg_cfg_t* cfg, int n_q, const float* par
     for (int k = 0; k < n_select; ++k) MPG_REQUIRE(select[k] >= 0 && select[k] <= n, "mpg_mpg_gradients: slice out of range");
     // the statistics block holds n_q losses + 2 sums per slice in 8 reduction jobs: checked before anything is enqueued
     MPG_REQUIRE(n_q + 2 * n_select <= 8, "mpg_mpg_gradients: too many statistics (n_select <= 3 with two critics)");
+    // with critics_ready_event the gradient is produced in two parts for an exchange between GPUs: the clip partials belong behind
+    // that exchange (mpg_sq_partials on the reduced buffer), so asking for them here is a caller error, not something to leave unwritten
+    MPG_REQUIRE(!(cfg->grad_opts && cfg->grad_opts->critics_ready_event && sq_part),
+                "mpg_mpg_gradients: sq_part must be null when grad_opts->critics_ready_event is set (take the clip partials after the exchange)");
     if (ws_bytes < mpg_mpg_gradients_workspace_bytes(cfg, rows, M, n, n_select, n_q)) {
         mpg_set_error("mpg_mpg_gradients: workspace too small");
         return MPG_EWORKSPACE;
@@ -521,6 +525,13 @@ extern "C" int mpg_mpg_gradients(const mpg_cfg_t* cfg, int n_q, const float* par
         for (int k = 0; k < n_q; ++k) {
             int rc = mpg_q_loss_grad(cfg, qp[k], rows, obs, act, y, inv_b_global, stats + k, gq[k], nullptr, w0, l.fallback0, stream);
             if (rc) return rc;
+        }
+        // critics_ready_event (mpg_grad_opts_t): the critics' slice of `grad` and their losses are final here in this path too - a
+        // caller that exchanges them on a second stream waits for THIS record, not for one left over from an earlier call
+        if (cfg->grad_opts && cfg->grad_opts->critics_ready_event &&
+            hipEventRecord(reinterpret_cast<hipEvent_t>(cfg->grad_opts->critics_ready_event), s) != hipSuccess) {
+            mpg_set_error("mpg_mpg_gradients: hipEventRecord(critics_ready_event) failed");
+            return MPG_EINVAL;
         }
         int rc = mpg_rollout_pg(cfg, policy, qp[0], rows, M, n, select, n_select, w, obs, eps, noise_seed, noise_ctr, inv_b_global, 0,
                                 stats + 2, stats + 2 + n_select, gp, w1, l.fallback1, stream);

@@ -7,7 +7,7 @@ import torch
 import torch.distributed as dist
 
 
-_oneshot = {}            # OneShotAllReduce objects of this process by buffer length (MPG_DIST_BACKEND=oneshot), built at the first exchange
+_oneshot = {}            # OneShotAllReduce objects of this process by (buffer length, tag) (MPG_DIST_BACKEND=oneshot), built at the first exchange
 _exchange = 'collective'  # 'collective': dist.all_reduce of the process group's backend; 'oneshot': the IPC one-shot form below
 
 
@@ -311,14 +311,16 @@ def world_size():
     return dist.get_world_size() if dist.is_initialized() else 1
 
 
-def all_reduce_sum_(flat, force=False):
+def all_reduce_sum_(flat, force=False, tag=0):
     """In-place sum over ranks of one flat float32 buffer (no-op on a single process unless `force`: a one-rank group
-    still runs the collective - the way the RCCL path is exercised on a 1-GPU box)."""
+    still runs the collective - the way the RCCL path is exercised on a 1-GPU box).  `tag`: exchanges that may be in flight at the
+    same time (on different streams) must not share a one-shot exchanger - staging parities, events and shared-memory counters are
+    per object - so concurrent callers pass distinct tags (mpg_amd/fused.py: 1 = the critics' slice under the sweep)."""
     if dist.is_initialized() and (dist.get_world_size() > 1 or force):
         if _exchange == 'oneshot':
-            ex = _oneshot.get(flat.numel())
+            ex = _oneshot.get((flat.numel(), tag))
             if ex is None:         # (a collective construction: every rank reaches it at the same exchange of the same length)
-                ex = _oneshot[flat.numel()] = OneShotAllReduce(flat.numel(), flat.device)
+                ex = _oneshot[(flat.numel(), tag)] = OneShotAllReduce(flat.numel(), flat.device)
             ex.all_reduce_sum_(flat)
         else:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM)

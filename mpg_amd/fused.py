@@ -199,7 +199,7 @@ class FusedMPGStep(object):
                 main = torch.cuda.current_stream()
                 side.wait_event(e1)
                 with torch.cuda.stream(side):
-                    D.all_reduce_sum_(flat[:n_crit], force=self.always_exchange)
+                    D.all_reduce_sum_(flat[:n_crit], force=self.always_exchange, tag=1)
                     e2.record(side)
                 D.all_reduce_sum_(flat[n_crit:], force=self.always_exchange)
                 main.wait_event(e2)

@@ -1,0 +1,162 @@
+"""The DEVICE loop against fixtures the reference's OWN, unmodified loop code produced (tests/golden/make_golden.py, round 6;
+the CPU twin is tests/test_reference_loop.py):
+
+    apply_gradients_ref.npz   PolicyWithQs.apply_gradients x 6                 policy.py:123-171, schedules :54-70
+    worker_sample_ref.npz     OffPolicyWorker.sample x 2                       worker.py:91-119
+    loop_v2_ref.npz           SingleProcessOffPolicyOptimizer.step x 20 (MPG-v2, reference defaults)   optimizer.py:286-397
+    loop_nadp_ref.npz         the same with NADPLearner on the pendulum model  learners/nadp.py:209-241
+
+The reference runs consumed the oracle's restatements of the device's Philox streams, so the device - drawing the real thing inside its
+kernels - must reproduce them iteration for iteration: replay indices and optimizer counters exactly, everything else to float32
+rounding.  All calls go through the C ABI (mpg_amd -> ctypes -> libmpg_hip.so)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.golden_inputs import NET_DIMS, apply_case_grads, loop_case_weights
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def rel_l2(a, b):
+    a, b = np.asarray(a, np.float64).ravel(), np.asarray(b, np.float64).ravel()
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def _args(case, **kw):
+    from mpg_amd.config import default_args
+    return default_args({'v2': 'MPG-v2', 'v1': 'MPG-v1', 'nadp': 'NADP'}[case], nan_check_interval=10 ** 9, **kw)
+
+
+@pytest.mark.parametrize('case', ['v2', 'v1', 'nadp'])
+def test_device_apply_gradients_vs_reference_policy_with_qs(golden, case):
+    """mpg_amd.PolicyWithQs.apply_gradients (k_adam_polyak behind mpg_adam_polyak) x 6 on the fixture's gradient lists against the
+    reference's PolicyWithQs.apply_gradients.  Exact: per-optimizer counters after every call, targets untouched on non-delayed
+    iterations.  Bars: parameter / target update within 1e-5 relative L2 of the reference's (float32 rounding of w - step: the kernel
+    may contract m * alpha / (sqrt(v) + eps) differently; measured: see the print) and within 4 x the reference's own
+    float32-vs-float64 gap."""
+    from mpg_amd.policy import PolicyWithQs
+    g = golden('apply_gradients_ref.npz')
+    names = [n for n, _, _ in NET_DIMS[case]]
+    pw = PolicyWithQs(**vars(_args(case)), device=DEV)
+    assert pw.names == names
+    w = loop_case_weights(case)
+    w0 = np.concatenate([w[n] for n in names])
+    pw.set_flat(w0, w0)
+    grads = apply_case_grads(case, int(g['n_iter']))
+    prev_t = w0.copy()
+    for it in range(int(g['n_iter'])):
+        flat = np.concatenate([grads[it][n] for n in names])
+        pw.apply_gradients(it, torch.as_tensor(flat).to(DEV))
+        assert [pw.opt_steps[n] for n in names] == list(g[case + '_opt_iterations'][it]), it
+        p, t = pw.params.cpu().numpy(), pw.targets.cpu().numpy()
+        assert (not np.array_equal(t, prev_t)) == (it % pw.delay_update == 0), it
+        prev_t = t.copy()
+        assert rel_l2(p[::64] - w0[::64], g[case + '_params_sub'][it] - w0[::64]) <= 1e-5, it
+        if it % pw.delay_update == 0 or it:
+            assert rel_l2(t[::64] - w0[::64], g[case + '_targets_sub'][it] - w0[::64]) <= 1e-5, it
+    every = int(g[case + '_every'])
+    e_p = rel_l2((p - w0)[::every], g[case + '_params'] - w0[::every])
+    e_t = rel_l2((t - w0)[::every], g[case + '_targets'] - w0[::every])
+    k4 = 4 // every
+    gap = rel_l2(g[case + '_params'][::k4] - w0[::4], g[case + '_update_f64'])
+    mine = rel_l2((p - w0)[::4], g[case + '_update_f64'])
+    nbits = int((p[::every] != g[case + '_params']).sum())
+    print('%s: device update vs reference float32 %.2e (targets %.2e; %d of %d entries not bit-identical); vs float64 %.2e, reference float32 %.2e'
+          % (case, e_p, e_t, nbits, g[case + '_params'].size, mine, gap))
+    assert e_p <= 1e-5 and e_t <= 1e-5 and mine <= 4 * gap + 1e-6
+    pw.check_status()
+
+
+def test_device_worker_sample_vs_reference_worker(golden):
+    """mpg_amd.OffPolicyWorker.sample x 2 (8 agents x 8 steps per call: policy launch with in-kernel exploration noise, env step, reset
+    launch) against the reference's OffPolicyWorker.sample on the restated streams.  Bars: observations / next observations 1e-4
+    relative-to-scale (hardware log2 / cos in the noise and 20 sub-steps of float32 dynamics with device sin / cos / atan), actions 2e-5,
+    raw rewards 1e-4; the done flag and the two stream counters exact."""
+    from mpg_amd.policy import PolicyWithQs
+    from mpg_amd.worker import OffPolicyWorker
+    g = golden('worker_sample_ref.npz')
+    NA, BS, calls = int(g['num_agent']), int(g['batch_size']), int(g['calls'])
+    args = _args('v2', num_agent=NA, batch_size=BS, seed=int(g['seed']))
+    worker = OffPolicyWorker(PolicyWithQs, args.env_id, args, 0)
+    w = loop_case_weights('v2')
+    w0 = np.concatenate([w[n] for n in worker.policy_with_value.names])
+    worker.policy_with_value.set_flat(w0, w0)
+    parts = [worker.sample_with_count() for _ in range(calls)]
+    assert all(c == BS for _, c in parts)
+    got = [torch.cat([p[0][k].reshape(BS, -1) for p in parts], 0).float().cpu().numpy() for k in range(5)]
+    assert [worker.env._ctr, worker._noise_ctr] == list(g['counters'])
+    for k, (name, tol) in enumerate((('obs', 1e-4), ('act', 2e-5), ('rew', 1e-4), ('obs2', 1e-4))):
+        ref = g[name].reshape(calls * BS, -1)
+        scale = np.maximum(1.0, np.abs(ref).max(0))
+        err = (np.abs(got[k] - ref) / scale).max()
+        gap = (np.abs(g[name + '_f64'].reshape(ref.shape) - ref) / scale).max()
+        print('%-4s max err relative to column scale %.2e (reference float32 vs float64 %.2e)' % (name, err, gap))
+        assert err <= tol, name
+    assert (got[4] != 0).all() and g['done'].all()
+    np.testing.assert_allclose(worker.obs.cpu().numpy(), g['final_obs'], rtol=1e-4, atol=1e-4)
+    worker.policy_with_value.check_status()
+
+
+@pytest.mark.parametrize('case', ['v2', 'nadp'])
+def test_device_loop_vs_reference_optimizer(golden, case):
+    """The device's SingleProcessOffPolicyOptimizer (native step driver: mpg_step_begin / mpg_step_end) at the reference's defaults
+    against the reference's own optimizer loop: 20 iterations, sampling at iterations 0 and 10.
+    v2: 8 agents x 64 steps per sample, replay batch 256, MPG-v2, delay_update 2.  nadp: ONE agent x 512 steps per sample (the
+    reference's DummyVecEnv form), NADP on the pendulum model, delay_update 1; the real env is the analytic cart-pole on both sides.
+    Exact: ring length after the fill, replay indices of every iteration, optimizer counters, stream counters.
+    Bars (as the oracle-loop tests of tests/test_noise_gpu.py): parameter update within 1e-3 relative L2 of the reference's at every
+    iteration (every 64th entry) and at the end (all entries) and within 4 x the reference's float32-vs-float64 gap + 1e-6; statistics
+    1e-3 relative; ring contents 1e-3."""
+    from mpg_amd.buffer import ReplayBuffer
+    from mpg_amd.learners import MPGLearner, NADPLearner
+    from mpg_amd.optimizer import SingleProcessOffPolicyOptimizer
+    from mpg_amd.policy import PolicyWithQs
+    from mpg_amd.worker import OffPolicyWorker
+    g = golden('loop_%s_ref.npz' % case)
+    names = [n for n, _, _ in NET_DIMS[case]]
+    args = _args(case, seed=int(g['seed']), max_buffer_size=8192)
+    assert (args.num_agent, args.batch_size, args.replay_batch_size, args.replay_starts) == ((8 if case == 'v2' else 1), 512, 256, 3000)
+    worker = OffPolicyWorker(PolicyWithQs, args.env_id, args, 0)
+    pw = worker.policy_with_value
+    w = loop_case_weights(case)
+    w0 = np.concatenate([w[n] for n in names])
+    pw.set_flat(w0, w0)
+    learner = (MPGLearner if case == 'v2' else NADPLearner)(PolicyWithQs, args)
+    rb = ReplayBuffer(args, 0)
+    opt = SingleProcessOffPolicyOptimizer(worker, learner, rb, None, args)            # sampling_interval 10: optimizer.py:331
+    assert opt._fused is not None and opt._fused.c.learner_version == (2 if case == 'v2' else 3)
+    assert len(rb) == int(g['fill'])
+    keys = [str(k) for k in g['stat_keys']]
+    worst = 0.0
+    for it in range(int(g['n_iter'])):
+        opt.step()
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(opt._fused.t['idx'].cpu().numpy(), g['idx'][it], err_msg='replay indices, iteration %d' % it)
+        assert [pw.opt_steps[n] for n in names] == list(g['opt_iterations'][it]), it
+        st = learner.get_stats()
+        for k, key in enumerate(keys):
+            if key in st:
+                got, ref = float(st[key]), float(g['stats'][it][k])
+                assert abs(got - ref) <= 1e-3 * abs(ref) + 1e-6, (it, key, got, ref)
+        p = pw.params.cpu().numpy()
+        e = rel_l2(p[::64] - w0[::64], g['params_sub'][it] - w0[::64])
+        worst = max(worst, e)
+        assert e <= 1e-3, (it, e)
+    n = int(g['ring_len'])
+    assert len(rb) == n and opt._fused.c.replay_times == int(g['replay_times']) and opt._fused.c.learner_counter == int(g['learner_counter'])
+    if case == 'v2':
+        assert [worker.env._ctr, worker._noise_ctr] == list(g['counters'][:2])
+    for k in ('obs', 'act') + (('obs2', 'rew') if case == 'v2' else ()):
+        ref = g['ring_' + k].reshape(n, -1)
+        got = getattr(rb, k)[:n].cpu().numpy().reshape(n, -1)
+        scale = np.maximum(1.0, np.abs(ref).max(0))
+        assert (np.abs(got - ref) / scale).max() <= 1e-3, k
+    p, t = pw.params.cpu().numpy(), pw.targets.cpu().numpy()
+    e_p, e_t = rel_l2(p - w0, g['params'] - w0), rel_l2(t - w0, g['targets'] - w0)
+    gap, mine = rel_l2((g['params'] - w0)[::4], g['update_f64']), rel_l2((p - w0)[::4], g['update_f64'])
+    print('%s device loop vs the reference optimizer, %d iterations: update %.2e (targets %.2e; worst sampled %.2e); vs float64 %.2e, '
+          'reference float32 %.2e' % (case, int(g['n_iter']), e_p, e_t, worst, mine, gap))
+    assert e_p <= 1e-3 and e_t <= 1e-3 and mine <= 4 * gap + 1e-6
+    pw.check_status()
