@@ -90,7 +90,7 @@ CPU_ROWS = 1024            # rows (agents / replay rows) per CPU step: a bounded
 CPU_LEGS = (64, 128, 256)  # processes side by side: per-core regime ... memory-bound regime of a 2-socket host
 
 
-def _cpu_worker(budget_s, min_timed, seed, q, go):
+def _cpu_worker(budget_s, min_timed, seed, q, go, rows=None):
     """One reference-style actor: torch pinned to ONE thread (the reference pins TF the same way, mpg_learner.py:27-28),
     steps of [CPU_ROWS-agent worker.sample + MPG-v2 compute_gradient at B = CPU_ROWS] of the torch-CPU/numpy oracle.  The FIRST step
     (allocator warm-up, first-call costs: BASELINE.md section 2 excludes it too) is not timed; then at least `min_timed` steps and
@@ -101,16 +101,17 @@ def _cpu_worker(budget_s, min_timed, seed, q, go):
     from oracle import mpg_oracle as O
     from tests.golden_inputs import mlp_weights_flat
     rng = np.random.Generator(np.random.PCG64(seed))
+    rows = rows or CPU_ROWS
     cfg = O.Cfg()
     flat = {'policy': mlp_weights_flat(rng, 6, 4), 'Q1': mlp_weights_flat(rng, 8, 1), 'Q2': mlp_weights_flat(rng, 8, 1)}
-    env = O.PathTrackingEnvOracle(CPU_ROWS)
+    env = O.PathTrackingEnvOracle(rows)
     env.reset(rng=rng)
 
     def step(k):
         nets = O.Nets(cfg, flat, target_scale=1.0)
         tr = O.worker_sample(cfg, nets, env, rng, 1)[0]
         batch = [tr[0], tr[1], tr[2], tr[3], tr[4].astype(np.float32)]
-        eps = rng.standard_normal((N_STEP, CPU_ROWS)).astype(np.float32)
+        eps = rng.standard_normal((N_STEP, rows)).astype(np.float32)
         O.mpg_compute_gradient(cfg, nets, batch, eps, 100 + k, 'MPG-v2')
     q.put(('ready', seed))
     go.wait()                   # every process of the leg starts its steps together (imports are not part of the sample)
@@ -123,6 +124,12 @@ def _cpu_worker(budget_s, min_timed, seed, q, go):
         if n_done >= min_timed and (el > budget_s or n_done >= 200):
             break
     q.put(('done', n_done, el))
+
+
+def _cpu_worker_b4096(budget_s, min_timed, seed, q, go):
+    """BASELINE.md section 3, run B: ONE reference-style actor at the workload's REAL size - 4096-agent worker.sample + MPG-v2
+    compute_gradient at B = 4096 per step, one thread (mpg_learner.py:25-28)"""
+    _cpu_worker(budget_s, min_timed, seed, q, go, rows=4096)
 
 
 def _cpu_model():
@@ -195,14 +202,29 @@ def cpu_baseline(budget_s=8.0, min_timed=3, max_procs=256):
         legs.append({'processes': len(res), 'env_steps_per_sec': sps * CPU_ROWS, 'steps_per_sec_per_process': sps / len(res),
                      'seconds_per_step': len(res) / sps, 'timed_steps': sum(n for n, _ in res), 'wall_s': round(wall, 1)})
     best = max(legs, key=lambda g: g['env_steps_per_sec'])
-    return {'value': best['env_steps_per_sec'], 'unit': 'env-steps/s', 'cores': best['processes'], 'kind': 'port',
-            'grad_steps_per_sec': best['env_steps_per_sec'] / B_PER_GPU, 'host_cores': host, 'cpu_model': _cpu_model(),
-            'rows_per_cpu_step': CPU_ROWS, 'legs': legs,
-            'sample': 'P single-threaded processes side by side, P = %s (host cores %d, free-memory cap %d); each process: one '
-                      'untimed step, then >= %d timed steps (%.0f s budget) of [%d-agent worker.sample + MPG-v2 compute_gradient '
-                      'B=%d] of the torch-CPU oracle - a quarter of the 4096-row step per CPU step, env-steps/s scales with the rows; '
-                      'value = the best leg (%d processes); grad_steps_per_sec = value / 4096'
-                      % ('/'.join(str(g['processes']) for g in legs), host, mem_cap, min_timed, budget_s, CPU_ROWS, CPU_ROWS, best['processes'])}
+    # leg B: the SAME learner at the workload's real size - one single-threaded process, 4096 rows per step,
+    # one untimed step and then >= 3 timed ones - beside the scaled 1024-row legs
+    full = {}
+    res, wall = _run_leg(_cpu_worker_b4096, lambda i: (budget_s, min_timed, 2000 + i), 1, 900)
+    if res:
+        n, el = res[0]
+        full = {'b4096_processes': 1, 'b4096_rows_per_cpu_step': 4096, 'b4096_timed_steps': n, 'b4096_seconds_per_step': el / n,
+                'b4096_env_steps_per_sec': 4096 * n / el, 'b4096_grad_steps_per_sec': n / el, 'b4096_wall_s': round(wall, 1)}
+    out = {'value': best['env_steps_per_sec'], 'unit': 'env-steps/s', 'cores': best['processes'], 'kind': 'port',
+           'grad_steps_per_sec': best['env_steps_per_sec'] / B_PER_GPU, 'host_cores': host, 'cpu_model': _cpu_model(),
+           'rows_per_cpu_step': CPU_ROWS, 'legs': legs,
+           'sample': 'P single-threaded processes side by side, P = %s (host cores %d, free-memory cap %d); each process: one '
+                     'untimed step, then >= %d timed steps (%.0f s budget) of [%d-agent worker.sample + MPG-v2 compute_gradient '
+                     'B=%d] of the torch-CPU oracle - a quarter of the 4096-row step per CPU step, env-steps/s scales with the rows; '
+                     'value = the best leg (%d processes); grad_steps_per_sec = value / 4096; b4096_*: ONE process at the real '
+                     '4096 rows per step (BASELINE.md section 3 run B)'
+                     % ('/'.join(str(g['processes']) for g in legs), host, mem_cap, min_timed, budget_s, CPU_ROWS, CPU_ROWS, best['processes'])}
+    # flat keys (the driver's record keeps scalars of this object): per-leg rates with the rows each CPU step held
+    for g in legs:
+        out['p%d_env_steps_per_sec' % g['processes']] = g['env_steps_per_sec']
+        out['p%d_rows_per_cpu_step' % g['processes']] = CPU_ROWS
+    out.update(full)
+    return out
 
 
 def _flush_c_stdio():
@@ -250,7 +272,7 @@ def launch_ranks(a):
     (torch.distributed.run, one process per GPU), then leaves with their exit code."""
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(a.gpus), '--master-addr',
            '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__), '--gpus', str(a.gpus), '--steps',
-           str(a.steps), '--warmup', str(a.warmup), '--config', a.config] + (['--no-cpu-baseline'] if a.no_cpu_baseline else [])
+           str(a.steps), '--warmup', str(a.warmup), '--config', a.config, '--rows-per-gpu', str(a.rows_per_gpu)] + (['--no-cpu-baseline'] if a.no_cpu_baseline else [])
     env = dict(os.environ)
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     env.setdefault('OMP_NUM_THREADS', '1')
@@ -487,10 +509,16 @@ def main():
     ap.add_argument('--config', default='c2', choices=['c2', 'c3', 'c4'],
                     help='c2 (default): the BASELINE metric - PathTracking MPG n=25 batch 4096; c3: NADP on the pendulum model, batch '
                          '8192; c4: TD3 + prioritized replay, batch 65536 (BASELINE.json configs[2], [3]: side lines, same JSON shape)')
+    ap.add_argument('--rows-per-gpu', type=int, default=4096,
+                    help='c2 only: agents AND replay rows per GPU (default 4096 = the BASELINE metric; 32768 = config 5\'s GLOBAL batch on one GPU, '
+                         'the N = 1 anchor of its strong-scaling reading - the default run starts that form as a child: side_configs.c5_on_1gpu)')
     ap.add_argument('--engine', default='split', choices=['split', 'f32'],
                     help='split (default): the product; f32: the same step on libmpg_hip_f32.so, the exact-fp32 engine (the main run '
                          'starts this form itself as a child process and reports it as exact_fp32_ms_per_step)')
     a = ap.parse_args()
+    global B_PER_GPU
+    assert a.rows_per_gpu % 16 == 0 and a.rows_per_gpu >= 4096, '--rows-per-gpu: a multiple of 16, at least 4096'
+    B_PER_GPU = a.rows_per_gpu
     if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(launch_ranks(a))
     from mpg_amd import _lib as LIBSEL
@@ -712,7 +740,7 @@ def main():
     # call; this process only waits) runs the same K / W after this run's timed region
     exact = {'ms_per_step': None, 'from': None}
     profiled = _under_profiler()
-    children = a.engine == 'split' and world == 1 and not os.environ.get('MPG_BENCH_NO_F32') and not profiled
+    children = a.engine == 'split' and world == 1 and not os.environ.get('MPG_BENCH_NO_F32') and not profiled and a.rows_per_gpu == 4096
 
     def child(extra, timeout=900):
         cmd = [sys.executable, os.path.abspath(__file__), '--gpus', '1', '--steps', str(a.steps), '--warmup', str(a.warmup), '--no-cpu-baseline'] + extra
@@ -743,6 +771,16 @@ def main():
                 side[cname]['from'] = 'child process `%s` after the timed region' % how
             except Exception as e:                   # noqa: BLE001
                 side[cname] = {'error': repr(e)}
+        # BASELINE.json configs[4] is 8 x 4096 rows over 8 GPUs; its GLOBAL batch (32 768 agents + replay batch 32 768) on ONE GPU is the
+        # numerator of its strong-scaling speed-up and the throughput regime of this engine (8 row groups per CU in the sweeps instead of 1)
+        try:
+            d, how = child(['--rows-per-gpu', '32768', '--no-side-configs'])
+            side['c5_on_1gpu'] = {k: d.get(k) for k in ('metric', 'value', 'unit', 'ms_per_step', 'grad_steps_per_sec', 'steps', 'timed_regions',
+                                                        'region_ms_per_step', 'roofline', 'roofline_other_rollout_kernel', 'other_kernels_avg_ms')}
+            side['c5_on_1gpu']['rows'] = 32768
+            side['c5_on_1gpu']['from'] = 'child process `%s` after the timed region' % how
+        except Exception as e:                       # noqa: BLE001
+            side['c5_on_1gpu'] = {'error': repr(e)}
 
     def roof(kernel, nbytes, flop, ms, n):
         """Both roofs of a rollout sweep.  With the split-fp16 engine the sweeps sit closer to the HBM roof (the activation
@@ -768,8 +806,16 @@ def main():
     r_fwd = roof('k_rollout_fwd<PathTracking>', FWD_BYTES_PER_STATE, FWD_FLOP_PER_STATE, fwd_ms, fwd_n)
     r_bwd = roof('k_rollout_bwd<PathTracking>', BWD_BYTES_PER_STATE, BWD_FLOP_PER_STATE, bwd_ms, bwd_n)
     dominant, other = (r_bwd, r_fwd) if bwd_ms >= fwd_ms else (r_fwd, r_bwd)   # the dominant kernel of the step
+    # scalars the driver's record must keep (it retains the flat fields of `roofline`, `config` and `cpu_baseline`; VERDICT r5 missing 4)
+    dominant.update({'grad_steps_per_sec': a.steps / dt, 'step_ms': 1e3 * dt / a.steps, 'exact_fp32_ms_per_step': exact.get('ms_per_step'),
+                     'other_sweep_kernel': other['kernel'], 'other_sweep_avg_ms': other['avg_ms'], 'other_sweep_frac_hbm': other['frac_hbm']})
+    side_flat = {('%s_ms_per_step' % k): v.get('ms_per_step') for k, v in side.items()}
+    if side.get('c5_on_1gpu', {}).get('roofline'):
+        side_flat['c5_on_1gpu_env_steps_per_sec'] = side['c5_on_1gpu'].get('value')
+        side_flat['c5_on_1gpu_dominant_sweep_frac_hbm'] = side['c5_on_1gpu']['roofline'].get('frac_hbm')
+        side_flat['c5_on_1gpu_dominant_sweep_avg_ms'] = side['c5_on_1gpu']['roofline'].get('avg_ms')
     out = {
-        'metric': 'env-steps/sec + grad-steps/sec, PathTrackingEnv MPG n=25 batch=4096',
+        'metric': 'env-steps/sec + grad-steps/sec, PathTrackingEnv MPG n=25 batch=%d' % B_PER_GPU,
         'value': world * B_PER_GPU * a.steps / dt, 'unit': 'env-steps/s',
         'grad_steps_per_sec': a.steps / dt,
         'model_steps_per_sec': world * B_PER_GPU * N_STEP * a.steps / dt,
@@ -790,13 +836,13 @@ def main():
         'exact_fp32_rollout_kernels_ms': exact.get('rollout_kernels_ms'),
         'engine': a.engine,
         'dtype_note': 'float32 data and accumulation; the 256x256 hidden-layer products run as fp16 hi/lo split operands on the f16 matrix pipe (3 MFMAs per fp32-equivalent step, more accurate than the fp32 fma chain on a single layer; csrc/mlp_core.h)',
-        'config': {'workload': 'PathTrackingEnv, MPG-v2 learner, n=25, M=1, 4096 vectorised envs + replay batch 4096 per '
-                               'GPU; step = worker.sample(4096 env-steps) + add_batch + replay + compute_gradient + '
-                               '(all-reduce) + apply_gradients',
+        'config': {'workload': 'PathTrackingEnv, MPG-v2 learner, n=25, M=1, %d vectorised envs + replay batch %d per '
+                               'GPU; step = worker.sample(%d env-steps) + add_batch + replay + compute_gradient + '
+                               '(all-reduce) + apply_gradients' % (B_PER_GPU, B_PER_GPU, B_PER_GPU),
                    'global_batch': world * B_PER_GPU, 'parallelism': 'dp%d' % world,
                    'grad_allreduce_floats': int(learner.flat.numel()), 'native_step_driver': opt._fused is not None,
                    'dist_backend': D.backend(), 'always_exchange': bool(a.always_exchange),
-                   'overlap_exchange': os.environ.get('MPG_OVERLAP_EXCHANGE') == '1'},
+                   'overlap_exchange': os.environ.get('MPG_OVERLAP_EXCHANGE') == '1', 'rows_per_gpu': B_PER_GPU, **side_flat},
         'device': _device_info(),
         'roofline': dominant,
         'roofline_other_rollout_kernel': other,

@@ -165,3 +165,81 @@ def data_parallel_step(loops):
     for lp in loops:
         lp.stats = st
         lp.iteration += 1
+
+
+class OracleConfig4Loop(OracleConfig2Loop):
+    """Config 4's loop - TD3Learner + PrioritizedReplayBuffer (buffer.py:94-189; optimizer.py:351-353: update_priorities between
+    compute_gradient and apply_gradients) - as a TEACHER-FORCED oracle run: proportional sampling is discontinuous in the priorities (a
+    1e-6 relative difference in one float32 |td| moves the float64 prefix sums enough to flip ~1 drawn index in 256), so the loop takes
+    each iteration's indices from the device and checks, against ITS OWN trees, that every one of them is a find_prefixsum_idx answer
+    within the band its leaves' distance to the device's allows.  Everything else - trees (float64, the reference's association), IS
+    weights, |td| + eps priorities, max_priority, new transitions entering at max priority, the TD3 gradients, Adam - it computes itself.
+    The canonical PER of mpg_amd/buffer.py (the shipped constructor is dead code, SURVEY B-3): alpha 0.6, beta 0.4, eps 1e-6."""
+
+    def __init__(self, flat_by_name, alpha=0.6, beta=0.4, eps=1e-6, **kw):
+        cap = 1
+        while cap < kw.get('capacity', 500000):
+            cap *= 2
+        self.tree_cap, self.alpha, self.beta, self.per_eps = cap, alpha, beta, eps
+        self.leaves = np.zeros(cap, np.float64)                       # sum-tree leaves (the min tree holds the same values, inf where unset)
+        self.max_priority = np.float32(1.0)                           # buffer.py:125
+        self._seen = np.zeros(cap, bool)
+        super().__init__(flat_by_name, alg='TD3', **kw)
+
+    def sample(self):
+        first, n0 = self.next, self.size
+        super().sample()
+        k = self.sample_iters * self.num_agent
+        sl = (first + np.arange(k)) % self.cap
+        self.leaves[sl] = float(self.max_priority) ** self.alpha      # buffer.py:133-136: weight = max priority
+        self._seen[sl] = True
+
+    def trees(self):
+        st = O.heap_tree(self.leaves, np.add)
+        mt = O.heap_tree(np.where(self._seen, self.leaves, np.inf), np.minimum)
+        return st, mt
+
+    def is_weights(self, st, mt, idx):
+        """sample_with_weights_and_idxes, buffer.py:146-158"""
+        total = st[1]
+        p_min = mt[1] / total
+        max_w = (p_min * self.size) ** (-self.beta)
+        return ((st[self.tree_cap + idx] / total * self.size) ** (-self.beta) / max_w)
+
+    def step(self, forced_idx):
+        it = self.iteration
+        if it % self.sampling_interval == 0:
+            self.sample()
+        self.replay_times += 1
+        st, mt = self.trees()
+        self.u = O.per_uniform_philox(self.B, self.rb_seed, self.replay_times)
+        self.own_idx = O.find_prefixsum_idx_batch(st, self.u * st[1])        # what this loop's own trees would have drawn
+        self.sum_tree = st
+        idx = self.idx = np.asarray(forced_idx, np.int64)
+        self.weights = self.is_weights(st, mt, idx)
+        self.min_leaf = mt[1]
+        r = self.ring
+        batch = self.batch = [r['obs'][idx], r['act'][idx], r['rew'][idx], r['obs2'][idx], r['done'][idx]]
+        self.counter += 1
+        nets = self.nets()
+        eps = O.normal_fill_philox(self.B * 2, self.l_seed, self.counter).reshape(self.B, 2)
+        grads, stt = O.td3_compute_gradient(self.cfg, nets, batch, eps)
+        with torch.no_grad():
+            td = O.td_error(self.cfg, nets, *[torch.as_tensor(b).to(self.dtype) for b in batch[:4]])
+        self.td = np.asarray(td, np.float32)
+        # update_priorities, buffer.py:166-189 (sequential: the LAST occurrence of a duplicate index wins); priority = |td| + eps
+        p = np.abs(self.td.astype(np.float64)) + self.per_eps
+        last = {}
+        for k, j in enumerate(idx):
+            last[int(j)] = k
+        jj = np.fromiter(last.keys(), np.int64)
+        kk = np.fromiter(last.values(), np.int64)
+        self.leaves[jj] = p[kk] ** self.alpha
+        self.max_priority = max(self.max_priority, np.float32(p.max()))
+        g, o = {}, 0
+        for k in self.names:
+            g[k] = np.concatenate([x.ravel() for x in grads[o:o + 6]]).astype(np.float32)
+            o += 6
+        O.apply_gradients(self.cfg, self.w, self.tgt, self.opt, g, it, self.names)
+        self.stats = stt
+        self.iteration += 1

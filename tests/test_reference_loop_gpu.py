@@ -99,7 +99,7 @@ def test_device_worker_sample_vs_reference_worker(golden):
     worker.policy_with_value.check_status()
 
 
-@pytest.mark.parametrize('case', ['v2', 'nadp'])
+@pytest.mark.parametrize('case', ['v2', 'nadp', 'nadp-ring-forced'])
 def test_device_loop_vs_reference_optimizer(golden, case):
     """The device's SingleProcessOffPolicyOptimizer (native step driver: mpg_step_begin / mpg_step_end) at the reference's defaults
     against the reference's own optimizer loop: 20 iterations, sampling at iterations 0 and 10.
@@ -108,12 +108,20 @@ def test_device_loop_vs_reference_optimizer(golden, case):
     Exact: ring length after the fill, replay indices of every iteration, optimizer counters, stream counters.
     Bars (as the oracle-loop tests of tests/test_noise_gpu.py): parameter update within 1e-3 relative L2 of the reference's at every
     iteration (every 64th entry) and at the end (all entries) and within 4 x the reference's float32-vs-float64 gap + 1e-6; statistics
-    1e-3 relative; ring contents 1e-3."""
+    1e-3 relative; ring contents 1e-3 (v2) - for the single-agent pendulum see the comment at the ring check.
+    nadp, free-running: the ONE agent's unstable trajectory amplifies float32 rounding differences between the device's RK4 and the
+    reference run's to 5e-3 in the stored states, so the minibatches differ at that level and so does the update (measured 8.6e-4): bar
+    2e-3, no float64 yard-stick (the reference's float32 and float64 runs share one float32 environment, the device cannot).
+    nadp-ring-forced: the same run with the reference's transitions written over the device's after the fill and after each sampling
+    iteration (the learner side on identical data; the two sampling iterations themselves still draw ~14 % device rows): the update
+    then has to agree like the path-tracking loop's does."""
     from mpg_amd.buffer import ReplayBuffer
     from mpg_amd.learners import MPGLearner, NADPLearner
     from mpg_amd.optimizer import SingleProcessOffPolicyOptimizer
     from mpg_amd.policy import PolicyWithQs
     from mpg_amd.worker import OffPolicyWorker
+    forced = case.endswith('-ring-forced')
+    case = case.split('-')[0]
     g = golden('loop_%s_ref.npz' % case)
     names = [n for n, _, _ in NET_DIMS[case]]
     args = _args(case, seed=int(g['seed']), max_buffer_size=8192)
@@ -130,9 +138,19 @@ def test_device_loop_vs_reference_optimizer(golden, case):
     assert len(rb) == int(g['fill'])
     keys = [str(k) for k in g['stat_keys']]
     worst = 0.0
+
+    def force_ring():
+        m = len(rb)
+        for k in ('obs', 'act', 'rew', 'obs2'):
+            getattr(rb, k)[:m].copy_(torch.as_tensor(g['ring_' + k][:m]).reshape(getattr(rb, k)[:m].shape))
+    if forced:
+        force_ring()
+    tol_u = 2e-3 if (case == 'nadp' and not forced) else 1e-3
     for it in range(int(g['n_iter'])):
         opt.step()
         torch.cuda.synchronize()
+        if forced and it % 10 == 0:
+            force_ring()
         np.testing.assert_array_equal(opt._fused.t['idx'].cpu().numpy(), g['idx'][it], err_msg='replay indices, iteration %d' % it)
         assert [pw.opt_steps[n] for n in names] == list(g['opt_iterations'][it]), it
         st = learner.get_stats()
@@ -143,20 +161,36 @@ def test_device_loop_vs_reference_optimizer(golden, case):
         p = pw.params.cpu().numpy()
         e = rel_l2(p[::64] - w0[::64], g['params_sub'][it] - w0[::64])
         worst = max(worst, e)
-        assert e <= 1e-3, (it, e)
+        assert e <= tol_u, (it, e)
     n = int(g['ring_len'])
     assert len(rb) == n and opt._fused.c.replay_times == int(g['replay_times']) and opt._fused.c.learner_counter == int(g['learner_counter'])
     if case == 'v2':
         assert [worker.env._ctr, worker._noise_ctr] == list(g['counters'][:2])
+    # ring contents.  v2: every agent is re-drawn after every step, so a row is ONE env step from a Philox draw: 1e-3 relative to the
+    # column scale.  nadp: ONE agent runs on until it falls (DummyVecEnv resets only when done), i.e. a row sits up to ~60 steps down an
+    # UNSTABLE trajectory (upright pole: perturbations grow ~e^(5 t), 0.04 s per step), where float32 rounding differences between the
+    # device's RK4 and the reference run's reach 5e-3: the trajectory bar is 2e-2 absolute, and every stored transition is checked one step
+    # at a time against the float64 cart-pole from the DEVICE's own (obs, act) at 2e-5 - the amplification-free statement.
+    tol = 1e-3 if case == 'v2' else 2e-2
     for k in ('obs', 'act') + (('obs2', 'rew') if case == 'v2' else ()):
         ref = g['ring_' + k].reshape(n, -1)
         got = getattr(rb, k)[:n].cpu().numpy().reshape(n, -1)
         scale = np.maximum(1.0, np.abs(ref).max(0))
-        assert (np.abs(got - ref) / scale).max() <= 1e-3, k
+        assert (np.abs(got - ref) / scale).max() <= tol, k
+    if case == 'nadp':
+        from oracle import mpg_oracle as O
+        env = O.InvertedPendulumContiOracle(n, dtype=np.float64)
+        env.reset(init_obs=rb.obs[:n].cpu().numpy().astype(np.float64))
+        nxt = env.step(rb.act[:n].cpu().numpy().astype(np.float64))[0]
+        np.testing.assert_allclose(rb.obs2[:n].cpu().numpy(), nxt, rtol=2e-5, atol=2e-5)
     p, t = pw.params.cpu().numpy(), pw.targets.cpu().numpy()
     e_p, e_t = rel_l2(p - w0, g['params'] - w0), rel_l2(t - w0, g['targets'] - w0)
     gap, mine = rel_l2((g['params'] - w0)[::4], g['update_f64']), rel_l2((p - w0)[::4], g['update_f64'])
     print('%s device loop vs the reference optimizer, %d iterations: update %.2e (targets %.2e; worst sampled %.2e); vs float64 %.2e, '
           'reference float32 %.2e' % (case, int(g['n_iter']), e_p, e_t, worst, mine, gap))
-    assert e_p <= 1e-3 and e_t <= 1e-3 and mine <= 4 * gap + 1e-6
+    assert e_p <= tol_u and e_t <= tol_u
+    if case == 'v2':
+        assert mine <= 4 * gap + 1e-6
+    elif forced:                # (two of the twenty minibatches still hold ~14 % device-made rows; measured: update 4.9e-6, 1.46e-5 from the
+        assert e_p <= 2e-4 and mine <= 4 * gap + 1e-6, (e_p, mine, gap)        # float64 run against the reference float32 run's 1.43e-5)
     pw.check_status()
