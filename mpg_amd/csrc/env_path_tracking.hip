@@ -559,6 +559,38 @@ __global__ void __launch_bounds__(64) k_step_store_reset(int n, float* __restric
     ENV_TL(8);
 }
 
+// The same launch with ONE lane per agent (step_agent, like k_step): the four-lane form above buys latency at 4096 agents (256 waves
+// instead of 64 on 256 CUs) at the price of ~2.3x the instructions per agent; from MPG_ENV_ONE_LANE_FROM agents on the chip is full either
+// way and the instruction count is what is left (2^20 agents: 264 us four-lane against k_step's 61).  step_agent and step_agent_quad
+// perform the same float32 operations on the same operands in the same order per variable, so the two forms are bit-identical
+// (tests/test_env_gpu.py compares fused and separate calls at both sizes).
+constexpr int MPG_ENV_ONE_LANE_FROM = 65536;
+__global__ void __launch_bounds__(64) k_step_store_reset_1(int n, float* __restrict__ st, const float* __restrict__ action,
+                                                           RingPtrs ring, int capacity, int next_idx, uint32_t k0, uint32_t k1,
+                                                           uint32_t c1, uint32_t c2, float* __restrict__ obs_out,
+                                                           uint8_t* __restrict__ done_out, int od, PreDraw pd) {
+    if (pd.rows > 0 && (int)blockIdx.x >= pd.env_blocks) {
+        const int gr = ((int)blockIdx.x - pd.env_blocks) * 64 + threadIdx.x;
+        if (gr < pd.rows) predraw_row(pd, ring, capacity, next_idx, n, gr);
+        return;
+    }
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Agent ag = load_agent(st, n, i);
+    const float2 an = reinterpret_cast<const float2*>(action)[i];
+    const size_t slot = (size_t)((next_idx + i) % capacity);
+    write_obs(ring.obs, (int)slot, od, ag);                     // obs before the step
+    reinterpret_cast<float2*>(ring.act)[slot] = an;
+    const StepOut o = step_agent(ag, an);
+    write_obs(ring.obs2, (int)slot, od, ag);
+    ring.rew[slot] = o.reward;
+    ring.done[slot] = o.done ? 1 : 0;
+    if (done_out) done_out[i] = o.done ? 1 : 0;
+    if (o.done) reset_agent(ag, i, k0, k1, c1, c2);
+    store_agent(st, n, i, ag);
+    write_obs(obs_out, i, od, ag);
+}
+
 // OffPolicyWorker.sample's whole inner body (worker.py:95-112) in ONE launch: the policy pass of a 16-agent group by a 512-thread
 // workgroup, then env.step -> ring -> env.reset of those 16 agents by the four-lane form on wave 0 (k_step_store_reset's body).  The
 // stand-alone pair is two launches of one wave per CU each (7 + 14 us at 4096 agents); fused, the env lanes start the moment their
@@ -653,7 +685,16 @@ int step_store_reset_impl(int env_kind, int n, int obs_dim, float* state, const 
     MPG_REQUIRE(pt_obs_dim_ok(obs_dim), "mpg_env_step_store_reset: obs_dim");
     RingPtrs ring{ring_obs, ring_act, ring_rew, ring_obs2, ring_done};
     PreDraw pd = pd_in;
-    pd.env_blocks = (4 * n + 63) / 64;            // four lanes per agent
+    if (n >= MPG_ENV_ONE_LANE_FROM) {             // one lane per agent: the throughput form
+        pd.env_blocks = (n + 63) / 64;
+        const int blocks1 = pd.env_blocks + (pd.rows + 63) / 64;
+        hipLaunchKernelGGL(k_step_store_reset_1, dim3(blocks1), dim3(64), 0, mpg_stream(stream), n, state, action, ring,
+                           capacity, next_idx, (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)ctr, (uint32_t)(ctr >> 32), obs_out,
+                           done_out, obs_dim, pd);
+        MPG_CHECK_LAUNCH("mpg_env_step_store_reset");
+        return MPG_OK;
+    }
+    pd.env_blocks = (4 * n + 63) / 64;            // four lanes per agent: the latency form
     const int blocks = pd.env_blocks + (pd.rows + 63) / 64;
     hipLaunchKernelGGL(k_step_store_reset, dim3(blocks), dim3(64), 0, mpg_stream(stream), n, state, action, ring,
                        capacity, next_idx, (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)ctr, (uint32_t)(ctr >> 32), obs_out,

@@ -29,7 +29,10 @@ def _init(rank, world, port):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
                       HSA_ENABLE_IPC_MODE_LEGACY='0')
     from mpg_amd import dist as D
-    torch.cuda.set_device(0)
+    # MPG_TEST_RANK_PER_DEVICE=1 (tools/first_8gpu.sh, on a multi-GPU node): rank r on device r - the same tests with real peers
+    # (IPC mappings and events across devices, copies over xGMI); default: every rank time-shares device 0 (the 1-GPU box)
+    per_dev = os.environ.get('MPG_TEST_RANK_PER_DEVICE') == '1' and torch.cuda.device_count() > 1
+    torch.cuda.set_device(rank % torch.cuda.device_count() if per_dev else 0)
     D.init_from_env(backend=os.environ.get('MPG_DIST_BACKEND', 'gloo'))
     return D
 

@@ -107,11 +107,13 @@ def test_env_25_step_rollout_stays_finite_and_matches_oracle_loosely():
     assert (full[:, 0] >= 1).all() and (full[:, 0] <= 35).all()
 
 
-def test_fused_step_store_reset_equals_separate_calls():
-    """mpg_env_step_store_reset == mpg_env_step + mpg_replay_add + mpg_env_reset, bit for bit, incl. a wrapping ring."""
+@pytest.mark.parametrize('n,cap,nxt', [(300, 1000, 850), (70001, 100000, 60000)])
+def test_fused_step_store_reset_equals_separate_calls(n, cap, nxt):
+    """mpg_env_step_store_reset == mpg_env_step + mpg_replay_add + mpg_env_reset, bit for bit, incl. a wrapping ring (850 + 300 and
+    60 000 + 70 001 wrap).  n = 70 001: from 65 536 agents on the launch takes its ONE-LANE-per-agent form (k_step_store_reset_1, round 6:
+    the four-lane form is built for 4096-agent latency) - the same bits by the same comparison."""
     import mpg_amd._lib as L
     from mpg_amd.envs import PathTrackingEnv
-    n, cap, nxt = 300, 1000, 850                      # 850 + 300 wraps around the ring
     rng = np.random.Generator(np.random.PCG64(3))
     act = torch.as_tensor(rng.uniform(-1.2, 1.2, (n, 2)).astype(np.float32)).cuda()
     env_a, env_b = PathTrackingEnv(num_agent=n, seed=9), PathTrackingEnv(num_agent=n, seed=9)
