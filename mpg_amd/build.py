@@ -17,7 +17,7 @@ LIB = os.path.join(HERE, 'libmpg_hip.so')
 VARIANTS = {'split': (OBJ, LIB, []), 'f32': (os.path.join(HERE, 'build_f32'), os.path.join(HERE, 'libmpg_hip_f32.so'), ['-DMPG_F32_MFMA'])}
 ARCH = os.environ.get('MPG_ARCH', 'gfx950')      # MPG_ARCH=gfx950:xnack- for experiments
 
-# MPG_EXTRA_CFLAGS: ablation / diagnostic builds only (e.g. -DMPG_AB_NODYN); never set in the product build
+# MPG_EXTRA_CFLAGS: ablation / diagnostic builds only (the experiment branches of archive/proto/ablation_macros.patch, -DMPG_STAMP, -DMPG_TIMELINE); never set in the product build
 COMMON = os.environ.get('MPG_EXTRA_CFLAGS', '').split() + ['-O3', '-fPIC', '-std=c++17', '--offload-arch=' + ARCH, '-Wall', '-Wno-unused-function', '-Wno-bitwise-instead-of-logical',
           # a private array the optimiser cannot keep in registers must not be moved to LDS: the LDS copy is addressed by the
           # flattened thread id, whose workgroup size the code then reads from the dispatch packet in HOST memory
@@ -25,7 +25,7 @@ COMMON = os.environ.get('MPG_EXTRA_CFLAGS', '').split() + ['-O3', '-fPIC', '-std
           '-mllvm', '-disable-promote-alloca-to-lds',
           # no SLP vectorizer anywhere: it is what forms v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 out of scalar float32 code, and
           # single products of such packed FMAs were lost nondeterministically beside matrix instructions ("lost
-          # packed-FMA products"; reproducible at 99.5 % of launches with -DMPG_AB_PKFMA).  With it off no kernel that issues MFMAs
+          # packed-FMA products"; reproducible at 99.5 % of launches with the packed-FMA experiment branch).  With it off no kernel that issues MFMAs
           # contains a packed fp32 instruction (tools/pk_census.py; tests/test_abi.py keeps it so).  Cost, same-box A/B of the bench
           # step (round 4): 0.2432 against 0.2400 / 0.2428 ms for the two baselines around it - inside the noise.
           '-fno-slp-vectorize',
@@ -42,7 +42,7 @@ EXTRA = {'env_path_tracking.hip': ['-ffp-contract=off'] + os.environ.get('MPG_EN
          'rollout_fwd.hip': os.environ.get('MPG_FWD_CFLAGS', '-mllvm -amdgpu-sched-strategy=iterative-ilp').split(),
          # experiments only (tools/ab_flags.sh): per-file flags of the other two engine translation units
          'fused_kernels.hip': os.environ.get('MPG_FUSED_CFLAGS', '').split(),
-         # (-DMPG_TR_IMAGE here - the transposed activation image for k_forward / k_backward only - measured k_forward -3.5 %, the TD3 step
+         # (the transposed-image experiment branch here - the transposed activation image for k_forward / k_backward only - measured k_forward -3.5 %, the TD3 step
          # at B = 65 536 0.896 -> 0.881 ms, null on the bench step (tools/ab_tr_files.sh, round 5); NOT shipped: its v_fma_mixhi_f16 forms
          # carry a low op_sel bit, which the containment rule of tests/test_abi.py keeps out of the shipped ISA altogether)
          'mlp_kernels.hip': os.environ.get('MPG_MLP_CFLAGS', '').split(),

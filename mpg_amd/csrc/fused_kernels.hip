@@ -21,11 +21,7 @@ __device__ __forceinline__ void load_w2(const float* pack, const float* W2, bool
 // order of a phase's loads: the small per-lane pieces first, so that layer 1 and its barrier run while the 256 KB
 // register image is still streaming in (the vector-memory counter retires in order)
 #define MPG_UNPAREN(...) __VA_ARGS__
-#ifdef MPG_AB_IMAGE_FIRST
-#define MPG_LOAD2(SMALL, IMAGE) do { MPG_UNPAREN IMAGE; MPG_UNPAREN SMALL; } while (0)
-#else
 #define MPG_LOAD2(SMALL, IMAGE) do { MPG_UNPAREN SMALL; MPG_UNPAREN IMAGE; } while (0)
-#endif
 
 
 constexpr int SMEM_FLOATS = 2 * A_IMG + GROUP * XS + NWAVE * GROUP * MAXOUT + GROUP * MAXOUT + NWAVE * GROUP * XS + 4 * GROUP;
@@ -512,16 +508,6 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_critic_fused(const CriticArgs ca
     }
     // ---- forward: the two slices (Q1 workgroups only; wave-uniform branch) ----
     if (slices) {
-#ifdef MPG_AB_CRITIC_SLICES_SEQ      // A/B: the two slices one after the other
-#pragma unroll
-        for (int sl = 0; sl < 2; ++sl) {
-            forward_group<QIN, 1>(sX2 + sl * GROUP * XS, m.sA, m.sPart, L, w2, r, h1[1 + sl], h2[1 + sl], nullptr, 0, nullptr, &zmax);
-            if (tid < GROUP) {
-                sQ2[sl * GROUP + tid] = gk_in[sl] + q.gpow[sl] * out_preact(m.sPart, b3v, tid, 0);   // mpg_learner.py:266
-                sD32[sl * GROUP * MAXOUT + d3_index(tid, 0)] = q.coef[sl];
-            }
-        }
-#else
         // the two slices as a pair behind one pair of barriers (forward_group2: the same arithmetic per group).  m.sPart of the
         // batch group was read by its 16 output lanes above, in front of the barriers inside
         forward_group2<QIN, 1>(sX2, sX2 + GROUP * XS, m.sA, m.sA1, m.sPart, m.sPartX, L, w2, r, h1[1], h2[1], h1[2], h2[2], &zmax);
@@ -532,7 +518,6 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_critic_fused(const CriticArgs ca
                 sD32[sl * GROUP * MAXOUT + d3_index(tid, 0)] = q.coef[sl];
             }
         }
-#endif
     }
     MPG_TL(4);
     report_activation_range(a.status, zmax);
@@ -749,7 +734,7 @@ __global__ void __launch_bounds__(NTHREAD, MPG_WGM_WAVES) k_wgrad_multi(const Wg
     constexpr int NQA = wgrad_nq<IA, OA>(), NQB = wgrad_nq<IB, OB>();
     __shared__ __attribute__((aligned(16))) float sRed[NWAVE * (NQA > NQB ? NQA : NQB) * 64];
     int gchunk, sl;
-#if defined(MPG_SPLIT) && !defined(MPG_AB_WG_ONE_ROLE)
+#if defined(MPG_SPLIT)
     // Two kinds of workgroup (round 4): the first third of the grid takes dW2 in 64-COLUMN slices (four workgroups per chunk re-read
     // the chunk's H1 through L2 instead of eight: mlp_wgrad.h NT = 4), the other two thirds the thin pieces of the (chunk, 32-column
     // slice) pairs - a chain of load round trips that used to run as a tail behind every matrix loop.  12 workgroups per chunk,
@@ -768,7 +753,7 @@ __global__ void __launch_bounds__(NTHREAD, MPG_WGM_WAVES) k_wgrad_multi(const Wg
     const int chunk = gchunk - m.chunk_off[j];
     MPG_TL_DECL
     MPG_TL(0);
-#if defined(MPG_SPLIT) && !defined(MPG_AB_WG_ONE_ROLE)
+#if defined(MPG_SPLIT)
     if (role == 1) {
         if (m.type[j] == 0) wgrad_body<IA, OA, 1, 4>(m.a[j], sl, chunk, sRed);
         else wgrad_body<IB, OB, 1, 4>(m.a[j], sl, chunk, sRed);
@@ -1071,7 +1056,7 @@ int launch_wgrad_multi(const mpg_cfg_t* cfg, const WgradJob* jobs, int n_jobs, c
     m.chunk0 = chunk0;
     if (phases & 1) {
     mpg_prof_begin(mpg_prof_of(cfg), 5, s);
-#if defined(MPG_SPLIT) && !defined(MPG_AB_WG_ONE_ROLE)
+#if defined(MPG_SPLIT)
     const int wg_per_chunk = 12;          // 4 matrix (64-column slices) + 8 thin (32-column slices)
 #else
     const int wg_per_chunk = 8;

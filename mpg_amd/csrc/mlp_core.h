@@ -63,25 +63,8 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 // group holds each row once: MI355X_MICROARCH.md §LDS), the writer's ds_write_b32 pairs are 2-way (free).  Two images: hi, lo.
 constexpr int ROW_H = 72, PLANE_H = GROUP * ROW_H, IMG_H = 4 * PLANE_H;      // 4608 halves = 9216 B per image
 __device__ __forceinline__ int h_index(int row, int k) { return ((k >> 3) & 3) * PLANE_H + row * ROW_H + 8 * (k >> 5) + (k & 7); }
-// TRANSPOSED activation image (round 4; the ping-pong kernels of mlp_pingpong.hip always use it, the lock-step engine with
-// -DMPG_TR_IMAGE - an A/B variant that measured null on the rollout sweeps): one 32-byte slot per contraction index k holding the group's 16 rows as fp16, rows
-// contiguous - what a C-layout lane owns (rows 4 rg .. 4 rg + 3 of ONE column) is one aligned 8-byte chunk, so the image store
-// is ONE ds_write_b64 per tile and image: no DPP exchange with the neighbouring column, no selects.  The MFMA A operand (row
-// l & 15, 8 consecutive k) comes back through ds_read_b64_tr_b16, gfx950's transposing LDS read (two reads of 4 k each per
-// operand; EXEC is all ones wherever the engine runs).  Slot order inside a k-block and an XOR on the chunk position make the
-// stores (the 16 lanes of a row quad) and the transposed reads (32-lane halves) bank-conflict free with no padding:
-//   k = 32 kb + 8 g + j  ->  slot = 32 kb + 16 (g >> 1) + 8 (j >> 2) + 4 (g & 1) + (j & 3),   chunk' = chunk ^ ((slot >> 2) & 3)
-// Same values as the row-major image (hi = fp16(16 x), lo = fp16(16 x - hi)): results are bit-identical.
-constexpr int TR_IMG_BYTES = 256 * 32;            // one image (hi or lo): 8 KB
-__device__ __forceinline__ int tr_slot(int k) { const int g = (k >> 3) & 3, j = k & 7; return (k & ~31) + 16 * (g >> 1) + 8 * (j >> 2) + 4 * (g & 1) + (j & 3); }
-__device__ __forceinline__ int tr_byte(int slot, int chunk) { return slot * 32 + 8 * (chunk ^ ((slot >> 2) & 3)); }
-// (a, b) -> packed fp16 words of a * S = hi + lo: two v_fma_mix per word do scale, conversion and packing at once
-__device__ __forceinline__ void split2_mix(float a, float b, float S, unsigned& hi, unsigned& lo) {
-    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hi) : "v"(a), "v"(S));
-    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hi) : "v"(b), "v"(S));
-    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(lo) : "v"(a), "v"(S), "v"(hi));
-    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lo) : "v"(b), "v"(S), "v"(hi));
-}
+// (A TRANSPOSED image read back through ds_read_b64_tr_b16 was built in round 4 and measured null on the sweeps: it lives in
+// archive/proto/ablation_macros.patch with the other experiment branches.)
 typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 constexpr float W_SCALE = 64.f;          // stationary weights are stored as W * 64
@@ -154,11 +137,9 @@ struct Lane {
 // arbitration, leaves each matrix block last and is the one the step's barriers wait for.  One s_setprio for waves 4..7 at
 // kernel entry (never flipped) evens the pair out: reverse sweep 81.9 -> 80.6 us, forward sweep 65.3 -> 64.8 us
 // (tools/ab_scale.sh; levels 3 for the young half or 1 for the OLD half are slower; in the critic / target / network kernels
-// it made no difference or a negative one and is not used).  -DMPG_AB_NO_PRIO: A/B build without it.
+// it made no difference or a negative one and is not used).
 __device__ __forceinline__ void prefer_young_waves() {
-#ifndef MPG_AB_NO_PRIO
     if (threadIdx.x >= 256) __builtin_amdgcn_s_setprio(1);
-#endif
 }
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding GLOBAL store
@@ -205,10 +186,6 @@ __device__ __forceinline__ float elu(float z) { return __builtin_amdgcn_fmed3f(z
 // chains keep the quarter-rate exp pipe busy; element by element through one temporary - what the scheduler picks at
 // this register pressure - every v_exp_f32 is followed by a hazard wait
 __device__ __forceinline__ void elu8(const f32x4& z0, const f32x4& z1, float (&h)[2][4]) {
-#ifdef MPG_AB_NO_ELU8
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { h[0][j] = elu(z0[j]); h[1][j] = elu(z1[j]); }
-#else
     float e[8];
 #pragma unroll
     for (int j = 0; j < 4; ++j) { e[j] = z0[j] * 1.4426950408889634f; e[4 + j] = z1[j] * 1.4426950408889634f; }
@@ -224,7 +201,6 @@ __device__ __forceinline__ void elu8(const f32x4& z0, const f32x4& z1, float (&h
         h[0][j] = __builtin_amdgcn_fmed3f(z0[j], e[j], 0.f);
         h[1][j] = __builtin_amdgcn_fmed3f(z1[j], e[4 + j], 0.f);
     }
-#endif
 }
 
 // ELU'(z) expressed through the stored output h = ELU(z): 1 for z > 0, exp(z) = h + 1 in (0, 1] otherwise, i.e. the
@@ -279,24 +255,6 @@ __device__ __forceinline__ void store_c_to_a_f32(float* sA, const Lane& L, const
 // of each tile; columns c and c^1 are adjacent k, so the pair of lanes exchanges values through one DPP quad_perm and each
 // lane writes packed (k even, k odd) words: even lanes the rows j = 0,1, odd lanes the rows j = 2,3 - 8 ds_write_b32 per
 // lane like the float32 image, and the reader's 8 consecutive k are one aligned 16-byte read per image.
-#ifdef MPG_TR_IMAGE
-__device__ __forceinline__ void store_c_to_a(float* sA, const Lane& L, const float (&v)[2][4]) {
-    char* img = reinterpret_cast<char*>(sA);
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        unsigned h01, l01, h23, l23;
-        split2_mix(v[t][0], v[t][1], A_SCALE, h01, l01);
-        split2_mix(v[t][2], v[t][3], A_SCALE, h23, l23);
-        const int byte = tr_byte(tr_slot(32 * L.wave + 16 * t + L.c), L.rg);
-#ifdef MPG_AB_NO_IMGWRITE
-        asm volatile("" :: "v"(h01), "v"(l01), "v"(h23), "v"(l23));
-#else
-        *reinterpret_cast<u32x2*>(img + byte) = u32x2{h01, h23};
-        *reinterpret_cast<u32x2*>(img + TR_IMG_BYTES + byte) = u32x2{l01, l23};
-#endif
-    }
-}
-#else
 __device__ __forceinline__ void store_c_to_a(float* sA, const Lane& L, const float (&v)[2][4]) {
     _Float16* sH = reinterpret_cast<_Float16*>(sA);
     const bool odd = L.c & 1;
@@ -312,16 +270,11 @@ __device__ __forceinline__ void store_c_to_a(float* sA, const Lane& L, const flo
             const float x = odd ? p[2 + u] : v[t][u], y = odd ? v[t][2 + u] : p[u];   // (k even, k odd) of row row0 + u
             float hi, lo;
             split_pack2(x * A_SCALE, y * A_SCALE, hi, lo);
-#ifdef MPG_AB_NO_IMGWRITE   // ablation build (tools/lds_conflicts.sh): the image stores are dropped, their operands kept alive
-            asm volatile("" :: "v"(hi), "v"(lo));
-#else
             *reinterpret_cast<float*>(sH + h_index(row0 + u, k)) = hi;
             *reinterpret_cast<float*>(sH + IMG_H + h_index(row0 + u, k)) = lo;
-#endif
         }
     }
 }
-#endif   // MPG_TR_IMAGE
 #else
 __device__ __forceinline__ void store_c_to_a(float* sA, const Lane& L, const float (&v)[2][4]) { store_c_to_a_f32(sA, L, v); }
 #endif
@@ -364,44 +317,12 @@ __device__ __forceinline__ void load_w2_bwd(const float* __restrict__ W2, const 
 // tried the eight waves' blocks INTERLEAVED (v * 8 + wave: the eight streams of a CU then read consecutive blocks instead of sitting
 // 32 KB apart) - it is SLOWER: bench step 0.2305 -> 0.2423 ms, the worker launch 21.4 -> 30.4 us; runs of 2 / 4 KB and a per-wave phase
 // shift: within the noise; runs of 8 KB: forward sweep -0.9 us three times out of three, the step within the noise (tools/ab_img.sh).
-#ifndef MPG_IMG_LAYOUT
-#ifdef MPG_IMG_INTERLEAVE
-#define MPG_IMG_LAYOUT 1
-#else
-#define MPG_IMG_LAYOUT 0
-#endif
-#endif
-// MPG_IMG_LAYOUT (experiments, tools/ab_img.sh): 0 one 32 KB run per wave (shipped); 1 blocks of the eight waves interleaved (1 KB runs);
-// 2 / 3 / 4: 2 / 4 / 8 KB runs; 5: 32 KB runs, every wave starting 4 KB further into its run (v ^ 4 wave)
+// (the other layouts: archive/proto/ablation_macros.patch)
 __host__ __device__ constexpr int img_slot(int wave, int v) {
-#if MPG_IMG_LAYOUT == 1
-    return v * 8 + wave;
-#elif MPG_IMG_LAYOUT == 2
-    return (v >> 1) * 16 + wave * 2 + (v & 1);
-#elif MPG_IMG_LAYOUT == 3
-    return (v >> 2) * 32 + wave * 4 + (v & 3);
-#elif MPG_IMG_LAYOUT == 4
-    return (v >> 3) * 64 + wave * 8 + (v & 7);
-#elif MPG_IMG_LAYOUT == 5
-    return wave * 32 + (v ^ ((wave * 4) & 31));
-#else
     return wave * 32 + v;
-#endif
 }
 __host__ __device__ inline void img_unslot(int slot, int& wave, int& v) {
-#if MPG_IMG_LAYOUT == 1
-    v = slot >> 3; wave = slot & 7;
-#elif MPG_IMG_LAYOUT == 2
-    v = (slot >> 4) * 2 + (slot & 1); wave = (slot >> 1) & 7;
-#elif MPG_IMG_LAYOUT == 3
-    v = (slot >> 5) * 4 + (slot & 3); wave = (slot >> 2) & 7;
-#elif MPG_IMG_LAYOUT == 4
-    v = (slot >> 6) * 8 + (slot & 7); wave = (slot >> 3) & 7;
-#elif MPG_IMG_LAYOUT == 5
-    wave = slot >> 5; v = (slot & 31) ^ ((wave * 4) & 31);
-#else
     wave = slot >> 5; v = slot & 31;
-#endif
 }
 // Same register images from the pre-packed copy kept by the weight cache (weight_cache.hip): 16-byte word index
 // img_slot(wave, v)*64 + lane holds w[4v .. 4v+3] -> 32 fully coalesced 1 KiB loads per wave.
@@ -459,36 +380,14 @@ __device__ __forceinline__ void mfma_16x256x32(const float* sA, const Lane& L, c
                                                f32x4& acc1) {
     const _Float16* bh = reinterpret_cast<const _Float16*>(sA) + L.rg * PLANE_H + L.c * ROW_H;   // hi image: row l&15, k = 8 (l>>4) + ..
     const _Float16* bl = bh + IMG_H;                                                             // lo image
-#ifdef MPG_AB_NOMFMA   // ablation build: one k-block instead of 8 (timing only)
-    constexpr int NKB = 1;
-#else
     constexpr int NKB = 8;
-#endif
     auto frag = [&](int v) {
         return __builtin_bit_cast(f16x8, f32x4{w[4 * v], w[4 * v + 1], w[4 * v + 2], w[4 * v + 3]});
     };
     f32x4 m0 = {0.f, 0.f, 0.f, 0.f}, m1 = m0;
-#ifdef MPG_TR_IMAGE
-    // lane 4 q' + p' of its 16-lane group supplies block row q' (k = 32 kb + 8 rg + q', + 4 for the second read), chunk p'
-    typedef __attribute__((address_space(3))) s16x4* lds_p;
-    const char* img = reinterpret_cast<const char*>(sA);
-    const int s0 = 16 * (L.rg >> 1) + 4 * (L.rg & 1) + ((L.lane >> 2) & 3);
-    const char* t0 = img + tr_byte(s0, L.lane & 3);
-    const char* t1 = img + tr_byte(s0 + 8, L.lane & 3);
-    (void)bh; (void)bl;
-#endif
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
-#ifdef MPG_TR_IMAGE
-        const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(t0 + 1024 * kb));
-        const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(t1 + 1024 * kb));
-        const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(t0 + TR_IMG_BYTES + 1024 * kb));
-        const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(t1 + TR_IMG_BYTES + 1024 * kb));
-        const f16x8 ah = __builtin_bit_cast(f16x8, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
-        const f16x8 al = __builtin_bit_cast(f16x8, __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
-#else
         const f16x8 ah = *reinterpret_cast<const f16x8*>(bh + 8 * kb), al = *reinterpret_cast<const f16x8*>(bl + 8 * kb);
-#endif
         const int v0 = (kb * 2 + 0) * 2, v1 = (kb * 2 + 1) * 2;
         m0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, frag(v0), m0, 0, 0, 0);
         m1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, frag(v1), m1, 0, 0, 0);
@@ -508,11 +407,7 @@ __device__ __forceinline__ void mfma_16x256x32(const float* sA, const Lane& L, c
 __device__ __forceinline__ void mfma_16x256x32(const float* sA, const Lane& L, const float (&w)[128], f32x4& acc0,
                                                f32x4& acc1) {
     const float* base = sA + L.c * LDA + L.rg * KS;
-#ifdef MPG_AB_NOMFMA   // ablation build: one k-block instead of 16 (timing only)
-    constexpr int NQ4 = 1;
-#else
     constexpr int NQ4 = 16;
-#endif
     // explicit one-block-ahead prefetch of the A fragments: the LDS latency of block q4+1 hides under the 8 MFMAs
     // (256 cycles) of block q4 instead of stalling the first MFMA of every block
     f32x4 a = *reinterpret_cast<const f32x4*>(base);
@@ -643,7 +538,6 @@ __device__ __forceinline__ void forward_group(const float* sX, float* sA, float*
         for (int o = 0; o < OU; ++o)
 #pragma unroll
             for (int j = 0; j < 4; ++j) p[o][j] = fmaf(h2[1][j], r.w3[1][o], h2[0][j] * r.w3[0][o]);
-#ifndef MPG_AB_NO_DPPASM
         // one v_add_f32_dpp per value and stage (the compiler's own lowering is v_mov_b32_dpp + a packed add: 1.5
         // instructions per value).  volatile keeps the stage-major order, which also keeps every DPP read >= 8
         // instructions behind the write of its operand (the 2-wait-state VALU->DPP hazard is not checked inside asm).
@@ -661,13 +555,6 @@ __device__ __forceinline__ void forward_group(const float* sX, float* sA, float*
         MPG_DPP_STAGE("quad_perm:[1,0,3,2]") MPG_DPP_STAGE("quad_perm:[2,3,0,1]")
         MPG_DPP_STAGE("row_half_mirror") MPG_DPP_STAGE("row_mirror")
 #undef MPG_DPP_STAGE
-#else
-#define MPG_DPP_STAGE(CTRL)                                     \
-        _Pragma("unroll") for (int o = 0; o < OU; ++o)           \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) p[o][j] += dpp_mov<CTRL>(p[o][j]);
-        MPG_DPP_STAGE(0xB1) MPG_DPP_STAGE(0x4E) MPG_DPP_STAGE(0x141) MPG_DPP_STAGE(0x140)
-#undef MPG_DPP_STAGE
-#endif
         if (L.c == 0) {
 #pragma unroll
             for (int o = 0; o < OU; ++o)

@@ -39,18 +39,6 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_forward(const FwdArgs a) {
     const long nunits = (ngroups + G2 - 1) / G2;                // units of G2 consecutive groups
     // the first unit's inputs are requested BEFORE the small pieces and the 256 KB image and consumed after them: loads
     // retire in order, so layer 1 and its barrier then run while the image is still streaming in
-#ifdef MPG_AB_FWD_NOPREFETCH
-    auto x_value = [&](long u) {
-        float v = 0.f;
-        if (threadIdx.x < G2 * GROUP * XSW) {
-            const int g2 = threadIdx.x / (GROUP * XSW), e = threadIdx.x % (GROUP * XSW), row = e / XSW, i = e % XSW;
-            const long gr = (u * G2 + g2) * GROUP + row;
-            if (gr < a.rows && i < a.in_dim) v = i < a.x.d0 ? a.x.x0[gr * a.x.ld0 + i] * a.x.scale[i] : a.x.x1[gr * a.x.ld1 + (i - a.x.d0)];
-        }
-        return v;
-    };
-    float xv = x_value(blockIdx.x);
-#else
     // Several units per workgroup (one workgroup per CU: nothing else covers a load's way to memory and back): the NEXT unit's inputs
     // are requested at the top of a unit, stay in flight across its passes and go into the other half of a double-buffered input
     // block BEFORE the unit's stash stores are issued - the vector-memory counter retires in order and the wait-count bookkeeping
@@ -73,14 +61,12 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_forward(const FwdArgs a) {
     };
     float xv = x_value(blockIdx.x);
     int cur = 0;
-#endif
     float b3v = 0.f;             // this output thread's bias, requested up front (at its point of use it is a memory round trip)
     if (threadIdx.x < G2 * GROUP * OU) b3v = net.b3[threadIdx.x % OU];
     float zmax = 0.f;
     bool saw_nan = false;                       // worker.py:95-107 judge_is_nan, on the device: inputs and outputs of the pass
     load_small<IN, OU>(net, L, r);
     if constexpr (PK) load_w2_packed(a.pack, L, w2); else load_w2_fwd(net.W2, L, w2);
-#ifndef MPG_AB_FWD_NOPREFETCH
     xv *= xsc;                                   // (x * 1.f is x: unscaled columns keep their bits)
     saw_nan |= xv != xv;
     if (threadIdx.x < G2 * GROUP * XSW) sX2[0][threadIdx.x] = xv;
@@ -89,18 +75,10 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_forward(const FwdArgs a) {
     // image request - measured nothing: EXPERIMENTS.md section 5.7.)
 #pragma unroll
     for (int v = 0; v < 32; ++v) asm volatile("" ::"v"(w2[4 * v]), "v"(w2[4 * v + 1]), "v"(w2[4 * v + 2]), "v"(w2[4 * v + 3]));
-#endif
     for (long u = blockIdx.x; u < nunits; u += gridDim.x) {
-#ifdef MPG_AB_FWD_NOPREFETCH
-        if (u != (long)blockIdx.x) xv = x_value(u);
-        saw_nan |= xv != xv;
-        if (threadIdx.x < G2 * GROUP * XSW) sX[threadIdx.x] = xv;
-        lds_barrier();
-#else
         lds_barrier();
         sX = sX2[cur];
         xv = u + gridDim.x < nunits ? x_value(u + gridDim.x) : 0.f;
-#endif
         // a NaN among a row's inputs stays a NaN in its outputs (row_poison, mlp_core.h): read here, while the block is this
         // unit's - the next unit's inputs are stored in front of the barrier above
         float pz = 0.f;
@@ -111,7 +89,6 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_forward(const FwdArgs a) {
                                    h2[1], &zmax);
         else
             forward_group<IN, OU>(sX, sA, sPart, L, w2, r, h1[0], h2[0], nullptr, 0, nullptr, &zmax);
-#ifndef MPG_AB_FWD_NOPREFETCH
         // the next unit's inputs, ahead of this unit's stores (ordered by the barrier at the top).  Unconditional - behind the last
         // unit it stores a zero nobody reads: as a second `if (more)` the consumption could be skipped on a path on which the request
         // was made, as far as the wait-count bookkeeping can tell, and the counter was drained at the top of every unit
@@ -119,7 +96,6 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_forward(const FwdArgs a) {
         saw_nan |= xv != xv;
         if (threadIdx.x < G2 * GROUP * XSW) sX2[cur ^ 1][threadIdx.x] = xv;
         cur ^= 1;
-#endif
 #pragma unroll
         for (int g2 = 0; g2 < G2; ++g2) {
             const long g = u * G2 + g2;
@@ -251,31 +227,6 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_backward(const BwdArgs a) {
         for (int i = 0; i < IN; ++i) gw1[t][i] = 0.f;
     }
     int par = 0;
-#ifdef MPG_AB_BWD_NOPREFETCH
-    for (long g = blockIdx.x; g < ngroups; g += gridDim.x, par ^= 1) {
-        if (tid < GROUP * OU) {
-            const int row = tid / OU, o = tid % OU;
-            const long gr = g * GROUP + row;
-            float d = 0.f;
-            if (gr < a.rows) {
-                d = a.dy[gr * a.lddy + o];
-                if (a.out_tanh) {   // a = S*tanh(z): da/dz = S*(1 - (a/S)^2)
-                    const float t = a.yout[gr * a.ldyo + o] / a.out_scale;
-                    d *= a.out_scale * (1.f - t * t);
-                }
-                if (a.dz3) a.dz3[gr * OU + o] = d;
-            }
-            sD3[d3_index(row, o)] = d;
-            if constexpr (THIN) gb3 += d;
-        }
-        // (the buffer of the other parity may still be read by a slower wave in the previous group's tail; this one was last read
-        // two groups ago, in front of the barrier every wave has passed since)
-        if constexpr (THIN) load_x_group<IN>(a.x, a.rows, g, sXt + par * GROUP * XSW);
-        float h1[2][4], h2[2][4], dz1[2][4], dz2[2][4];
-        stash_load(a.h1, g, L, h1);
-        stash_load(a.h2, g, L, h2);
-        lds_barrier();
-#else
     // Software pipeline over the row groups (one workgroup per CU: nothing else covers a load's way to memory and back): the loads of
     // group g + 1 - two stash fragments each of h1 and h2, the output gradient, the THIN input row - are requested at the top of
     // group g, stay in flight across its pass and are consumed behind it, AHEAD of the group's own stash stores (the vector-memory
@@ -345,7 +296,6 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_backward(const BwdArgs a) {
         lds_barrier();                           // sD3 / the THIN input block of this group are in place
         const long gn = g + gridDim.x < ngroups ? g + gridDim.x : g;      // (behind the last group: its own, again - nobody reads it)
         request(gn, nx);
-#endif
         if constexpr (THIN) {           // dW3 += h2 dz3^T (sD3 is stable until backward_group's last barrier)
 #pragma unroll
             for (int k = 0; k < OU; ++k) {
@@ -358,7 +308,6 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_backward(const BwdArgs a) {
             }
         }
         backward_group<IN, OU, WANT_DX>(sD3, sA, sA1, sPartX, L, w2t, r, h1, h2, dz1, dz2);
-#ifndef MPG_AB_BWD_NOPREFETCH
         // the next group's requests, consumed ahead of this group's stores (sD3 was last read in front of backward_group's final
         // barrier; the input block of the other parity two groups ago)
         if (g + gridDim.x < ngroups) publish(g + gridDim.x, nx, par ^ 1);
@@ -366,7 +315,6 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_backward(const BwdArgs a) {
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int j = 0; j < 4; ++j) { h1[t][j] = nx.h1[t][j]; h2[t][j] = nx.h2[t][j]; }
-#endif
         if (!THIN && a.dz1) stash_store(a.dz1, g, L, dz1);
         if (a.dz2) stash_store(a.dz2, g, L, dz2);
         if constexpr (THIN) {           // db2 += dz2, db1 += dz1, dW1 += x^T dz1
@@ -542,9 +490,6 @@ static void launch_backward_thin(const BwdArgs& a, int grid, hipStream_t s) {
 }
 
 bool backward_takes_thin(int in_dim, int ou) {
-#ifdef MPG_AB_NO_BWD_THIN      // A/B build (tools/ab_bwd_thin.sh): thin gradients in the weight-gradient launch, as before round 4
-    return false;
-#endif
     return in_dim <= 8 && !(in_dim == 7 && ou == 2) && !(in_dim == 8 && ou == 2);
 }
 int backward_thin_parts(int rows) { return grid_for((rows + GROUP - 1) / GROUP); }
@@ -637,7 +582,7 @@ int launch_wgrad(const mpg_cfg_t* cfg, int in_dim, int out_dim, int ou, int rows
     a.h1 = h1; a.h2 = h2; a.dz1 = dz1; a.dz2 = dz2; a.dz3 = dz3; a.slabs = ws;
     (void)inv_b;
     const long ngroups = (rows + GROUP - 1) / GROUP;
-#if defined(MPG_SPLIT) && !defined(MPG_AB_NO_WGRAD_W2)
+#if defined(MPG_SPLIT)
     const bool w2_only = no_thin && backward_takes_thin(in_dim, ou);       // (the base input widths: where the thin pieces can live elsewhere)
 #else
     const bool w2_only = false;

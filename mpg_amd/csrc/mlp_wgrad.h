@@ -106,9 +106,6 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int sl, con
     };
     auto thin_accumulate = [&](long g, const Thin& t, const Staged& st) {
         stage_write(g, st);
-#ifdef MPG_AB_PKFMA_WAIT   // hypothesis test (tools/pk_anomaly.sh): the staged values are fully written before anything reads them
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
         __builtin_amdgcn_wave_barrier();      // same wave writes and reads: LDS is in order within a wave
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -123,40 +120,15 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int sl, con
             // lost nondeterministically: first the (row 13, even i) terms of dW1 in ~85 % of launches, after dW1 was
             // unpacked the t = 1 half of dW3 in ~5 % (found by the repeated-launch determinism
             // check, not reproduced in isolation by archive/proto/pk_hazard.hip; a build without packed fp32 is clean).
-#ifdef MPG_AB_PKFMA
-            // ablation build (tools/pk_anomaly.sh): the form the compiler is free to pack (v_pk_fma_f32 / v_pk_add_f32 with
-            // op_sel) - the one that lost products in round 2
-#define MPG_FMAC(acc, a_, b_) acc = fmaf(a_, b_, acc)
-#define MPG_ADD(acc, a_) acc += a_
-#else
 #define MPG_FMAC(acc, a_, b_) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(acc) : "v"(a_), "v"(b_))
 #define MPG_ADD(acc, a_) asm volatile("v_add_f32 %0, %0, %1" : "+v"(acc) : "v"(a_))
-#endif
             MPG_ADD(gb1[0], t.d10[j]); MPG_ADD(gb1[1], t.d11[j]);
             MPG_ADD(gb2[0], t.d20[j]); MPG_ADD(gb2[1], t.d21[j]);
-#ifdef MPG_AB_PKFMA
-            {   // explicitly packed: (gW1[t][i], gW1[t][i + 1]) += (x[i], x[i + 1]) * d1t[j] - v_pk_fma_f32 with an op_sel splat
-                typedef float f32x2 __attribute__((ext_vector_type(2)));
-#pragma unroll
-                for (int i = 0; i + 1 < IN; i += 2) {
-                    const f32x2 xx = {x[i], x[i + 1]};
-                    f32x2 a0 = {gW1[0][i], gW1[0][i + 1]}, a1 = {gW1[1][i], gW1[1][i + 1]};
-                    a0 = __builtin_elementwise_fma(xx, f32x2{t.d10[j], t.d10[j]}, a0);
-                    a1 = __builtin_elementwise_fma(xx, f32x2{t.d11[j], t.d11[j]}, a1);
-                    gW1[0][i] = a0[0]; gW1[0][i + 1] = a0[1]; gW1[1][i] = a1[0]; gW1[1][i + 1] = a1[1];
-                }
-                if (IN & 1) {
-                    MPG_FMAC(gW1[0][IN - 1], x[IN - 1], t.d10[j]);
-                    MPG_FMAC(gW1[1][IN - 1], x[IN - 1], t.d11[j]);
-                }
-            }
-#else
 #pragma unroll
             for (int i = 0; i < IN; ++i) {
                 MPG_FMAC(gW1[0][i], x[i], t.d10[j]);
                 MPG_FMAC(gW1[1][i], x[i], t.d11[j]);
             }
-#endif
 #pragma unroll
             for (int o = 0; o < OU; ++o) {
                 MPG_FMAC(gW3[0][o], t.h20[j], d3[o]);
@@ -195,11 +167,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int sl, con
     }
 #endif
     long tg = g0 + L.wave;
-#ifdef MPG_AB_WG_NOTHIN
-    const bool has_thin = false;
-#else
     const bool has_thin = tg < g1 && !a.no_thin && ROLE != 1;
-#endif
 
     // ---- dW2 on the matrix pipe.  A operand: this wave's 32 rows of dW2 = 2 fragments of H1 per row group, straight
     //      from the stash (HBM / Infinity Cache, ~1.5 us away).  B operand: the workgroup's 32-column slice of DZ2 - the
@@ -233,11 +201,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int sl, con
     f32x2* sB2 = reinterpret_cast<f32x2*>(sRed);          // 8-byte slots: (((pair*2 + tile)*2 + part)*64 + lane)*2 + (group & 1)
     a_load(g0);
     MPG_TL(1);
-#ifdef MPG_AB_WG_NOMFMA
-    for (long tile = g0; tile < g0; tile += NWAVE) {
-#else
     for (long tile = g0; tile < g1; tile += NWAVE) {
-#endif
         const long gb = tile + L.wave;
         f32x4 bt[NT];
 #pragma unroll
@@ -311,11 +275,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int sl, con
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d)
         if (g0 + d < g1) a_load(g0 + d, d);
-#ifdef MPG_AB_WG_NOMFMA
-    for (long tile = g0; tile < g0; tile += NWAVE) {
-#else
     for (long tile = g0; tile < g1; tile += NWAVE) {
-#endif
         const long gb = tile + L.wave;
         f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
         if (gb < g1) {
@@ -347,18 +307,6 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int sl, con
 #endif
     }
     MPG_TL(2);
-#ifdef MPG_AB_WG_W2_FIRST      // diagnosis build (archive/proto/pk_repro): dW2 leaves its registers before the thin pieces start
-    if constexpr (ROLE != 2) {
-        float* sW2e = a.slabs + (size_t)chunk * net_size(a.in_dim, a.out_dim) + a.in_dim * H + H;
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    sW2e[(16 * (2 * L.wave + u) + 4 * L.rg + j) * H + 16 * NT * sl + 16 * t + L.c] = acc[u][t][j];
-    }
-#endif
     __syncthreads();                                      // the staging corners of the thin part alias the B tile
     MPG_TL(3);
     // thin pieces after the matrix loop (their registers are then free): the chunk's groups are dealt round-robin to
@@ -383,7 +331,6 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int sl, con
     float* sb2 = sW2 + H * H;
     float* sW3 = sb2 + H;
     float* sb3 = sW3 + H * a.out_dim;
-#ifndef MPG_AB_WG_W2_FIRST
     if constexpr (ROLE != 2) {
 #pragma unroll
         for (int u = 0; u < 2; ++u)
@@ -393,7 +340,6 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int sl, con
                 for (int j = 0; j < 4; ++j)
                     sW2[(16 * (2 * L.wave + u) + 4 * L.rg + j) * H + 16 * NT * sl + 16 * t + L.c] = acc[u][t][j];
     }
-#endif
     if constexpr (ROLE == 1) return;                      // (the thin entries of the slab belong to the ROLE 2 workgroup of this slice)
     MPG_TL(5);
     // thin pieces: sum over the 8 waves and the 4 row quads through LDS in a fixed order

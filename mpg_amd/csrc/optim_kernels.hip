@@ -26,10 +26,6 @@ constexpr int HH = MPG_HIDDEN * MPG_HIDDEN;
 // Packed images of the split engine (mlp_core.h / weight_cache.hip): the fp16 hi and lo halves of W2[row][col] * W_SCALE,
 // where contraction index k owns the lane group and register, output index n the lane column.  Writes both halves.
 __device__ __forceinline__ void pack_store(float* __restrict__ image, int k, int n, float w) {
-#ifdef MPG_AB_NO_PACKSTORE     // timing-only ablation (stale images): the sub-dword image stores are 3.2 us of k_clip_adam_polyak's 11.3
-                               // (HIP events; round 4) - the bound on what word-wide stores from 2 x 2 element tiles could save
-    return;
-#endif
     const int wave = n >> 5, t = (n >> 4) & 1, c = n & 15, kb = k >> 5, rg = (k >> 3) & 3, r = (k >> 1) & 3, e = k & 1;
     const int v = (kb * 2 + t) * 2;                                                       // hi block; the lo block is v + 1
     const int word = ((mlp::img_slot(wave, v) * 64 + rg * 16 + c) << 2) + r, word_lo = ((mlp::img_slot(wave, v + 1) * 64 + rg * 16 + c) << 2) + r;

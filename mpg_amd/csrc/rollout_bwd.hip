@@ -88,7 +88,6 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_bwd(const RollBwdArgs a)
         stash_load(a.H2, (long)a.n * ngroups + g, L, h2_cur);
         for (int t = a.n; t >= 0; --t) {
             float h1[2][4];
-#if !defined(MPG_AB_H1_LATE) && !defined(MPG_AB_NO_H1)
             // h1 of this step is requested at the TOP of the step: nothing older is pending here (the step before consumed its
             // prefetches when it copied them), nothing before the matrix block waits on the vector-memory counter, and the seven
             // waves that would only wait for the chain lanes at the first barrier put the request ~2 k cycles further ahead of
@@ -102,7 +101,6 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_bwd(const RollBwdArgs a)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { rec_pre[i] = r0[i]; rec_pre[4 + i] = r1[i]; }
             }
-#endif
             if (own) {
                 float ga[2] = {0.f, 0.f};
 #pragma unroll
@@ -120,15 +118,9 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_bwd(const RollBwdArgs a)
                         float lam_next[8];
 #pragma unroll
                         for (int i = 0; i < 8; ++i) lam_next[i] = sCarry[tid * 16 + i];
-                        #ifdef MPG_AB_BWD_KERNARG
-                        ENV::vjp(o, act, on, lam_next, a.rho[t], lam, ga);
-#else
                         ENV::vjp(o, act, on, lam_next, sRho[t], lam, ga);
-#endif
                     }
-#ifndef MPG_AB_BWD_KERNARG
                     if ((selmask >> t) & 1u)             // (two of the 26 steps: the slice search stays a plain loop)
-#endif
                     for (int ks = 0; ks < a.n_sel; ++ks)
                         if (a.sel[ks] == t) {
                             const float* gx = a.GXQ + ((long)ks * R + tr) * QIN;
@@ -195,26 +187,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_bwd(const RollBwdArgs a)
             }
             // all global loads of the step are issued HERE, behind the dz2 phase: h1 is consumed after the MFMA block,
             // the record and h2 stash of step t-1 in the next iteration (software pipeline)
-#ifdef MPG_AB_NO_H1
-            if (t == 0) stash_load(a.H1, (long)t * ngroups + g, L, h1);
-            else {
-#pragma unroll
-                for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) h1[tt][j] = h2_cur[tt][j];
-            }
-#elif defined(MPG_AB_H1_LATE)      // A/B: requested behind the dz2 phase, as before round 5
-            stash_load(a.H1, (long)t * ngroups + g, L, h1);
-#endif
             if (t > 0) {
-#if defined(MPG_AB_H1_LATE) || defined(MPG_AB_NO_H1)
-                if (live) {
-                    const f32x4* rp = reinterpret_cast<const f32x4*>(a.SA + ((long)(t - 1) * R + tr) * SAW);
-                    const f32x4 r0 = rp[0], r1 = rp[1];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) { rec_pre[i] = r0[i]; rec_pre[4 + i] = r1[i]; }
-                }
-#endif
                 stash_load(a.H2, (long)(t - 1) * ngroups + g, L, h2_pre);
             }
             if (t > 0)
@@ -229,11 +202,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_bwd(const RollBwdArgs a)
             if (own) {
                 if (t > 0) {
                     float dxr[XSW];
-                    #ifdef MPG_AB_DXROW_FULL    // A/B: full-width reads, as before round 5
-                    dx_reduce_row<XSW>(sPartX, tid, dxr);
-#else
                     dx_reduce_row<XSW, WIDE ? XSW : OBS>(sPartX, tid, dxr);
-#endif
 #pragma unroll
                     for (int i = 0; i < OBS; ++i) lam[i] += dxr[i] * a.obs_scale[i];
                     if constexpr (WIDE) {       // t > 0 here: the observation of this step came out of the model

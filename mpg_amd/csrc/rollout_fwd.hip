@@ -119,9 +119,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_fwd(const RollArgs a) {
                 // constant indices only: a dynamically indexed kernel-argument array is re-read from memory by a scalar load
                 // (+ wait) on every use - ~200 cycles each.  The slice search runs only on the steps a bit mask marks (two of 26):
                 // the book lanes' work behind the second barrier is as long as the chain lanes' - every step waits for it too.
-#ifndef MPG_AB_FWD_NOSELMASK
                 if ((selmask >> tb) & 1u)
-#endif
 #pragma unroll
                 for (int ks = 0; ks < MAXSEL; ++ks)
                     if (ks < a.n_sel && a.sel[ks] == tb) {
@@ -143,22 +141,16 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_fwd(const RollArgs a) {
             }
         };
         if (chain) publish(o, true);
-#ifndef MPG_AB_B3R_PENDING
         // The output bias was requested in the prologue; consumed HERE once, it is not a pending load anywhere in the step loop.
         // Left pending across the loop header, the wait-count bookkeeping re-waits for it in every step - `s_waitcnt vmcnt(4)` in the
         // middle of the serial chain, which in fact waits for the stash stores of the step before (the counter retires in order).
 #pragma unroll
         for (int k = 0; k < ACT; ++k) asm volatile("" ::"v"(b3r[k]));
-#endif
         for (int t = 0; t <= a.n; ++t) {
             lds_barrier();
             MPG_STAMP_AT(0);
             float h1[2][4], h2[2][4];
-            #ifdef MPG_AB_NO_H1
-            forward_group<NIN, ACT, false>(sX, sA, sPart, L, w2, r, h1, h2, t == 0 ? a.H1 : nullptr, (long)t * ngroups + g, nullptr, &zmax);
-#else
             forward_group<NIN, ACT, false>(sX, sA, sPart, L, w2, r, h1, h2, a.H1, (long)t * ngroups + g, nullptr, &zmax);
-#endif
             if (a.H1) stash_store(a.H2, (long)t * ngroups + g, L, h2);
             // book lanes, before B2: fetch what the chain lanes left in sTraj (they overwrite it right after B2) and prepare
             // the action-independent half of this step's model step - the only part of their work the chain waits for
@@ -214,9 +206,7 @@ __global__ void __launch_bounds__(NTHREAD, 2) k_rollout_fwd(const RollArgs a) {
 #pragma unroll
                         for (int i = 0; i < OBS; ++i) rec[i] = o[i];
                     }
-#ifndef MPG_AB_FWD_NOSELMASK
                     if ((selmask >> t) & 1u)
-#endif
 #pragma unroll
                     for (int ks = 0; ks < MAXSEL; ++ks)
                         if (ks < a.n_sel && a.sel[ks] == t) {

@@ -37,11 +37,7 @@ __global__ void __launch_bounds__(1024) k_returns(int rows, int M, int n_sel, co
     const long R = (long)rows * M;
     for (int k = 0; k < n_sel; ++k) {
         float s = 0.f, s2 = 0.f;
-#ifdef MPG_AB_RETURNS_SERIAL
-        if (false) {
-#else
         if (M == 1) {
-#endif
             // eight row blocks of a thread at a time: their sixteen loads are requested together (unconditional, from clamped rows) and
             // then summed in the order of the plain loop - one memory round trip where the plain loop makes eight, one after the other
             for (int b0 = threadIdx.x; b0 < rows; b0 += 8 * 1024) {
@@ -560,11 +556,7 @@ extern "C" int mpg_mpg_gradients(const mpg_cfg_t* cfg, int n_q, const float* par
     // launch would leave half of the chip idle (256 groups = 128 workgroups of two); instead workgroup (p, h) runs the target
     // policy and target critic h on pair p - 256 workgroups, two image loads and two passes each instead of three - and the
     // critic launch finishes y = r~ + gamma * min(Q1t, Q2t) (same arithmetic, bit-identical y) and writes y_out.
-#ifdef MPG_AB_TARGET_SINGLE          // A/B build (tools/ab_split.sh): the single target launch
-    const bool split = false;
-#else
     const bool split = !y_in && n_q == 2 && n_select == 2 && qt[1] && rows / GROUP >= 256;
-#endif
     const float* y = y_in;
     if (!y) {   // 1. clipped double-Q (or single-Q) target, mpg_learner.py:126-134
         const DrawOut dout{obs, act, rew, obs_tp1};
@@ -622,31 +614,17 @@ extern "C" int mpg_mpg_gradients(const mpg_cfg_t* cfg, int n_q, const float* par
     //                         the event recorded there, so that a caller can exchange it between GPUs under the reverse sweep; the
     //                         policy's follows the sweep as a second weight-gradient + reduction pair (one launch more; the critics'
     //                         chunk products ahead of the sweep cost ~9 us on one GPU, EXPERIMENTS.md "Why nothing overlaps the exchange");
-    // -DMPG_AB_WGRAD_EARLY (A/B build, tools/ab_early.sh): the early chunk products with ONE reduction at the end.
     const mpg_grad_opts_t* opts = cfg->grad_opts;
     hipEvent_t critics_ready = opts ? reinterpret_cast<hipEvent_t>(opts->critics_ready_event) : nullptr;
-#ifdef MPG_AB_WGRAD_EARLY
-    constexpr bool early = true;
-#else
-    constexpr bool early = false;
-#endif
     if (critics_ready) {
         // the loss sums are the first n_q scalar jobs; no clip partials: an exchanged gradient gets them afterwards (mpg_sq_partials)
         rc = launch_wgrad_multi(cfg, jobs, n_q, sums, n_q, nullptr, s);
         if (rc) return rc;
         if (hipEventRecord(critics_ready, s) != hipSuccess) { mpg_set_error("mpg_mpg_gradients: hipEventRecord(critics_ready_event) failed"); return MPG_EINVAL; }
-    } else if (early) {
-        rc = launch_wgrad_multi(cfg, jobs, n_q, nullptr, 0, nullptr, s, 1, 0);
-        if (rc) return rc;
     }
     // 5. reverse sweep
     rc = run_rollout_bwd(cfg, policy, rows, 1, n, select, n_select, cf.rho, H1, H2, SA, GXQ, 0, DZ1, DZ2, DZ3, s);
     if (rc) return rc;
     if (critics_ready) return launch_wgrad_multi(cfg, jobs + n_q, 1, sums + n_q, ns - n_q, nullptr, s);
-    if (early) {
-        rc = launch_wgrad_multi(cfg, jobs, n_q + 1, nullptr, 0, nullptr, s, 1, n_q);
-        if (rc) return rc;
-        return launch_wgrad_multi(cfg, jobs, n_q + 1, sums, ns, sq_part, s, 2, 0);
-    }
     return launch_wgrad_multi(cfg, jobs, n_q + 1, sums, ns, sq_part, s);
 }

@@ -91,11 +91,7 @@ bool ctx_ok(const mpg_train_ctx_t* c) {
 // ---- worker.sample + replay_buffer.add_batch (optimizer.py:332-337, worker.py:91-119), the plain form (NADP, TD3) ----
 // worker.py:95-112 as one launch (mpg_worker_step) where it exists: path-tracking env, six-entry observations
 inline bool worker_step_fused(const mpg_train_ctx_t* c) {
-#ifdef MPG_AB_NO_WORKER_FUSION      // A/B build (tools/ab_worker.sh): the policy pass and the env step as two launches (rounds 1 - 3)
-    return false;
-#else
     return c->cfg.env_kind == MPG_ENV_PATH_TRACKING && c->cfg.obs_dim == 6 && c->cfg.act_dim == 2;
-#endif
 }
 
 int sample_and_add(mpg_train_ctx_t* c, const float* policy, mpg_stream_t s) {
@@ -214,11 +210,7 @@ extern "C" int mpg_step_begin(mpg_train_ctx_t* c, int iteration, mpg_stream_t s)
     if (iteration % c->sampling_interval == 0) {
         for (int it = 0; it < c->sample_iters; ++it) {
             MPG_REQUIRE(c->num_agent <= c->ring_capacity, "mpg_step_begin: ring smaller than one sample");
-#ifdef MPG_AB_NO_PREDRAW
-            const bool predraw = false;
-#else
             const bool predraw = draws_now && it == c->sample_iters - 1 && kind == MPG_ENV_PATH_TRACKING && od == 6;
-#endif
             mpg_replay_draw_t pd = {};
             if (predraw) {
                 pd.n_storage = std::min(c->ring_size + c->num_agent, c->ring_capacity);

@@ -17,6 +17,7 @@
 #   -DMPG_AB_BWD_KERNARG                       reverse sweep with run-time indices into the kernel arguments (rho[t], sel[ks]) as before
 #   -DMPG_STAMP / -DMPG_TIMELINE              per-phase cycle stamps (tools/stamp.sh, tools/timeline.sh)
 cd ${GRAFT_REPO_ROOT:-$(dirname "$0")/..}
+. tools/ab_scaffold.sh      # the experiment branches live in archive/proto/ablation_macros.patch since round 6
 STEPS=${STEPS:-400}
 run() {
   local spec="$1" fwd bwd extra

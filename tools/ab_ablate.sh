@@ -1,5 +1,6 @@
 # timing-only ablations of the engine (results wrong): how much of a sweep's time does each phase of a step carry?
 cd $GRAFT_REPO_ROOT
+. tools/ab_scaffold.sh      # the experiment branches live in archive/proto/ablation_macros.patch since round 6
 export MPG_BENCH_NO_F32=1
 export MPG_FWD_CFLAGS="-mllvm -amdgpu-sched-strategy=max-memory-clause" MPG_BWD_CFLAGS="-mllvm -amdgpu-sched-strategy=max-memory-clause"
 for V in "" "-DMPG_AB_NOMFMA" "-DMPG_AB_NO_IMGWRITE" "-DMPG_AB_NO_ELU8" "-DMPG_AB_NO_H1" "-DMPG_AB_NOMFMA -DMPG_AB_NO_IMGWRITE -DMPG_AB_NO_ELU8 -DMPG_AB_NO_H1" ""; do

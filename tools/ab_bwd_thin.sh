@@ -1,5 +1,6 @@
 # same-box A/B: thin parameter gradients inside k_backward (default) against the weight-gradient launch (-DMPG_AB_NO_BWD_THIN)
 cd $GRAFT_REPO_ROOT
+. tools/ab_scaffold.sh      # the experiment branches live in archive/proto/ablation_macros.patch since round 6
 export MPG_BENCH_NO_F32=1
 for V in "-DMPG_AB_NO_BWD_THIN" "" "-DMPG_AB_NO_BWD_THIN" ""; do
   echo "== [$V]"; MPG_EXTRA_CFLAGS="$V" python3 -m mpg_amd.build --split-only > /tmp/b.log 2>&1 || tail -3 /tmp/b.log

@@ -1,6 +1,7 @@
 # same-box A/B of the bench step: packed weight images with the eight waves' 1 KiB blocks interleaved (-DMPG_IMG_INTERLEAVE, mlp_core.h
 # img_slot) against one contiguous 32 KB run per wave (default).  Round 4: interleaved is slower (0.2305 -> 0.2423 ms).
 cd $GRAFT_REPO_ROOT
+. tools/ab_scaffold.sh      # the experiment branches live in archive/proto/ablation_macros.patch since round 6
 export MPG_BENCH_NO_F32=1
 for V in ${VARIANTS:-"" "-DMPG_IMG_LAYOUT=5" "-DMPG_IMG_LAYOUT=4" "-DMPG_IMG_LAYOUT=3" "-DMPG_IMG_LAYOUT=2" "-DMPG_IMG_LAYOUT=1" ""}; do
   [ "$V" = "-" ] && V=""

@@ -2,6 +2,7 @@
 # split target launch (shipped) against the single launch (-DMPG_AB_TARGET_SINGLE): parity tests with both, bench runs of both.
 # Leaves the tree built with the shipped flags.   bash tools/ab_split.sh
 cd ${GRAFT_REPO_ROOT:-$(dirname "$0")/..}
+. tools/ab_scaffold.sh      # the experiment branches live in archive/proto/ablation_macros.patch since round 6
 P='import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(sys.argv[1], round(d["ms_per_step"],4), "target %.1f critic %.1f us" % (d["other_kernels_avg_ms"]["k_target_fused"]*1e3, d["other_kernels_avg_ms"]["k_critic_fused"]*1e3))'
 for v in "-DMPG_AB_TARGET_SINGLE" ""; do
   echo "== [$v]"

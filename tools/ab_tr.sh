@@ -1,4 +1,5 @@
 cd $GRAFT_REPO_ROOT
+. tools/ab_scaffold.sh      # the experiment branches live in archive/proto/ablation_macros.patch since round 6
 mkdir -p gpurun_out/r04_tr
 export MPG_BENCH_NO_F32=1
 P='import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); o=d["other_kernels_avg_ms"]; print("ms/step %.4f (median %.4f) fwd %.4f bwd %.4f target %.4f critic %.4f wgrad %.4f pol %.4f env %.4f adam %.4f" % (d["ms_per_step"], d["step_ms_median"], d["roofline_other_rollout_kernel"]["avg_ms"], d["roofline"]["avg_ms"], o["k_target_fused"], o["k_critic_fused"], o["k_wgrad_multi"], o["k_forward (worker policy)"], o["k_step_store_reset (env)"], o["k_clip_adam_polyak"]))'

@@ -1,4 +1,5 @@
 cd $GRAFT_REPO_ROOT
+. tools/ab_scaffold.sh      # the experiment branches live in archive/proto/ablation_macros.patch since round 6
 export MPG_BENCH_NO_F32=1
 for V in "" "-DMPG_AB_WG_NOTHIN" "" "-DMPG_AB_WG_NOTHIN"; do
   echo "== [$V]"; MPG_EXTRA_CFLAGS="$V" python3 -m mpg_amd.build --split-only > /tmp/b.log 2>&1 || tail -3 /tmp/b.log

@@ -1,6 +1,7 @@
 # same-box A/B of the bench step: worker.sample's policy pass and env step as ONE launch (mpg_worker_step, default) against two
 # (-DMPG_AB_NO_WORKER_FUSION: rounds 1 - 3)
 cd $GRAFT_REPO_ROOT
+. tools/ab_scaffold.sh      # the experiment branches live in archive/proto/ablation_macros.patch since round 6
 export MPG_BENCH_NO_F32=1
 for V in "-DMPG_AB_NO_WORKER_FUSION" "" "-DMPG_AB_NO_WORKER_FUSION" ""; do
   echo "== [$V]"; MPG_EXTRA_CFLAGS="$V" python3 -m mpg_amd.build --split-only > /tmp/b.log 2>&1 || tail -3 /tmp/b.log

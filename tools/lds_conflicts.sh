@@ -6,6 +6,7 @@ export MPG_BENCH_NO_F32=1   # no child processes under the profiler (their kerne
 # LDS instructions, array cycles and conflict cycles of both and what the image stores account for.
 export TMPDIR=/tmp
 cd ${GRAFT_REPO_ROOT:-$(dirname "$0")/..}
+. tools/ab_scaffold.sh      # the experiment branches live in archive/proto/ablation_macros.patch since round 6
 OUT=gpurun_out/lds_conflicts
 mkdir -p $OUT
 for V in shipped noimg; do

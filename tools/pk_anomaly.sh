@@ -7,6 +7,7 @@
 #   + _WAIT          hypothesis: s_waitcnt lgkmcnt(0) + s_nop 4 between the staged LDS reads and the first packed consumer
 # and leaves the thin block's ISA of the last two (and their diff) in gpurun_out/pk_anomaly/.
 cd ${GRAFT_REPO_ROOT:-$(dirname "$0")/..}
+. tools/ab_scaffold.sh      # the experiment branches live in archive/proto/ablation_macros.patch since round 6
 N=${1:-5000}
 OUT=gpurun_out/pk_anomaly
 mkdir -p $OUT
