@@ -533,7 +533,8 @@ def main():
     if a.always_exchange and a.gpus == 1 and 'WORLD_SIZE' not in os.environ:
         os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()))
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-    rank, world, local = D.init_from_env(backend='nccl' if a.always_exchange and a.gpus == 1 else None)
+    # (--always-exchange on one GPU: a ONE-rank RCCL group, or - MPG_DIST_BACKEND=oneshot - the one-shot IPC exchange with itself)
+    rank, world, local = D.init_from_env(backend=(os.environ.get('MPG_DIST_BACKEND') or 'nccl') if a.always_exchange and a.gpus == 1 else None)
     assert world == a.gpus, '--gpus %d but WORLD_SIZE=%d' % (a.gpus, world)
     assert torch.cuda.is_available(), 'bench.py needs a GPU: the product path has no CPU fallback'
     ndev = torch.cuda.device_count()

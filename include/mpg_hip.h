@@ -177,6 +177,13 @@ int mpg_sum_slots(const float* slots, int n_slots, int n, float* out, mpg_stream
  * The reduce half of the two-shot (reduce-scatter + all-gather) form of the exchange: rank r sums only its 1/world slice, in the
  * same rank order, and distributes the result (mpg_amd/dist.py OneShotAllReduce, mode 'twoshot'; optimizer.py:60-94). */
 int mpg_sum_slots_strided(const float* slots, int n_slots, size_t slot_stride, int n, float* out, mpg_stream_t stream);
+/* The same sum with the clip's partial sums of squares of the RESULT as a by-product (round 6, ABI 10): sq_part[k*MPG_CLIP_PARTS + b]
+ * exactly as mpg_sq_partials(out, seg_sizes, n_seg, ...) would compute them - the same bits - so that an exchanged gradient
+ * (optimizer.py:60-94) reaches mpg_clip_adam_polyak / mpg_step_end (mpg_train_ctx_t.clip_partials_ready) without another pass over it.
+ * seg_sizes[0..n_seg) (host): the networks at the head of the buffer; the n - sum(seg_sizes) floats behind them (statistics) are
+ * summed too.  n_slots = 1: a copy with the partials (the gather array of the two-shot form). */
+int mpg_sum_slots_sq(const float* slots, int n_slots, size_t slot_stride, int n, float* out, const int* seg_sizes, int n_seg,
+                     float* sq_part /* n_seg * MPG_CLIP_PARTS floats */, mpg_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Networks (K3), critic targets, losses and gradients (K5, K6)
@@ -565,6 +572,12 @@ typedef struct {
     /* scheduling option (round 5, ABI 9; MPG only, optional) */
     void* critics_ready_event;        /* hipEvent_t, nullable: see mpg_grad_opts_t (the caller overlaps the critics' exchange) */
     mpg_grad_opts_t grad_opts;        /* storage for cfg.grad_opts during mpg_step_begin */
+    /* round 6, ABI 10 */
+    int clip_partials_ready;          /* != 0 (meaningful with grads_exchanged): the caller's exchange left the clip partials of the
+                                         REDUCED gradient in clip_scratch (mpg_sum_slots_sq) - mpg_step_end takes them as given
+                                         instead of re-reading grad[] (mpg_sq_partials).  `grad` may differ between mpg_step_begin
+                                         (where the partial gradient is written: e.g. the caller's own staging slot of the
+                                         exchange) and mpg_step_end (the reduced buffer): it is read at call time. */
 } mpg_train_ctx_t;
 
 /* workspace requirements of a context (ws0: targets / critic; ws1: rollout) */

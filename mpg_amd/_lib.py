@@ -17,7 +17,7 @@ ENGINES = {'split': LIB_PATH, 'f32': os.path.join(HERE, 'libmpg_hip_f32.so')}
 
 _libs = {}
 _engine = 'split'
-ABI_VERSION = 9      # the struct mirrors of ops.py (CfgStruct, WCacheStruct, ...) follow include/mpg_hip.h at this version
+ABI_VERSION = 10      # the struct mirrors of ops.py (CfgStruct, WCacheStruct, ...) follow include/mpg_hip.h at this version
 
 
 class MpgError(RuntimeError):

@@ -6,12 +6,13 @@
 
 #include "../../include/mpg_hip.h"
 
-#define MPG_ABI_VERSION 9   // 3: caller-owned handles (mpg_wcache_t, mpg_prof_t) instead of process-wide state
+#define MPG_ABI_VERSION 10  // 3: caller-owned handles (mpg_wcache_t, mpg_prof_t) instead of process-wide state
                             // 4: mpg_replay_draw_t gained the pre-gathered window, mpg_env_step_store_reset_draw
                             // 5: status words (mpg_cfg_t.status, mpg_wcache_t.status), step entry points for TD3 / NADP
                             // 6: mpg_cfg_t.obs_scale has 16 entries (observations with look-ahead entries: obs_dim up to 14)
                             // 8: mpg_worker_step
                             // 9: mpg_sum_slots_strided (two-shot exchange), mpg_cfg_t.grad_opts (critics_ready_event)
+                            // 10: mpg_sum_slots_sq, mpg_train_ctx_t.clip_partials_ready
                             // 7: MPG_PROF_SLOTS 10 (gradient exchange, k_clip_adam_polyak), mpg_prof_region_begin / _end
 
 void mpg_set_error(const char* fmt, ...);

@@ -391,7 +391,41 @@ __global__ void k_sum_slots(const float* __restrict__ slots, int n_slots, size_t
     for (int r = 1; r < n_slots; ++r) s += slots[(size_t)r * stride + i];       // rank order: the same association on every replica
     out[i] = s;
 }
+// The rank-order sum AND the clip's partial sums of squares of the result in one pass (round 6: an exchanged gradient no longer
+// needs a launch of k_sq_blocks behind the exchange).  Block (b, k), k < n_seg, owns exactly the elements k_sq_blocks' block (b, k)
+// reads - same per-thread order, same block reduction - so the partials are the same bits; row n_seg of the grid sums the tail behind
+// the networks (the statistics) without partials.
+__global__ void __launch_bounds__(256) k_sum_slots_sq(const Segs sg, const float* __restrict__ slots, int n_slots, size_t stride, int n,
+                                                      float* __restrict__ out, float* __restrict__ part) {
+    __shared__ float red[256];
+    const int k = blockIdx.y, b = blockIdx.x;
+    const bool tail = k == sg.n_seg;
+    const int off = tail ? sg.off[sg.n_seg - 1] + sg.n[sg.n_seg - 1] : sg.off[k];
+    const int len = tail ? n - off : sg.n[k];
+    float a = 0.f;
+    for (int i = b * 256 + threadIdx.x; i < len; i += CLIP_PARTS * 256) {
+        float s = slots[off + i];
+        for (int r = 1; r < n_slots; ++r) s += slots[(size_t)r * stride + off + i];    // rank order: the same association on every replica
+        out[off + i] = s;
+        a = fmaf(s, s, a);
+    }
+    if (tail) return;                                   // (block-uniform)
+    const float tot = mpg_block_sum256(a, red);
+    if (threadIdx.x == 0) part[k * CLIP_PARTS + b] = tot;
+}
 }  // namespace
+
+extern "C" int mpg_sum_slots_sq(const float* slots, int n_slots, size_t slot_stride, int n, float* out, const int* seg_sizes, int n_seg,
+                                float* sq_part, mpg_stream_t stream) {
+    Segs sg;
+    const int covered = fill(sg, n_seg, seg_sizes);
+    MPG_REQUIRE(slots && out && sq_part && n_slots > 0 && n > 0 && slot_stride >= (size_t)n && covered > 0 && covered <= n,
+                "mpg_sum_slots_sq: bad argument");
+    hipLaunchKernelGGL(k_sum_slots_sq, dim3(CLIP_PARTS, n_seg + (covered < n ? 1 : 0)), dim3(256), 0, mpg_stream(stream), sg, slots, n_slots,
+                       slot_stride, n, out, sq_part);
+    MPG_CHECK_LAUNCH("k_sum_slots_sq");
+    return MPG_OK;
+}
 
 extern "C" int mpg_sum_slots(const float* slots, int n_slots, int n, float* out, mpg_stream_t stream) {
     MPG_REQUIRE(slots && out && n_slots > 0 && n > 0, "mpg_sum_slots: bad argument");

@@ -304,8 +304,9 @@ extern "C" int mpg_step_end(mpg_train_ctx_t* c, int iteration, mpg_stream_t s) {
     const Layout l = layout(c);
     // per-network clip_by_global_norm (mpg_learner.py:415-431): on one GPU the partial sums of squares were left in
     // clip_scratch by mpg_mpg_gradients; after an all-reduce they are recomputed from the reduced gradient
-    // (NADP / TD3: their gradient launches leave no partials, they are always taken from the gradient buffer)
-    if (exchanged(c) || !is_mpg(c)) TRY(mpg_sq_partials(c->grad, l.sizes, l.n_nets, c->clip_scratch, s));
+    // (NADP / TD3: their gradient launches leave no partials, they are always taken from the gradient buffer); an exchange that
+    // sums with mpg_sum_slots_sq has left them already (clip_partials_ready)
+    if ((exchanged(c) && !c->clip_partials_ready) || (!exchanged(c) && !is_mpg(c))) TRY(mpg_sq_partials(c->grad, l.sizes, l.n_nets, c->clip_scratch, s));
     // PolicyWithQs.apply_gradients, policy.py:123-156
     const bool delayed = iteration % c->delay_update == 0;
     float lr_t[3];

@@ -222,7 +222,30 @@ class OneShotAllReduce(object):
         self.theirs[g] = {p: [torch.cuda.Event.from_ipc_handle(self.dev, h) for h in self.shm.peer_handles(p, g)]
                           for p in range(self.world) if p != self.rank}
 
-    def all_reduce_sum_(self, flat):
+    def grad_slot(self):
+        """This rank's slot of its OWN staging array for the NEXT exchange (round 6): a producer that writes its buffer straight into it
+        and then calls all_reduce_sum_(out, in_slot=True) saves the copy into the slot - on one GPU the whole exchange is then ONE
+        launch (the sum), between GPUs world - 1 peer copies + the sum.  Stream-ordered behind this rank's own earlier sums, which are
+        the only readers of that slot."""
+        return self.stage[self.calls & 1, self.rank]
+
+    def _finish(self, src, n_slots, flat, seg_sizes, sq_part):
+        """the final rank-order sum (or, n_slots = 1, the copy out of the gather array); with sq_part also the clip's partial sums of
+        squares of the result (mpg_sum_slots_sq: the bits mpg_sq_partials would produce from `flat`)"""
+        L = self.L
+        if sq_part is not None:
+            import ctypes
+            sizes = (ctypes.c_int * len(seg_sizes))(*[int(x) for x in seg_sizes])
+            L.call('mpg_sum_slots_sq', L.ptr(src), L.c_int(n_slots), L.c_size_t(self.n), L.c_int(self.n), L.ptr(flat), sizes,
+                   L.c_int(len(seg_sizes)), L.ptr(sq_part), L.stream())
+        elif n_slots == 1:
+            flat.copy_(src, non_blocking=True)
+        else:
+            L.call('mpg_sum_slots', L.ptr(src), L.c_int(n_slots), L.c_int(self.n), L.ptr(flat), L.stream())
+
+    def all_reduce_sum_(self, flat, in_slot=False, seg_sizes=None, sq_part=None):
+        """flat <- sum over ranks.  in_slot: this rank's contribution already sits in grad_slot() (taken BEFORE this call) and `flat` is
+        only the destination; seg_sizes + sq_part: see _finish."""
         assert flat.numel() == self.n and flat.dtype == torch.float32 and flat.is_contiguous()
         par = self.calls & 1
         self.calls += 1
@@ -231,12 +254,18 @@ class OneShotAllReduce(object):
         two = self.mode == 'twoshot'
         me = self.rank
         lo, hi = self.slices[me]
+        src = self.stage[par, me] if in_slot else flat
 
         def scatter():                                  # two-shot (A): slice p of my buffer into slot `rank` of rank p's array
             for p in range(self.world):
                 a, b = self.slices[p]
-                if b > a:
-                    self.peers[p][par, me, a:b].copy_(flat[a:b], non_blocking=True)
+                if b > a and not (in_slot and p == me):  # (in_slot: my own slice is where it belongs already)
+                    self.peers[p][par, me, a:b].copy_(src[a:b], non_blocking=True)
+
+        def spread():                                   # one-shot 1.: my buffer into slot `rank` of every rank's array
+            for r in range(self.world):
+                if not (in_slot and r == me):
+                    self.peers[r][par, me].copy_(src, non_blocking=True)
 
         def reduce_and_gather():                        # two-shot (B): the rank-order sum of MY slice, then into every rank's gather array
             if hi > lo:
@@ -253,13 +282,12 @@ class OneShotAllReduce(object):
                 reduce_and_gather()
                 st.synchronize()
                 dist.barrier()
-                flat.copy_(self.gath[par], non_blocking=True)
+                self._finish(self.gath[par], 1, flat, seg_sizes, sq_part)
                 return flat
-            for r in range(self.world):                 # 1. my buffer into slot `rank` of every rank's array
-                self.peers[r][par, self.rank].copy_(flat, non_blocking=True)
+            spread()                                    # 1.
             st.synchronize()                            # 2. my writes have landed ...
             dist.barrier()                              #    ... and so have everybody else's
-            L.call('mpg_sum_slots', L.ptr(self.stage[par]), L.c_int(self.world), L.c_int(self.n), L.ptr(flat), L.stream())
+            self._finish(self.stage[par], self.world, flat, seg_sizes, sq_part)
             return flat
         it = self.calls
         g = (it - 1) // self.GEN_LEN
@@ -277,8 +305,7 @@ class OneShotAllReduce(object):
         if two:
             scatter()
         else:
-            for r in range(self.world):                 # 1. my buffer into slot `rank` of every rank's array
-                self.peers[r][par, self.rank].copy_(flat, non_blocking=True)
+            spread()                                    # 1.
         self.mine[g][par].record(st)                    # W[par]
         self.shm.publish(it)                            # host: "my record of exchange `it` has been issued"
         for p, ev in self.theirs[g].items():            # 2. behind every peer's writes - a stream wait, not a host wait
@@ -291,9 +318,9 @@ class OneShotAllReduce(object):
             for p, ev in self.theirs[g].items():        # 4. behind every peer's slice
                 self.shm.wait2(p, it)
                 st.wait_event(ev[4 + par])
-            flat.copy_(self.gath[par], non_blocking=True)
+            self._finish(self.gath[par], 1, flat, seg_sizes, sq_part)
         else:
-            L.call('mpg_sum_slots', L.ptr(self.stage[par]), L.c_int(self.world), L.c_int(self.n), L.ptr(flat), L.stream())   # 3.
+            self._finish(self.stage[par], self.world, flat, seg_sizes, sq_part)     # 3.
         self.mine[g][2 + par].record(st)                # S[par]: my reads of this parity's slots (and gather array) are done
         return flat
 
@@ -311,19 +338,33 @@ def world_size():
     return dist.get_world_size() if dist.is_initialized() else 1
 
 
-def all_reduce_sum_(flat, force=False, tag=0):
+def _exchanger(n, device, tag):
+    ex = _oneshot.get((n, tag))
+    if ex is None:         # (a collective construction: every rank reaches it at the same exchange of the same length)
+        ex = _oneshot[(n, tag)] = OneShotAllReduce(n, device)
+    return ex
+
+
+def grad_slot(n, device, force=False, tag=0):
+    """With the one-shot backend: the staging slot the NEXT exchange of an n-float buffer takes this rank's contribution from
+    (OneShotAllReduce.grad_slot) - write the buffer there and pass in_slot=True to all_reduce_sum_.  None with any other backend
+    (or without an exchange): the caller keeps its own buffer."""
+    if dist.is_initialized() and (dist.get_world_size() > 1 or force) and _exchange == 'oneshot':
+        return _exchanger(n, device, tag).grad_slot()
+    return None
+
+
+def all_reduce_sum_(flat, force=False, tag=0, in_slot=False, seg_sizes=None, sq_part=None):
     """In-place sum over ranks of one flat float32 buffer (no-op on a single process unless `force`: a one-rank group
     still runs the collective - the way the RCCL path is exercised on a 1-GPU box).  `tag`: exchanges that may be in flight at the
     same time (on different streams) must not share a one-shot exchanger - staging parities, events and shared-memory counters are
     per object - so concurrent callers pass distinct tags (mpg_amd/fused.py: 1 = the critics' slice under the sweep)."""
     if dist.is_initialized() and (dist.get_world_size() > 1 or force):
         if _exchange == 'oneshot':
-            ex = _oneshot.get((flat.numel(), tag))
-            if ex is None:         # (a collective construction: every rank reaches it at the same exchange of the same length)
-                ex = _oneshot[(flat.numel(), tag)] = OneShotAllReduce(flat.numel(), flat.device)
-            ex.all_reduce_sum_(flat)
-        else:
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            _exchanger(flat.numel(), flat.device, tag).all_reduce_sum_(flat, in_slot=in_slot, seg_sizes=seg_sizes, sq_part=sq_part)
+            return flat
+        assert not in_slot, 'in_slot is the one-shot backend\'s (grad_slot returned None)'
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     return flat
 
 

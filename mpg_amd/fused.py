@@ -42,7 +42,7 @@ class TrainCtx(ctypes.Structure):
         ('per_sum', _P), ('per_min', _P), ('per_stamp', _P), ('per_capacity', ctypes.c_int), ('per_max_priority', _P),
         ('per_alpha', ctypes.c_double), ('per_beta', ctypes.c_double), ('per_eps', ctypes.c_double),
         ('b_weights', _P), ('scratch', _P),
-        ('critics_ready_event', _P), ('grad_opts', GradOpts)]
+        ('critics_ready_event', _P), ('grad_opts', GradOpts), ('clip_partials_ready', ctypes.c_int)]
 
 
 class FusedMPGStep(object):
@@ -133,6 +133,12 @@ class FusedMPGStep(object):
                 n_crit = int(sum(pw.sizes[:len(pw.names) - 1]))
                 self.overlap = (side, e1, e2, n_crit)
                 c.critics_ready_event = e1.cuda_event
+        # round 6, one-shot backend without the overlap option: the step writes its partial gradient STRAIGHT into this rank's staging
+        # slot of the exchange (no copy into it) and the exchange's sum leaves the clip's partials of the reduced gradient behind
+        # (mpg_sum_slots_sq; mpg_train_ctx_t.clip_partials_ready) - on one GPU the exchange path is then one launch on top of the
+        # unexchanged step instead of three
+        self.slot_exchange = bool(c.grads_exchanged) and self.overlap is None and D._exchange == 'oneshot' and \
+            os.environ.get('MPG_SLOT_EXCHANGE', '1') != '0'
         w0, w1 = ctypes.c_size_t(0), ctypes.c_size_t(0)
         L.call('mpg_step_workspace_bytes', ctypes.byref(c), ctypes.byref(w0), ctypes.byref(w1))
         self.ws0 = torch.empty(w0.value + 256, dtype=torch.uint8, device=dev)
@@ -185,13 +191,16 @@ class FusedMPGStep(object):
     def step(self, iteration):
         self.sync_in()           # a few host scalar copies; the tensor copies only happen after a stock-method call
         s = L.stream()
+        flat = self.learner.flat
+        slot = D.grad_slot(flat.numel(), flat.device, force=self.always_exchange) if self.slot_exchange else None
+        if slot is not None:
+            self.c.grad = slot.data_ptr()
         L.check(self._lib.mpg_step_begin(self._ref, ctypes.c_int(iteration), s), 'mpg_step_begin')
         if self.c.grads_exchanged:
             # the ONE exchange step, timed under the caller's kernel timer (slot 8, HIP events on the launch stream: bench.py's
             # `exchange_ms`) - a null or stopped timer makes both calls no-ops
             prof = ctypes.c_void_p(self.c.cfg.prof)
             self._lib.mpg_prof_region_begin(prof, ctypes.c_int(8), s)
-            flat = self.learner.flat
             if self.overlap is not None:
                 # the critics' slice was complete when the library recorded e1 (ahead of the reverse sweep): its exchange runs on
                 # the side stream under the sweep, the policy's slice + statistics follow the sweep on the launch stream
@@ -203,6 +212,9 @@ class FusedMPGStep(object):
                     e2.record(side)
                 D.all_reduce_sum_(flat[n_crit:], force=self.always_exchange)
                 main.wait_event(e2)
+            elif slot is not None:
+                D.all_reduce_sum_(flat, force=self.always_exchange, in_slot=True, seg_sizes=self.pw.sizes, sq_part=self.learner.clip_scratch)
+                self.c.grad, self.c.clip_partials_ready = flat.data_ptr(), 1
             else:
                 D.all_reduce_sum_(flat, force=self.always_exchange)
             self._lib.mpg_prof_region_end(prof, ctypes.c_int(8), s)

@@ -22,7 +22,7 @@ def test_library_builds_and_exports_every_declared_symbol(built):
     lib = ctypes.CDLL(built)
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
-    assert lib.mpg_abi_version() == 9          # mpg_common.h: bumped with every layout or signature change (ops.py mirrors the structs)
+    assert lib.mpg_abi_version() == 10         # mpg_common.h: bumped with every layout or signature change (ops.py mirrors the structs)
 
 
 def test_no_undeclared_exports(built):

@@ -345,3 +345,32 @@ def test_bench_in_the_drivers_multi_rank_form(backend, nproc):
     assert abs(d['ms_per_step'] - sorted(d['region_ms_per_step'])[2]) <= 1e-9 * d['ms_per_step']
     forms = d['exchange_forms_ms']
     assert set(forms) >= {'oneshot', 'twoshot'} and all(isinstance(forms[k], float) and forms[k] > 0 for k in ('oneshot', 'twoshot')), forms
+
+
+@pytest.mark.parametrize('n_slots', [1, 2, 8])
+def test_sum_slots_sq_equals_sum_slots_then_sq_partials(n_slots):
+    """mpg_sum_slots_sq (round 6: the exchange's rank-order sum with the clip's partial sums of squares of the RESULT as a by-product) ==
+    mpg_sum_slots followed by mpg_sq_partials, bit for bit - sums, partials, and the statistics tail behind the networks - for the
+    MPG-v2 layout (two critics + policy + 16 statistics), a strided slot array, and n_slots = 1 (the two-shot form's copy out of its
+    gather array)."""
+    import ctypes
+    import mpg_amd._lib as L
+    from mpg_amd import ops
+    sizes = [ops.net_size(8, 1), ops.net_size(8, 1), ops.net_size(6, 4)]
+    n = sum(sizes) + 16
+    stride = n + 48
+    g = torch.Generator().manual_seed(n_slots)
+    slots = (torch.randn(n_slots, stride, generator=g) * 10.0 ** torch.randint(-4, 1, (n_slots, stride), generator=g).float()).cuda()
+    csz = (ctypes.c_int * 3)(*sizes)
+    out_a, out_b = torch.empty(n).cuda(), torch.full((n,), float('nan')).cuda()
+    part_a, part_b = torch.zeros(3 * 272).cuda(), torch.full((3 * 272,), float('nan')).cuda()
+    L.call('mpg_sum_slots_strided', L.ptr(slots), L.c_int(n_slots), L.c_size_t(stride), L.c_int(n), L.ptr(out_a), L.stream())
+    L.call('mpg_sq_partials', L.ptr(out_a), csz, L.c_int(3), L.ptr(part_a), L.stream())
+    L.call('mpg_sum_slots_sq', L.ptr(slots), L.c_int(n_slots), L.c_size_t(stride), L.c_int(n), L.ptr(out_b), csz, L.c_int(3), L.ptr(part_b),
+           L.stream())
+    torch.cuda.synchronize()
+    assert torch.equal(out_a, out_b) and torch.equal(part_a, part_b)
+    ref = slots[0, :n].clone()
+    for r in range(1, n_slots):
+        ref += slots[r, :n]
+    assert torch.equal(out_b, ref)

@@ -10,4 +10,8 @@ for i in 1 2; do
   echo -n "(a) one GPU, no exchange:                "; python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-side-configs 2>/dev/null | python3 -c "$P"
   echo -n "(b) one-rank RCCL exchange:              "; python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-side-configs --always-exchange 2>/dev/null | python3 -c "$P"
   echo -n "(c) ... + critics under the sweep:       "; MPG_OVERLAP_EXCHANGE=1 python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-side-configs --always-exchange 2>/dev/null | python3 -c "$P"
+  # round 6: the one-shot IPC exchange with itself - the round-5 form (copy into the staging slot, sum, mpg_sq_partials) against the
+  # slot form (the step writes its gradient straight into the slot; the sum leaves the clip partials: ONE launch more than (a))
+  echo -n "(d) one-rank one-shot, round-5 form:     "; MPG_DIST_BACKEND=oneshot MPG_SLOT_EXCHANGE=0 python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-side-configs --always-exchange 2>/dev/null | python3 -c "$P"
+  echo -n "(e) one-rank one-shot, slot form:        "; MPG_DIST_BACKEND=oneshot python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-side-configs --always-exchange 2>/dev/null | python3 -c "$P"
 done
