@@ -640,6 +640,8 @@ def loop_args(case, **kw):
         args = mpg_args('NADP', 256, 256, env='InvertedPendulumConti-v0')
         args.num_rollout_list_for_policy_update, args.num_rollout_list_for_q_estimation = [25], [25]
         args.delay_update, args.num_agent, args.explore_sigma = 1, 1, None
+    elif case == 'td3':
+        args = mpg_args('TD3', 256, 256)
     else:
         args = mpg_args('MPG-' + case, 256, 256)
         if case == 'v1':
@@ -834,8 +836,9 @@ def _register_cart_pole(seed):
 
 def fx_loop(case, n_iter=20):
     """SingleProcessOffPolicyOptimizer (optimizer.py:286-397) at the reference's defaults - OffPolicyWorker (8 agents, 512 transitions
-    per sample) / ReplayBuffer (replay_starts 3000, batch 256) / MPGLearner MPG-v2 (case 'v2') or NADPLearner on the pendulum model
-    (case 'nadp': 1 agent behind DummyVecEnv) / PolicyWithQs - constructed (fills the ring) and stepped n_iter times (sampling at
+    per sample) / ReplayBuffer (replay_starts 3000, batch 256) / MPGLearner MPG-v2 (case 'v2'), MPG-v1 ('v1': Q1 + policy, the 25-step
+    real-env target of the learner's own 256-agent env recomputed every 10th call), TD3Learner ('td3', uniform replay) or NADPLearner on the
+    pendulum model (case 'nadp': 1 agent behind DummyVecEnv) / PolicyWithQs - constructed (fills the ring) and stepped n_iter times (sampling at
     iterations 0 and 10).  All reference classes unmodified; random inputs: DeviceStreams(LOOP_SEED); initial weights:
     golden_inputs.loop_case_weights.  Per iteration: replay indices, learner statistics, per-optimizer counters, per-network update
     norms, every 64th parameter; at the end: all parameters and targets, the ring."""
@@ -843,26 +846,33 @@ def fx_loop(case, n_iter=20):
     from optimizer import SingleProcessOffPolicyOptimizer
     from policy import PolicyWithQs
     from worker import OffPolicyWorker
+    dims = 'v2' if case == 'td3' else case                  # (TD3: the MPG-v2 network set and initial weights)
+    smoothing = False
     if case == 'nadp':
         from learners.nadp import NADPLearner as Learner
         _register_cart_pole(LOOP_SEED)
         keys = ('q_loss', 'policy_loss', 'value_mean', 'q_gradient_norm', 'policy_gradient_norm')
         counters = lambda k: [2 * k, 2 * k + 1]             # Q-target rollout, then the policy rollout (nadp.py:175,188)
+    elif case == 'td3':
+        from learners.td3 import TD3Learner as Learner      # learners/td3.py:150-188; the only tf draw is the smoothing noise (:74)
+        keys = ('q_loss1', 'q_loss2', 'policy_loss', 'value_mean', 'q_gradient_norm1', 'q_gradient_norm2', 'policy_gradient_norm')
+        counters, smoothing = (lambda k: [k]), True
     else:
         from learners.mpg_learner import MPGLearner as Learner
-        keys = ('q_loss1', 'q_loss2', 'value_mean', 'policy_total_loss', 'q_gradient_norm1', 'q_gradient_norm2', 'policy_gradient_norm')
+        keys = ('q_loss1', 'q_loss2', 'value_mean', 'policy_total_loss', 'q_gradient_norm1', 'q_gradient_norm2', 'policy_gradient_norm') \
+            if case == 'v2' else ('q_loss1', 'value_mean', 'policy_total_loss', 'q_gradient_norm1', 'policy_gradient_norm')
         counters = lambda k: [k]
-    w0 = loop_case_weights(case)
-    w0_flat = np.concatenate([w0[name] for name, _, _ in NET_DIMS[case]])
+    w0 = loop_case_weights(dims)
+    w0_flat = np.concatenate([w0[name] for name, _, _ in NET_DIMS[dims]])
     out = dict(n_iter=n_iter, seed=LOOP_SEED)
     for tag, dt in (('', torch.float32), ('_f64', torch.float64)):
         tf.set_ref_dtype(dt)
         args = loop_args(case)
-        st = DeviceStreams(LOOP_SEED, args.num_agent, args.explore_sigma, args.replay_batch_size, noise_counters=counters)
+        st = DeviceStreams(LOOP_SEED, args.num_agent, args.explore_sigma, args.replay_batch_size, noise_counters=counters, smoothing=smoothing)
         st.install()
         try:
             worker = OffPolicyWorker(PolicyWithQs, args.env_id, args, 0)
-            set_online_and_targets(worker.policy_with_value, case, w0)
+            set_online_and_targets(worker.policy_with_value, dims, w0)
             learner = Learner(PolicyWithQs, args)
             rb = ReplayBuffer(args, 0)
             opt = SingleProcessOffPolicyOptimizer(worker, learner, rb, None, args)
@@ -876,7 +886,7 @@ def fx_loop(case, n_iter=20):
                 iters.append([o.iterations for o in pwq.optimizers])
                 p, t = flat_models(pwq)
                 o, row = 0, []
-                for name, _, _ in NET_DIMS[case]:
+                for name, _, _ in NET_DIMS[dims]:
                     n = w0[name].size
                     row.append(float(np.linalg.norm(p[o:o + n].astype(np.float64) - w0[name])))
                     o += n
@@ -905,7 +915,7 @@ ROUND2['trained_c2'] = lambda: fx_bench_case('c2_mpg_v2_B4096', trained=True)   
 ROUND2['mpg_future'] = lambda: fx_mpg('MPG-v2', 256, 64, seed=12, K=3)               # round 3: num_future_data = 3
 ROUND2['mpg_future10'] = lambda: fx_mpg('MPG-v2', 256, 64, seed=13, K=10)           # round 4: num_future_data = 10 (obs_dim 16, critics 18 wide)
 ROUND2.update(apply_gradients=fx_apply_gradients, worker_sample=fx_worker_sample,           # round 6: the reference's own loop code
-              loop_v2=lambda: fx_loop('v2'), loop_nadp=lambda: fx_loop('nadp'))
+              loop_v2=lambda: fx_loop('v2'), loop_nadp=lambda: fx_loop('nadp'), loop_td3=lambda: fx_loop('td3'), loop_v1=lambda: fx_loop('v1'))
 
 
 def main():

@@ -102,7 +102,8 @@ def _check_loop_against_fixture(g, loop, names, ring_keys, idx_of, stat_of, n_it
     worst = 0.0
     for it in range(n_iter):
         loop.step()
-        np.testing.assert_array_equal(idx_of(loop), g['idx'][it], err_msg='replay indices, iteration %d' % it)
+        if idx_of(loop) is not None:
+            np.testing.assert_array_equal(idx_of(loop), g['idx'][it], err_msg='replay indices, iteration %d' % it)
         assert [loop.opt[n].step for n in names] == list(g['opt_iterations'][it]), it
         p = np.concatenate([loop.w[n] for n in names])
         for k, key in enumerate(g['stat_keys']):
@@ -122,8 +123,12 @@ def _check_loop_against_fixture(g, loop, names, ring_keys, idx_of, stat_of, n_it
     return worst
 
 
-def test_config2_loop_restatement_vs_reference_optimizer(golden):
-    """tests/c2_loop.py x 20 iterations against the reference's SingleProcessOffPolicyOptimizer + OffPolicyWorker + ReplayBuffer +
+@pytest.mark.parametrize('case', ['v2', 'td3', 'v1'])
+def test_config2_loop_restatement_vs_reference_optimizer(golden, case):
+    """[td3: the same with the reference's TD3Learner (learners/td3.py:150-188, uniform replay; the smoothing noise td3.py:74 on the
+    restated mpg_normal_fill stream).  v1: MPGLearner MPG-v1 - networks [Q1 | policy], the critic's target = the 25-step REAL-env return of
+    the learner's own 256-agent env (mpg_learner.py:109-124,146-169), recomputed with a new minibatch every num_batch_reuse = 10 calls.]
+    tests/c2_loop.py x 20 iterations against the reference's SingleProcessOffPolicyOptimizer + OffPolicyWorker + ReplayBuffer +
     MPGLearner (MPG-v2) + PolicyWithQs at the reference's defaults (8 agents, 512 transitions per sample, replay_starts 3000, batch
     256, sampling at iterations 0 and 10, delay_update 2), same Philox inputs, same initial weights.
     Exact: ring length after the fill and at the end, the replay indices of every iteration (they depend on the ring length, i.e. on
@@ -131,17 +136,21 @@ def test_config2_loop_restatement_vs_reference_optimizer(golden):
     Bars: learner statistics 2e-4 relative; per-network update norms 1e-3; parameter update (every 64th entry, every iteration, and
     all entries at the end) 1e-3 relative L2 and within 4 x the reference's own float32-vs-float64 gap; ring contents 2e-5."""
     from tests.c2_loop import OracleConfig2Loop
-    g = golden('loop_v2_ref.npz')
-    names = [n for n, _, _ in NET_DIMS['v2']]
-    w = loop_case_weights('v2')
+    g = golden('loop_%s_ref.npz' % case)
+    dims = 'v1' if case == 'v1' else 'v2'
+    names = [n for n, _, _ in NET_DIMS[dims]]
+    w = loop_case_weights(dims)
     w0 = np.concatenate([w[n] for n in names])
     nthreads = torch.get_num_threads()
     torch.set_num_threads(4)
     loop = OracleConfig2Loop(w, seed=int(g['seed']), num_agent=8, batch_size=512, replay_batch_size=256, replay_starts=3000,
-                             capacity=8192, sampling_interval=10)
+                             capacity=8192, sampling_interval=10, alg={'v2': 'MPG-v2', 'td3': 'TD3', 'v1': 'MPG-v1'}[case])
     n_iter = int(g['n_iter'])
     stat = lambda lp, key: float(np.asarray(lp.stats[key])) if key in lp.stats else None
-    worst = _check_loop_against_fixture(g, loop, names, None, lambda lp: lp.idx, stat, n_iter, w0)
+    # (MPG-v1: the reference's buffer draws every iteration, the learner takes a new minibatch every 10th call - the restated loop draws
+    # only those; the Philox counter is the replay count in both, so the draws it does make are the fixture's rows 0 and 10)
+    idx_of = lambda lp: lp.idx if (lp.counter - 1) % lp.reuse == 0 else None
+    worst = _check_loop_against_fixture(g, loop, names, None, idx_of, stat, n_iter, w0)
     torch.set_num_threads(nthreads)
     n = int(g['ring_len'])
     assert loop.size == n and loop.next == int(g['ring_next']) and loop.replay_times == int(g['replay_times']) == n_iter
@@ -154,8 +163,8 @@ def test_config2_loop_restatement_vs_reference_optimizer(golden):
     p, t = loop.flat()
     e_p, e_t = rel_l2(p - w0, g['params'] - w0), rel_l2(t - w0, g['targets'] - w0)
     gap, mine = rel_l2((g['params'] - w0)[::4], g['update_f64']), rel_l2((p - w0)[::4], g['update_f64'])
-    print('config-2 loop restatement vs the reference optimizer, %d iterations: update %.2e (targets %.2e; worst sampled %.2e); '
-          'vs float64 %.2e, reference float32 %.2e' % (n_iter, e_p, e_t, worst, mine, gap))
+    print('config-2 loop restatement (%s) vs the reference optimizer, %d iterations: update %.2e (targets %.2e; worst sampled %.2e); '
+          'vs float64 %.2e, reference float32 %.2e' % (case, n_iter, e_p, e_t, worst, mine, gap))
     assert e_p <= 1e-3 and e_t <= 1e-3 and mine <= 4 * gap + 1e-6
 
 

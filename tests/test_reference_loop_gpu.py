@@ -26,7 +26,7 @@ def rel_l2(a, b):
 
 def _args(case, **kw):
     from mpg_amd.config import default_args
-    return default_args({'v2': 'MPG-v2', 'v1': 'MPG-v1', 'nadp': 'NADP'}[case], nan_check_interval=10 ** 9, **kw)
+    return default_args({'v2': 'MPG-v2', 'v1': 'MPG-v1', 'nadp': 'NADP', 'td3': 'TD3'}[case], nan_check_interval=10 ** 9, **kw)
 
 
 @pytest.mark.parametrize('case', ['v2', 'v1', 'nadp'])
@@ -99,11 +99,13 @@ def test_device_worker_sample_vs_reference_worker(golden):
     worker.policy_with_value.check_status()
 
 
-@pytest.mark.parametrize('case', ['v2', 'nadp', 'nadp-ring-forced'])
+@pytest.mark.parametrize('case', ['v2', 'td3', 'v1', 'nadp', 'nadp-ring-forced'])
 def test_device_loop_vs_reference_optimizer(golden, case):
     """The device's SingleProcessOffPolicyOptimizer (native step driver: mpg_step_begin / mpg_step_end) at the reference's defaults
     against the reference's own optimizer loop: 20 iterations, sampling at iterations 0 and 10.
-    v2: 8 agents x 64 steps per sample, replay batch 256, MPG-v2, delay_update 2.  nadp: ONE agent x 512 steps per sample (the
+    v2: 8 agents x 64 steps per sample, replay batch 256, MPG-v2, delay_update 2.  td3: the same with TD3Learner (learner_version 4,
+    uniform replay, in-kernel smoothing noise).  v1: MPG-v1 (learner_version 1: networks [Q1 | policy]; the 25-step real-env target of
+    the learner's own 256-agent env, recomputed with a new minibatch every 10th call and cached in between).  nadp: ONE agent x 512 steps per sample (the
     reference's DummyVecEnv form), NADP on the pendulum model, delay_update 1; the real env is the analytic cart-pole on both sides.
     Exact: ring length after the fill, replay indices of every iteration, optimizer counters, stream counters.
     Bars (as the oracle-loop tests of tests/test_noise_gpu.py): parameter update within 1e-3 relative L2 of the reference's at every
@@ -120,21 +122,24 @@ def test_device_loop_vs_reference_optimizer(golden, case):
     from mpg_amd.optimizer import SingleProcessOffPolicyOptimizer
     from mpg_amd.policy import PolicyWithQs
     from mpg_amd.worker import OffPolicyWorker
+    from mpg_amd.learners import TD3Learner
     forced = case.endswith('-ring-forced')
     case = case.split('-')[0]
     g = golden('loop_%s_ref.npz' % case)
-    names = [n for n, _, _ in NET_DIMS[case]]
+    dims = 'v2' if case == 'td3' else case
+    names = [n for n, _, _ in NET_DIMS[dims]]
     args = _args(case, seed=int(g['seed']), max_buffer_size=8192)
-    assert (args.num_agent, args.batch_size, args.replay_batch_size, args.replay_starts) == ((8 if case == 'v2' else 1), 512, 256, 3000)
+    assert (args.num_agent, args.batch_size, args.replay_batch_size, args.replay_starts) == ((1 if case == 'nadp' else 8), 512, 256, 3000)
     worker = OffPolicyWorker(PolicyWithQs, args.env_id, args, 0)
     pw = worker.policy_with_value
-    w = loop_case_weights(case)
+    w = loop_case_weights(dims)
     w0 = np.concatenate([w[n] for n in names])
     pw.set_flat(w0, w0)
-    learner = (MPGLearner if case == 'v2' else NADPLearner)(PolicyWithQs, args)
+    learner = {'v2': MPGLearner, 'v1': MPGLearner, 'td3': TD3Learner, 'nadp': NADPLearner}[case](PolicyWithQs, args)
     rb = ReplayBuffer(args, 0)
     opt = SingleProcessOffPolicyOptimizer(worker, learner, rb, None, args)            # sampling_interval 10: optimizer.py:331
-    assert opt._fused is not None and opt._fused.c.learner_version == (2 if case == 'v2' else 3)
+    assert opt._fused is not None and opt._fused.c.learner_version == {'v2': 2, 'v1': 1, 'td3': 4, 'nadp': 3}[case]
+    assert case != 'v1' or learner.num_batch_reuse == 10
     assert len(rb) == int(g['fill'])
     keys = [str(k) for k in g['stat_keys']]
     worst = 0.0
@@ -151,7 +156,8 @@ def test_device_loop_vs_reference_optimizer(golden, case):
         torch.cuda.synchronize()
         if forced and it % 10 == 0:
             force_ring()
-        np.testing.assert_array_equal(opt._fused.t['idx'].cpu().numpy(), g['idx'][it], err_msg='replay indices, iteration %d' % it)
+        if case != 'v1' or it % 10 == 0:      # (MPG-v1 draws a new minibatch every 10th call; the reference's buffer draws - and discards - in between)
+            np.testing.assert_array_equal(opt._fused.t['idx'].cpu().numpy(), g['idx'][it], err_msg='replay indices, iteration %d' % it)
         assert [pw.opt_steps[n] for n in names] == list(g['opt_iterations'][it]), it
         st = learner.get_stats()
         for k, key in enumerate(keys):
@@ -164,15 +170,15 @@ def test_device_loop_vs_reference_optimizer(golden, case):
         assert e <= tol_u, (it, e)
     n = int(g['ring_len'])
     assert len(rb) == n and opt._fused.c.replay_times == int(g['replay_times']) and opt._fused.c.learner_counter == int(g['learner_counter'])
-    if case == 'v2':
+    if case != 'nadp':
         assert [worker.env._ctr, worker._noise_ctr] == list(g['counters'][:2])
     # ring contents.  v2: every agent is re-drawn after every step, so a row is ONE env step from a Philox draw: 1e-3 relative to the
     # column scale.  nadp: ONE agent runs on until it falls (DummyVecEnv resets only when done), i.e. a row sits up to ~60 steps down an
     # UNSTABLE trajectory (upright pole: perturbations grow ~e^(5 t), 0.04 s per step), where float32 rounding differences between the
     # device's RK4 and the reference run's reach 5e-3: the trajectory bar is 2e-2 absolute, and every stored transition is checked one step
     # at a time against the float64 cart-pole from the DEVICE's own (obs, act) at 2e-5 - the amplification-free statement.
-    tol = 1e-3 if case == 'v2' else 2e-2
-    for k in ('obs', 'act') + (('obs2', 'rew') if case == 'v2' else ()):
+    tol = 1e-3 if case != 'nadp' else 2e-2
+    for k in ('obs', 'act') + (('obs2', 'rew') if case != 'nadp' else ()):
         ref = g['ring_' + k].reshape(n, -1)
         got = getattr(rb, k)[:n].cpu().numpy().reshape(n, -1)
         scale = np.maximum(1.0, np.abs(ref).max(0))
@@ -189,7 +195,7 @@ def test_device_loop_vs_reference_optimizer(golden, case):
     print('%s device loop vs the reference optimizer, %d iterations: update %.2e (targets %.2e; worst sampled %.2e); vs float64 %.2e, '
           'reference float32 %.2e' % (case, int(g['n_iter']), e_p, e_t, worst, mine, gap))
     assert e_p <= tol_u and e_t <= tol_u
-    if case == 'v2':
+    if case != 'nadp':
         assert mine <= 4 * gap + 1e-6
     elif forced:                # (two of the twenty minibatches still hold ~14 % device-made rows; measured: update 4.9e-6, 1.46e-5 from the
         assert e_p <= 2e-4 and mine <= 4 * gap + 1e-6, (e_p, mine, gap)        # float64 run against the reference float32 run's 1.43e-5)
