@@ -908,6 +908,70 @@ def fx_loop(case, n_iter=20):
     np.savez_compressed(os.path.join(HERE, 'loop_%s_ref.npz' % case), **out)
 
 
+def fx_per_buffer(seed=80):
+    """PrioritizedReplayBuffer (buffer.py:94-189) - its METHODS, unmodified: add (max priority), _sample_proportional (scripted
+    random.random), sample_with_weights_and_idxes (IS weights), update_priorities (sequential: the last duplicate wins; max_priority).
+    The shipped CONSTRUCTOR is dead code (it asserts `args.alpha > 0` - an attribute no parser defines - and reads `args.size`,
+    SURVEY B-3), so the object is made with __new__ and given exactly what :114-125 evidently intends: alpha / beta from replay_alpha /
+    replay_beta, trees of the next power of two above max_buffer_size, max priority 1.  Likewise `add_batch` hands `add` a weight of 0
+    (buffer.py:82: priority 0 ** alpha = 0: never drawn); transitions are added through `add(..., None)`, the max-priority path the
+    code evidently means.  Sequence: 500 adds -> draw 256 -> update -> 300 adds (wraps the 700-slot ring: old slots back to max
+    priority) -> draw -> update (with duplicate indices) -> draw.  Leaves, indices, weights, max priority after every phase."""
+    import random
+    from buffer import PrioritizedReplayBuffer, ReplayBuffer
+    from utils.segment_tree import MinSegmentTree, SumSegmentTree
+    rng = np.random.Generator(np.random.PCG64(seed))
+    cap, B = 700, 256
+    args = argparse.Namespace(max_buffer_size=cap, replay_starts=100, replay_batch_size=B, buffer_log_interval=10 ** 9,
+                              replay_alpha=0.6, replay_beta=0.4)
+    rb = PrioritizedReplayBuffer.__new__(PrioritizedReplayBuffer)
+    ReplayBuffer.__init__(rb, args, 0)
+    rb._alpha, rb._beta = args.replay_alpha, args.replay_beta
+    it_capacity = 1
+    while it_capacity < cap:
+        it_capacity *= 2
+    rb._it_sum, rb._it_min, rb._max_priority = SumSegmentTree(it_capacity), MinSegmentTree(it_capacity), 1.0
+    n_tr = 800
+    obs = rng.standard_normal((n_tr, 6)).astype(np.float32)
+    act = rng.uniform(-1, 1, (n_tr, 2)).astype(np.float32)
+    rew = rng.uniform(-30, 0, n_tr).astype(np.float32)
+    u = rng.uniform(0, 1, (3, B))
+    td = (rng.standard_normal((2, B)) * 10.0 ** rng.uniform(-4, 1, (2, B))).astype(np.float32)        # signed, four decades
+    out = dict(capacity=cap, tree_capacity=it_capacity, B=B, alpha=0.6, beta=0.4, eps=1e-6, obs=obs, act=act, rew=rew, u=u, td=td)
+
+    def leaves():
+        return np.array([rb._it_sum[i] for i in range(it_capacity)], np.float64)
+
+    def draw(k):
+        stream = iter(u[k])
+        saved, random.random = random.random, lambda: float(next(stream))
+        try:
+            idx = rb.sample_idxes(B)
+        finally:
+            random.random = saved
+        enc = rb.sample_with_weights_and_idxes(idx)
+        out['draw%d_idx' % k], out['draw%d_weights' % k] = np.asarray(idx, np.int64), np.asarray(enc[5], np.float64)
+        out['draw%d_obs' % k], out['draw%d_rew' % k] = np.asarray(enc[0]), np.asarray(enc[2])
+        out['draw%d_total' % k], out['draw%d_min' % k] = rb._it_sum.sum(), rb._it_min.min()
+        return idx
+    for i in range(500):
+        rb.add(obs[i], act[i], rew[i], obs[i], True, None)
+    out['leaves_a'] = leaves()
+    idx = draw(0)
+    rb.update_priorities(idx, [abs(float(x)) + 1e-6 for x in td[0]])
+    out['leaves_b'], out['max_priority_b'] = leaves(), rb._max_priority
+    for i in range(500, 800):
+        rb.add(obs[i], act[i], rew[i], obs[i], True, None)
+    out['leaves_c'], out['next_idx_c'], out['len_c'] = leaves(), rb._next_idx, len(rb)
+    idx = draw(1)
+    idx = np.concatenate([idx[:200], idx[:56]])                 # duplicates: the LAST occurrence wins (sequential loop, :181-187)
+    out['update2_idx'] = np.asarray(idx, np.int64)
+    rb.update_priorities(idx, [abs(float(x)) + 1e-6 for x in td[1]])
+    out['leaves_d'], out['max_priority_d'] = leaves(), rb._max_priority
+    draw(2)
+    np.savez_compressed(os.path.join(HERE, 'per_buffer_ref.npz'), **out)
+
+
 ROUND2 = {'replay_buffer': fx_replay_buffer, 'evaluator': fx_evaluator, 'env_future': fx_env_future,
           'q_estimation': fx_q_estimation}
 ROUND2.update({n: (lambda n=n: fx_bench_case(n)) for n in BENCH_CASES})
@@ -915,7 +979,7 @@ ROUND2['trained_c2'] = lambda: fx_bench_case('c2_mpg_v2_B4096', trained=True)   
 ROUND2['mpg_future'] = lambda: fx_mpg('MPG-v2', 256, 64, seed=12, K=3)               # round 3: num_future_data = 3
 ROUND2['mpg_future10'] = lambda: fx_mpg('MPG-v2', 256, 64, seed=13, K=10)           # round 4: num_future_data = 10 (obs_dim 16, critics 18 wide)
 ROUND2.update(apply_gradients=fx_apply_gradients, worker_sample=fx_worker_sample,           # round 6: the reference's own loop code
-              loop_v2=lambda: fx_loop('v2'), loop_nadp=lambda: fx_loop('nadp'), loop_td3=lambda: fx_loop('td3'), loop_v1=lambda: fx_loop('v1'))
+              loop_v2=lambda: fx_loop('v2'), loop_nadp=lambda: fx_loop('nadp'), loop_td3=lambda: fx_loop('td3'), loop_v1=lambda: fx_loop('v1'), per_buffer=fx_per_buffer)
 
 
 def main():

@@ -575,3 +575,49 @@ def test_td3_prioritized_loop_teacher_forced_against_the_oracle_loop(size):
     torch.set_num_threads(nthreads)
     print('TD3 + prioritized replay, teacher-forced (%s), %d iterations: parameters %.1e, update %.1e, %d of %d draws flipped' %
           (size, total, worst_p, worst_u, flips, total * B))
+
+
+def test_device_per_vs_reference_prioritized_buffer(golden):
+    """mpg_amd.PrioritizedReplayBuffer (mpg_per_add / _sample / _update behind it) against the reference's OWN PrioritizedReplayBuffer
+    methods run unmodified (per_buffer_ref.npz; its dead constructor bypassed, see the generator): 500 transitions at max priority -> draw
+    256 with the fixture's uniforms -> |td| + eps priorities -> 300 more transitions through the wrapping 700-slot ring -> draw ->
+    priorities with duplicate indices (the last one wins) -> draw.  Leaves within 1 ulp of python's `**` (4e-16), every drawn index
+    exact, IS weights 2e-6 (float32 output), max priority to float32 rounding, gathered rows exact."""
+    from mpg_amd.buffer import PrioritizedReplayBuffer
+    from mpg_amd.config import default_args
+    g = golden('per_buffer_ref.npz')
+    cap, tcap, B = int(g['capacity']), int(g['tree_capacity']), int(g['B'])
+    args = default_args('TD3', max_buffer_size=cap, replay_starts=100, replay_batch_size=B, buffer_type='priority')
+    rb = PrioritizedReplayBuffer(args, 0)
+    assert rb._cap == tcap and abs(rb._alpha - float(g['alpha'])) < 1e-12 and abs(rb._beta - float(g['beta'])) < 1e-12
+
+    def add(lo, hi):
+        rb.add_batch((dev(g['obs'][lo:hi]), dev(g['act'][lo:hi]), dev(g['rew'][lo:hi]), dev(g['obs'][lo:hi]),
+                      torch.ones(hi - lo, dtype=torch.uint8, device=DEV)))
+
+    def leaves():
+        return rb._it_sum[tcap:2 * tcap].cpu().numpy()
+
+    def draw(k):
+        idx = rb.sample_idxes(B, u=dev(g['u'][k], torch.float64))
+        w = rb._last_weights.cpu().numpy()
+        np.testing.assert_array_equal(idx.cpu().numpy(), g['draw%d_idx' % k], err_msg='draw %d' % k)
+        np.testing.assert_allclose(w, g['draw%d_weights' % k], rtol=2e-6)
+        enc = rb._encode_sample(idx)
+        assert np.array_equal(enc[0].cpu().numpy(), g['draw%d_obs' % k]) and np.array_equal(enc[2].cpu().numpy(), g['draw%d_rew' % k])
+        assert abs(rb._it_sum[1].item() - float(g['draw%d_total' % k])) <= 1e-13 * float(g['draw%d_total' % k])
+        return idx
+    add(0, 500)
+    np.testing.assert_allclose(leaves(), g['leaves_a'], rtol=4e-16)
+    idx = draw(0)
+    rb.update_priorities(idx, dev(g['td'][0]))                      # signed TD errors: |.| + eps on the device
+    np.testing.assert_allclose(leaves(), g['leaves_b'], rtol=4e-16)
+    assert abs(rb._max_priority.item() - float(g['max_priority_b'])) <= 1e-6 * float(g['max_priority_b'])
+    add(500, 800)
+    assert rb._next_idx == int(g['next_idx_c']) and len(rb) == cap
+    np.testing.assert_allclose(leaves(), g['leaves_c'], rtol=4e-16)
+    draw(1)
+    rb.update_priorities(dev(g['update2_idx'], torch.int32), dev(g['td'][1]))
+    np.testing.assert_allclose(leaves(), g['leaves_d'], rtol=4e-16)
+    assert abs(rb._max_priority.item() - float(g['max_priority_d'])) <= 1e-6 * float(g['max_priority_d'])
+    draw(2)

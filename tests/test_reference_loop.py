@@ -235,3 +235,54 @@ def test_config4_oracle_loop_pieces_vs_the_pinned_segment_tree(golden):
         assert w.max() <= 1.0 + 1e-12 and w.min() > 0
     assert loop.max_priority >= 1.0 and loop.size == 128 + 3 * 16
     assert np.count_nonzero(loop.leaves) == loop.size
+
+
+def test_per_oracle_pieces_vs_reference_prioritized_buffer(golden):
+    """The oracle's PER pieces (heap_tree, find_prefixsum_idx_batch, the IS-weight formula of OracleConfig4Loop, per_is_weights over
+    SegmentTreeOracle) against the reference's OWN PrioritizedReplayBuffer methods run unmodified (per_buffer_ref.npz: add at max
+    priority, _sample_proportional, sample_with_weights_and_idxes, update_priorities with duplicates, a wrapping ring) - the shipped
+    constructor and add_batch's weight 0 are dead code and are bypassed, see the generator.  Everything float64: leaves, every drawn
+    index, totals and minima bit for bit; weights to 1e-15."""
+    g = golden('per_buffer_ref.npz')
+    cap, tcap, B, alpha, beta, eps = int(g['capacity']), int(g['tree_capacity']), int(g['B']), float(g['alpha']), float(g['beta']), float(g['eps'])
+    leaves = np.zeros(tcap)
+    seen = np.zeros(tcap, bool)
+    max_p = 1.0
+
+    def add(lo, hi, nxt):
+        for i in range(lo, hi):
+            leaves[nxt] = max_p ** alpha
+            seen[nxt] = True
+            nxt = (nxt + 1) % cap
+        return nxt
+
+    def draw(k, n_storage):
+        st = O.heap_tree(leaves, np.add)
+        mt = O.heap_tree(np.where(seen, leaves, np.inf), np.minimum)
+        assert st[1] == float(g['draw%d_total' % k]) and mt[1] == float(g['draw%d_min' % k])
+        idx = O.find_prefixsum_idx_batch(st, g['u'][k] * st[1])
+        np.testing.assert_array_equal(idx, g['draw%d_idx' % k])
+        w = (st[tcap + idx] / st[1] * n_storage) ** (-beta) / ((mt[1] / st[1] * n_storage) ** (-beta))
+        np.testing.assert_allclose(w, g['draw%d_weights' % k], rtol=1e-15)
+        return idx
+
+    def update(idx, td):
+        nonlocal max_p
+        for j, x in zip(idx, td):                       # sequential: the last duplicate wins
+            p = abs(float(x)) + eps
+            leaves[j] = p ** alpha
+            max_p = max(max_p, p)
+    nxt = add(0, 500, 0)
+    np.testing.assert_array_equal(leaves, g['leaves_a'])
+    idx = draw(0, 500)
+    update(idx, g['td'][0])
+    np.testing.assert_array_equal(leaves, g['leaves_b'])
+    assert max_p == float(g['max_priority_b'])
+    nxt = add(500, 800, nxt)
+    assert nxt == int(g['next_idx_c']) and int(g['len_c']) == cap
+    np.testing.assert_array_equal(leaves, g['leaves_c'])
+    idx = draw(1, cap)
+    update(g['update2_idx'], g['td'][1])
+    np.testing.assert_array_equal(leaves, g['leaves_d'])
+    assert max_p == float(g['max_priority_d'])
+    draw(2, cap)
