@@ -477,14 +477,15 @@ int mpg_per_init(double* sum_tree, double* min_tree, int* stamp, int capacity, m
  * (buffer.py:127-136,166-189): leaf[idx[i]] = (|prio[i]| + eps)^alpha in both trees (the reference asserts
  * priority > 0; learners hand signed td errors, SURVEY.md B-3, hence |.| + eps), then every internal node is
  * recomputed as left + right / min(left, right).  Duplicates: the last entry of the batch wins, like the
- * reference's sequential loop.  max_priority (device float, nullable) tracks max(|prio| + eps) (buffer.py:189). */
+ * reference's sequential loop.  max_priority (device DOUBLE since ABI 10 - the reference's _max_priority is a python float -,
+ * nullable) tracks max(|prio| + eps) (buffer.py:189). */
 int mpg_per_update(double* sum_tree, double* min_tree, int* stamp, int capacity, int n, const int* idx,
-                   const float* prio, double alpha, double eps, float* max_priority, mpg_stream_t stream);
+                   const float* prio, double alpha, double eps, double* max_priority, mpg_stream_t stream);
 
 /* PrioritizedReplayBuffer.add for n consecutive ring slots start, start + 1, ... (mod ring_capacity): their leaves enter at the
- * current max priority (buffer.py:127-136).  idx_scratch / prio_scratch: n ints / floats of device scratch. */
+ * current max priority, (*max_priority) ** alpha in float64 (buffer.py:127-136).  idx_scratch: n ints of device scratch. */
 int mpg_per_add(double* sum_tree, double* min_tree, int* stamp, int capacity, int ring_capacity, int start, int n,
-                double alpha, float* max_priority, int* idx_scratch, float* prio_scratch, mpg_stream_t stream);
+                double alpha, double* max_priority, int* idx_scratch, mpg_stream_t stream);
 
 /* PrioritizedReplayBuffer._sample_proportional + IS weights (buffer.py:138-160):
  *   mass_i = u_i * sum(0, n_storage)  (inclusive end, buffer.py:141);  idx_i = find_prefixsum_idx(mass_i)
@@ -564,7 +565,7 @@ typedef struct {
     double *per_sum, *per_min;        /* segment trees, 2 * per_capacity doubles each (mpg_per_init) */
     int* per_stamp;
     int per_capacity;
-    float* per_max_priority;
+    double* per_max_priority;         /* float64 (ABI 10): the reference's _max_priority is a python float */
     double per_alpha, per_beta, per_eps;
     float* b_weights;                 /* [batch] IS weights of the draw (buffer.py:146-160; the TD3 loss does not use them) */
     float* scratch;                   /* max(batch * (act_dim + 3), 2 * num_agent) floats: smoothing noise | y1 | td | priority errors

@@ -94,7 +94,7 @@ class PrioritizedReplayBuffer(ReplayBuffer):
         self._it_sum = torch.empty(2 * cap, dtype=torch.float64, device=self.device)
         self._it_min = torch.empty(2 * cap, dtype=torch.float64, device=self.device)
         self._stamp = torch.empty(cap, dtype=torch.int32, device=self.device)
-        self._max_priority = torch.ones(1, dtype=torch.float32, device=self.device)          # buffer.py:125
+        self._max_priority = torch.ones(1, dtype=torch.float64, device=self.device)          # buffer.py:125 (a python float there: float64)
         L.call('mpg_per_init', L.ptr(self._it_sum), L.ptr(self._it_min), L.ptr(self._stamp), L.c_int(cap), L.stream())
 
     def _set(self, idx, prio, eps):
@@ -104,9 +104,12 @@ class PrioritizedReplayBuffer(ReplayBuffer):
 
     def add_batch(self, batch):
         n = batch[0].shape[0]
-        idx = ((torch.arange(n, device=self.device, dtype=torch.int64) + self._next_idx) % self._maxsize).to(torch.int32)
+        idx = torch.empty(n, dtype=torch.int32, device=self.device)          # scratch: the slots (start + i) % capacity
+        start = self._next_idx
         super().add_batch(batch)
-        self._set(idx, self._max_priority.expand(n).contiguous(), 0.0)   # weight = max priority (buffer.py:133-136)
+        # weight = max priority (buffer.py:133-136): leaves (max_priority ** alpha) in float64
+        L.call('mpg_per_add', L.ptr(self._it_sum), L.ptr(self._it_min), L.ptr(self._stamp), L.c_int(self._cap), L.c_int(self._maxsize),
+               L.c_int(start), L.c_int(n), L.c_double(self._alpha), L.ptr(self._max_priority), L.ptr(idx), L.stream())
 
     def sample_idxes(self, batch_size, u=None, want_weights=True):
         idx = torch.empty(batch_size, dtype=torch.int32, device=self.device)

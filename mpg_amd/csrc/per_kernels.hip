@@ -18,26 +18,27 @@ __global__ void k_stamp(int n, const int* __restrict__ idx, int* __restrict__ st
     if (i < n) atomicMax(&stamp[idx[i]], i);
 }
 
+// const_prio (nullable): every entry takes THIS priority instead of prio[i] - the max-priority leaves of freshly added transitions
+// (buffer.py:133-136), read as the float64 it is kept in (the reference's _max_priority is a python float)
 __global__ void k_set_leaves(int n, int capacity, const int* __restrict__ idx, const float* __restrict__ prio,
                              double alpha, double eps, int* __restrict__ stamp, double* __restrict__ sum_tree,
-                             double* __restrict__ min_tree, float* __restrict__ max_prio) {
+                             double* __restrict__ min_tree, const double* __restrict__ const_prio) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int leaf = idx[i];
     if (stamp[leaf] != i) return;                      // a later entry of the batch overrides this one
-    const double p = fabs((double)prio[i]) + eps;      // canonical PER: |td| + eps (the shipped ctor is dead code, SURVEY B-3)
+    const double p = const_prio ? *const_prio : fabs((double)prio[i]) + eps;      // canonical PER: |td| + eps (the shipped ctor is dead code, SURVEY B-3)
     const double v = pow(p, alpha);                    // buffer.py:185-187
     sum_tree[capacity + leaf] = v;
     min_tree[capacity + leaf] = v;
-    if (max_prio) atomicMax(reinterpret_cast<unsigned int*>(max_prio), __float_as_uint((float)p));   // p > 0: bit order == value order
 }
 // the same with ONE atomic per wave for the running maximum (65 536 atomics on one address were 12 of the kernel's 17.6 us at TD3's batch):
 // every lane takes part in the wave's maximum (lanes without a leaf of their own contribute 0: every p is > 0)
 __global__ void __launch_bounds__(256) k_set_leaves_wmax(int n, int capacity, const int* __restrict__ idx, const float* __restrict__ prio,
                                                          double alpha, double eps, const int* __restrict__ stamp, double* __restrict__ sum_tree,
-                                                         double* __restrict__ min_tree, float* __restrict__ max_prio) {
+                                                         double* __restrict__ min_tree, double* __restrict__ max_prio) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    float mine = 0.f;
+    double mine = 0.0;
     if (i < n) {
         const int leaf = idx[i];
         const float pr = prio[i];                        // (requested with the index: behind the stamp test it was a third round trip)
@@ -46,15 +47,16 @@ __global__ void __launch_bounds__(256) k_set_leaves_wmax(int n, int capacity, co
             const double v = pow(p, alpha);
             sum_tree[capacity + leaf] = v;
             min_tree[capacity + leaf] = v;
-            mine = (float)p;
+            mine = p;
         }
     }
 #pragma unroll
-    for (int m = 32; m > 0; m >>= 1) mine = fmaxf(mine, __shfl_xor(mine, m, 64));
+    for (int m = 32; m > 0; m >>= 1) mine = fmax(mine, __shfl_xor(mine, m, 64));
     // (the running maximum only grows: a wave whose maximum does not exceed what it reads there has nothing to add - a stale read costs
-    // one redundant atomic, never a lost one; 1024 atomics on one address are ~35 ns each)
-    if ((threadIdx.x & 63) == 0 && mine > 0.f && mine > *reinterpret_cast<volatile float*>(max_prio))
-        atomicMax(reinterpret_cast<unsigned int*>(max_prio), __float_as_uint(mine));
+    // one redundant atomic, never a lost one; 1024 atomics on one address are ~35 ns each).  Float64 like the reference's python float
+    // (buffer.py:189); p > 0, so the bit pattern orders like the value
+    if ((threadIdx.x & 63) == 0 && mine > 0.0 && mine > *reinterpret_cast<volatile double*>(max_prio))
+        atomicMax(reinterpret_cast<unsigned long long*>(max_prio), (unsigned long long)__double_as_longlong(mine));
 }
 
 __global__ void k_unstamp(int n, const int* __restrict__ idx, int* __restrict__ stamp) {
@@ -199,13 +201,11 @@ int rebuild(int capacity, double* sum_tree, double* min_tree, hipStream_t s, int
 
 inline bool pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
 
-// idx[i] = (start + i) % ring_capacity, prio[i] = *max_priority: the leaves of freshly added transitions (buffer.py:127-136)
-__global__ void k_per_add_fill(int n, int start, int ring_capacity, const float* __restrict__ max_priority, int* __restrict__ idx,
-                               float* __restrict__ prio) {
+// idx[i] = (start + i) % ring_capacity: the slots of freshly added transitions (buffer.py:127-136; their leaves take *max_priority)
+__global__ void k_per_add_fill(int n, int start, int ring_capacity, int* __restrict__ idx) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     idx[i] = (start + i) % ring_capacity;
-    prio[i] = max_priority[0];
 }
 
 }  // namespace
@@ -218,15 +218,25 @@ extern "C" int mpg_per_init(double* sum_tree, double* min_tree, int* stamp, int 
     return MPG_OK;
 }
 
+namespace {
+int per_update_impl(double* sum_tree, double* min_tree, int* stamp, int capacity, int n, const int* idx, const float* prio, double alpha,
+                    double eps, double* max_priority, const double* const_prio, mpg_stream_t stream);
+}
 extern "C" int mpg_per_update(double* sum_tree, double* min_tree, int* stamp, int capacity, int n, const int* idx,
-                              const float* prio, double alpha, double eps, float* max_priority, mpg_stream_t stream) {
-    MPG_REQUIRE(sum_tree && min_tree && stamp && idx && prio && pow2(capacity) && n > 0, "mpg_per_update: bad argument");
+                              const float* prio, double alpha, double eps, double* max_priority, mpg_stream_t stream) {
+    MPG_REQUIRE(prio, "mpg_per_update: bad argument");
+    return per_update_impl(sum_tree, min_tree, stamp, capacity, n, idx, prio, alpha, eps, max_priority, nullptr, stream);
+}
+namespace {
+int per_update_impl(double* sum_tree, double* min_tree, int* stamp, int capacity, int n, const int* idx, const float* prio, double alpha,
+                    double eps, double* max_priority, const double* const_prio, mpg_stream_t stream) {
+    MPG_REQUIRE(sum_tree && min_tree && stamp && idx && pow2(capacity) && n > 0, "mpg_per_update: bad argument");
     hipStream_t s = mpg_stream(stream);
     const dim3 g((n + 255) / 256), b(256);
     const bool paths = (long)n * 64 <= (long)capacity;
     hipLaunchKernelGGL(k_stamp, g, b, 0, s, n, idx, stamp);
     if (max_priority) hipLaunchKernelGGL(k_set_leaves_wmax, g, b, 0, s, n, capacity, idx, prio, alpha, eps, stamp, sum_tree, min_tree, max_priority);
-    else hipLaunchKernelGGL(k_set_leaves, g, b, 0, s, n, capacity, idx, prio, alpha, eps, stamp, sum_tree, min_tree, max_priority);
+    else hipLaunchKernelGGL(k_set_leaves, g, b, 0, s, n, capacity, idx, prio, alpha, eps, stamp, sum_tree, min_tree, const_prio);
     if (paths) hipLaunchKernelGGL(k_unstamp, g, b, 0, s, n, idx, stamp);
     MPG_CHECK_LAUNCH("mpg_per_update");
     // n log2(capacity) node updates by one workgroup against 2 * capacity by the whole chip: the paths win for small batches (B = 256
@@ -238,6 +248,7 @@ extern "C" int mpg_per_update(double* sum_tree, double* min_tree, int* stamp, in
     }
     return rebuild(capacity, sum_tree, min_tree, s, n, idx, stamp);        // (clears the stamps on its way)
 }
+}  // namespace
 
 extern "C" int mpg_per_sample(const double* sum_tree, const double* min_tree, int capacity, int n_storage, int n,
                               const double* u, uint64_t seed, uint64_t ctr, double beta, int* idx, float* is_weight,
@@ -273,13 +284,12 @@ extern "C" int mpg_per_sample_gather(const double* sum_tree, const double* min_t
 }
 
 extern "C" int mpg_per_add(double* sum_tree, double* min_tree, int* stamp, int capacity, int ring_capacity, int start, int n,
-                           double alpha, float* max_priority, int* idx_scratch, float* prio_scratch, mpg_stream_t stream) {
-    MPG_REQUIRE(sum_tree && min_tree && stamp && max_priority && idx_scratch && prio_scratch && n > 0 && ring_capacity > 0 &&
+                           double alpha, double* max_priority, int* idx_scratch, mpg_stream_t stream) {
+    MPG_REQUIRE(sum_tree && min_tree && stamp && max_priority && idx_scratch && n > 0 && ring_capacity > 0 &&
                     ring_capacity <= capacity && start >= 0 && start < ring_capacity,
                 "mpg_per_add: bad argument");
-    hipLaunchKernelGGL(k_per_add_fill, dim3((n + 255) / 256), dim3(256), 0, mpg_stream(stream), n, start, ring_capacity, max_priority,
-                       idx_scratch, prio_scratch);
+    hipLaunchKernelGGL(k_per_add_fill, dim3((n + 255) / 256), dim3(256), 0, mpg_stream(stream), n, start, ring_capacity, idx_scratch);
     MPG_CHECK_LAUNCH("k_per_add_fill");
-    return mpg_per_update(sum_tree, min_tree, stamp, capacity, n, idx_scratch, prio_scratch, alpha, 0.0, nullptr, stream);
+    return per_update_impl(sum_tree, min_tree, stamp, capacity, n, idx_scratch, nullptr, alpha, 0.0, nullptr, max_priority, stream);
 }
 

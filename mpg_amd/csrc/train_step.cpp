@@ -111,7 +111,7 @@ int sample_and_add(mpg_train_ctx_t* c, const float* policy, mpg_stream_t s) {
         }
         if (c->learner_version == 4 && c->prioritized)       // new transitions enter at the max priority (buffer.py:127-136)
             TRY(mpg_per_add(c->per_sum, c->per_min, c->per_stamp, c->per_capacity, c->ring_capacity, c->ring_next, c->num_agent,
-                            c->per_alpha, c->per_max_priority, reinterpret_cast<int*>(c->scratch), c->scratch + c->num_agent, s));
+                            c->per_alpha, c->per_max_priority, reinterpret_cast<int*>(c->scratch), s));
         c->ring_next = (c->ring_next + c->num_agent) % c->ring_capacity;
         c->ring_size = std::min(c->ring_size + c->num_agent, c->ring_capacity);
     }

@@ -182,7 +182,7 @@ class OracleConfig4Loop(OracleConfig2Loop):
             cap *= 2
         self.tree_cap, self.alpha, self.beta, self.per_eps = cap, alpha, beta, eps
         self.leaves = np.zeros(cap, np.float64)                       # sum-tree leaves (the min tree holds the same values, inf where unset)
-        self.max_priority = np.float32(1.0)                           # buffer.py:125
+        self.max_priority = 1.0                                       # buffer.py:125 (a python float: float64)
         self._seen = np.zeros(cap, bool)
         super().__init__(flat_by_name, alg='TD3', **kw)
 
@@ -235,7 +235,7 @@ class OracleConfig4Loop(OracleConfig2Loop):
         jj = np.fromiter(last.keys(), np.int64)
         kk = np.fromiter(last.values(), np.int64)
         self.leaves[jj] = p[kk] ** self.alpha
-        self.max_priority = max(self.max_priority, np.float32(p.max()))
+        self.max_priority = max(self.max_priority, float(p.max()))
         g, o = {}, 0
         for k in self.names:
             g[k] = np.concatenate([x.ravel() for x in grads[o:o + 6]]).astype(np.float32)
