@@ -507,11 +507,11 @@ def test_td3_prioritized_loop_teacher_forced_against_the_oracle_loop(size):
     L.call('mpg_per_init', L.ptr(p_sum), L.ptr(p_min), L.ptr(p_stamp), L.c_int(2), L.stream())
 
     def device_leaf(priority):
-        """pow((double)(float)priority, alpha) as the library's leaf update computes it (k_set_leaves; mpg_per_add writes new transitions
-        through the same kernel with eps = 0): one update of a scratch two-leaf tree"""
-        pr = torch.full((1,), priority, dtype=torch.float32, device=DEV)
-        L.call('mpg_per_update', L.ptr(p_sum), L.ptr(p_min), L.ptr(p_stamp), L.c_int(2), L.c_int(1), L.ptr(p_idx), L.ptr(pr),
-               L.c_double(alpha), L.c_double(0.0), L.ptr(p_max), L.stream())
+        """pow(max priority, alpha) in float64 exactly as mpg_per_add computes the leaf of a newly added transition: one add into a
+        scratch two-leaf tree whose max priority is set to the value"""
+        p_max.fill_(priority)
+        L.call('mpg_per_add', L.ptr(p_sum), L.ptr(p_min), L.ptr(p_stamp), L.c_int(2), L.c_int(2), L.c_int(0), L.c_int(1),
+               L.c_double(alpha), L.ptr(p_max), L.ptr(p_idx), L.stream())
         return float(p_sum[2].item())
     for it in range(total):
         pre, max_p_pre, next_pre = leaves_of(), float(rb._max_priority.item()), rb._next_idx
