@@ -112,8 +112,9 @@ def _driver_worker(rank, world, port, q):
     from mpg_amd.optimizer import SingleProcessOffPolicyOptimizer
     from mpg_amd.policy import PolicyWithQs
     from mpg_amd.worker import OffPolicyWorker
-    args = default_args('MPG-v2', num_agent=64, batch_size=64, replay_batch_size=64, replay_starts=128, max_buffer_size=4096,
-                        seed=rank, init_seed=0)
+    # MPG_TEST_REPLAY_ROWS (default 64): a batch that is not a multiple of 16 takes mpg_mpg_gradients' launch-per-stage path
+    args = default_args('MPG-v2', num_agent=64, batch_size=64, replay_batch_size=int(os.environ.get('MPG_TEST_REPLAY_ROWS', '64')),
+                        replay_starts=128, max_buffer_size=4096, seed=rank, init_seed=0)
     worker = OffPolicyWorker(PolicyWithQs, args.env_id, args, 0)
     worker.policy_with_value.sync_from_rank0()
     opt = SingleProcessOffPolicyOptimizer(worker, MPGLearner(PolicyWithQs, args), ReplayBuffer(args, 0), None, args,
@@ -192,12 +193,18 @@ def test_native_step_driver_keeps_four_replicas_bit_identical(monkeypatch):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize('backend', ['gloo', 'oneshot'])
+@pytest.mark.parametrize('backend', ['gloo', 'oneshot', 'gloo-rows60'])
 def test_critics_exchange_under_the_reverse_sweep_leaves_the_same_bits(backend, monkeypatch):
     """SURVEY f4 "overlap with the Q-grad kernel" (off by default, MPG_OVERLAP_EXCHANGE=1): the library finishes the critics' gradient
     ahead of the reverse sweep and records the caller's event there (mpg_grad_opts_t.critics_ready_event); the driver exchanges
     the critics' slice on a second stream under the sweep and the policy's slice + statistics behind it.  Two exchanges instead of
-    one, the same sums in the same order: 20 native steps on two ranks must leave the same bits as the single exchange."""
+    one, the same sums in the same order: 20 native steps on two ranks must leave the same bits as the single exchange.
+    [gloo-rows60: a replay batch of 60 rows - not a multiple of 16 - takes the launch-per-stage path of mpg_mpg_gradients,
+    which did not record critics_ready_event before round 6: the side stream then waited on a STALE record and exchanged the critics'
+    slice while mpg_q_loss_grad was still writing it.]"""
+    if backend.endswith('-rows60'):
+        backend = backend.split('-')[0]
+        monkeypatch.setenv('MPG_TEST_REPLAY_ROWS', '60')
     monkeypatch.setenv('MPG_DIST_BACKEND', backend)
     monkeypatch.setenv('MPG_ONESHOT_SYNC', 'event')
     runs = []
