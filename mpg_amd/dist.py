@@ -130,8 +130,8 @@ class OneShotAllReduce(object):
 
     Step 2, `sync='event'` (default, round 4): INTERPROCESS EVENTS (hipEventInterprocess / hipIpcGetEventHandle /
     hipIpcOpenEventHandle).  Rank r records W_r[parity] on its stream behind its copies and makes its stream wait
-    (hipStreamWaitEvent) for every peer's W_p[parity]; the sum kernel is enqueued behind those waits and S_r[parity] is recorded
-    behind it, which the peers wait for before they overwrite r's slots two exchanges later.  The HOST never waits for the GPU:
+    (hipStreamWaitEvent) for every peer's W_p[parity]; the sum kernel is enqueued behind those waits.  That a peer does not overwrite r's
+    slots of this parity (two exchanges later) before r has read them follows from the W events alone (round 6; see all_reduce_sum_).  The HOST never waits for the GPU:
     the only host-side coupling is a per-rank call counter in shared memory (_HostShm) that orders "peer issued its record"
     before "I issue my wait" - sub-microsecond when the peers' host threads run ahead of their GPUs, which they do (the native
     step driver enqueues a 0.24 ms step in ~40 us).  So the launch queue of the native driver no longer drains at the exchange.
@@ -163,6 +163,7 @@ class OneShotAllReduce(object):
         self.world, self.rank = dist.get_world_size(), dist.get_rank()
         self.n = int(n)
         self.sync = sync or os.environ.get('MPG_ONESHOT_SYNC', 'event')
+        self.s_events = os.environ.get('MPG_ONESHOT_S_EVENTS') == '1'
         assert self.sync in ('event', 'host')
         mode = mode or os.environ.get('MPG_ONESHOT_MODE', 'oneshot')
         assert mode in ('oneshot', 'twoshot', 'auto')
@@ -305,9 +306,13 @@ class OneShotAllReduce(object):
             self._make_generation(g + 1)
             self.mine.pop(g - 2, None)
             self.theirs.pop(g - 2, None)
-        # 0. a peer's slots of this parity were last read by its sum two exchanges ago: S_p[par] of THAT exchange's generation (the
-        #    peer's host issued that record before it published exchange it - 1, which this rank waited for in exchange it - 1)
-        if it > 2:
+        # 0. A peer's slots (and gather array) of this parity were last read by its exchange it - 2.  No event of their own is needed for
+        #    that (round 6): this rank waited for the peer's W of exchange it - 1 during exchange it - 1, and that record sits BEHIND the
+        #    whole of the peer's exchange it - 2 in the peer's stream - so everything this rank enqueues from here on already follows the
+        #    peer's reads.  (Rounds 4 - 5 recorded and waited for a separate "reads done" event S per exchange; an interprocess event
+        #    record costs ~16 us of host time and a system-scope release on the stream, tools/ipc_event_cost.py.  MPG_ONESHOT_S_EVENTS=1
+        #    keeps them, as the control for a first multi-GPU run.)
+        if self.s_events and it > 2:
             g2 = (it - 3) // self.GEN_LEN
             for p, ev in self.theirs[g2].items():
                 st.wait_event(ev[2 + par])
@@ -330,7 +335,8 @@ class OneShotAllReduce(object):
             self._finish(self.gath[par], 1, flat, seg_sizes, sq_part)
         else:
             self._finish(self.stage[par], self.world, flat, seg_sizes, sq_part)     # 3.
-        self.mine[g][2 + par].record(st)                # S[par]: my reads of this parity's slots (and gather array) are done
+        if self.s_events:
+            self.mine[g][2 + par].record(st)            # S[par]: my reads of this parity's slots (and gather array) are done
         return flat
 
 
