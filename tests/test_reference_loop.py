@@ -96,7 +96,7 @@ def test_worker_sample_vs_reference_worker(golden):
     np.testing.assert_allclose(loop.env.obs, g['final_obs'], rtol=2e-5, atol=2e-5)
 
 
-def _check_loop_against_fixture(g, loop, names, ring_keys, idx_of, stat_of, n_iter, w0, tol_update=1e-3):
+def _check_loop_against_fixture(g, loop, names, idx_of, stat_of, n_iter, w0, tol_update=1e-3):
     """shared by the two loop tests: step the restated loop n_iter times beside the fixture of the reference's own loop"""
     assert loop.size == int(g['fill']), 'ring after the constructor fill (optimizer.py:310-313)'
     worst = 0.0
@@ -150,7 +150,7 @@ def test_config2_loop_restatement_vs_reference_optimizer(golden, case):
     # (MPG-v1: the reference's buffer draws every iteration, the learner takes a new minibatch every 10th call - the restated loop draws
     # only those; the Philox counter is the replay count in both, so the draws it does make are the fixture's rows 0 and 10)
     idx_of = lambda lp: lp.idx if (lp.counter - 1) % lp.reuse == 0 else None
-    worst = _check_loop_against_fixture(g, loop, names, None, idx_of, stat, n_iter, w0)
+    worst = _check_loop_against_fixture(g, loop, names, idx_of, stat, n_iter, w0)
     torch.set_num_threads(nthreads)
     n = int(g['ring_len'])
     assert loop.size == n and loop.next == int(g['ring_next']) and loop.replay_times == int(g['replay_times']) == n_iter
@@ -185,7 +185,7 @@ def test_config3_loop_restatement_vs_reference_optimizer(golden):
                              replay_starts=3000, capacity=8192, sampling_interval=10)
     n_iter = int(g['n_iter'])
     stat = lambda lp, key: float(np.asarray(lp.stats[key])) if key in lp.stats else None
-    worst = _check_loop_against_fixture(g, loop, names, None, lambda lp: lp.idx, stat, n_iter, w0)
+    worst = _check_loop_against_fixture(g, loop, names, lambda lp: lp.idx, stat, n_iter, w0)
     torch.set_num_threads(nthreads)
     n = int(g['ring_len'])
     assert loop.size == n and loop.next == int(g['ring_next']) and loop.replay_times == int(g['replay_times']) == n_iter
@@ -226,10 +226,8 @@ def test_config4_oracle_loop_pieces_vs_the_pinned_segment_tree(golden):
                              capacity=1000)
     assert loop.tree_cap == 1024 and loop.leaves[:128].min() == 1.0 and loop.leaves[128:].max() == 0.0
     for _ in range(3):
-        loop.trees()
-        st, _ = loop.trees()
+        st, _ = loop.trees()      # (any valid indices will do as the forced draw: here what the tree BEFORE this step's 16 additions gives)
         own = O.find_prefixsum_idx_batch(st, O.per_uniform_philox(64, loop.rb_seed, loop.replay_times + 1) * st[1])
-        # (the step below samples first - 16 new leaves at max priority - so predict its draw after a dry sample instead: just run it)
         loop.step(np.minimum(own, loop.size - 1))
         w = loop.weights
         assert w.max() <= 1.0 + 1e-12 and w.min() > 0
