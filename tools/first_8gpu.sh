@@ -37,6 +37,8 @@ for n in 2 4 8; do
         run "n${n}_oneshot_ov$ov" "$n" MPG_DIST_BACKEND=oneshot MPG_ONESHOT_MODE=oneshot MPG_OVERLAP_EXCHANGE=$ov
         run "n${n}_twoshot_ov$ov" "$n" MPG_DIST_BACKEND=oneshot MPG_ONESHOT_MODE=twoshot MPG_OVERLAP_EXCHANGE=$ov
     done
+    # control of round 6's hand-shake: the separate "reads done" events of rounds 4 - 5 (EXPERIMENTS.md 6.2)
+    run "n${n}_oneshot_ov0_Sevents" "$n" MPG_DIST_BACKEND=oneshot MPG_ONESHOT_MODE=oneshot MPG_OVERLAP_EXCHANGE=0 MPG_ONESHOT_S_EVENTS=1
 done
 echo "== 3. config 5's global batch on one GPU ==" | tee -a "$OUT/table.txt"
 timeout 1500 python3 bench.py --gpus 1 --steps 200 --warmup 20 --no-cpu-baseline --no-side-configs --rows-per-gpu 32768 \
