@@ -18,14 +18,16 @@ from oracle import mpg_oracle as O
 
 class OracleConfig2Loop(object):
     def __init__(self, flat_by_name, seed=0, num_agent=64, batch_size=64, replay_batch_size=256, replay_starts=512, capacity=500000,
-                 sampling_interval=1, explore_sigma=0.1, dtype=torch.float32, alg='MPG-v2'):
+                 sampling_interval=1, explore_sigma=0.1, dtype=torch.float32, alg='MPG-v2', num_future_data=0):
         # TD3 (learners/td3.py:150-188, uniform replay): the same loop, another learner.  MPG-v1 (networks [Q1 | policy]): the critic's
         # target is the 25-step REAL-env return from (s, a_replay) (mpg_learner.py:109-124,146-169), recomputed with a new minibatch every
         # num_batch_reuse = 10 gradient calls and kept in between (mpg_learner.py:402-403; train_script.py's default for v1)
         assert alg in ('MPG-v2', 'TD3', 'MPG-v1')
         self.alg = alg
         self.reuse = 10 if alg == 'MPG-v1' else 1
-        self.cfg = O.Cfg()                                # PathTracking-v0 defaults (select [0, 25], delay_update 2, smoothing .2 / .5, ...)
+        K = self.K = num_future_data                      # look-ahead entries of the observation (path_tracking_env.py:385-402)
+        # PathTracking-v0 defaults (select [0, 25], delay_update 2, smoothing .2 / .5, ...)
+        self.cfg = O.Cfg() if K == 0 else O.Cfg(obs_dim=6 + K, obs_scale=list(O.OBS_SCALE_PT) + [1.] * K)
         self.names = ['Q1', 'policy'] if alg == 'MPG-v1' else ['Q1', 'Q2', 'policy']
         self.w = {k: np.array(flat_by_name[k], np.float32) for k in self.names}
         self.tgt = {k: v.copy() for k, v in self.w.items()}
@@ -37,11 +39,11 @@ class OracleConfig2Loop(object):
         self.rb_seed = seed * 7919
         self.l_seed = seed + 12345
         self.noise_ctr = self.env_ctr = self.replay_times = self.counter = 0
-        self.env = O.PathTrackingEnvOracle(num_agent)
+        self.env = O.PathTrackingEnvOracle(num_agent, K)
         self._redraw(np.ones(num_agent, bool))            # OffPolicyWorker.__init__: env.reset()
         self.cap = capacity
-        self.ring = dict(obs=np.zeros((capacity, 6), np.float32), act=np.zeros((capacity, 2), np.float32), rew=np.zeros(capacity, np.float32),
-                         obs2=np.zeros((capacity, 6), np.float32), done=np.zeros(capacity, np.float32))
+        self.ring = dict(obs=np.zeros((capacity, 6 + K), np.float32), act=np.zeros((capacity, 2), np.float32), rew=np.zeros(capacity, np.float32),
+                         obs2=np.zeros((capacity, 6 + K), np.float32), done=np.zeros(capacity, np.float32))
         self.size = self.next = 0
         self.iteration = 0
         self.stats = None

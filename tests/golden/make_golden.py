@@ -642,6 +642,9 @@ def loop_args(case, **kw):
         args.delay_update, args.num_agent, args.explore_sigma = 1, 1, None
     elif case == 'td3':
         args = mpg_args('TD3', 256, 256)
+    elif case == 'v2k3':                     # num_future_data = 3 (train_script.py:90,146-147: obs_dim 6 + K, obs_scale padded with ones)
+        args = mpg_args('MPG-v2', 256, 256)
+        args.num_future_data, args.obs_dim, args.obs_scale = 3, 9, OBS_SCALE_PT + [1.] * 3
     else:
         args = mpg_args('MPG-' + case, 256, 256)
         if case == 'v1':
@@ -837,7 +840,8 @@ def _register_cart_pole(seed):
 def fx_loop(case, n_iter=20):
     """SingleProcessOffPolicyOptimizer (optimizer.py:286-397) at the reference's defaults - OffPolicyWorker (8 agents, 512 transitions
     per sample) / ReplayBuffer (replay_starts 3000, batch 256) / MPGLearner MPG-v2 (case 'v2'), MPG-v1 ('v1': Q1 + policy, the 25-step
-    real-env target of the learner's own 256-agent env recomputed every 10th call), TD3Learner ('td3', uniform replay) or NADPLearner on the
+    real-env target of the learner's own 256-agent env recomputed every 10th call; 'v2k3': MPG-v2 with num_future_data = 3 - observations
+    with three look-ahead entries through env, worker, ring, model and learner), TD3Learner ('td3', uniform replay) or NADPLearner on the
     pendulum model (case 'nadp': 1 agent behind DummyVecEnv) / PolicyWithQs - constructed (fills the ring) and stepped n_iter times (sampling at
     iterations 0 and 10).  All reference classes unmodified; random inputs: DeviceStreams(LOOP_SEED); initial weights:
     golden_inputs.loop_case_weights.  Per iteration: replay indices, learner statistics, per-optimizer counters, per-network update
@@ -860,7 +864,7 @@ def fx_loop(case, n_iter=20):
     else:
         from learners.mpg_learner import MPGLearner as Learner
         keys = ('q_loss1', 'q_loss2', 'value_mean', 'policy_total_loss', 'q_gradient_norm1', 'q_gradient_norm2', 'policy_gradient_norm') \
-            if case == 'v2' else ('q_loss1', 'value_mean', 'policy_total_loss', 'q_gradient_norm1', 'policy_gradient_norm')
+            if case in ('v2', 'v2k3') else ('q_loss1', 'value_mean', 'policy_total_loss', 'q_gradient_norm1', 'policy_gradient_norm')
         counters = lambda k: [k]
     w0 = loop_case_weights(dims)
     w0_flat = np.concatenate([w0[name] for name, _, _ in NET_DIMS[dims]])
@@ -979,7 +983,8 @@ ROUND2['trained_c2'] = lambda: fx_bench_case('c2_mpg_v2_B4096', trained=True)   
 ROUND2['mpg_future'] = lambda: fx_mpg('MPG-v2', 256, 64, seed=12, K=3)               # round 3: num_future_data = 3
 ROUND2['mpg_future10'] = lambda: fx_mpg('MPG-v2', 256, 64, seed=13, K=10)           # round 4: num_future_data = 10 (obs_dim 16, critics 18 wide)
 ROUND2.update(apply_gradients=fx_apply_gradients, worker_sample=fx_worker_sample,           # round 6: the reference's own loop code
-              loop_v2=lambda: fx_loop('v2'), loop_nadp=lambda: fx_loop('nadp'), loop_td3=lambda: fx_loop('td3'), loop_v1=lambda: fx_loop('v1'), per_buffer=fx_per_buffer)
+              loop_v2=lambda: fx_loop('v2'), loop_nadp=lambda: fx_loop('nadp'), loop_td3=lambda: fx_loop('td3'), loop_v1=lambda: fx_loop('v1'), per_buffer=fx_per_buffer,
+              loop_v2k3=lambda: fx_loop('v2k3'))
 
 
 def main():

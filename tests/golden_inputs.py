@@ -85,6 +85,7 @@ NET_DIMS = {                  # case -> ordered (name, in, out) like PolicyWithQ
     'v2': [('Q1', 8, 1), ('Q2', 8, 1), ('policy', 6, 4)],
     'v1': [('Q1', 8, 1), ('policy', 6, 4)],
     'nadp': [('Q1', 5, 1), ('policy', 4, 2)],
+    'v2k3': [('Q1', 11, 1), ('Q2', 11, 1), ('policy', 9, 4)],      # MPG-v2 with num_future_data = 3 (obs 9 wide)
 }
 
 

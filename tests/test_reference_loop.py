@@ -123,11 +123,13 @@ def _check_loop_against_fixture(g, loop, names, idx_of, stat_of, n_iter, w0, tol
     return worst
 
 
-@pytest.mark.parametrize('case', ['v2', 'td3', 'v1'])
+@pytest.mark.parametrize('case', ['v2', 'td3', 'v1', 'v2k3'])
 def test_config2_loop_restatement_vs_reference_optimizer(golden, case):
     """[td3: the same with the reference's TD3Learner (learners/td3.py:150-188, uniform replay; the smoothing noise td3.py:74 on the
     restated mpg_normal_fill stream).  v1: MPGLearner MPG-v1 - networks [Q1 | policy], the critic's target = the 25-step REAL-env return of
-    the learner's own 256-agent env (mpg_learner.py:109-124,146-169), recomputed with a new minibatch every num_batch_reuse = 10 calls.]
+    the learner's own 256-agent env (mpg_learner.py:109-124,146-169), recomputed with a new minibatch every num_batch_reuse = 10 calls.
+    v2k3: MPG-v2 with num_future_data = 3 - nine-entry observations (three look-ahead delta_y terms, path_tracking_env.py:385-402) through
+    env, worker, ring, model (:262-268) and learner.]
     tests/c2_loop.py x 20 iterations against the reference's SingleProcessOffPolicyOptimizer + OffPolicyWorker + ReplayBuffer +
     MPGLearner (MPG-v2) + PolicyWithQs at the reference's defaults (8 agents, 512 transitions per sample, replay_starts 3000, batch
     256, sampling at iterations 0 and 10, delay_update 2), same Philox inputs, same initial weights.
@@ -137,14 +139,15 @@ def test_config2_loop_restatement_vs_reference_optimizer(golden, case):
     all entries at the end) 1e-3 relative L2 and within 4 x the reference's own float32-vs-float64 gap; ring contents 2e-5."""
     from tests.c2_loop import OracleConfig2Loop
     g = golden('loop_%s_ref.npz' % case)
-    dims = 'v1' if case == 'v1' else 'v2'
+    dims = case if case in ('v1', 'v2k3') else 'v2'
     names = [n for n, _, _ in NET_DIMS[dims]]
     w = loop_case_weights(dims)
     w0 = np.concatenate([w[n] for n in names])
     nthreads = torch.get_num_threads()
     torch.set_num_threads(4)
     loop = OracleConfig2Loop(w, seed=int(g['seed']), num_agent=8, batch_size=512, replay_batch_size=256, replay_starts=3000,
-                             capacity=8192, sampling_interval=10, alg={'v2': 'MPG-v2', 'td3': 'TD3', 'v1': 'MPG-v1'}[case])
+                             capacity=8192, sampling_interval=10, alg={'v2': 'MPG-v2', 'td3': 'TD3', 'v1': 'MPG-v1', 'v2k3': 'MPG-v2'}[case],
+                             num_future_data=3 if case == 'v2k3' else 0)
     n_iter = int(g['n_iter'])
     stat = lambda lp, key: float(np.asarray(lp.stats[key])) if key in lp.stats else None
     # (MPG-v1: the reference's buffer draws every iteration, the learner takes a new minibatch every 10th call - the restated loop draws

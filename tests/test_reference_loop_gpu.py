@@ -26,7 +26,7 @@ def rel_l2(a, b):
 
 def _args(case, **kw):
     from mpg_amd.config import default_args
-    return default_args({'v2': 'MPG-v2', 'v1': 'MPG-v1', 'nadp': 'NADP', 'td3': 'TD3'}[case], nan_check_interval=10 ** 9, **kw)
+    return default_args({'v2': 'MPG-v2', 'v2k3': 'MPG-v2', 'v1': 'MPG-v1', 'nadp': 'NADP', 'td3': 'TD3'}[case], nan_check_interval=10 ** 9, **kw)
 
 
 @pytest.mark.parametrize('case', ['v2', 'v1', 'nadp'])
@@ -99,13 +99,14 @@ def test_device_worker_sample_vs_reference_worker(golden):
     worker.policy_with_value.check_status()
 
 
-@pytest.mark.parametrize('case', ['v2', 'td3', 'v1', 'nadp', 'nadp-ring-forced'])
+@pytest.mark.parametrize('case', ['v2', 'td3', 'v1', 'v2k3', 'nadp', 'nadp-ring-forced'])
 def test_device_loop_vs_reference_optimizer(golden, case):
     """The device's SingleProcessOffPolicyOptimizer (native step driver: mpg_step_begin / mpg_step_end) at the reference's defaults
     against the reference's own optimizer loop: 20 iterations, sampling at iterations 0 and 10.
     v2: 8 agents x 64 steps per sample, replay batch 256, MPG-v2, delay_update 2.  td3: the same with TD3Learner (learner_version 4,
     uniform replay, in-kernel smoothing noise).  v1: MPG-v1 (learner_version 1: networks [Q1 | policy]; the 25-step real-env target of
-    the learner's own 256-agent env, recomputed with a new minibatch every 10th call and cached in between).  nadp: ONE agent x 512 steps per sample (the
+    the learner's own 256-agent env, recomputed with a new minibatch every 10th call and cached in between).  v2k3: MPG-v2 with
+    num_future_data = 3 (nine-entry observations; the wide network kernels and `WIDE` sweeps, launch-per-stage gradients).  nadp: ONE agent x 512 steps per sample (the
     reference's DummyVecEnv form), NADP on the pendulum model, delay_update 1; the real env is the analytic cart-pole on both sides.
     Exact: ring length after the fill, replay indices of every iteration, optimizer counters, stream counters.
     Bars (as the oracle-loop tests of tests/test_noise_gpu.py): parameter update within 1e-3 relative L2 of the reference's at every
@@ -128,17 +129,17 @@ def test_device_loop_vs_reference_optimizer(golden, case):
     g = golden('loop_%s_ref.npz' % case)
     dims = 'v2' if case == 'td3' else case
     names = [n for n, _, _ in NET_DIMS[dims]]
-    args = _args(case, seed=int(g['seed']), max_buffer_size=8192)
+    args = _args(case, seed=int(g['seed']), max_buffer_size=8192, **({'num_future_data': 3} if case == 'v2k3' else {}))
     assert (args.num_agent, args.batch_size, args.replay_batch_size, args.replay_starts) == ((1 if case == 'nadp' else 8), 512, 256, 3000)
     worker = OffPolicyWorker(PolicyWithQs, args.env_id, args, 0)
     pw = worker.policy_with_value
     w = loop_case_weights(dims)
     w0 = np.concatenate([w[n] for n in names])
     pw.set_flat(w0, w0)
-    learner = {'v2': MPGLearner, 'v1': MPGLearner, 'td3': TD3Learner, 'nadp': NADPLearner}[case](PolicyWithQs, args)
+    learner = {'v2': MPGLearner, 'v2k3': MPGLearner, 'v1': MPGLearner, 'td3': TD3Learner, 'nadp': NADPLearner}[case](PolicyWithQs, args)
     rb = ReplayBuffer(args, 0)
     opt = SingleProcessOffPolicyOptimizer(worker, learner, rb, None, args)            # sampling_interval 10: optimizer.py:331
-    assert opt._fused is not None and opt._fused.c.learner_version == {'v2': 2, 'v1': 1, 'td3': 4, 'nadp': 3}[case]
+    assert opt._fused is not None and opt._fused.c.learner_version == {'v2': 2, 'v2k3': 2, 'v1': 1, 'td3': 4, 'nadp': 3}[case]
     assert case != 'v1' or learner.num_batch_reuse == 10
     assert len(rb) == int(g['fill'])
     keys = [str(k) for k in g['stat_keys']]
